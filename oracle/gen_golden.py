@@ -1,0 +1,130 @@
+"""
+oracle/gen_golden.py -- generate tests/golden/*.npz by running the LIVE reference (/root/reference) on CPU.
+Run in the build container only (/root/reference does not exist on the GPU box):
+    python oracle/gen_golden.py
+The fixtures pin oracle/encoder_np.py and oracle/decoder_ref.py (and, through them, the HIP path) to the
+reference's own Model.encode / CTC.forward / CTC.infer / ctc_decoder.decode outputs.
+
+Import recipe: the reference imports four third-party modules that are absent here
+(editdistance, soundfile, functions.ctc = warp-ctc binding, transducer); they are stubbed in sys.modules.
+Nothing is copied from the reference; it is only executed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    for name in ["editdistance", "soundfile", "functions", "functions.ctc", "transducer", "transducer.decoders",
+                 "transducer.functions", "transducer.functions.transducer"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["functions.ctc"].CTCLoss = object
+    sys.modules["functions"].ctc = sys.modules["functions.ctc"]
+    sys.modules["transducer.functions.transducer"].TransducerLoss = object
+    sys.modules["transducer.decoders"].decode_static = None
+    sys.modules["transducer"].decoders = sys.modules["transducer.decoders"]
+    sys.modules["transducer"].functions = sys.modules["transducer.functions"]
+    sys.modules["transducer.functions"].transducer = sys.modules["transducer.functions.transducer"]
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import speech.models as models  # noqa
+    from speech.models import ctc_decoder  # noqa
+    return models, ctc_decoder
+
+
+def encoder_case(models, name, freq_dim, vocab, cfg, B, T, seed):
+    """Reference CTC model (random init under a fixed seed) on a seeded fake batch (tests/shared.py:18-26 shapes)."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = models.CTC(freq_dim, vocab, cfg)
+    model.eval()
+    inputs = tuple(np.random.randn(T, freq_dim) for _ in range(B))
+    labels = tuple(np.random.randint(0, vocab, 20) for _ in range(B))
+    with torch.no_grad():
+        logits = model((inputs, labels))                      # CTC.forward -> collate -> forward_impl
+        x = torch.FloatTensor(models.model.zero_pad_concat(inputs))
+        enc = model.encode(x)
+        preds = model.infer((inputs, labels))                 # beam_size=1 prefix search, blank = vocab
+    out = {"param." + k: v.numpy() for k, v in model.state_dict().items()}
+    out["x"] = x.numpy()
+    out["logits"] = logits.numpy()
+    out["enc"] = enc.numpy()
+    out["t_out"] = np.array(model.conv_out_size(T, 0))
+    out["f_out"] = np.array(model.conv_out_size(freq_dim, 1))
+    out["infer_flat"] = np.array([l for p in preds for l in p], dtype=np.int32)
+    out["infer_lens"] = np.array([len(p) for p in preds], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "logits", logits.shape, "enc", enc.shape, "infer lens", out["infer_lens"])
+
+
+def decoder_cases(ctc_decoder):
+    cases = {}
+
+    def add(name, probs, beam, blank):
+        probs = np.asarray(probs)
+        with np.errstate(divide="ignore"):
+            labels, nll = ctc_decoder.decode(probs, beam_size=beam, blank=blank)
+        cases[name + ".probs"] = probs
+        cases[name + ".meta"] = np.array([beam, blank], dtype=np.int32)
+        cases[name + ".labels"] = np.array(labels, dtype=np.int32)
+        cases[name + ".nll"] = np.array(float(nll), dtype=np.float64)
+        print(name, "beam", beam, "blank", blank, "len", len(labels), "nll", float(nll))
+
+    # the reference's own demo vector (ctc_decoder.py:115-126): float64 probs, beam 10, blank 0
+    np.random.seed(3)
+    probs = np.random.rand(50, 20)
+    probs = probs / np.sum(probs, axis=1, keepdims=True)
+    add("demo", probs, 10, 0)
+
+    rng = np.random.RandomState(2017)
+
+    def softmax(z):
+        z = z - z.max(axis=1, keepdims=True)
+        e = np.exp(z)
+        return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+    for i, (T, S, scale, beam, blank) in enumerate([
+            (60, 11, 1.0, 1, 10), (60, 11, 4.0, 1, 10), (80, 29, 4.0, 1, 28), (80, 29, 1.0, 1, 28),
+            (60, 11, 4.0, 4, 10), (80, 29, 4.0, 8, 28), (80, 29, 2.0, 8, 28), (50, 20, 3.0, 10, 0),
+            (40, 6, 8.0, 3, 5), (120, 29, 6.0, 8, 28), (120, 29, 6.0, 1, 28), (30, 5, 1.0, 16, 4)]):
+        add("rand%d" % i, softmax(scale * rng.randn(T, S)), beam, blank)
+    # hard zeros (log -> -inf) and exact ties
+    p = softmax(3.0 * rng.randn(40, 8))
+    p[::3, 2] = 0.0
+    p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32)
+    add("zeros", p, 4, 7)
+    add("zeros_b1", p, 1, 7)
+    add("uniform", np.full((20, 5), 0.2, dtype=np.float32), 3, 4)
+    add("uniform_b1", np.full((20, 5), 0.2, dtype=np.float32), 1, 4)
+    onehot = np.zeros((12, 4), dtype=np.float32)
+    onehot[np.arange(12), [0, 0, 3, 1, 1, 3, 1, 2, 2, 3, 3, 0]] = 1.0
+    add("onehot", onehot, 2, 3)
+    add("onehot_b1", onehot, 1, 3)
+    add("single_frame", softmax(rng.randn(1, 7)), 5, 6)
+    np.savez_compressed(os.path.join(OUT, "decoder.npz"), **cases)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    models, ctc_decoder = import_reference()
+    sys.path.insert(0, os.path.join(REF, "tests"))
+    import shared  # the reference's own test config (tests/shared.py:4-16)
+    encoder_case(models, "encoder_tiny", 40, 10, shared.model_config, B=4, T=100, seed=2017)
+    cfg_bi = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2], [8, 3, 7, 1]],
+                                          "rnn": {"dim": 24, "bidirectional": True, "layers": 2}}}
+    encoder_case(models, "encoder_bi2", 40, 12, cfg_bi, B=3, T=61, seed=7)
+    cfg_uni3 = {"dropout": 0.0, "encoder": {"conv": [[16, 5, 32, 2]],
+                                            "rnn": {"dim": 32, "bidirectional": False, "layers": 3}}}
+    encoder_case(models, "encoder_uni3", 80, 28, cfg_uni3, B=2, T=75, seed=11)
+    decoder_cases(ctc_decoder)
+
+
+if __name__ == "__main__":
+    main()
