@@ -1,0 +1,160 @@
+/*
+ * speech_amd.h -- C ABI of libspeech_amd.so: the MI355X (gfx950) implementation of the awni/speech CTC hot path.
+ *
+ * Plain C: pointers, sizes, a stream handle.  No torch types, no C++ in the signatures.  Every pointer named
+ * d_* / acts / grads / workspace is DEVICE memory owned by the caller; the library allocates nothing and keeps no
+ * global state, so every entry point is re-entrant.  All work is enqueued on the caller's stream (a hipStream_t
+ * passed as void*; NULL = the default stream); only the entry points that return HOST results (marked SYNC)
+ * wait for it.  Every function returns a ctcStatus_t; nothing throws.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef SPEECH_AMD_H
+#define SPEECH_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 1. The warp-ctc C API.  The reference binds it through cffi: `import functions.ctc as ctc`
+ *    (speech/models/ctc_model.py:9) -> ctc.CTCLoss()(out, y, x_lens, y_lens) (ctc_model.py:38-39); the library is
+ *    cloned un-pinned by Makefile:4-7 and is NOT in the reference tree, so the shapes below restate upstream
+ *    warp-ctc's public ctc.h from memory (SURVEY.md 8b "[recalled]").  Exported under the same names so that the
+ *    binding's `gpu_ctc` can link against this library unchanged.
+ * ----------------------------------------------------------------------------------------------------------------*/
+typedef enum {
+    CTC_STATUS_SUCCESS = 0,
+    CTC_STATUS_MEMOPS_FAILED = 1,
+    CTC_STATUS_INVALID_VALUE = 2,
+    CTC_STATUS_EXECUTION_FAILED = 3,
+    CTC_STATUS_UNKNOWN_ERROR = 4
+} ctcStatus_t;
+
+typedef enum { CTC_CPU = 0, CTC_GPU = 1 } ctcComputeLocation;
+
+typedef struct ctcOptions {
+    ctcComputeLocation loc; /* must be CTC_GPU: this library has no CPU path (CTC_CPU -> CTC_STATUS_EXECUTION_FAILED) */
+    union {
+        unsigned int num_threads; /* unused */
+        void* stream;             /* hipStream_t */
+    };
+    int blank_label; /* the reference model uses blank = alphabet_size - 1 (ctc_model.py:18) */
+} ctcOptions;
+
+int get_warpctc_version(void);
+const char* ctcGetStatusString(ctcStatus_t status);
+
+/* activations: DEVICE, (T, B, alphabet_size) row-major, un-normalised logits (softmax is applied inside).
+ * gradients:   DEVICE, same shape, or NULL for score-only.   flat_labels / label_lengths / input_lengths / costs: HOST.
+ * costs[b] = -log p(labels_b | acts_b); infeasible alignment -> +inf with zero gradient; rows t >= input_lengths[b]
+ * get zero gradient.  SYNC (costs are returned on the host). */
+ctcStatus_t compute_ctc_loss(const float* activations, float* gradients, const int* flat_labels,
+                             const int* label_lengths, const int* input_lengths, int alphabet_size, int minibatch,
+                             float* costs, void* workspace, ctcOptions options);
+
+ctcStatus_t get_workspace_size(const int* label_lengths, const int* input_lengths, int alphabet_size, int minibatch,
+                               ctcOptions options, size_t* size_bytes);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 2. Stream-ordered, layout-agnostic CTC loss -- what speech_amd.ctc.CTCLoss (the replacement for
+ *    functions.ctc.CTCLoss, ctc_model.py:38-39) calls.  The model hands over batch-first logits (B, T', V+1)
+ *    (ctc_model.py:29-32,36); strides let both layouts run without a transpose copy:
+ *        acts[b * stride_b + t * stride_t + k],  grads likewise.
+ *    All pointers DEVICE.  d_costs[b] per-utterance cost.  No host synchronisation.
+ * ----------------------------------------------------------------------------------------------------------------*/
+size_t sa_ctc_workspace_bytes(int max_T, int max_L, int alphabet_size, int minibatch);
+
+ctcStatus_t sa_ctc_loss(const float* acts, float* grads /* or NULL */, long stride_t, long stride_b,
+                        const int* d_flat_labels, const int* d_label_lengths, const int* d_input_lengths,
+                        int alphabet_size, int minibatch, int max_T, int max_L, int blank_label, float* d_costs,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 3. CTC decoding.
+ *    sa_ctc_beam_decode  replaces speech/models/ctc_decoder.py:38-113 decode(probs, beam_size, blank) as called per
+ *        utterance by CTC.infer (ctc_model.py:55-60, beam_size = 1, blank = V) -- same float32/double arithmetic,
+ *        same first-touch tie order, same stable descending sort.  input_is_logits != 0 fuses the softmax of
+ *        ctc_model.py:30-31 (probs = softmax(logits), then log, as the reference does).
+ *    sa_ctc_greedy_decode replaces np.argmax + CTC.max_decode (ctc_model.py:62-70).
+ *    in[b * stride_b + t * stride_t + s]; d_out_labels (B, max_T) int32; d_out_lens (B); d_out_nll (B) float or NULL.
+ * ----------------------------------------------------------------------------------------------------------------*/
+size_t sa_ctc_beam_workspace_bytes(int max_T, int alphabet_size, int minibatch, int beam_size);
+
+ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long stride_b, const int* d_input_lengths,
+                               int alphabet_size, int minibatch, int max_T, int beam_size, int blank_label,
+                               int input_is_logits, int* d_out_labels, int* d_out_lens, float* d_out_nll,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, const int* d_input_lengths,
+                                 int alphabet_size, int minibatch, int max_T, int blank_label, int* d_out_labels,
+                                 int* d_out_lens, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 4. Encoder building blocks (speech/models/model.py:60-79 Model.encode and ctc_model.py:19,29 fc).
+ *    fp32 throughout; GEMMs on the f32-input MFMA (exact fp32 products).
+ * ----------------------------------------------------------------------------------------------------------------*/
+
+/* C[M,N] = alpha * op(A) * op(B) (+ bias[N]) (+ beta * C),  row-major, leading dimensions in elements.
+ *   trans_a == 0: A is (M,K), lda >= K;  trans_a != 0: A is stored (K,M), lda >= M.
+ *   trans_b == 0: B is (K,N), ldb >= N;  trans_b != 0: B is stored (N,K), ldb >= K   (nn.Linear / GRU weight layout).
+ * Replaces the cuBLAS calls under nn.Linear (model.py:126-133) and nn.GRU's input projections (model.py:35-39). */
+ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
+                        const float* B, long ldb, float beta, float* C, long ldc, const float* bias /* or NULL */,
+                        void* stream);
+
+/* Conv2d(in_c, out_c, (kh, kw), stride (s, s), padding 0) + ReLU, model.py:19-29,61-62.
+ * x (B, in_c, T, F) NCHW contiguous; w (out_c, in_c, kh, kw); y written with caller-given strides so the last conv
+ * can emit the GRU-ready (B, T', out_c * F') layout of model.py:66-71 directly:
+ *     y[b * ys_b + c * ys_c + t * ys_t + f]. */
+ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in_c, int T,
+                               int F, int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t, void* stream);
+
+/* Backward of the above: dy (same strides as y), y (to mask the ReLU) -> dw (+=0: overwritten), dbias, and dx
+ * (NCHW, overwritten) unless dx == NULL.  workspace >= sa_conv2d_bwd_workspace_bytes(). */
+size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s);
+ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                               float* dbias, int B, int in_c, int T, int F, int out_c, int kh, int kw, int s,
+                               long ys_b, long ys_c, long ys_t, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One direction of one nn.GRU layer (model.py:35-39,73; equations SURVEY.md App. B; gate order [r; z; n]).
+ *   ai   (B, T, 3H): input pre-activations x W_ih^T + b_ih (from sa_gemm_f32), batch-first.
+ *   w_hh (3H, H), b_hh (3H).   h_out[b * hs_b + t * hs_t + j], j < H  (strides allow writing one half of a
+ *   bidirectional (B, T, 2H) output).  reverse != 0 runs t = T-1 .. 0.
+ *   stash (B, T, 4H) or NULL: r, z, n, q = W_hn h + b_hn saved for the backward pass.
+ * All utterances run the full T steps (the reference passes the padded length for every utterance, ctc_model.py:43-45). */
+ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const float* b_hh, float* h_out, long hs_b, long hs_t,
+                       float* stash, int B, int T, int H, int reverse, void* stream);
+
+/* Backward through time of sa_gru_fwd.
+ *   dh_out: gradient wrt h_out (same strides);  outputs: dai (B,T,3H) = grad wrt ai, dah (B,T,3H) = grad wrt the
+ *   h2h pre-activations (for dW_hh = dah^T h_prev and db_hh via sa_gemm_f32 / sa_colsum).  workspace holds the
+ *   running dh (2 * B * H floats). */
+size_t sa_gru_bwd_workspace_bytes(int B, int T, int H);
+ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, const float* h_out, const float* stash,
+                       const float* w_hh, float* dai, float* dah, int B, int T, int H, int reverse, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients. */
+ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream);
+
+/* y[i] = a[i] + b[i] (bidirectional sum, model.py:75-77, and gradient fan-in); strided rows. */
+ctcStatus_t sa_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* y, long ldy, int rows,
+                            int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 5. Optimiser step on a flat fp32 parameter / gradient buffer (train.py:32 clip_grad_norm(params, 200) and
+ *    train.py:35,95-97 SGD(lr, momentum)).  d_norm_out receives the pre-clip global L2 norm (device float).
+ *    grad_scale multiplies the gradient first (1/world_size after the RCCL all-reduce).
+ * ----------------------------------------------------------------------------------------------------------------*/
+size_t sa_sgd_workspace_bytes(size_t n);
+ctcStatus_t sa_clip_sgd_step(float* params, float* grads, float* momentum_buf /* or NULL */, size_t n, float lr,
+                             float momentum, float max_norm, float grad_scale, float* d_norm_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECH_AMD_H */

@@ -1,0 +1,117 @@
+"""ctypes face of libspeech_amd.so (the C ABI declared in include/speech_amd.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, the product path raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspeech_amd.so")
+
+STATUS_NAMES = {0: "CTC_STATUS_SUCCESS", 1: "CTC_STATUS_MEMOPS_FAILED", 2: "CTC_STATUS_INVALID_VALUE",
+                3: "CTC_STATUS_EXECUTION_FAILED", 4: "CTC_STATUS_UNKNOWN_ERROR"}
+
+c_int, c_long, c_size_t, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p
+
+
+class ctcOptions(ctypes.Structure):
+    class _U(ctypes.Union):
+        _fields_ = [("num_threads", ctypes.c_uint), ("stream", c_void_p)]
+
+    _anonymous_ = ("u",)
+    _fields_ = [("loc", c_int), ("u", _U), ("blank_label", c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/speech_amd.h declares
+SIGNATURES = {
+    "get_warpctc_version": (c_int, []),
+    "ctcGetStatusString": (ctypes.c_char_p, [c_int]),
+    "compute_ctc_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                 ctcOptions]),
+    "get_workspace_size": (c_int, [c_void_p, c_void_p, c_int, c_int, ctcOptions, ctypes.POINTER(c_size_t)]),
+    "sa_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sa_ctc_loss": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                            c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_ctc_beam_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sa_ctc_beam_decode": (c_int, [c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_ctc_greedy_decode": (c_int, [c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p]),
+    "sa_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_float,
+                            c_void_p, c_long, c_void_p, c_void_p]),
+    "sa_conv2d_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_long, c_long, c_long, c_void_p]),
+    "sa_conv2d_bwd_workspace_bytes": (c_size_t, [c_int] * 8),
+    "sa_conv2d_relu_bwd": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_long] * 3 + [c_void_p, c_size_t, c_void_p]),
+    "sa_gru_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int,
+                           c_int, c_void_p]),
+    "sa_gru_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sa_gru_bwd": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                           c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),
+    "sa_clip_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+}
+
+_LIB = None
+
+
+class SpeechAmdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library once.  Raises if it has not been built -- there is no CPU path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpeechAmdError("libspeech_amd.so is missing (%s): build it with `python -m speech_amd.build` "
+                                 "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().ctcGetStatusString(status).decode()
+        raise SpeechAmdError("%s failed: %s (%s)" % (what, STATUS_NAMES.get(status, status), msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def cur_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise SpeechAmdError("%s must live on the GPU: speech_amd has no CPU compute path" % name)
+
+
+class Workspace:
+    """A grow-only byte buffer per device, reused across calls on the same stream."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, nbytes, device, tag="default"):
+        import torch
+        key = (str(device), tag)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+WORKSPACE = Workspace()

@@ -1,0 +1,103 @@
+"""speech_amd.ctc -- the replacement for `functions.ctc` (the warp-ctc PyTorch binding the reference imports at
+/root/reference/speech/models/ctc_model.py:9 and calls at :38-39):
+
+    loss_fn = ctc.CTCLoss()                       # no-arg constructor, built per call
+    loss = loss_fn(out, y, x_lens, y_lens)        # out (B, T', V+1) raw logits on the GPU, requires grad
+                                                  # y flat int32, x_lens / y_lens int32 (B,) -- CPU tensors
+    loss.backward(); loss.data[0]                 # train.py:30,33
+
+Conventions the reference tree does not pin are constructor keywords with documented defaults:
+  blank=None        -> the LAST class (alphabet_size - 1), matching CTC.blank = output_dim (ctc_model.py:18)
+  size_average=True -> the summed cost is divided by the batch size (as seq2seq.py:61-63 does for its loss)
+  batch_first=True  -> logits are (B, T, V) as the model passes them; False accepts warp-ctc's (T, B, V)
+Like warp-ctc, the gradient is produced in the forward pass and handed back in backward.
+All compute is the HIP library (sa_ctc_loss); a CPU tensor raises.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _host_i32(v):
+    if torch.is_tensor(v):
+        return v.detach().cpu().numpy().astype(np.int32, copy=False).reshape(-1)
+    return np.asarray(v, np.int32).reshape(-1)
+
+
+def ctc_loss_raw(acts, labels, act_lens, label_lens, blank=None, batch_first=True, want_grad=True):
+    """Un-reduced face of the HIP kernels: returns (costs (B,), grads like acts or None), both on the GPU.
+    costs[b] = -log p(labels_b | acts_b);  grads = d costs[b] / d acts (no batch scaling)."""
+    _lib.require_cuda(acts, "acts")
+    if acts.dtype != torch.float32 or acts.dim() != 3:
+        raise _lib.SpeechAmdError("acts must be a float32 (B, T, V) tensor")
+    L = _lib.lib()
+    a = acts.detach()
+    if not a.is_contiguous():
+        a = a.contiguous()
+    if batch_first:
+        B, T, K = a.shape
+        st, sb = K, T * K
+    else:
+        T, B, K = a.shape
+        st, sb = B * K, K
+    if blank is None:
+        blank = K - 1
+    dev = a.device
+    lab_h, alen_h, llen_h = _host_i32(labels), _host_i32(act_lens), _host_i32(label_lens)
+    if alen_h.shape[0] != B or llen_h.shape[0] != B or lab_h.shape[0] != int(llen_h.sum()):
+        raise _lib.SpeechAmdError("CTCLoss: label / length tensors do not match the batch")
+    if lab_h.size and (lab_h.min() < 0 or lab_h.max() >= K or (lab_h == blank).any()):
+        raise _lib.SpeechAmdError("CTCLoss: labels must be in [0, %d) and differ from blank=%d" % (K, blank))
+    if alen_h.min() < 0 or alen_h.max() > T or llen_h.min() < 0:
+        raise _lib.SpeechAmdError("CTCLoss: bad lengths")
+    max_T, max_L = max(int(alen_h.max()), 1), int(llen_h.max())
+    ints = torch.from_numpy(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)])).to(dev)
+    d_alen, d_llen, d_lab = ints[:B], ints[B:2 * B], ints[2 * B:]
+    costs = torch.empty(B, dtype=torch.float32, device=dev)
+    grads = None
+    if want_grad:
+        # rows beyond every utterance's length are never visited by the kernels
+        grads = torch.zeros_like(a) if max_T < T else torch.empty_like(a)
+    nbytes = L.sa_ctc_workspace_bytes(max_T, max_L, K, B)
+    ws = _lib.WORKSPACE.get(nbytes, dev, "ctc")
+    _lib.check(L.sa_ctc_loss(_lib.ptr(a), _lib.ptr(grads), st, sb, _lib.ptr(d_lab), _lib.ptr(d_llen),
+                             _lib.ptr(d_alen), K, B, max_T, max_L, blank, _lib.ptr(costs), _lib.ptr(ws),
+                             ws.numel(), _lib.cur_stream()), "sa_ctc_loss")
+    return costs, grads
+
+
+class _CTCFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, size_average, batch_first, denom):
+        costs, grads = ctc_loss_raw(acts, labels, act_lens, label_lens, blank, batch_first,
+                                    want_grad=ctx.needs_input_grad[0])
+        B = costs.shape[0]
+        ctx.grads = grads
+        ctx.scale = 1.0 / (denom if denom else B) if size_average else 1.0
+        return (costs.sum() * ctx.scale).reshape(1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.grads
+        if g is None:
+            return (None,) * 8
+        return (g * (grad_out.reshape(()) * ctx.scale),) + (None,) * 7
+
+
+class CTCLoss(torch.nn.Module):
+    """Drop-in for functions.ctc.CTCLoss (no-arg constructor; see module docstring for the keyword defaults).
+
+    denom: optional explicit divisor for size_average (data-parallel training passes the GLOBAL batch size so
+    that the all-reduced gradient equals the single-GPU gradient on the same global batch)."""
+
+    def __init__(self, blank=None, size_average=True, batch_first=True, denom=None):
+        super().__init__()
+        self.blank = blank
+        self.size_average = size_average
+        self.batch_first = batch_first
+        self.denom = denom
+
+    def forward(self, acts, labels, act_lens, label_lens):
+        return _CTCFunction.apply(acts, labels, act_lens, label_lens, self.blank, self.size_average,
+                                  self.batch_first, self.denom)

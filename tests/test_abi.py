@@ -1,0 +1,51 @@
+"""The C ABI: the built library loads on a CPU-only host and exports every symbol include/speech_amd.h declares."""
+import os
+import re
+
+import pytest
+
+from speech_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "speech_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(?:ctcStatus_t|size_t|int|const char\s*\*)\s+([a-zA-Z_][a-zA-Z0-9_]*)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_and_ctypes_table_agree():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()  # raises if the .so is missing or a symbol is absent
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert L.get_warpctc_version() >= 2
+    assert L.ctcGetStatusString(0) == b"no error"
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    L = _lib.lib()
+    assert L.sa_ctc_workspace_bytes(1000, 100, 29, 32) > 32 * 1000 * 29 * 4
+    assert L.sa_ctc_workspace_bytes(10, 5, 0, 1) == 0
+    # null pointers / bad sizes are rejected before anything touches a device
+    assert L.sa_ctc_loss(None, None, 1, 1, None, None, None, 29, 32, 10, 5, 28, None, None, 0, None) == 2
+    opts = _lib.ctcOptions()
+    opts.loc = 0  # CTC_CPU: this library has no CPU path
+    import ctypes
+    n = ctypes.c_size_t(0)
+    arr = (ctypes.c_int * 1)(5)
+    assert L.get_workspace_size(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(arr, ctypes.c_void_p), 29, 1, opts,
+                                ctypes.byref(n)) == 3
+
+
+def test_cpu_tensor_fails_loudly():
+    import torch
+    from speech_amd.ctc import CTCLoss
+    with pytest.raises(_lib.SpeechAmdError):
+        CTCLoss()(torch.zeros(2, 5, 4, requires_grad=True), torch.IntTensor([1, 2]), torch.IntTensor([5, 5]),
+                  torch.IntTensor([1, 1]))

@@ -1,0 +1,159 @@
+"""HIP CTC loss (speech_amd.ctc -> sa_ctc_loss / compute_ctc_loss) against the CPU oracle (oracle/ctc_ref.c, fp64).
+
+Tolerances (fp32 log-space kernels vs an fp64 oracle):
+  per-utterance cost: rtol 1e-5 (north_star asks 1e-4);  gradient: atol 2e-4 absolute on values in [-1, 1]."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_ref
+
+pytestmark = pytest.mark.gpu
+
+COST_RTOL = 1e-5
+GRAD_ATOL = 2e-4
+
+
+def make(seed, B, T, K, Lmin, Lmax, ragged_T=False, scale=1.0):
+    rng = np.random.RandomState(seed)
+    acts = (scale * rng.randn(B, T, K)).astype(np.float32)
+    ll = rng.randint(Lmin, Lmax + 1, B).astype(np.int32)
+    labs = np.concatenate([rng.randint(0, K - 1, l) for l in ll] + [np.zeros(0, int)]).astype(np.int32)
+    al = (rng.randint(max(T // 2, 1), T + 1, B) if ragged_T else np.full(B, T)).astype(np.int32)
+    return acts, labs, al, ll
+
+
+def run_hip(acts, labs, al, ll, blank=None, batch_first=True, want_grad=True):
+    from speech_amd.ctc import ctc_loss_raw
+    a = torch.from_numpy(acts).cuda()
+    costs, grads = ctc_loss_raw(a, torch.from_numpy(labs), torch.from_numpy(al), torch.from_numpy(ll), blank=blank,
+                                batch_first=batch_first, want_grad=want_grad)
+    torch.cuda.synchronize()
+    return costs.cpu().numpy(), (grads.cpu().numpy() if grads is not None else None)
+
+
+def compare(acts, labs, al, ll, blank=None, batch_first=True):
+    c, g = run_hip(acts, labs, al, ll, blank, batch_first)
+    co, go = ctc_ref.ctc_loss(acts, labs, al, ll, blank=blank, batch_first=batch_first)
+    finite = np.isfinite(co)
+    assert np.array_equal(np.isinf(c), ~finite), (c, co)
+    np.testing.assert_allclose(c[finite], co[finite], rtol=COST_RTOL)
+    assert np.isfinite(g).all()
+    err = np.abs(g - go).max()
+    assert err < GRAD_ATOL, err
+    return err
+
+
+@pytest.mark.parametrize("B,T,K,Lmin,Lmax", [
+    (4, 100, 11, 20, 20),      # tests/shared.py shapes of the reference (B=4, T'~48..100, V=10, L=20)
+    (3, 48, 11, 0, 20),        # includes empty label sequences
+    (8, 144, 49, 10, 70),      # TIMIT-config-like
+    (5, 300, 29, 60, 130),     # two and three 64-pair chunks
+    (2, 50, 29, 63, 64),       # chunk-boundary label lengths
+    (2, 700, 29, 300, 400),    # many chunks
+    (1, 1, 5, 0, 0), (1, 1, 5, 1, 1), (2, 7, 3, 1, 3),
+])
+def test_matches_oracle(B, T, K, Lmin, Lmax):
+    compare(*make(B * 1000 + T, B, T, K, Lmin, Lmax))
+
+
+def test_ragged_input_lengths_and_time_major():
+    acts, labs, al, ll = make(7, 6, 120, 29, 5, 40, ragged_T=True)
+    compare(acts, labs, al, ll)
+    compare(np.ascontiguousarray(acts.transpose(1, 0, 2)), labs, al, ll, batch_first=False)
+
+
+def test_blank_zero():
+    rng = np.random.RandomState(3)
+    acts = rng.randn(3, 40, 9).astype(np.float32)
+    ll = np.array([5, 9, 1], dtype=np.int32)
+    labs = rng.randint(1, 9, int(ll.sum())).astype(np.int32)
+    compare(acts, labs, np.full(3, 40, np.int32), ll, blank=0)
+
+
+def test_infeasible_and_repeats():
+    rng = np.random.RandomState(5)
+    acts = rng.randn(3, 6, 4).astype(np.float32)
+    labs = np.array([0, 0, 0, 0, 0, 0, 1, 2, 1, 1, 1, 2], dtype=np.int32)  # utt0 needs T>=11 -> inf
+    ll = np.array([6, 3, 3], dtype=np.int32)
+    c, g = run_hip(acts, labs, np.full(3, 6, np.int32), ll)
+    co, go = ctc_ref.ctc_loss(acts, labs, np.full(3, 6, np.int32), ll)
+    assert np.isinf(c[0]) and c[0] > 0 and np.all(g[0] == 0)
+    np.testing.assert_allclose(c[1:], co[1:], rtol=COST_RTOL)
+    assert np.abs(g - go).max() < GRAD_ATOL
+
+
+def test_peaky_logits():
+    # confident (large-magnitude) logits: exercises the SA_NEG sentinel arithmetic and exp underflow
+    acts, labs, al, ll = make(11, 4, 200, 29, 20, 60, scale=8.0)
+    compare(acts, labs, al, ll)
+
+
+def test_full_size_m_ctc():
+    # BASELINE.json M-CTC: B=32, T=1000, V+1=29, L=100, seed 2017
+    acts, labs, al, ll = make(2017, 32, 1000, 29, 100, 100)
+    err = compare(acts, labs, al, ll)
+    print("M-CTC max |grad err| vs fp64 oracle:", err)
+
+
+def test_score_only_matches():
+    acts, labs, al, ll = make(13, 4, 90, 29, 10, 30)
+    c1, _ = run_hip(acts, labs, al, ll, want_grad=True)
+    c2, g2 = run_hip(acts, labs, al, ll, want_grad=False)
+    assert g2 is None and np.array_equal(c1, c2)
+
+
+def test_autograd_module_reduction_and_backward():
+    from speech_amd.ctc import CTCLoss
+    acts, labs, al, ll = make(17, 4, 60, 11, 5, 20)
+    x = torch.from_numpy(acts).cuda().requires_grad_(True)
+    loss = CTCLoss()(x, torch.IntTensor(labs), torch.IntTensor(al), torch.IntTensor(ll))
+    assert loss.shape == (1,)
+    loss.backward()
+    co, go = ctc_ref.ctc_loss(acts, labs, al, ll)
+    assert abs(float(loss.data[0]) - co.sum() / 4) < 1e-5 * co.sum()
+    assert np.abs(x.grad.cpu().numpy() - go / 4).max() < GRAD_ATOL
+    x2 = torch.from_numpy(acts).cuda().requires_grad_(True)
+    loss2 = CTCLoss(size_average=False)(x2, torch.IntTensor(labs), torch.IntTensor(al), torch.IntTensor(ll))
+    (2.0 * loss2).sum().backward()
+    assert np.abs(x2.grad.cpu().numpy() - 2.0 * go).max() < 2 * GRAD_ATOL
+
+
+def test_linearity_in_batch_order():
+    # size-independent property: permuting utterances permutes costs and gradients bit-exactly
+    acts, labs, al, ll = make(19, 6, 80, 29, 10, 30)
+    c, g = run_hip(acts, labs, al, ll)
+    perm = np.array([3, 0, 5, 1, 4, 2])
+    offs = np.concatenate([[0], np.cumsum(ll)])
+    labs_p = np.concatenate([labs[offs[i]:offs[i + 1]] for i in perm]).astype(np.int32)
+    cp, gp = run_hip(acts[perm], labs_p, al[perm], ll[perm])
+    assert np.array_equal(cp, c[perm]) and np.array_equal(gp, g[perm])
+
+
+def test_warpctc_shaped_entry_point():
+    """compute_ctc_loss / get_workspace_size: (T,B,V) activations on the device, labels / lengths / costs on the host."""
+    from speech_amd import _lib
+    L = _lib.lib()
+    acts, labs, al, ll = make(23, 5, 70, 29, 5, 25, ragged_T=True)
+    tm = np.ascontiguousarray(acts.transpose(1, 0, 2))
+    d_acts = torch.from_numpy(tm).cuda()
+    d_grads = torch.zeros_like(d_acts)
+    opts = _lib.ctcOptions()
+    opts.loc = 1
+    opts.stream = torch.cuda.current_stream().cuda_stream
+    opts.blank_label = 28
+    n = ctypes.c_size_t(0)
+    _lib.check(L.get_workspace_size(ll.ctypes.data, al.ctypes.data, 29, 5, opts, ctypes.byref(n)), "get_workspace_size")
+    ws = torch.empty(n.value, dtype=torch.uint8, device="cuda")
+    costs = np.zeros(5, dtype=np.float32)
+    _lib.check(L.compute_ctc_loss(d_acts.data_ptr(), d_grads.data_ptr(), labs.ctypes.data, ll.ctypes.data,
+                                  al.ctypes.data, 29, 5, costs.ctypes.data, ws.data_ptr(), opts), "compute_ctc_loss")
+    co, go = ctc_ref.ctc_loss(tm, labs, al, ll, batch_first=False)
+    np.testing.assert_allclose(costs, co, rtol=COST_RTOL)
+    assert np.abs(d_grads.cpu().numpy() - go).max() < GRAD_ATOL
+    bad = labs.copy()
+    bad[0] = 28  # label == blank
+    assert L.compute_ctc_loss(d_acts.data_ptr(), None, bad.ctypes.data, ll.ctypes.data, al.ctypes.data, 29, 5,
+                              costs.ctypes.data, ws.data_ptr(), opts) == 2
