@@ -32,7 +32,11 @@ def build_lib(force=False, verbose=False):
         obj = src[:-4] + ".o"
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            extra = []
+            for line in open(src):  # per-file flags: a `// HIPCC_FLAGS: ...` comment line
+                if line.startswith("// HIPCC_FLAGS:"):
+                    extra += line.split(":", 1)[1].split()
+            cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

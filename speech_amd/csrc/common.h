@@ -37,6 +37,31 @@ __device__ __forceinline__ float sa_wave_shl1(float v, float edge) {
                                                                  __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// Full-wave reductions on the DPP network (no LDS traffic): 4 row_shr steps fold each 16-lane row into its
+// lane 15, row_bcast15 / row_bcast31 fold the four rows into lane 63, v_readlane broadcasts.  ~7 VALU ops.
+#define SA_DPP_F(old_, src_, ctrl_, rmask_)                                                                \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (old_)),                 \
+                                                          __builtin_bit_cast(int, (src_)), (ctrl_), (rmask_), \
+                                                          0xf, false))
+__device__ __forceinline__ float sa_wave_max_dpp(float v) {
+    v = fmaxf(v, SA_DPP_F(v, v, 0x111, 0xf));  // row_shr:1
+    v = fmaxf(v, SA_DPP_F(v, v, 0x112, 0xf));  // row_shr:2
+    v = fmaxf(v, SA_DPP_F(v, v, 0x114, 0xf));  // row_shr:4
+    v = fmaxf(v, SA_DPP_F(v, v, 0x118, 0xf));  // row_shr:8
+    v = fmaxf(v, SA_DPP_F(v, v, 0x142, 0xa));  // row_bcast:15 -> rows 1, 3
+    v = fmaxf(v, SA_DPP_F(v, v, 0x143, 0xc));  // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float sa_wave_sum_dpp(float v) {
+    v += SA_DPP_F(0.f, v, 0x111, 0xf);
+    v += SA_DPP_F(0.f, v, 0x112, 0xf);
+    v += SA_DPP_F(0.f, v, 0x114, 0xf);
+    v += SA_DPP_F(0.f, v, 0x118, 0xf);
+    v += SA_DPP_F(0.f, v, 0x142, 0xa);
+    v += SA_DPP_F(0.f, v, 0x143, 0xc);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float sa_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -13,62 +13,66 @@
 //                          a one-way software pipeline: the producing chunk runs kU steps ahead and hands its edge
 //                          lane's value to the next chunk through an LDS array -- no workgroup barrier inside the
 //                          T-step loop.  alpha waves and beta waves run concurrently in the same workgroup (the
-//                          serial chain is T steps, not 2T) and stash alpha/beta planes to HBM.
+//                          serial chain is T steps, not 2T) and stash alpha/beta planes to HBM with fire-and-forget
+//                          stores.  The utterance's emission rows are staged in LDS once, so the T-step loop issues
+//                          no VGPR-destination VMEM load: on gfx9 loads and stores retire through one in-order
+//                          vmcnt queue, and a waited load behind a store would put HBM store latency on every step.
+//                          Every kU steps a wave subtracts the integer part of its running maximum from its states
+//                          (an exact operation) and carries the integer offset separately, so alpha/beta stay O(100)
+//                          where fp32 resolves ~1e-5 instead of O(|log2 p|) ~ 4000 where it resolves 5e-4.
 //   K_C  ctc_grad          all rows in parallel again: occupancy gamma = exp2(alpha + beta - ly2 - log2 p),
-//                          blank states by a wave reduction, label states by LDS float atomics,
+//                          blank states by a DPP wave reduction, label states by LDS float atomics,
 //                          grad = softmax - occupancy written with the caller's strides.
 // log(0) is the finite sentinel SA_NEG, so no inf/NaN guards sit on the dependent chain.
+// HIPCC_FLAGS: -fno-honor-nans
+// (no NaN is ever an operand here -- log(0) is the finite SA_NEG -- so fmaxf/fminf need no canonicalising v_max.)
 #include "common.h"
 
 namespace {
 
-constexpr int kU = 8;          // steps per hand-off batch (producer lead, emission prefetch depth)
+constexpr int kU = 8;          // steps per hand-off batch (producer lead, emission prefetch depth, renorm period)
+constexpr int kRenorm = 4;     // renormalise every kRenorm batches (32 steps): states drift <~ 200 log2 units between
 constexpr int kMaxChunks = 8;  // chunks per direction: labels up to 64 * 8 - 1 = 511 per utterance
 
 // ---------------------------------------------------------------------------------------------------------- K_A
-// G lanes cooperate on one row (G = 16, 32 or 64); a wave handles 64 / G rows at a time.
+// grid (row blocks, B).  G lanes cooperate on one row (G = 16, 32 or 64); a wave handles 64 / G rows at a time.
 template <int G>
 __global__ __launch_bounds__(256) void ctc_logsoftmax2_kernel(const float* __restrict__ acts, long st, long sb,
-                                                              const int* __restrict__ in_lens, int K, int B, int T,
+                                                              const int* __restrict__ in_lens, int K, long ly_sb,
                                                               float* __restrict__ ly2) {
     constexpr int RPW = 64 / G;
+    const int b = blockIdx.y;
+    const int T = in_lens[b];
     const int lane = threadIdx.x & 63;
     const int sub = lane / G, gl = lane % G;
-    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
-    const long rows = (long)B * T;
-    for (long r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
-        const long r = r0 + sub;
-        const bool live = r < rows;
-        const int b = live ? (int)(r / T) : 0;
-        const int t = live ? (int)(r % T) : 0;
-        const bool act = live && t < in_lens[b];
-        const float* a = acts + (long)b * sb + (long)t * st;
-        float m = -3.0e38f;
-        if (act)
-            for (int k = gl; k < K; k += G) m = fmaxf(m, a[k]);
+    const int t = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+    const bool act = t < T;
+    const float* a = acts + (long)b * sb + (long)t * st;
+    float m = -3.0e38f;
+    if (act)
+        for (int k = gl; k < K; k += G) m = fmaxf(m, a[k]);
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float z = 0.f;
-        if (act)
-            for (int k = gl; k < K; k += G) z += sa_exp2((a[k] - m) * SA_LOG2E);
+    for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float z = 0.f;
+    if (act)
+        for (int k = gl; k < K; k += G) z += sa_exp2((a[k] - m) * SA_LOG2E);
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
-        const float lz = sa_log2(z);
-        if (act) {
-            float* o = ly2 + r * K;
-            for (int k = gl; k < K; k += G) o[k] = fmaxf((a[k] - m) * SA_LOG2E - lz, SA_NEG);
-        }
+    for (int o = G / 2; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+    const float lz = sa_log2(z);
+    if (act) {
+        float* o = ly2 + (long)b * ly_sb + (long)t * K;
+        for (int k = gl; k < K; k += G) o[k] = fmaxf((a[k] - m) * SA_LOG2E - lz, SA_NEG);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------- K_B
 struct AbShared {
     int prog[2][kMaxChunks];  // steps completed by (direction, chunk)
-    float fin[2];             // alpha[T-1, 2L], alpha[T-1, 2L-1]
+    float fin[4];             // alpha-hat[T-1, 2L], its offset, alpha-hat[T-1, 2L-1], its offset
     int label_off;
     int timeout;
 };
+constexpr int kAbSharedBytes = 256;
 
 __device__ __forceinline__ float lse2_1p(float a, float b) {  // log2(2^a + 2^b)
     const float m = fmaxf(a, b);
@@ -81,106 +85,91 @@ __device__ __forceinline__ float lse3_1p(float a, float b, float c) {
     return m + sa_log2(1.0f + sa_exp2(md - m) + sa_exp2(mn - m));
 }
 
-template <bool WITH_BETA>
-__global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __restrict__ ly2,
-                                                             const int* __restrict__ labels,
-                                                             const int* __restrict__ label_lens,
-                                                             const int* __restrict__ in_lens, int K, int T_max,
-                                                             int blank, int nchunks, int Ppad, int hand_stride,
-                                                             float* __restrict__ stash, float* __restrict__ logp2_out,
-                                                             float* __restrict__ costs) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    AbShared* sh = reinterpret_cast<AbShared*>(smem_raw);
-    float* hand_all = reinterpret_cast<float*>(smem_raw + 128);  // [2][nchunks][hand_stride]
+struct AbArgs {
+    const float* ly2;     // [B][T_max][K] global
+    const int* labels;
+    const int* label_lens;
+    const int* in_lens;
+    int K, T_max, blank, nchunks, Ppad, hand_stride, nbatch;
+    long ly_sb;           // per-utterance stride of ly2 in floats (multiple of 4: 16-byte aligned rows block)
+    float* stash;         // [B][T_max][4][Ppad]
+    float* goffs;         // [B][2][nchunks][nbatch]
+    float* logp2_out;     // [B][2]: log2 p = hat + offset
+    float* costs;         // [B]
+};
 
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dir = wave / nchunks;          // 0 = alpha (forward in time), 1 = beta (backward in time)
-    const int chunk = wave - dir * nchunks;  // which 64 pairs
-    const int L = label_lens[b];
-    const int T = in_lens[b];
-
-    if (wave == 0) {  // flat-label offset of this utterance
-        int acc = 0;
-        for (int i = lane; i < b; i += 64) acc += label_lens[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) {
-            sh->label_off = acc;
-            sh->timeout = 0;
-            sh->fin[0] = SA_NEG;
-            sh->fin[1] = SA_NEG;
-        }
-    }
-    float* hand_w = hand_all + (long)(dir * nchunks + chunk) * hand_stride;  // what this chunk publishes
-    if (lane == 0) {
-        sh->prog[dir][chunk] = 0;
-        hand_w[0] = SA_NEG;
-    }
-    __syncthreads();
-
-    const int* lab = labels + sh->label_off;
+// One (direction, chunk) wave over all T steps.  DIR 0 = alpha (time forward), 1 = beta (time backward).
+template <int DIR, bool WITH_BETA, bool LDS_EM>
+__device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* hand_all, float* hoff_all,
+                                          const float* em_lds, int b, int chunk, int lane, int L, int T) {
+    const int nchunks = A.nchunks, K = A.K, Ppad = A.Ppad;
+    const int* lab = A.labels + sh->label_off;
     const int j = chunk * 64 + lane;  // pair index: (blank_j, label_j) for alpha, (label_{j-1}, blank_j) for beta
-    const int own = dir == 0 ? j : j - 1;
+    const int own = DIR == 0 ? j : j - 1;
     const bool own_ok = own >= 0 && own < L;
-    const int own_lab = own_ok ? lab[own] : blank;
+    const int own_lab = own_ok ? lab[own] : A.blank;
     const bool skip = (j >= 1 && j <= L - 1) ? (lab[j] != lab[j - 1]) : false;
-    const bool in_lattice = j <= L;
 
-    // producer / consumer wiring of the chunk pipeline
-    const int prod_chunk = dir == 0 ? chunk - 1 : chunk + 1;
+    const int prod_chunk = DIR == 0 ? chunk - 1 : chunk + 1;
     const bool has_prod = prod_chunk >= 0 && prod_chunk < nchunks;
-    const bool has_cons = dir == 0 ? (chunk + 1 < nchunks) : (chunk > 0);
-    const float* hand_r = hand_all + (long)(dir * nchunks + (has_prod ? prod_chunk : 0)) * hand_stride;
-    const int edge_lane = dir == 0 ? 63 : 0;
+    const bool has_cons = DIR == 0 ? (chunk + 1 < nchunks) : (chunk > 0);
+    float* hand_w = hand_all + (long)(DIR * nchunks + chunk) * A.hand_stride;
+    float* hoff_w = hoff_all + (long)(DIR * nchunks + chunk) * A.nbatch;
+    const float* hand_r = hand_all + (long)(DIR * nchunks + (has_prod ? prod_chunk : 0)) * A.hand_stride;
+    const float* hoff_r = hoff_all + (long)(DIR * nchunks + (has_prod ? prod_chunk : 0)) * A.nbatch;
+    constexpr int edge_lane = DIR == 0 ? 63 : 0;
 
-    float Bst = (dir == 0 ? (j == 0) : (j == L)) ? 0.0f : SA_NEG;
+    float Bst = (DIR == 0 ? (j == 0) : (j == L)) ? 0.0f : SA_NEG;
     float Lst = SA_NEG;
+    float off = 0.f;  // integer-valued: true state = hat state + off
 
-    // Running pointers: time moves forward for alpha, backward for beta.
-    const int t0 = dir == 0 ? 0 : (T > 0 ? T - 1 : 0);
-    const long dK = dir == 0 ? (long)K : -(long)K;
-    const long dS = dir == 0 ? 4L * Ppad : -4L * Ppad;
-    const float* lyb = ly2 + (long)b * T_max * K;
-    const float* erow = lyb + (long)t0 * K;  // emission row of the next step to prefetch
+    // time moves forward for alpha, backward for beta
+    const int t0 = DIR == 0 ? 0 : (T > 0 ? T - 1 : 0);
+    const int dK = DIR == 0 ? K : -K;
+    const long dS = DIR == 0 ? 4L * Ppad : -4L * Ppad;
+    const float* em = LDS_EM ? em_lds : A.ly2 + (long)b * A.ly_sb;
+    int e_l = t0 * K + own_lab;   // element index of the next step's label emission
+    int e_b = t0 * K + A.blank;
     float* pB = nullptr;
     float* pL = nullptr;
+    float* goff = nullptr;
     if (WITH_BETA) {
         // stash planes per (b, t): [alpha blank | alpha label | beta blank | beta label], Ppad floats each.
         // beta's label state belongs to pair j-1; lanes without a label state dump into a never-read slot
         // (label index Ppad-1 cannot exist because Ppad >= L+1).
-        float* base = stash + ((long)b * T_max + t0) * 4 * Ppad;
-        pB = base + (dir == 0 ? 0 : 2) * Ppad + j;
-        pL = base + (dir == 0 ? 1 : 3) * Ppad + (own >= 0 ? own : Ppad - 1);
+        float* base = A.stash + ((long)b * A.T_max + t0) * 4 * Ppad;
+        pB = base + (DIR == 0 ? 0 : 2) * Ppad + j;
+        pL = base + (DIR == 0 ? 1 : 3) * Ppad + (own >= 0 ? own : Ppad - 1);
+        goff = A.goffs + ((long)(b * 2 + DIR) * nchunks + chunk) * A.nbatch;
     }
 
     float el[kU], eb[kU];
     auto load_emissions = [&](int r0, float* pel, float* peb) {
-        if (r0 + kU <= T) {  // full batch: no clamping
+        if (r0 + kU <= T) {
 #pragma unroll
             for (int k = 0; k < kU; ++k) {
-                peb[k] = erow[blank];
-                pel[k] = erow[own_lab];
-                erow += dK;
+                peb[k] = em[e_b];
+                pel[k] = em[e_l];
+                e_b += dK;
+                e_l += dK;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < kU; ++k) {
                 const bool ok = r0 + k < T;
-                peb[k] = ok ? erow[blank] : 0.f;
-                pel[k] = ok ? erow[own_lab] : 0.f;
-                if (ok) erow += dK;
+                peb[k] = ok ? em[e_b] : 0.f;
+                pel[k] = ok ? em[e_l] : 0.f;
+                if (ok) { e_b += dK; e_l += dK; }
             }
         }
     };
     load_emissions(0, el, eb);
 
-    auto do_step = [&](float e_l_raw, float e_b, float h, int r) {
-        const float n = dir == 0 ? sa_wave_shr1(Lst, h) : sa_wave_shl1(Lst, h);
-        const float e_l = own_ok ? e_l_raw : SA_NEG;
-        const float nB = e_b + lse2_1p(Bst, n);
-        const float nL = e_l + lse3_1p(Lst, Bst, skip ? n : SA_NEG);
+    auto do_step = [&](float e_l_raw, float e_b_, float h, int r) {
+        const float n = DIR == 0 ? sa_wave_shr1(Lst, h) : sa_wave_shl1(Lst, h);
+        const float e_lv = own_ok ? e_l_raw : SA_NEG;
+        const float nB = e_b_ + lse2_1p(Bst, n);
+        const float nL = e_lv + lse3_1p(Lst, Bst, skip ? n : SA_NEG);
         Bst = nB;
         Lst = nL;
         if (WITH_BETA) {
@@ -193,18 +182,31 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     };
 
     int avail = 0;  // producer progress last seen
-    for (int r0 = 0; r0 < T; r0 += kU) {
+    int bi = 0;     // batch index
+    for (int r0 = 0; r0 < T; r0 += kU, ++bi) {
+        // (1) every kRenorm batches: subtract the integer part of the wave maximum (exact in fp32), carry it in `off`
+        if ((bi & (kRenorm - 1)) == 0) {
+            const float m = sa_wave_max_dpp(fmaxf(Bst, Lst));
+            const float d = m > SA_NEG_TEST ? __builtin_rintf(m) : 0.f;
+            Bst -= d;
+            Lst -= d;
+            off += d;
+            if (has_cons && lane == edge_lane) hand_w[r0] = Lst;  // re-express the carried edge value
+        }
+        if (has_cons && lane == 0) hoff_w[bi] = off;
+        if (WITH_BETA && lane == 0) goff[bi] = off;
         float nel[kU], neb[kU];
-        load_emissions(r0 + kU, nel, neb);  // prefetch the next batch's emissions
+        load_emissions(r0 + kU, nel, neb);  // prefetch the next batch's emissions (LDS)
 
+        // (2) the neighbour chunk's edge values for this batch, re-based to this wave's offset
         float hv[kU];
         if (has_prod) {
             const int need = min(r0 + kU, T);
             if (avail < need) {
                 int spins = 0;
-                while ((avail = __hip_atomic_load(&sh->prog[dir][prod_chunk], __ATOMIC_ACQUIRE,
+                while ((avail = __hip_atomic_load(&sh->prog[DIR][prod_chunk], __ATOMIC_ACQUIRE,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1 << 24)) {  // bounded: never hang the GPU on a protocol bug
                         sh->timeout = 1;
                         break;
@@ -213,13 +215,15 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             }
             const float4 h0 = *reinterpret_cast<const float4*>(hand_r + r0);
             const float4 h1 = *reinterpret_cast<const float4*>(hand_r + r0 + 4);
-            hv[0] = h0.x; hv[1] = h0.y; hv[2] = h0.z; hv[3] = h0.w;
-            hv[4] = h1.x; hv[5] = h1.y; hv[6] = h1.z; hv[7] = h1.w;
+            const float delta = hoff_r[bi] - off;  // integers: exact
+            hv[0] = h0.x + delta; hv[1] = h0.y + delta; hv[2] = h0.z + delta; hv[3] = h0.w + delta;
+            hv[4] = h1.x + delta; hv[5] = h1.y + delta; hv[6] = h1.z + delta; hv[7] = h1.w + delta;
         } else {
 #pragma unroll
             for (int k = 0; k < kU; ++k) hv[k] = SA_NEG;
         }
 
+        // (3) kU dependent steps
         if (r0 + kU <= T) {
 #pragma unroll
             for (int k = 0; k < kU; ++k) do_step(el[k], eb[k], hv[k], r0 + k);
@@ -229,96 +233,149 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                 if (r0 + k < T) do_step(el[k], eb[k], hv[k], r0 + k);
         }
         if (has_cons && lane == 0)
-            __hip_atomic_store(&sh->prog[dir][chunk], min(r0 + kU, T), __ATOMIC_RELEASE,
+            __hip_atomic_store(&sh->prog[DIR][chunk], min(r0 + kU, T), __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
     }
 
-    if (dir == 0) {
-        if (j == L) sh->fin[0] = Bst;
-        if (j == L - 1) sh->fin[1] = Lst;
+    if (DIR == 0) {
+        if (j == L) { sh->fin[0] = Bst; sh->fin[1] = off; }
+        if (j == L - 1) { sh->fin[2] = Lst; sh->fin[3] = off; }
+    }
+}
+
+template <bool WITH_BETA, bool LDS_EM>
+__global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AbShared* sh = reinterpret_cast<AbShared*>(smem_raw);
+    float* hand_all = reinterpret_cast<float*>(smem_raw + kAbSharedBytes);     // [2][nchunks][hand_stride]
+    float* hoff_all = hand_all + (long)2 * A.nchunks * A.hand_stride;           // [2][nchunks][nbatch]
+    float* em_lds = hoff_all + (long)2 * A.nchunks * A.nbatch;                  // [T][K] (LDS_EM only)
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = wave / A.nchunks;
+    const int chunk = wave - dir * A.nchunks;
+    const int L = A.label_lens[b];
+    const int T = A.in_lens[b];
+
+    if (wave == 0) {  // flat-label offset of this utterance
+        int acc = 0;
+        for (int i = lane; i < b; i += 64) acc += A.label_lens[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            sh->label_off = acc;
+            sh->timeout = 0;
+            sh->fin[0] = SA_NEG; sh->fin[1] = 0.f; sh->fin[2] = SA_NEG; sh->fin[3] = 0.f;
+        }
+    }
+    if (lane == 0) {
+        sh->prog[dir][chunk] = 0;
+        hand_all[(long)(dir * A.nchunks + chunk) * A.hand_stride] = SA_NEG;
+    }
+    if (LDS_EM) {
+        // Stage this utterance's emission rows once: contiguous T*K floats, 16-byte aligned at both ends, as
+        // float4 with 8 independent loads in flight per lane (a dependent load->store loop would cost ~0.5 us
+        // per trip and dominate the kernel).
+        const float4* src = reinterpret_cast<const float4*>(A.ly2 + (long)b * A.ly_sb);
+        float4* dst = reinterpret_cast<float4*>(em_lds);
+        const int n4 = (T * A.K + 3) >> 2;
+        const int nt = blockDim.x;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * nt) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * nt;
+                v[u] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * nt;
+                if (i < n4) dst[i] = v[u];
+            }
+        }
     }
     __syncthreads();
+
+    if (dir == 0)
+        ctc_chain<0, WITH_BETA, LDS_EM>(A, sh, hand_all, hoff_all, em_lds, b, chunk, lane, L, T);
+    else
+        ctc_chain<1, WITH_BETA, LDS_EM>(A, sh, hand_all, hoff_all, em_lds, b, chunk, lane, L, T);
+
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float lp = lse2_1p(sh->fin[0], sh->fin[1]);
+        // log2 p = lse2(fin0 + off0, fin2 + off2), kept as (hat, integer offset)
+        const float o0 = sh->fin[1];
+        const float f0 = sh->fin[0];
+        const float f1 = sh->fin[2] + (sh->fin[3] - o0);
+        const float lp = lse2_1p(f0, f1);
         const bool dead = lp < SA_NEG_TEST;
-        logp2_out[b] = dead ? SA_NEG : lp;
-        float c = dead ? __builtin_inff() : -lp * SA_LN2;
-        if (sh->timeout) c = __builtin_nanf("");
-        costs[b] = c;
+        A.logp2_out[2 * b] = dead ? SA_NEG : lp;
+        A.logp2_out[2 * b + 1] = dead ? 0.f : o0;
+        float c = dead ? __builtin_inff() : (float)(-((double)lp + (double)o0) * 0.6931471805599453);
+        if (sh->timeout) c = __builtin_bit_cast(float, 0x7fc00000);  // NaN marks a hand-off timeout (never expected)
+        A.costs[b] = c;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------- K_C
-constexpr int kGradRowsPerBlock = 16;
-
-__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ ly2, const float* __restrict__ stash,
-                                                       const float* __restrict__ logp2,
-                                                       const int* __restrict__ labels,
-                                                       const int* __restrict__ label_lens,
-                                                       const int* __restrict__ in_lens, int K, int T_max, int blank,
-                                                       int nchunks, int Ppad, float* __restrict__ grads, long st,
-                                                       long sb) {
+// grid (ceil(T_max / 4), B), 256 threads: one wave per lattice row.
+__global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restrict__ grads, long st, long sb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* occ_all = reinterpret_cast<float*>(smem_raw);  // [4 waves][K]
-    __shared__ int s_off;
+    const int K = A.K, Ppad = A.Ppad, nchunks = A.nchunks;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int L = label_lens[b];
-    const int T = in_lens[b];
-    if (wave == 0) {
-        int acc = 0;
-        for (int i = lane; i < b; i += 64) acc += label_lens[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) s_off = acc;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= A.T_max) return;
+    const int L = A.label_lens[b];
+    const int T = A.in_lens[b];
+    float* g = grads + (long)b * sb + (long)t * st;
+    const float lp = A.logp2_out[2 * b];
+    const float lpo = A.logp2_out[2 * b + 1];
+    if (t >= T || lp < SA_NEG_TEST) {  // padding row, or infeasible alignment: zero gradient
+        for (int k = lane; k < K; k += 64) g[k] = 0.f;
+        return;
     }
-    __syncthreads();
-    const int* lab = labels + s_off;
-    int mylab[kMaxChunks];
+    int loff = 0;
+    for (int i = lane; i < b; i += 64) loff += A.label_lens[i];
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
-        const int j = c * 64 + lane;
-        mylab[c] = (c < nchunks && j < L) ? lab[j] : -1;
-    }
-    const float lp = logp2[b];
-    const bool dead = lp < SA_NEG_TEST;
+    for (int o = 32; o > 0; o >>= 1) loff += __shfl_xor(loff, o, 64);
+    const int* lab = A.labels + loff;
     float* occ = occ_all + wave * K;
+    for (int k = lane; k < K; k += 64) occ[k] = 0.f;
 
-    const int t_end = min(T_max, (int)(blockIdx.x + 1) * kGradRowsPerBlock);
-    for (int t = blockIdx.x * kGradRowsPerBlock + wave; t < t_end; t += 4) {
-        float* g = grads + (long)b * sb + (long)t * st;
-        if (t >= T || dead) {
-            for (int k = lane; k < K; k += 64) g[k] = 0.f;
-            continue;
+    const float* row = A.ly2 + (long)b * A.ly_sb + (long)t * K;
+    const float* sp = A.stash + ((long)b * A.T_max + t) * 4 * Ppad;
+    const float* goA = A.goffs + (long)(b * 2 + 0) * nchunks * A.nbatch + t / kU;
+    const float* goB = A.goffs + (long)(b * 2 + 1) * nchunks * A.nbatch + (T - 1 - t) / kU;
+    const float lyblank = row[A.blank];
+    float accB = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int j = c * 64 + lane;
+        const float oA = goA[c * A.nbatch];
+        const float oB = goB[c * A.nbatch];
+        // beta's label state i lives in the wave of pair i+1: lane 63 crosses into the next chunk
+        const float oBn = (c + 1 < nchunks) ? goB[(c + 1) * A.nbatch] : oB;
+        const float io_b = oA + oB - lpo;                       // integers: exact
+        const float io_l = oA + (lane == 63 ? oBn : oB) - lpo;
+        if (j <= L) accB += sa_exp2((sp[j] + sp[2 * Ppad + j] - lyblank - lp) + io_b);
+        if (j < L) {
+            const int k = lab[j];
+            const float gm = sa_exp2((sp[Ppad + j] + sp[3 * Ppad + j] - row[k] - lp) + io_l);
+            atomicAdd(&occ[k], gm);  // LDS float atomic (ds_add_f32); this wave owns the row
         }
-        const float* row = ly2 + ((long)b * T_max + t) * K;
-        const float* sp = stash + ((long)b * T_max + t) * 4 * Ppad;
-        for (int k = lane; k < K; k += 64) occ[k] = 0.f;
-        __threadfence_block();
-        const float lyblank = row[blank];
-        float accB = 0.f;
-#pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c) {
-            if (c < nchunks) {
-                const int j = c * 64 + lane;
-                if (j <= L) accB += sa_exp2(sp[j] + sp[2 * Ppad + j] - lyblank - lp);
-                if (mylab[c] >= 0) {
-                    const float gm = sa_exp2(sp[Ppad + j] + sp[3 * Ppad + j] - row[mylab[c]] - lp);
-                    atomicAdd(&occ[mylab[c]], gm);  // LDS float atomic; one wave owns this row
-                }
-            }
-        }
-        accB = sa_wave_sum(accB);
-        __threadfence_block();
-        for (int k = lane; k < K; k += 64) {
-            const float y = sa_exp2(row[k]);
-            const float o = (k == blank) ? accB : occ[k];
-            g[k] = y - o;
-        }
-        __threadfence_block();
+    }
+    accB = sa_wave_sum_dpp(accB);
+    __threadfence_block();
+    for (int k = lane; k < K; k += 64) {
+        const float y = sa_exp2(row[k]);
+        const float o = (k == A.blank) ? accB : occ[k];
+        g[k] = y - o;
     }
 }
 
@@ -327,14 +384,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------ host side
 static inline int ctc_nchunks(int max_L) { return (max_L + 1 + 63) / 64; }
 
+static inline int ctc_nbatch(int max_T) { return (max_T + kU - 1) / kU + 1; }
+
 static size_t ctc_ws_layout(int max_T, int max_L, int K, int B, size_t* off_ly2, size_t* off_stash, size_t* off_lp,
-                            size_t* off_ints) {
+                            size_t* off_goffs) {
     const int nch = ctc_nchunks(max_L);
     size_t o = 0;
-    *off_ly2 = o;   o += sa_align_up((size_t)B * max_T * K * sizeof(float), 256);
+    *off_ly2 = o;   o += sa_align_up((size_t)B * sa_align_up((size_t)max_T * K, 4) * sizeof(float), 256);
     *off_stash = o; o += sa_align_up((size_t)B * max_T * 4 * nch * 64 * sizeof(float), 256);
     *off_lp = o;    o += sa_align_up((size_t)B * sizeof(float) * 2, 256);
-    *off_ints = o;  // scratch for the warp-ctc-shaped entry: labels + 2 length vectors (sized by the caller there)
+    *off_goffs = o; o += sa_align_up((size_t)B * 2 * nch * ctc_nbatch(max_T) * sizeof(float), 256);
     return o;
 }
 
@@ -342,6 +401,17 @@ extern "C" size_t sa_ctc_workspace_bytes(int max_T, int max_L, int alphabet_size
     if (max_T < 0 || max_L < 0 || alphabet_size <= 0 || minibatch <= 0) return 0;
     size_t a, b, c, d;
     return ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d);
+}
+
+template <bool WITH_BETA, bool LDS_EM>
+static ctcStatus_t launch_alphabeta(const AbArgs& A, int B, int threads, size_t smem, hipStream_t stream) {
+    const void* fn = (const void*)ctc_alphabeta_kernel<WITH_BETA, LDS_EM>;
+    if (smem > 48 * 1024 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return CTC_STATUS_EXECUTION_FAILED;
+    hipLaunchKernelGGL((ctc_alphabeta_kernel<WITH_BETA, LDS_EM>), dim3(B), dim3(threads), smem, stream, A);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
 }
 
 extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_t, long stride_b,
@@ -359,60 +429,61 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     if (workspace_bytes < sa_ctc_workspace_bytes(max_T, max_L, alphabet_size, minibatch))
         return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
-    const int K = alphabet_size, B = minibatch, Ppad = nch * 64;
-    size_t o_ly2, o_stash, o_lp, o_ints;
-    ctc_ws_layout(max_T, max_L, K, B, &o_ly2, &o_stash, &o_lp, &o_ints);
+    const int K = alphabet_size, B = minibatch;
+    size_t o_ly2, o_stash, o_lp, o_goffs;
+    ctc_ws_layout(max_T, max_L, K, B, &o_ly2, &o_stash, &o_lp, &o_goffs);
     char* ws = (char*)workspace;
-    float* ly2 = (float*)(ws + o_ly2);
-    float* stash = (float*)(ws + o_stash);
-    float* logp2 = (float*)(ws + o_lp);
+
+    AbArgs A;
+    A.ly2 = (float*)(ws + o_ly2);
+    A.labels = d_flat_labels;
+    A.label_lens = d_label_lengths;
+    A.in_lens = d_input_lengths;
+    A.K = K; A.T_max = max_T; A.blank = blank_label; A.nchunks = nch; A.Ppad = nch * 64;
+    A.hand_stride = (int)sa_align_up((size_t)max_T + kU + 1, 4);
+    A.nbatch = ctc_nbatch(max_T);
+    A.ly_sb = (long)sa_align_up((size_t)max_T * K, 4);
+    A.stash = (float*)(ws + o_stash);
+    A.goffs = (float*)(ws + o_goffs);
+    A.logp2_out = (float*)(ws + o_lp);
+    A.costs = d_costs;
 
     {  // K_A
-        const long rows = (long)B * max_T;
         const int G = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
-        const long waves = (rows + (64 / G) - 1) / (64 / G);
-        int grid = (int)((waves + 3) / 4);
-        if (grid > 4096) grid = 4096;
-        if (grid < 1) grid = 1;
+        const int rows_per_block = 4 * (64 / G);
+        dim3 grid((max_T + rows_per_block - 1) / rows_per_block, B);
+        float* ly2 = (float*)(ws + o_ly2);
         if (G == 16)
-            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<16>, dim3(grid), dim3(256), 0, stream, acts, stride_t,
-                               stride_b, d_input_lengths, K, B, max_T, ly2);
+            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<16>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
+                               d_input_lengths, K, A.ly_sb, ly2);
         else if (G == 32)
-            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<32>, dim3(grid), dim3(256), 0, stream, acts, stride_t,
-                               stride_b, d_input_lengths, K, B, max_T, ly2);
+            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<32>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
+                               d_input_lengths, K, A.ly_sb, ly2);
         else
-            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<64>, dim3(grid), dim3(256), 0, stream, acts, stride_t,
-                               stride_b, d_input_lengths, K, B, max_T, ly2);
+            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<64>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
+                               d_input_lengths, K, A.ly_sb, ly2);
         SA_CHECK_LAUNCH();
     }
     {  // K_B
-        const int hand_stride = (int)sa_align_up((size_t)max_T + kU + 1, 4);
-        const size_t smem = 128 + (size_t)2 * nch * hand_stride * sizeof(float);
+        const size_t fixed = kAbSharedBytes + (size_t)2 * nch * (A.hand_stride + A.nbatch) * sizeof(float);
+        const size_t with_em = fixed + sa_align_up((size_t)max_T * K * sizeof(float), 16);
+        const bool lds_em = with_em <= 150 * 1024;  // stage the utterance's emissions in LDS when they fit
+        const size_t smem = lds_em ? with_em : fixed;
         if (smem > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
-        if (grads) {
-            if (smem > 48 * 1024)
-                if (hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                    return CTC_STATUS_EXECUTION_FAILED;
-            hipLaunchKernelGGL(ctc_alphabeta_kernel<true>, dim3(B), dim3(64 * nch * 2), smem, stream, ly2,
-                               d_flat_labels, d_label_lengths, d_input_lengths, K, max_T, blank_label, nch, Ppad,
-                               hand_stride, stash, logp2, d_costs);
-        } else {
-            if (smem > 48 * 1024)
-                if (hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                    return CTC_STATUS_EXECUTION_FAILED;
-            hipLaunchKernelGGL(ctc_alphabeta_kernel<false>, dim3(B), dim3(64 * nch), smem, stream, ly2,
-                               d_flat_labels, d_label_lengths, d_input_lengths, K, max_T, blank_label, nch, Ppad,
-                               hand_stride, stash, logp2, d_costs);
-        }
-        SA_CHECK_LAUNCH();
+        const int threads = 64 * nch * (grads ? 2 : 1);
+        ctcStatus_t s;
+        if (grads)
+            s = lds_em ? launch_alphabeta<true, true>(A, B, threads, smem, stream)
+                       : launch_alphabeta<true, false>(A, B, threads, smem, stream);
+        else
+            s = lds_em ? launch_alphabeta<false, true>(A, B, threads, smem, stream)
+                       : launch_alphabeta<false, false>(A, B, threads, smem, stream);
+        if (s != CTC_STATUS_SUCCESS) return s;
     }
     if (grads) {  // K_C
-        dim3 grid((max_T + kGradRowsPerBlock - 1) / kGradRowsPerBlock, B);
-        hipLaunchKernelGGL(ctc_grad_kernel, grid, dim3(256), 4 * (size_t)K * sizeof(float), stream, ly2, stash,
-                           logp2, d_flat_labels, d_label_lengths, d_input_lengths, K, max_T, blank_label, nch, Ppad,
-                           grads, stride_t, stride_b);
+        dim3 grid((max_T + 3) / 4, B);
+        hipLaunchKernelGGL(ctc_grad_kernel, grid, dim3(256), 4 * (size_t)K * sizeof(float), stream, A, grads,
+                           stride_t, stride_b);
         SA_CHECK_LAUNCH();
     }
     return CTC_STATUS_SUCCESS;

@@ -1,7 +1,10 @@
 """HIP CTC loss (speech_amd.ctc -> sa_ctc_loss / compute_ctc_loss) against the CPU oracle (oracle/ctc_ref.c, fp64).
 
 Tolerances (fp32 log-space kernels vs an fp64 oracle):
-  per-utterance cost: rtol 1e-5 (north_star asks 1e-4);  gradient: atol 2e-4 absolute on values in [-1, 1]."""
+  per-utterance cost: rtol 1e-5 (north_star asks 1e-4).
+  gradient (values in [-1, 1]): the occupancy is exp2(alpha + beta - ly - log2 p) with alpha, beta ~ |log2 p| held in
+  fp32, so its absolute error is a few ulp(|log2 p|): atol = max(2e-5, 4 * 2^-24 * |log2 p|max) -- the same error
+  class as any fp32 log-space implementation (oracle/ctc_ref.c's own float port shows it, test_oracle_ctc.py)."""
 import ctypes
 
 import numpy as np
@@ -13,7 +16,13 @@ from oracle import ctc_ref
 pytestmark = pytest.mark.gpu
 
 COST_RTOL = 1e-5
-GRAD_ATOL = 2e-4
+
+
+def grad_atol(costs):
+    c = np.asarray(costs)
+    c = c[np.isfinite(c)]
+    lp2 = (np.abs(c).max() if c.size else 0.0) / np.log(2.0)
+    return max(2e-5, 4.0 * 2.0 ** -24 * lp2 * 2)
 
 
 def make(seed, B, T, K, Lmin, Lmax, ragged_T=False, scale=1.0):
@@ -42,7 +51,7 @@ def compare(acts, labs, al, ll, blank=None, batch_first=True):
     np.testing.assert_allclose(c[finite], co[finite], rtol=COST_RTOL)
     assert np.isfinite(g).all()
     err = np.abs(g - go).max()
-    assert err < GRAD_ATOL, err
+    assert err < grad_atol(co), (err, grad_atol(co))
     return err
 
 
@@ -82,7 +91,7 @@ def test_infeasible_and_repeats():
     co, go = ctc_ref.ctc_loss(acts, labs, np.full(3, 6, np.int32), ll)
     assert np.isinf(c[0]) and c[0] > 0 and np.all(g[0] == 0)
     np.testing.assert_allclose(c[1:], co[1:], rtol=COST_RTOL)
-    assert np.abs(g - go).max() < GRAD_ATOL
+    assert np.abs(g - go).max() < grad_atol(co[1:])
 
 
 def test_peaky_logits():
@@ -114,11 +123,11 @@ def test_autograd_module_reduction_and_backward():
     loss.backward()
     co, go = ctc_ref.ctc_loss(acts, labs, al, ll)
     assert abs(float(loss.data[0]) - co.sum() / 4) < 1e-5 * co.sum()
-    assert np.abs(x.grad.cpu().numpy() - go / 4).max() < GRAD_ATOL
+    assert np.abs(x.grad.cpu().numpy() - go / 4).max() < grad_atol(co)
     x2 = torch.from_numpy(acts).cuda().requires_grad_(True)
     loss2 = CTCLoss(size_average=False)(x2, torch.IntTensor(labs), torch.IntTensor(al), torch.IntTensor(ll))
     (2.0 * loss2).sum().backward()
-    assert np.abs(x2.grad.cpu().numpy() - 2.0 * go).max() < 2 * GRAD_ATOL
+    assert np.abs(x2.grad.cpu().numpy() - 2.0 * go).max() < 2 * grad_atol(co)
 
 
 def test_linearity_in_batch_order():
@@ -152,7 +161,7 @@ def test_warpctc_shaped_entry_point():
                                   al.ctypes.data, 29, 5, costs.ctypes.data, ws.data_ptr(), opts), "compute_ctc_loss")
     co, go = ctc_ref.ctc_loss(tm, labs, al, ll, batch_first=False)
     np.testing.assert_allclose(costs, co, rtol=COST_RTOL)
-    assert np.abs(d_grads.cpu().numpy() - go).max() < GRAD_ATOL
+    assert np.abs(d_grads.cpu().numpy() - go).max() < grad_atol(co)
     bad = labs.copy()
     bad[0] = 28  # label == blank
     assert L.compute_ctc_loss(d_acts.data_ptr(), None, bad.ctypes.data, ll.ctypes.data, al.ctypes.data, 29, 5,

@@ -32,3 +32,26 @@ if __name__ == "__main__":
     bench(32, 1000, 29, 100)
     bench(256, 1000, 29, 100)
     bench(2048, 1000, 29, 100, iters=5)
+
+
+def bench_score_only(B, T, K, L, iters=20):
+    rng = np.random.RandomState(2017)
+    acts = torch.from_numpy(rng.randn(B, T, K).astype(np.float32)).cuda()
+    labs = torch.from_numpy(rng.randint(0, K - 1, B * L).astype(np.int32))
+    al = torch.full((B,), T, dtype=torch.int32)
+    ll = torch.full((B,), L, dtype=torch.int32)
+    for _ in range(3):
+        ctc_loss_raw(acts, labs, al, ll, want_grad=False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ctc_loss_raw(acts, labs, al, ll, want_grad=False)
+    e1.record()
+    torch.cuda.synchronize()
+    print("score-only B=%d T=%d L=%d: %.3f ms/call" % (B, T, L, e0.elapsed_time(e1) / iters))
+
+
+if __name__ == "__main__":
+    bench_score_only(32, 1000, 29, 100)
+    bench_score_only(32, 1000, 29, 60)
