@@ -100,17 +100,23 @@ ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, 
 /* C[M,N] = alpha * op(A) * op(B) (+ bias[N]) (+ beta * C),  row-major, leading dimensions in elements.
  *   trans_a == 0: A is (M,K), lda >= K;  trans_a != 0: A is stored (K,M), lda >= M.
  *   trans_b == 0: B is (K,N), ldb >= N;  trans_b != 0: B is stored (N,K), ldb >= K   (nn.Linear / GRU weight layout).
- * Replaces the cuBLAS calls under nn.Linear (model.py:126-133) and nn.GRU's input projections (model.py:35-39). */
+ * Replaces the cuBLAS calls under nn.Linear (model.py:126-133) and nn.GRU's input projections (model.py:35-39).
+ * Products with few output tiles and a long K (the weight gradients, K = B*T') are split along K into `workspace`
+ * (sa_gemm_workspace_bytes; may be NULL / too small, then K is not split) and reduced in a fixed order. */
+size_t sa_gemm_workspace_bytes(int M, int N, int K);
 ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
                         const float* B, long ldb, float beta, float* C, long ldc, const float* bias /* or NULL */,
-                        void* stream);
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Conv2d(in_c, out_c, (kh, kw), stride (s, s), padding 0) + ReLU, model.py:19-29,61-62.
  * x (B, in_c, T, F) NCHW contiguous; w (out_c, in_c, kh, kw); y written with caller-given strides so the last conv
  * can emit the GRU-ready (B, T', out_c * F') layout of model.py:66-71 directly:
- *     y[b * ys_b + c * ys_c + t * ys_t + f]. */
+ *     y[b * ys_b + c * ys_c + t * ys_t + f].
+ * workspace >= sa_conv2d_fwd_workspace_bytes() holds the im2col matrix. */
+size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s);
 ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in_c, int T,
-                               int F, int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t, void* stream);
+                               int F, int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above: dy (same strides as y), y (to mask the ReLU) -> dw (+=0: overwritten), dbias, and dx
  * (NCHW, overwritten) unless dx == NULL.  workspace >= sa_conv2d_bwd_workspace_bytes(). */
@@ -123,7 +129,7 @@ ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, c
  *   ai   (B, T, 3H): input pre-activations x W_ih^T + b_ih (from sa_gemm_f32), batch-first.
  *   w_hh (3H, H), b_hh (3H).   h_out[b * hs_b + t * hs_t + j], j < H  (strides allow writing one half of a
  *   bidirectional (B, T, 2H) output).  reverse != 0 runs t = T-1 .. 0.
- *   stash (B, T, 4H) or NULL: r, z, n, q = W_hn h + b_hn saved for the backward pass.
+ *   stash (B, T, 5H) or NULL: r, z, n, q = W_hn h + b_hn, and h_{t-1}, saved for the backward pass.
  * All utterances run the full T steps (the reference passes the padded length for every utterance, ctc_model.py:43-45). */
 ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const float* b_hh, float* h_out, long hs_b, long hs_t,
                        float* stash, int B, int T, int H, int reverse, void* stream);

@@ -1,0 +1,164 @@
+// conv.hip -- Conv2d(in_c, out_c, (kh, kw), stride (s, s), padding 0) + ReLU of the encoder front end
+// (reference: /root/reference/speech/models/model.py:19-29,61-62) and the layout change of model.py:66-71.
+//
+// Round-1 formulation: im2col into a workspace (coalesced reads of the padded feature tensor: a window row is kw
+// contiguous floats) followed by the fp32 MFMA GEMM  y[pos, c] = cols[pos, :] . w[c, :] + bias[c]  with ReLU and the
+// output scatter fused into the GEMM epilogue, so the last conv writes the GRU-ready (B, T', out_c * F')
+// channel-major feature layout directly (no transpose pass).  Backward: mask + repack dy, dW = dyp^T cols (split-K
+// GEMM over ~4e5 positions), db = column sums, dx = col2im gather of dyp W (only for stacked convs).
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+struct ConvGeom {
+    int B, C, T, F, O, kh, kw, s, To, Fo, K;  // K = C * kh * kw
+};
+
+__host__ __device__ inline int conv_out(int n, int k, int s) { return (n - k + 1 + s - 1) / s; }
+
+// cols[pos][k], pos = (b, t', f'), k = (c, i, j)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols,
+                                                     ConvGeom g) {
+    const long total = (long)g.B * g.To * g.Fo * g.K;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % g.K);
+        const long pos = idx / g.K;
+        const int fo = (int)(pos % g.Fo);
+        const int to = (int)((pos / g.Fo) % g.To);
+        const int b = (int)(pos / ((long)g.Fo * g.To));
+        const int j = k % g.kw, i = (k / g.kw) % g.kh, c = k / (g.kw * g.kh);
+        cols[idx] = x[(((long)b * g.C + c) * g.T + (g.s * to + i)) * g.F + g.s * fo + j];
+    }
+}
+
+// dyp[pos][o] = dy[b, o, t', f'] * (y > 0), reading dy / y through the caller's strides
+__global__ __launch_bounds__(256) void relu_mask_pack_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             float* __restrict__ dyp, ConvGeom g, long ys_b, long ys_c,
+                                                             long ys_t) {
+    const long total = (long)g.B * g.To * g.Fo * g.O;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        // thread order: f' fastest (coalesced reads), then o, then (b, t')
+        const int fo = (int)(idx % g.Fo);
+        const int o = (int)((idx / g.Fo) % g.O);
+        const long bt = idx / ((long)g.Fo * g.O);
+        const int to = (int)(bt % g.To);
+        const int b = (int)(bt / g.To);
+        const long off = (long)b * ys_b + (long)o * ys_c + (long)to * ys_t + fo;
+        const float v = y[off] > 0.f ? dy[off] : 0.f;
+        dyp[((bt * g.Fo) + fo) * g.O + o] = v;
+    }
+}
+
+// dx[b, c, t, f] = sum over windows covering (t, f) of dcols[(b, t', f')][(c, i, j)]   (gather: deterministic)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx,
+                                                     ConvGeom g) {
+    const long total = (long)g.B * g.C * g.T * g.F;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int f = (int)(idx % g.F);
+        const int t = (int)((idx / g.F) % g.T);
+        const int c = (int)((idx / ((long)g.F * g.T)) % g.C);
+        const int b = (int)(idx / ((long)g.F * g.T * g.C));
+        float acc = 0.f;
+        for (int i = t % g.s; i < g.kh; i += g.s) {
+            const int to = (t - i) / g.s;
+            if (t - i < 0 || to >= g.To) continue;
+            for (int j = f % g.s; j < g.kw; j += g.s) {
+                const int fo = (f - j) / g.s;
+                if (f - j < 0 || fo >= g.Fo) continue;
+                acc += dcols[(((long)b * g.To + to) * g.Fo + fo) * g.K + (c * g.kh + i) * g.kw + j];
+            }
+        }
+        dx[idx] = acc;
+    }
+}
+
+bool make_geom(ConvGeom* g, int B, int C, int T, int F, int O, int kh, int kw, int s) {
+    if (B <= 0 || C <= 0 || T <= 0 || F <= 0 || O <= 0 || kh <= 0 || kw <= 0 || s <= 0) return false;
+    g->B = B; g->C = C; g->T = T; g->F = F; g->O = O; g->kh = kh; g->kw = kw; g->s = s;
+    g->To = conv_out(T, kh, s); g->Fo = conv_out(F, kw, s); g->K = C * kh * kw;
+    return g->To > 0 && g->Fo > 0;
+}
+
+int grid_for(long total) {
+    long gsz = (total + 255) / 256;
+    return (int)(gsz > 8192 ? 8192 : (gsz < 1 ? 1 : gsz));
+}
+
+}  // namespace
+
+extern "C" size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s) {
+    ConvGeom g;
+    if (!make_geom(&g, B, in_c, T, F, out_c, kh, kw, s)) return 0;
+    const long npos = (long)g.B * g.To * g.Fo;
+    return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +
+           sa_align_up(sa_gemm_workspace_bytes((int)npos, g.O, g.K), 256);
+}
+
+extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B,
+                                          int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
+                                          long ys_c, long ys_t, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
+    ConvGeom g;
+    if (!x || !w || !bias || !y || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
+        return CTC_STATUS_INVALID_VALUE;
+    if (workspace_bytes < sa_conv2d_fwd_workspace_bytes(B, in_c, T, F, out_c, kh, kw, s)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long npos = (long)g.B * g.To * g.Fo;
+    float* cols = (float*)workspace;
+    char* gws = (char*)workspace + sa_align_up((size_t)npos * g.K * sizeof(float), 256);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
+    SA_CHECK_LAUNCH();
+    SaGemmEpilogue ep;
+    ep.m_inner = g.Fo; ep.m_mid = g.To; ep.s_outer = ys_b; ep.s_mid = ys_t; ep.col_stride = ys_c; ep.relu = 1;
+    return sa_gemm_f32_impl(0, 1, (int)npos, g.O, g.K, 1.0f, cols, g.K, w, g.K, 0.f, y, 0, bias, &ep, gws,
+                            workspace_bytes - (size_t)(gws - (char*)workspace), stream);
+}
+
+extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s) {
+    ConvGeom g;
+    if (!make_geom(&g, B, in_c, T, F, out_c, kh, kw, s)) return 0;
+    const long npos = (long)g.B * g.To * g.Fo;
+    size_t gw = sa_gemm_workspace_bytes(g.O, g.K, (int)npos);
+    const size_t gw2 = sa_gemm_workspace_bytes((int)npos, g.K, g.O);
+    if (gw2 > gw) gw = gw2;
+    return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +   // cols, reused for dcols
+           sa_align_up((size_t)npos * g.O * sizeof(float), 256) +   // dyp
+           sa_align_up(gw, 256);
+}
+
+extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                                          float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh,
+                                          int kw, int s, long ys_b, long ys_c, long ys_t, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    ConvGeom g;
+    if (!x || !w || !y || !dy || !dw || !dbias || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
+        return CTC_STATUS_INVALID_VALUE;
+    if (workspace_bytes < sa_conv2d_bwd_workspace_bytes(B, in_c, T, F, out_c, kh, kw, s)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long npos = (long)g.B * g.To * g.Fo;
+    float* cols = (float*)workspace;
+    float* dyp = (float*)((char*)cols + sa_align_up((size_t)npos * g.K * sizeof(float), 256));
+    char* gws = (char*)dyp + sa_align_up((size_t)npos * g.O * sizeof(float), 256);
+    const size_t gws_bytes = workspace_bytes - (size_t)(gws - (char*)workspace);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
+    hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, dyp, g, ys_b,
+                       ys_c, ys_t);
+    SA_CHECK_LAUNCH();
+    // dW[o, k] = sum_pos dyp[pos, o] * cols[pos, k]
+    ctcStatus_t st = sa_gemm_f32_impl(1, 0, g.O, g.K, (int)npos, 1.0f, dyp, g.O, cols, g.K, 0.f, dw, g.K, nullptr,
+                                      nullptr, gws, gws_bytes, stream);
+    if (st != CTC_STATUS_SUCCESS) return st;
+    st = sa_colsum_f32(dyp, g.O, (int)npos, g.O, dbias, 0, stream_);
+    if (st != CTC_STATUS_SUCCESS) return st;
+    if (dx) {
+        // dcols[pos, k] = sum_o dyp[pos, o] * w[o, k]   (overwrites cols), then gather into dx
+        st = sa_gemm_f32_impl(0, 0, (int)npos, g.K, g.O, 1.0f, dyp, g.O, w, g.K, 0.f, cols, g.K, nullptr, nullptr,
+                              gws, gws_bytes, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)g.B * g.C * g.T * g.F)), dim3(256), 0, stream, cols,
+                           dx, g);
+        SA_CHECK_LAUNCH();
+    }
+    return CTC_STATUS_SUCCESS;
+}

@@ -1,0 +1,287 @@
+// gemm_f32.hip -- fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate),
+// the GEMM-shaped part of the encoder: nn.GRU's input projections and nn.Linear (reference:
+// /root/reference/speech/models/model.py:35-39,126-133) and their weight / input gradients.
+//
+//   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ beta * C)
+//
+// Tiling (CDNA4): 128x128 block tile, BK = 16, 256 threads = 4 waves as 2x2, each wave a 64x64 sub-tile =
+// 2x2 MFMA 32x32 tiles (4 x 16 accumulator VGPRs).  Operand tiles are staged in LDS k-major ([k][m], [k][n]):
+// an MFMA fragment read is then 32 consecutive floats per half-wave (conflict-free ds_read_b32).  An operand that
+// is k-contiguous in memory (A of an NT product, nn.Linear weights) is transposed on the way into LDS; an operand
+// that is m/n-contiguous is copied with 16-byte accesses.  Global loads for tile i+1 are issued before the MFMAs of
+// tile i (register staging, double-buffered LDS, one barrier per K tile).
+// Tall-K products with few output tiles (dW = dA^T X, K = B*T' ~ 16k) are split along K across blockIdx.z into a
+// workspace and reduced by a second kernel in a fixed order (deterministic, unlike atomics).
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = 132;  // LDS row pitch in floats (128 + 4): keeps 16-byte alignment, spreads transposed writes
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    long lda, ldb, ldc;
+    int M, N, K;
+    float alpha, beta;
+    int k_per_split;  // multiple of BK
+    int vecA, vecB;   // 16-byte loads are legal for this operand
+    // optional output remap (conv: row m = (b, t', f'), column n = channel):
+    //   addr(m, n) = (m / (m_inner * m_mid)) * s_outer + ((m / m_inner) % m_mid) * s_mid + (m % m_inner)
+    //                + n * col_stride                                           (m_inner == 0: m * ldc + n)
+    int m_inner, m_mid;
+    long s_outer, s_mid, col_stride;
+    int relu;
+    float* partial;   // split-K workspace [splits][M][N] or null
+};
+
+__device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
+    const int q = row / g.m_inner;
+    return (long)(q / g.m_mid) * g.s_outer + (long)(q % g.m_mid) * g.s_mid + (row % g.m_inner);
+}
+
+// Load this thread's slice of one operand tile into registers.
+// KCONTIG: memory is [rows][k] (k contiguous)  -> 2 x float4: row = tid/4 + 64p, k = 4*(tid%4)
+// else:    memory is [k][cols] (cols contiguous) -> 2 x float4: k = tid/32 + 8p, col = 4*(tid%32)
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int r0, int R, int k0, int kend,
+                                          int vec, int tid, float4 v[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KCONTIG) {
+            const int row = r0 + (tid >> 2) + 64 * p;
+            const int k = k0 + 4 * (tid & 3);
+            if (row < R) {
+                const float* q = P + (long)row * ld + k;
+                if (vec && k + 3 < kend) {
+                    x = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (k + 0 < kend) x.x = q[0];
+                    if (k + 1 < kend) x.y = q[1];
+                    if (k + 2 < kend) x.z = q[2];
+                    if (k + 3 < kend) x.w = q[3];
+                }
+            }
+        } else {
+            const int k = k0 + (tid >> 5) + 8 * p;
+            const int col = r0 + 4 * (tid & 31);
+            if (k < kend) {
+                const float* q = P + (long)k * ld + col;
+                if (vec && col + 3 < R) {
+                    x = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (col + 0 < R) x.x = q[0];
+                    if (col + 1 < R) x.y = q[1];
+                    if (col + 2 < R) x.z = q[2];
+                    if (col + 3 < R) x.w = q[3];
+                }
+            }
+        }
+        v[p] = x;
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(float* __restrict__ S /* [BK][LDT] */, int tid, const float4 v[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (KCONTIG) {
+            const int row = (tid >> 2) + 64 * p;
+            const int k = 4 * (tid & 3);
+            S[(k + 0) * LDT + row] = v[p].x;
+            S[(k + 1) * LDT + row] = v[p].y;
+            S[(k + 2) * LDT + row] = v[p].z;
+            S[(k + 3) * LDT + row] = v[p].w;
+        } else {
+            const int k = (tid >> 5) + 8 * p;
+            const int col = 4 * (tid & 31);
+            *reinterpret_cast<float4*>(&S[k * LDT + col]) = v[p];
+        }
+    }
+}
+
+// TA: A is stored (K, M) (m-contiguous);  !TA: A is stored (M, K) (k-contiguous)
+// TB: B is stored (N, K) (k-contiguous);  !TB: B is stored (K, N) (n-contiguous)
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+    auto As = [&](int i) { return smem + i * (BK * LDT); };
+    auto Bs = [&](int i) { return smem + (2 + i) * (BK * LDT); };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    if (ntiles > 0) {
+        load_tile<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+        load_tile<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+        store_tile<!TA>(As(0), tid, ra);
+        store_tile<TB>(Bs(0), tid, rb);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < ntiles;
+        if (more) {  // issue the next tile's global loads before this tile's MFMAs
+            const int k0 = kbeg + (it + 1) * BK;
+            load_tile<!TA>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+            load_tile<TB>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+        }
+        const float* a_s = As(cur) + (lane >> 5) * LDT + wm * 64 + (lane & 31);
+        const float* b_s = Bs(cur) + (lane >> 5) * LDT + wn * 64 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const float a0 = a_s[(2 * ks) * LDT];
+            const float a1 = a_s[(2 * ks) * LDT + 32];
+            const float b0 = b_s[(2 * ks) * LDT];
+            const float b1 = b_s[(2 * ks) * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<!TA>(As(cur ^ 1), tid, ra);
+            store_tile<TB>(Bs(cur ^ 1), tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool split = g.partial != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            float bv = 0.f;
+            if (!split && g.bias) bv = g.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                if (split) {
+                    g.partial[((long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                } else {
+                    float* c = g.m_inner > 0 ? g.C + remap_row(g, row) + col * g.col_stride
+                                             : g.C + (long)row * g.ldc + col;
+                    float v = g.alpha * acc[i][j][r] + bv;
+                    if (g.beta != 0.f) v += g.beta * *c;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int splits) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)g.M * g.N;
+    if (idx >= total) return;
+    const int row = (int)(idx / g.N), col = (int)(idx % g.N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += g.partial[(long)z * total + idx];  // fixed order: deterministic
+    float* c = g.m_inner > 0 ? g.C + remap_row(g, row) + col * g.col_stride : g.C + (long)row * g.ldc + col;
+    float v = g.alpha * s + (g.bias ? g.bias[col] : 0.f);
+    if (g.beta != 0.f) v += g.beta * *c;
+    if (g.relu) v = fmaxf(v, 0.f);
+    *c = v;
+}
+
+int choose_splits(int M, int N, int K) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (tiles >= 192 || K < 8 * BK) return 1;
+    int s = (int)((512 + tiles - 1) / tiles);       // aim for ~2 blocks per CU
+    const int max_by_k = K / (4 * BK);              // at least 4 K-tiles per split
+    if (s > max_by_k) s = max_by_k;
+    if (s > 128) s = 128;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
+                             const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                             const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
+    if (M < 0 || N < 0 || K < 0) return CTC_STATUS_INVALID_VALUE;
+    if (M == 0 || N == 0) return CTC_STATUS_SUCCESS;
+    if (!A || !B || !C) return CTC_STATUS_INVALID_VALUE;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta;
+    g.vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
+    g.vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
+    g.m_inner = ep ? ep->m_inner : 0;
+    g.m_mid = ep ? ep->m_mid : 1;
+    g.s_outer = ep ? ep->s_outer : 0;
+    g.s_mid = ep ? ep->s_mid : 0;
+    g.col_stride = ep ? ep->col_stride : 1;
+    g.relu = ep ? ep->relu : 0;
+    int splits = choose_splits(M, N, K);
+    if (splits > 1) {
+        const size_t need = (size_t)splits * M * N * sizeof(float);
+        if (!workspace || workspace_bytes < need) splits = 1;  // no room: fall back to one pass (still correct)
+    }
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    if (kps < BK) kps = BK;
+    splits = K > 0 ? (K + kps - 1) / kps : 1;
+    g.k_per_split = kps;
+    g.partial = splits > 1 ? (float*)workspace : nullptr;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+    if (trans_a) {
+        if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, g);
+    }
+    SA_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long total = (long)M * N;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, g,
+                           splits);
+        SA_CHECK_LAUNCH();
+    }
+    return CTC_STATUS_SUCCESS;
+}
+
+extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = choose_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+                                   long lda, const float* B, long ldb, float beta, float* C, long ldc,
+                                   const float* bias, void* workspace, size_t workspace_bytes, void* stream) {
+    return sa_gemm_f32_impl(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, nullptr, workspace,
+                            workspace_bytes, (hipStream_t)stream);
+}

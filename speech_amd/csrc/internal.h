@@ -1,0 +1,15 @@
+// internal.h -- C++-side interfaces shared between translation units of libspeech_amd (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+struct SaGemmEpilogue {
+    // addr(m, n) = (m / (m_inner * m_mid)) * s_outer + ((m / m_inner) % m_mid) * s_mid + (m % m_inner) + n * col_stride
+    int m_inner, m_mid;   // m_inner == 0: plain ldc layout
+    long s_outer, s_mid, col_stride;
+    int relu;         // clamp the result at zero
+};
+
+ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
+                             const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                             const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K);

@@ -1,0 +1,181 @@
+"""HIP encoder building blocks (through the C ABI via speech_amd.ops) against the fp64 NumPy oracle
+(oracle/encoder_np.py, itself pinned to the live reference by tests/golden/encoder_*.npz).
+
+Tolerances: fp32 kernels vs fp64 oracle.  A length-K fp32 dot product of O(1) terms carries ~1e-7 * sqrt(K) .. 1e-7 * K
+relative error; tests use rtol 2e-5 / atol scaled by the result magnitude unless noted."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_np as E
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def close(got, want, rtol=2e-5, atol_scale=2e-6):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    atol = atol_scale * max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (130, 29, 29), (1, 1, 1), (257, 200, 100), (64, 1536, 800),
+                                   (300, 512, 37)])
+def test_gemm_forms(ta, tb, M, N, K):
+    from speech_amd import ops
+    rng = np.random.RandomState(M * 7 + N * 3 + K + ta * 2 + tb)
+    a = rng.randn(K, M) if ta else rng.randn(M, K)
+    b = rng.randn(N, K) if tb else rng.randn(K, N)
+    bias = rng.randn(N)
+    c = ops.gemm(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb), bias=dev(bias))
+    want = (a.T if ta else a) @ (b.T if tb else b) + bias
+    close(c, want, rtol=1e-5, atol_scale=1e-6 * np.sqrt(K))
+
+
+def test_gemm_is_exact_fp32_on_integers():
+    # f32-input MFMA = an fp32 fma chain: products of small integers are exact, so the result is bit-exact
+    from speech_amd import ops
+    rng = np.random.RandomState(0)
+    a = rng.randint(-8, 9, (200, 96)).astype(np.float32)
+    b = rng.randint(-8, 9, (96, 72)).astype(np.float32)
+    c = ops.gemm(dev(a), dev(b))
+    assert np.array_equal(c.cpu().numpy(), a @ b)
+
+
+def test_gemm_split_k_alpha_beta_and_strided():
+    from speech_amd import ops
+    rng = np.random.RandomState(1)
+    # weight-gradient shape: few output tiles, long K -> split-K path (deterministic reduce)
+    K, M, N = 5000, 96, 200
+    a, b = rng.randn(K, M), rng.randn(K, N)
+    c0 = rng.randn(M, N)
+    out = dev(c0)
+    ops.gemm(dev(a), dev(b), trans_a=True, out=out, alpha=0.5, beta=2.0)
+    close(out, 0.5 * a.T @ b + 2.0 * c0, rtol=1e-5, atol_scale=1e-6 * np.sqrt(K))
+    out2 = dev(c0)
+    ops.gemm(dev(a), dev(b), trans_a=True, out=out2, alpha=0.5, beta=2.0)
+    assert torch.equal(out, out2)  # run-to-run deterministic
+    # strided operands: a column slice (lda > K) and an output slice (ldc > N)
+    big = dev(rng.randn(64, 300))
+    w = dev(rng.randn(40, 100))
+    outbig = torch.zeros(64, 90, device="cuda")
+    ops.gemm(big[:, 100:200], w, trans_b=True, out=outbig[:, 10:50])
+    close(outbig[:, 10:50], big[:, 100:200].cpu().numpy().astype(np.float64) @ w.cpu().numpy().astype(np.float64).T)
+    assert float(outbig[:, :10].abs().max()) == 0 and float(outbig[:, 50:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("B,C,T,F,O,kh,kw,s", [(2, 1, 40, 40, 8, 5, 32, 2), (3, 4, 21, 17, 6, 5, 7, 1),
+                                               (1, 1, 9, 33, 32, 5, 32, 2), (2, 3, 30, 30, 5, 3, 4, 3)])
+@pytest.mark.parametrize("feature_layout", [False, True])
+def test_conv_relu_fwd_bwd(B, C, T, F, O, kh, kw, s, feature_layout):
+    from speech_amd import ops
+    rng = np.random.RandomState(B + C + T)
+    x = rng.randn(B, C, T, F)
+    w = rng.randn(O, C, kh, kw) / np.sqrt(C * kh * kw)
+    b = rng.randn(O) * 0.1
+    y_ref, cols = E.conv_relu_fwd(x, w, b, s)
+    y, ys = ops.conv2d_relu_fwd(dev(x), dev(w), dev(b), s, feature_layout)
+    Bo, Oo, To, Fo = y_ref.shape
+    y_nchw = y.view(B, To, O, Fo).permute(0, 2, 1, 3) if feature_layout else y
+    close(y_nchw, y_ref, rtol=1e-5, atol_scale=2e-6)
+    dy = rng.randn(*y_ref.shape)
+    dx_ref, dw_ref, db_ref = E.conv_relu_bwd(dy, y_ref, cols, x.shape, w, s, need_dx=True)
+    dy_dev = dev(dy.transpose(0, 2, 1, 3).reshape(B, To, O * Fo)) if feature_layout else dev(dy)
+    dx, dw, db = ops.conv2d_relu_bwd(dev(x), dev(w), y, dy_dev, ys, s, need_dx=True)
+    close(dw, dw_ref, rtol=2e-5, atol_scale=1e-5)
+    close(db, db_ref, rtol=2e-5, atol_scale=1e-5)
+    close(dx, dx_ref, rtol=2e-5, atol_scale=1e-5)
+
+
+# -------------------------------------------------------------------------------------------------------------- GRU
+def gru_case(B, T, I, H, reverse, seed):
+    rng = np.random.RandomState(seed)
+    k = 1.0 / np.sqrt(H)
+    x = rng.randn(B, T, I)
+    Wih, Whh = rng.uniform(-k, k, (3 * H, I)), rng.uniform(-k, k, (3 * H, H))
+    bih, bhh = rng.uniform(-k, k, 3 * H), rng.uniform(-k, k, 3 * H)
+    hs, cache = E.gru_dir_fwd(x, Wih, Whh, bih, bhh, reverse)
+    return x, Wih, Whh, bih, bhh, hs, cache
+
+
+@pytest.mark.parametrize("B,T,I,H", [(4, 12, 20, 16), (3, 9, 8, 24), (32, 6, 64, 512), (17, 7, 12, 36), (1, 1, 4, 4)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_gru_fwd_bwd(B, T, I, H, reverse):
+    from speech_amd import ops
+    x, Wih, Whh, bih, bhh, hs_ref, cache = gru_case(B, T, I, H, reverse, B * 100 + T + H)
+    ai = ops.gemm(dev(x.reshape(B * T, I)), dev(Wih), trans_b=True, bias=dev(bih)).view(B, T, 3 * H)
+    # write into one half of a (B, T, 2H) buffer to exercise the strided output
+    hbuf = torch.zeros(B, T, 2 * H, device="cuda")
+    h_out = hbuf[:, :, H:]
+    stash = torch.empty(B, T, 5 * H, device="cuda")
+    ops.gru_fwd(ai, dev(Whh), dev(bhh), h_out, stash, reverse)
+    close(h_out, hs_ref, rtol=2e-5, atol_scale=2e-6)
+    assert float(hbuf[:, :, :H].abs().max()) == 0
+    _, _, r_, z_, n_, q_, _ = cache
+    close(stash[:, :, :H], r_), close(stash[:, :, H:2 * H], z_), close(stash[:, :, 2 * H:3 * H], n_)
+    close(stash[:, :, 3 * H:4 * H], q_)
+    rng = np.random.RandomState(5)
+    dhs = rng.randn(B, T, H)
+    dx_ref, dWih_ref, dWhh_ref, dbih_ref, dbhh_ref = E.gru_dir_bwd(dhs, cache, Wih, Whh)
+    dbuf = torch.zeros(B, T, 2 * H, device="cuda")
+    dbuf[:, :, H:] = dev(dhs)
+    dai = torch.empty(B, T, 3 * H, device="cuda")
+    dah = torch.empty(B, T, 3 * H, device="cuda")
+    ops.gru_bwd(dbuf[:, :, H:], h_out, stash, dev(Whh), dai, dah, reverse)
+    dai2, dah2 = dai.view(B * T, 3 * H), dah.view(B * T, 3 * H)
+    tol = dict(rtol=5e-5, atol_scale=2e-5)
+    close(ops.gemm(dai2, dev(Wih)), dx_ref.reshape(B * T, I), **tol)
+    close(ops.gemm(dai2, dev(x.reshape(B * T, I)), trans_a=True), dWih_ref, **tol)
+    close(ops.gemm(dah2, stash.view(B * T, 5 * H)[:, 4 * H:], trans_a=True), dWhh_ref, **tol)
+    close(ops.colsum(dai2), dbih_ref, **tol)
+    close(ops.colsum(dah2), dbhh_ref, **tol)
+
+
+def test_gru_long_sequence_stays_accurate():
+    from speech_amd import ops
+    B, T, I, H = 2, 300, 16, 32
+    x, Wih, Whh, bih, bhh, hs_ref, _ = gru_case(B, T, I, H, False, 3)
+    ai = ops.gemm(dev(x.reshape(B * T, I)), dev(Wih), trans_b=True, bias=dev(bih)).view(B, T, 3 * H)
+    h = torch.empty(B, T, H, device="cuda")
+    ops.gru_fwd(ai, dev(Whh), dev(bhh), h, None, False)
+    close(h, hs_ref, rtol=5e-5, atol_scale=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------------ small helpers
+def test_colsum_add_rows():
+    from speech_amd import ops
+    rng = np.random.RandomState(0)
+    a, b = rng.randn(1000, 70), rng.randn(1000, 70)
+    close(ops.colsum(dev(a)), a.sum(0), rtol=1e-5, atol_scale=1e-5)
+    acc = dev(np.ones(70))
+    ops.colsum(dev(a), out=acc, accumulate=True)
+    close(acc, a.sum(0) + 1.0, rtol=1e-5, atol_scale=1e-5)
+    wide = dev(np.concatenate([a, b], axis=1))
+    close(ops.add_rows(wide[:, :70], wide[:, 70:]), a + b, rtol=1e-6)
+
+
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+@pytest.mark.parametrize("gscale", [1.0, 300.0])
+def test_clip_sgd_step(momentum, gscale):
+    from speech_amd import ops
+    rng = np.random.RandomState(1)
+    n = 100003
+    p0, g0 = rng.randn(n), gscale * rng.randn(n) / np.sqrt(n)
+    P, G = {"p": p0}, {"p": g0}
+    bufs = {}
+    p, g = dev(p0), dev(g0)
+    mom = torch.zeros(n, device="cuda")
+    for step in range(2):
+        P, total = E.clip_and_sgd(P, G, 1e-2, 200.0, momentum, bufs)
+        norm = ops.clip_sgd_step(p, g, mom if momentum else None, 1e-2, momentum, 200.0)
+        assert abs(float(norm) - total) < 1e-5 * total
+        close(p, P["p"], rtol=1e-5, atol_scale=1e-6)
+    if gscale > 1:
+        assert total > 200.0  # the clip branch was exercised
