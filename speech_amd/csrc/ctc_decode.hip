@@ -1,0 +1,349 @@
+// ctc_decode.hip -- CTC decoding on the device.
+//
+// sa_ctc_beam_decode: the prefix beam search of /root/reference/speech/models/ctc_decoder.py:38-113, one wave per
+// utterance, T sequential steps.  CTC.infer (ctc_model.py:55-60) calls it with beam_size = 1 on softmax outputs copied
+// to the host; here it consumes logits (softmax of ctc_model.py:30-31 fused) or probabilities on the device.
+// It reproduces the reference's arithmetic and ordering, not just its math:
+//   * scores are float32; logsumexp (ctc_decoder.py:27-36) is  f32(a_max) + f32(log_d(sum_d exp_d(f32(a - a_max))))
+//     with the sum taken in argument order in double (what NumPy-2 scalar promotion does to the reference's code);
+//   * the per-step candidate set is the reference's dict: one "stay" entry per beam prefix plus one entry per
+//     (prefix, non-blank symbol); an extension that equals another beam prefix is merged into that prefix's entry,
+//     with the two updates applied in beam order (ctc_decoder.py:71 inner loop);
+//   * ties sort by first-touch order -- vocab-major, beam-minor (ctc_decoder.py:65,71) -- under a stable descending
+//     sort (ctc_decoder.py:107-110).
+// Prefixes are nodes of a trie (parent, symbol) made canonical by a hash table, so "same prefix" is "same node id".
+//
+// sa_ctc_greedy_decode: argmax per frame + CTC.max_decode collapse (ctc_model.py:62-70), one wave per utterance.
+#include "common.h"
+
+namespace {
+
+#define NEG_INF_F (-__builtin_inff())
+
+// ctc_decoder.py:27-36 on up to three arguments, in order.  Arguments are float32 values or -inf.
+__device__ __forceinline__ float ref_lse3(float a, float b, float c, int n) {
+    float m = a;
+    if (n > 1 && b > m) m = b;
+    if (n > 2 && c > m) m = c;
+    if (m == NEG_INF_F) return NEG_INF_F;
+    double tot = 0.0;
+    tot += (a == NEG_INF_F) ? 0.0 : exp((double)(a - m));
+    if (n > 1) tot += (b == NEG_INF_F) ? 0.0 : exp((double)(b - m));
+    if (n > 2) tot += (c == NEG_INF_F) ? 0.0 : exp((double)(c - m));
+    return m + (float)log(tot);
+}
+
+struct BeamArgs {
+    const float* in;
+    long st, sb;
+    const int* in_lens;
+    int S, B, T_max, W, blank, is_logits;
+    int* out_labels;   // (B, T_max)
+    int* out_lens;     // (B)
+    float* out_nll;    // (B) or null
+    // per-utterance workspace
+    int* node_parent;  // [B][max_nodes]
+    int* node_sym;     // [B][max_nodes]
+    unsigned long long* hkeys;  // [B][hsize]   (0 = empty)
+    int* hvals;        // [B][hsize]
+    int max_nodes, hsize;
+};
+
+__device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (unsigned)k;
+}
+
+// one wave (64 threads) per utterance
+__global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int S = A.S, W = A.W;
+    const int ncand_max = W * S;
+    float* lp = reinterpret_cast<float*>(smem_raw);             // [S]
+    float* b_pb = lp + S;                                       // [W] beam: p_blank
+    float* b_pnb = b_pb + W;                                    // [W] beam: p_non_blank
+    int* b_node = reinterpret_cast<int*>(b_pnb + W);            // [W]
+    int* b_last = b_node + W;                                   // [W] last symbol, -1 for the empty prefix
+    int* b_ip = b_last + W;                                     // [W] beam index of the parent prefix, -1 if absent
+    float* n_pb = reinterpret_cast<float*>(b_ip + W);           // [W] next beam
+    float* n_pnb = n_pb + W;
+    int* n_node = reinterpret_cast<int*>(n_pnb + W);
+    int* n_last = n_node + W;
+    float* c_pb = reinterpret_cast<float*>(n_last + W);         // [W*S] candidates
+    float* c_pnb = c_pb + ncand_max;
+    float* c_score = c_pnb + ncand_max;
+    float* c_ord = c_score + ncand_max;                         // first-touch order (exact small integers in fp32)
+    int* c_state = reinterpret_cast<int*>(c_ord + ncand_max);   // 0 = void, 1 = live, 2 = taken
+    int* node_count = c_state + ncand_max;                      // [1]
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int T = A.in_lens[b];
+    int* node_parent = A.node_parent + (long)b * A.max_nodes;
+    int* node_sym = A.node_sym + (long)b * A.max_nodes;
+    unsigned long long* hkeys = A.hkeys + (long)b * A.hsize;
+    int* hvals = A.hvals + (long)b * A.hsize;
+    const unsigned hmask = (unsigned)A.hsize - 1;
+
+    if (lane == 0) {
+        b_pb[0] = 0.0f; b_pnb[0] = NEG_INF_F; b_node[0] = 0; b_last[0] = -1;
+        node_parent[0] = -1; node_sym[0] = -1;
+        *node_count = 1;
+    }
+    int nb = 1;  // beam entries in use (wave-uniform)
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        // ---- log-probabilities of this frame (ctc_decoder.py:52 after ctc_model.py:30-31)
+        const float* row = A.in + (long)b * A.sb + (long)t * A.st;
+        if (A.is_logits) {
+            float m = -3.0e38f;
+            for (int s = lane; s < S; s += 64) m = fmaxf(m, row[s]);
+            m = sa_wave_max(m);
+            float z = 0.f;
+            for (int s = lane; s < S; s += 64) z += expf(row[s] - m);
+            z = sa_wave_sum(z);
+            for (int s = lane; s < S; s += 64) lp[s] = logf(expf(row[s] - m) / z);
+        } else {
+            for (int s = lane; s < S; s += 64) lp[s] = logf(row[s]);  // log(0) = -inf, as np.log
+        }
+        // ---- where is each beam prefix's parent in the beam?
+        if (lane < nb) {
+            const int par = node_parent[b_node[lane]];
+            int ip = -1;
+            for (int k = 0; k < nb; ++k)
+                if (b_node[k] == par) ip = k;
+            b_ip[lane] = ip;
+        }
+        __syncthreads();
+
+        // ---- candidates: slot (i, s); the blank slot of beam entry i carries its "stay" entry
+        const int ncand = nb * S;
+        for (int c = lane; c < ncand; c += 64) {
+            const int i = c / S, s = c - i * S;
+            const float pb = b_pb[i], pnb = b_pnb[i];
+            const int last = b_last[i];
+            float npb, npnb, ord;
+            int state = 1;
+            if (s == A.blank) {
+                const float p = lp[s];
+                npb = ref_lse3(NEG_INF_F, pb + p, pnb + p, 3);
+                npnb = NEG_INF_F;
+                ord = (float)((s * W + i) * 2);
+                if (last >= 0) {  // non-empty prefix: repeat-merge and (if the parent is in the beam) parent extension
+                    const float q = lp[last];
+                    const int ip = b_ip[i];
+                    float vpar_b = 0.f, vpar_nb = 0.f;
+                    int par_n = 0;
+                    if (ip >= 0) {
+                        vpar_b = b_pb[ip] + q;
+                        vpar_nb = b_pnb[ip] + q;
+                        par_n = (last != b_last[ip]) ? 3 : 2;  // ctc_decoder.py:88-96
+                    }
+                    const float merge = pnb + q;
+                    if (ip >= 0 && ip < i) {
+                        npnb = ref_lse3(NEG_INF_F, vpar_b, vpar_nb, par_n);
+                        npnb = ref_lse3(npnb, merge, 0.f, 2);
+                    } else {
+                        npnb = ref_lse3(NEG_INF_F, merge, 0.f, 2);
+                        if (ip >= 0) npnb = ref_lse3(npnb, vpar_b, vpar_nb, par_n);
+                    }
+                    // first touch of this dict entry
+                    float o2 = (float)((last * W + i) * 2 + 1);
+                    if (ip >= 0) o2 = fminf(o2, (float)((last * W + ip) * 2));
+                    ord = fminf(ord, o2);
+                }
+            } else {
+                // does (prefix_i + s) equal another beam prefix?  then that prefix's stay entry owns the update
+                bool merged = false;
+                for (int k = 0; k < nb; ++k)
+                    if (b_ip[k] == i && b_last[k] == s) merged = true;
+                if (merged) state = 0;
+                const float p = lp[s];
+                npb = NEG_INF_F;
+                npnb = (s != last) ? ref_lse3(NEG_INF_F, pb + p, pnb + p, 3) : ref_lse3(NEG_INF_F, pb + p, 0.f, 2);
+                ord = (float)((s * W + i) * 2);
+            }
+            c_pb[c] = npb; c_pnb[c] = npnb;
+            c_score[c] = ref_lse3(npb, npnb, 0.f, 2);
+            c_ord[c] = ord;
+            c_state[c] = state;
+        }
+        __syncthreads();
+
+        // ---- stable descending selection of the top W (ctc_decoder.py:107-110)
+        int nlive = 0;
+        for (int c = lane; c < ncand; c += 64) nlive += c_state[c] != 0;
+        nlive = (int)sa_wave_sum((float)nlive);
+        const int nsel = min(W, nlive);
+        for (int r = 0; r < nsel; ++r) {
+            float best = NEG_INF_F, bord = 3.0e38f;
+            int bidx = -1;
+            for (int c = lane; c < ncand; c += 64) {
+                if (c_state[c] != 1) continue;
+                const float sc = c_score[c], od = c_ord[c];
+                if (bidx < 0 || sc > best || (sc == best && od < bord)) { best = sc; bord = od; bidx = c; }
+            }
+            // wave argmax: score first, then the smallest first-touch order (unique per live candidate)
+            const bool have = bidx >= 0;
+            const float wbest = sa_wave_max_dpp(have ? best : NEG_INF_F);
+            const bool tie = have && best == wbest;
+            const float word = -sa_wave_max_dpp(tie ? -bord : -3.0e38f);
+            if (tie && bord == word) {
+                c_state[bidx] = 2;
+                const int i = bidx / S, s = bidx - i * S;
+                n_pb[r] = c_pb[bidx]; n_pnb[r] = c_pnb[bidx];
+                if (s == A.blank) {
+                    n_node[r] = b_node[i]; n_last[r] = b_last[i];
+                } else {
+                    n_node[r] = -(i * S + s) - 1;  // resolved to a trie node below
+                    n_last[r] = s;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- canonical trie nodes for the surviving extensions (hash table keyed by (parent node, symbol))
+        if (lane < nsel && n_node[lane] < 0) {
+            const int code = -(n_node[lane] + 1);
+            const int i = code / S, s = code - i * S;
+            const int par = b_node[i];
+            const unsigned long long key = ((unsigned long long)(unsigned)(par + 1) << 32) | (unsigned)(s + 1);
+            unsigned slot = hash_u64(key) & hmask;
+            int id = -1;
+            for (int probe = 0; probe <= (int)hmask; ++probe) {
+                const unsigned long long old = atomicCAS(&hkeys[slot], 0ULL, key);
+                if (old == 0ULL) {  // new prefix
+                    id = atomicAdd(node_count, 1);
+                    if (id < A.max_nodes) { node_parent[id] = par; node_sym[id] = s; }
+                    hvals[slot] = id;
+                    break;
+                }
+                if (old == key) { id = hvals[slot]; break; }
+                slot = (slot + 1) & hmask;
+            }
+            n_node[lane] = id;
+        }
+        __syncthreads();
+        if (lane < nsel) {
+            b_pb[lane] = n_pb[lane]; b_pnb[lane] = n_pnb[lane];
+            b_node[lane] = n_node[lane]; b_last[lane] = n_last[lane];
+        }
+        nb = nsel;
+        __syncthreads();
+    }
+
+    // ---- best prefix: walk the trie back to the root
+    if (lane == 0) {
+        int node = b_node[0];
+        int len = 0;
+        for (int n = node; n > 0 && len < A.T_max; n = node_parent[n]) ++len;
+        int* out = A.out_labels + (long)b * A.T_max;
+        int pos = len;
+        for (int n = node; n > 0 && pos > 0; n = node_parent[n]) out[--pos] = node_sym[n];
+        A.out_lens[b] = len;
+        if (A.out_nll) A.out_nll[b] = -ref_lse3(b_pb[0], b_pnb[0], 0.f, 2);
+    }
+}
+
+// one wave per utterance: argmax per frame (first maximal index), keep p iff p != blank and p != previous frame's p
+__global__ __launch_bounds__(64) void ctc_greedy_kernel(const float* __restrict__ in, long st, long sb,
+                                                        const int* __restrict__ in_lens, int S, int T_max, int blank,
+                                                        int* __restrict__ out_labels, int* __restrict__ out_lens) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int T = in_lens[b];
+    int* out = out_labels + (long)b * T_max;
+    int base = 0, carry = -1;  // carry: label of the frame before this chunk (-1: none)
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        int arg = -1;
+        if (t < T) {
+            const float* row = in + (long)b * sb + (long)t * st;
+            float best = row[0];
+            arg = 0;
+            for (int s = 1; s < S; ++s) {
+                const float v = row[s];
+                if (v > best) { best = v; arg = s; }
+            }
+        }
+        int prev = __shfl_up(arg, 1, 64);
+        if (lane == 0) prev = carry;
+        const bool keep = t < T && arg != blank && arg != prev;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) out[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = arg;
+        base += __popcll(mask);
+        carry = __shfl(arg, 63, 64);
+    }
+    if (lane == 0) out_lens[b] = base;
+}
+
+size_t beam_lds_bytes(int S, int W) {
+    return (size_t)(S + 9 * W + 5 * W * S + 4) * sizeof(float);
+}
+
+}  // namespace
+
+static void beam_ws_layout(int max_T, int B, int W, int* max_nodes, int* hsize, size_t* o_par, size_t* o_sym,
+                           size_t* o_keys, size_t* o_vals, size_t* total) {
+    *max_nodes = max_T * W + 2;
+    int h = 64;
+    while (h < 2 * (*max_nodes)) h <<= 1;
+    *hsize = h;
+    size_t o = 0;
+    *o_keys = o; o += sa_align_up((size_t)B * h * sizeof(unsigned long long), 256);  // first: one memset clears it
+    *o_vals = o; o += sa_align_up((size_t)B * h * sizeof(int), 256);
+    *o_par = o;  o += sa_align_up((size_t)B * (*max_nodes) * sizeof(int), 256);
+    *o_sym = o;  o += sa_align_up((size_t)B * (*max_nodes) * sizeof(int), 256);
+    *total = o;
+}
+
+extern "C" size_t sa_ctc_beam_workspace_bytes(int max_T, int alphabet_size, int minibatch, int beam_size) {
+    if (max_T <= 0 || alphabet_size <= 0 || minibatch <= 0 || beam_size <= 0) return 0;
+    int mn, hs;
+    size_t a, b, c, d, total;
+    beam_ws_layout(max_T, minibatch, beam_size, &mn, &hs, &a, &b, &c, &d, &total);
+    return total;
+}
+
+extern "C" ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long stride_b, const int* d_input_lengths,
+                                          int alphabet_size, int minibatch, int max_T, int beam_size,
+                                          int blank_label, int input_is_logits, int* d_out_labels, int* d_out_lens,
+                                          float* d_out_nll, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!in || !d_input_lengths || !d_out_labels || !d_out_lens || !workspace) return CTC_STATUS_INVALID_VALUE;
+    if (alphabet_size <= 0 || minibatch <= 0 || max_T <= 0 || beam_size <= 0 || beam_size > 64 || blank_label < 0 ||
+        blank_label >= alphabet_size)
+        return CTC_STATUS_INVALID_VALUE;
+    const size_t lds = beam_lds_bytes(alphabet_size, beam_size);
+    if (lds > 150 * 1024) return CTC_STATUS_INVALID_VALUE;  // beam_size * alphabet too large for one workgroup
+    if ((long)alphabet_size * beam_size * 2 + 2 * beam_size >= (1 << 24)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    BeamArgs A;
+    size_t o_par, o_sym, o_keys, o_vals, total;
+    beam_ws_layout(max_T, minibatch, beam_size, &A.max_nodes, &A.hsize, &o_par, &o_sym, &o_keys, &o_vals, &total);
+    if (workspace_bytes < total) return CTC_STATUS_INVALID_VALUE;
+    char* ws = (char*)workspace;
+    A.in = in; A.st = stride_t; A.sb = stride_b; A.in_lens = d_input_lengths;
+    A.S = alphabet_size; A.B = minibatch; A.T_max = max_T; A.W = beam_size; A.blank = blank_label;
+    A.is_logits = input_is_logits;
+    A.out_labels = d_out_labels; A.out_lens = d_out_lens; A.out_nll = d_out_nll;
+    A.node_parent = (int*)(ws + o_par); A.node_sym = (int*)(ws + o_sym);
+    A.hkeys = (unsigned long long*)(ws + o_keys); A.hvals = (int*)(ws + o_vals);
+    if (hipMemsetAsync(A.hkeys, 0, (size_t)minibatch * A.hsize * sizeof(unsigned long long), stream) != hipSuccess)
+        return CTC_STATUS_MEMOPS_FAILED;
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds) != hipSuccess)
+        return CTC_STATUS_EXECUTION_FAILED;
+    hipLaunchKernelGGL(ctc_beam_kernel, dim3(minibatch), dim3(64), lds, stream, A);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+extern "C" ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, const int* d_input_lengths,
+                                            int alphabet_size, int minibatch, int max_T, int blank_label,
+                                            int* d_out_labels, int* d_out_lens, void* stream_) {
+    if (!in || !d_input_lengths || !d_out_labels || !d_out_lens || alphabet_size <= 0 || minibatch <= 0 || max_T <= 0)
+        return CTC_STATUS_INVALID_VALUE;
+    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(minibatch), dim3(64), 0, (hipStream_t)stream_, in, stride_t, stride_b,
+                       d_input_lengths, alphabet_size, max_T, blank_label, d_out_labels, d_out_lens);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
