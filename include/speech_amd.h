@@ -143,8 +143,32 @@ ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, const float* h
                        const float* w_hh, float* dai, float* dah, int B, int T, int H, int reverse, void* workspace,
                        size_t workspace_bytes, void* stream);
 
-/* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients. */
-ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, float* out, int accumulate, void* stream);
+/* The whole GRU stack of Model.encode (model.py:35-39,73), TIME-MAJOR arrays: x (T, B, I0); h_out[l] (T, B, D*H);
+ * stash[l*D+d] (T, B, 5H) or stash == NULL (inference).  Parameter arrays hold L*D device pointers, index l*D + d
+ * (d = 1: the reverse direction), in nn.GRU's layouts.  Includes the input projections (MFMA GEMMs).
+ * Unidirectional stacks run as a chunked layer wavefront (`chunk` time steps per chunk, <= 0: default): layer l
+ * processes chunk c while layer l+1 processes chunk c-1, up to L layer-steps per launch.  Bidirectional stacks run
+ * layer by layer with both directions sharing each launch.  L <= 8. */
+size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, int H, int I0);
+ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
+                             const float* const* w_hh, const float* const* b_hh, float* const* h_out,
+                             float* const* stash, int L, int D, int B, int T, int H, int chunk, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* Backward through the stack.  dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d]
+ * (T, B, 3H) (gradients wrt the i2h / h2h pre-activations of every layer and direction: the weight and bias gradients
+ * are dai^T x_l, dah^T h_prev, column sums -- sa_gemm_f32 / sa_colsum_f32) and dx (T, B, I0), the gradient wrt the
+ * stack input (may be NULL). */
+size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, int H, int I0);
+ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, const float* const* w_ih,
+                             const float* const* w_hh, float* const* dai, float* const* dah, float* dx, int I0, int L,
+                             int D, int B, int T, int H, int chunk, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients; two deterministic stages through `workspace`. */
+size_t sa_colsum_workspace_bytes(int M, int N);
+ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, float* out, int accumulate, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* y[i] = a[i] + b[i] (bidirectional sum, model.py:75-77, and gradient fan-in); strided rows. */
 ctcStatus_t sa_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* y, long ldy, int rows,

@@ -1,0 +1,78 @@
+"""
+oracle/torch_ref.py -- the reference's CTC train step restated with the SAME torch.nn CPU modules the reference
+builds (so it times what the reference's CPU path actually executes), plus the C CTC restatement for the loss.
+TEST INFRASTRUCTURE ONLY: used by tests/ (pinned to tests/golden/encoder_*.npz) and as bench.py's cpu_baseline
+("port": /root/reference is not present on the GPU box and its warp-ctc dependency is not vendored at all).
+
+Restates /root/reference/speech/models/model.py:12-42,60-79 (Conv2d+ReLU stack, nn.GRU batch_first, bi-sum),
+ctc_model.py:17-19,25-40 (fc to |V|+1, CTC loss on raw logits, blank = last) and train.py:28-35
+(zero_grad, loss, backward, clip_grad_norm(200), SGD step).  The CTC loss/gradient is oracle/ctc_ref.c (float
+log-space, OpenMP over utterances -- the threading model of warp-ctc's CPU path), mean over the batch.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ctc_ref
+
+
+class TorchRefCTC(nn.Module):
+    def __init__(self, freq_dim, output_dim, config):
+        super().__init__()
+        convs, in_c = [], 1
+        for out_c, h, w, s in config["encoder"]["conv"]:
+            convs.extend([nn.Conv2d(in_c, out_c, (h, w), stride=(s, s), padding=0), nn.ReLU()])
+            if config["dropout"] != 0:
+                convs.append(nn.Dropout(p=config["dropout"]))
+            in_c = out_c
+        self.conv = nn.Sequential(*convs)
+        f = freq_dim
+        for out_c, h, w, s in config["encoder"]["conv"]:
+            f = int(math.ceil((f - w + 1) / s))
+        rnn = config["encoder"]["rnn"]
+        self.rnn = nn.GRU(input_size=out_c * f, hidden_size=rnn["dim"], num_layers=rnn["layers"], batch_first=True,
+                          dropout=config["dropout"], bidirectional=rnn["bidirectional"])
+        self.fc = nn.Module()
+        self.fc.fc = nn.Linear(rnn["dim"], output_dim + 1)
+        self.blank = output_dim
+
+    def encode(self, x):
+        x = self.conv(x.unsqueeze(1))
+        x = torch.transpose(x, 1, 2).contiguous()
+        b, t, f, c = x.size()
+        x, _ = self.rnn(x.view((b, t, f * c)))
+        if self.rnn.bidirectional:
+            half = x.size()[-1] // 2
+            x = x[:, :, :half] + x[:, :, half:]
+        return x
+
+    def forward(self, x):
+        return self.fc.fc(self.encode(x))
+
+
+class _CTCRef(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, act_lens, label_lens, blank, threads):
+        costs, grads = ctc_ref.ctc_loss(logits.detach().numpy(), labels, act_lens, label_lens, blank=blank,
+                                        dtype=np.float32, num_threads=threads)
+        B = logits.shape[0]
+        ctx.g = torch.from_numpy(grads) / B
+        return torch.tensor([costs.sum() / B], dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, go):
+        return ctx.g * go.reshape(()), None, None, None, None, None
+
+
+def train_step(model, opt, x, labels, label_lens, threads=0):
+    """One train.py:28-35 step on CPU.  x float32 (B,T,F); labels flat int32.  Returns (loss, grad_norm)."""
+    opt.zero_grad()
+    logits = model(x)
+    B, Tp, _ = logits.shape
+    loss = _CTCRef.apply(logits, labels, np.full(B, Tp, np.int32), label_lens, model.blank, threads)
+    loss.backward()
+    gn = nn.utils.clip_grad_norm_(model.parameters(), 200)
+    opt.step()
+    return float(loss.item()), float(gn)

@@ -4,6 +4,11 @@ There is NO fallback: if the HIP library is missing or a call fails, the product
 import ctypes
 import os
 
+# torch bundles its own copy of the HIP runtime (same SONAME as /opt/rocm's).  It must be mapped BEFORE
+# libspeech_amd.so so that the loader resolves our libamdhip64.so.7 dependency to that copy: two HIP runtimes in one
+# process would not share streams (launches on torch's stream handle fail).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeech_amd.so")
 
@@ -49,7 +54,12 @@ SIGNATURES = {
     "sa_gru_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sa_gru_bwd": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                            c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sa_gru_stack_fwd_workspace_bytes": (c_size_t, [c_int] * 6),
+    "sa_gru_stack_fwd": (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "sa_gru_stack_bwd_workspace_bytes": (c_size_t, [c_int] * 6),
+    "sa_gru_stack_bwd": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "sa_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
     "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),
     "sa_clip_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_void_p,

@@ -15,6 +15,10 @@
 #define SA_LOG2E 1.4426950408889634f
 #define SA_LN2 0.6931471805599453f
 
+// hipGetLastError() is per-thread sticky state shared with the host framework: clear what others left behind
+// before launching, so that SA_CHECK_LAUNCH reports only this library's own launch failures.
+#define SA_CLEAR_ERR() ((void)hipGetLastError())
+
 #define SA_CHECK_LAUNCH()                                             \
     do {                                                              \
         hipError_t e__ = hipGetLastError();                           \

@@ -99,6 +99,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
                                           int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
                                           long ys_c, long ys_t, void* workspace, size_t workspace_bytes,
                                           void* stream_) {
+    SA_CLEAR_ERR();
     ConvGeom g;
     if (!x || !w || !bias || !y || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
         return CTC_STATUS_INVALID_VALUE;
@@ -122,6 +123,8 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
     size_t gw = sa_gemm_workspace_bytes(g.O, g.K, (int)npos);
     const size_t gw2 = sa_gemm_workspace_bytes((int)npos, g.K, g.O);
     if (gw2 > gw) gw = gw2;
+    const size_t gw3 = sa_colsum_workspace_bytes((int)npos, g.O);
+    if (gw3 > gw) gw = gw3;
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +   // cols, reused for dcols
            sa_align_up((size_t)npos * g.O * sizeof(float), 256) +   // dyp
            sa_align_up(gw, 256);
@@ -131,6 +134,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
                                           float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh,
                                           int kw, int s, long ys_b, long ys_c, long ys_t, void* workspace,
                                           size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
     ConvGeom g;
     if (!x || !w || !y || !dy || !dw || !dbias || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
         return CTC_STATUS_INVALID_VALUE;
@@ -149,7 +153,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
     ctcStatus_t st = sa_gemm_f32_impl(1, 0, g.O, g.K, (int)npos, 1.0f, dyp, g.O, cols, g.K, 0.f, dw, g.K, nullptr,
                                       nullptr, gws, gws_bytes, stream);
     if (st != CTC_STATUS_SUCCESS) return st;
-    st = sa_colsum_f32(dyp, g.O, (int)npos, g.O, dbias, 0, stream_);
+    st = sa_colsum_f32(dyp, g.O, (int)npos, g.O, dbias, 0, gws, gws_bytes, stream_);
     if (st != CTC_STATUS_SUCCESS) return st;
     if (dx) {
         // dcols[pos, k] = sum_o dyp[pos, o] * w[o, k]   (overwrites cols), then gather into dx

@@ -308,6 +308,7 @@ extern "C" ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long s
                                           int alphabet_size, int minibatch, int max_T, int beam_size,
                                           int blank_label, int input_is_logits, int* d_out_labels, int* d_out_lens,
                                           float* d_out_nll, void* workspace, size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
     if (!in || !d_input_lengths || !d_out_labels || !d_out_lens || !workspace) return CTC_STATUS_INVALID_VALUE;
     if (alphabet_size <= 0 || minibatch <= 0 || max_T <= 0 || beam_size <= 0 || beam_size > 64 || blank_label < 0 ||
         blank_label >= alphabet_size)
@@ -340,6 +341,7 @@ extern "C" ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long s
 extern "C" ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, const int* d_input_lengths,
                                             int alphabet_size, int minibatch, int max_T, int blank_label,
                                             int* d_out_labels, int* d_out_lens, void* stream_) {
+    SA_CLEAR_ERR();
     if (!in || !d_input_lengths || !d_out_labels || !d_out_lens || alphabet_size <= 0 || minibatch <= 0 || max_T <= 0)
         return CTC_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(ctc_greedy_kernel, dim3(minibatch), dim3(64), 0, (hipStream_t)stream_, in, stride_t, stride_b,

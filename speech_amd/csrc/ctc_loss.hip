@@ -419,6 +419,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
                                    const int* d_input_lengths, int alphabet_size, int minibatch, int max_T,
                                    int max_L, int blank_label, float* d_costs, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
     if (!acts || !d_flat_labels || !d_label_lengths || !d_input_lengths || !d_costs || !workspace)
         return CTC_STATUS_INVALID_VALUE;
     if (alphabet_size <= 0 || minibatch <= 0 || max_T <= 0 || max_L < 0 || blank_label < 0 ||
@@ -517,6 +518,7 @@ static bool host_shape(const int* label_lengths, const int* input_lengths, int B
 
 extern "C" ctcStatus_t get_workspace_size(const int* label_lengths, const int* input_lengths, int alphabet_size,
                                           int minibatch, ctcOptions options, size_t* size_bytes) {
+    SA_CLEAR_ERR();
     if (!label_lengths || !input_lengths || !size_bytes || alphabet_size <= 0 || minibatch <= 0)
         return CTC_STATUS_INVALID_VALUE;
     if (options.loc != CTC_GPU) return CTC_STATUS_EXECUTION_FAILED;
@@ -536,6 +538,7 @@ extern "C" ctcStatus_t get_workspace_size(const int* label_lengths, const int* i
 extern "C" ctcStatus_t compute_ctc_loss(const float* activations, float* gradients, const int* flat_labels,
                                         const int* label_lengths, const int* input_lengths, int alphabet_size,
                                         int minibatch, float* costs, void* workspace, ctcOptions options) {
+    SA_CLEAR_ERR();
     if (!activations || !flat_labels || !label_lengths || !input_lengths || !costs || !workspace ||
         alphabet_size <= 0 || minibatch <= 0)
         return CTC_STATUS_INVALID_VALUE;

@@ -228,6 +228,7 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
                              const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
                              const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes,
                              hipStream_t stream) {
+    SA_CLEAR_ERR();
     if (M < 0 || N < 0 || K < 0) return CTC_STATUS_INVALID_VALUE;
     if (M == 0 || N == 0) return CTC_STATUS_SUCCESS;
     if (!A || !B || !C) return CTC_STATUS_INVALID_VALUE;
@@ -282,6 +283,7 @@ extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) {
 extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                                    long lda, const float* B, long ldb, float beta, float* C, long ldc,
                                    const float* bias, void* workspace, size_t workspace_bytes, void* stream) {
+    SA_CLEAR_ERR();
     return sa_gemm_f32_impl(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, nullptr, workspace,
                             workspace_bytes, (hipStream_t)stream);
 }

@@ -7,6 +7,11 @@
 //
 // One launch per time step ("job list" kernel: blockIdx.z selects one of up to 8 independent (layer, direction, t)
 // jobs, so both directions of a bidirectional layer -- or a diagonal of a layer stack -- share a launch).
+// The step is a dependent-latency chain (operand fetch from other CUs' output -> MFMA -> LDS reduce -> gate math), not
+// a throughput problem, so sa_gru_stack_fwd/bwd run a unidirectional stack as a CHUNKED LAYER WAVEFRONT: layer l works
+// on time chunk c while layer l+1 works on chunk c-1, one launch carrying up to L layer-steps (L x fewer serial
+// launches, all 256 CUs busy); the input projections of a chunk are a plain row-range GEMM because activations are
+// kept time-major (T, B, .) inside the stack.
 // A block owns a 16 (batch) x 16 (hidden units) output tile: the small-M product is computed on
 // v_mfma_f32_16x16x4_f32 with the K dimension split over the block's 4 waves (one per SIMD), operands loaded
 // straight from L2 into MFMA fragments with 16-byte loads (k-contiguous rows on both sides, so no LDS staging),
@@ -15,6 +20,7 @@
 //   backward: 1 tile of dh_{t-1} = dah_t W_hh (rows of W_hh^T, transposed once per call) x K = 3H, then the gate
 //             gradients of step t-1 in the epilogue (they become the next launch's A operand).
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -61,18 +67,22 @@ __device__ __forceinline__ void smallm_mfma(const float* __restrict__ a_row, con
     }
 }
 
+
+// Row-structured arrays (ai, stash, dai, dah) address row (b, t) as  b * rb + t * rt  (time-major: rb = 1, rt = B;
+// batch-major: rb = T, rt = 1).
 // ------------------------------------------------------------------------------------------------------ forward step
 struct FwdJob {
-    const float* ai;     // (B, T, 3H)
+    const float* ai;     // rows x 3H
     const float* w_hh;   // (3H, H)
     const float* b_hh;   // (3H)
     float* h_out;        // [b * hs_b + t * hs_t + j]
-    float* stash;        // (B, T, 5H) or null: r, z, n, q, h_{t-1}
+    float* stash;        // rows x 5H or null: r, z, n, q, h_{t-1}
     long hs_b, hs_t;
     int t, t_prev;       // t_prev < 0: first step (h_{t-1} = 0)
 };
 struct FwdJobs {
-    int n, B, T, H;
+    int n, B, H;
+    long rb, rt;
     FwdJob j[kMaxJobs];
 };
 
@@ -83,8 +93,22 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const bool first = J.t_prev < 0;
 
-    if (J.t_prev >= 0) {
+    // epilogue operands first: their latency overlaps the operand fetch + MFMA phase
+    const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B && u < H;
+    float e_ai_r = 0.f, e_ai_z = 0.f, e_ai_n = 0.f, e_br = 0.f, e_bz = 0.f, e_bn = 0.f, hp = 0.f;
+    const long row = live ? (long)b * P.rb + (long)J.t * P.rt : 0;
+    if (live) {
+        const float* ai = J.ai + row * 3 * H;
+        e_ai_r = ai[u]; e_ai_z = ai[H + u]; e_ai_n = ai[2 * H + u];
+        e_br = J.b_hh[u]; e_bz = J.b_hh[H + u]; e_bn = J.b_hh[2 * H + u];
+        if (!first) hp = J.h_out[(long)b * J.hs_b + (long)J.t_prev * J.hs_t + u];
+    }
+
+    if (!first) {
         const int kslice = ((H + 63) / 64) * 16;  // per-wave K slice, multiple of 16
         const int kbeg = wave * kslice, kend = min(H, kbeg + kslice);
         const int brow = min(b0 + i, B - 1);
@@ -103,50 +127,44 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
             for (int r = 0; r < 4; ++r) red[wave][n][(g * 4 + r) * 16 + i] = acc[n][r];
     }
     __syncthreads();
-
-    const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
-    const int b = b0 + bi, u = u0 + uj;
-    if (b >= B || u >= H) return;
-    float sr = 0.f, sz = 0.f, sn = 0.f, hp = 0.f;
-    if (J.t_prev >= 0) {
+    if (!live) return;
+    float sr = 0.f, sz = 0.f, sn = 0.f;
+    if (!first) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             sr += red[w][0][threadIdx.x];
             sz += red[w][1][threadIdx.x];
             sn += red[w][2][threadIdx.x];
         }
-        hp = J.h_out[(long)b * J.hs_b + (long)J.t_prev * J.hs_t + u];
     }
-    const float* ai = J.ai + ((long)b * P.T + J.t) * 3 * H;
-    const float r = sigmoidf_(ai[u] + sr + J.b_hh[u]);
-    const float z = sigmoidf_(ai[H + u] + sz + J.b_hh[H + u]);
-    const float q = sn + J.b_hh[2 * H + u];
-    const float n = tanhf(ai[2 * H + u] + r * q);
+    const float r = sigmoidf_(e_ai_r + sr + e_br);
+    const float z = sigmoidf_(e_ai_z + sz + e_bz);
+    const float q = sn + e_bn;
+    const float n = tanhf(e_ai_n + r * q);
     const float h = (1.0f - z) * n + z * hp;
     J.h_out[(long)b * J.hs_b + (long)J.t * J.hs_t + u] = h;
     if (J.stash) {
-        float* s = J.stash + ((long)b * P.T + J.t) * 5 * H;
+        float* s = J.stash + row * 5 * H;
         s[u] = r; s[H + u] = z; s[2 * H + u] = n; s[3 * H + u] = q; s[4 * H + u] = hp;
     }
 }
 
 // ----------------------------------------------------------------------------------------------------- backward step
 struct BwdJob {
-    const float* dh_out;  // gradient wrt h_out, same strides
-    const float* h_out;
-    const float* stash;   // (B, T, 5H)
+    const float* dh_out;  // gradient wrt h_out, [b * ds_b + t * ds_t + j]
+    const float* stash;   // rows x 5H
     const float* w_hh_t;  // (H, 3H): W_hh transposed
-    float* dai;           // (B, T, 3H)
-    float* dah;           // (B, T, 3H)
+    float* dai;           // rows x 3H
+    float* dah;           // rows x 3H
     float* dh_ping;       // (B, H) running dh of the step being produced (write)
     const float* dh_pong; // (B, H) running dh of the previously produced step (read)
-    long hs_b, hs_t;
+    long ds_b, ds_t;
     int t;                // step whose gate gradients this launch produces
-    int t_next;           // step processed by the previous launch (t+1 forward-in-time layers), < 0: none
-    int t_prev;           // step feeding h_{t-1} into step t (t-1), < 0: h_{t-1} = 0
+    int t_next;           // step processed by the previous launch of this job (< 0: none)
 };
 struct BwdJobs {
-    int n, B, T, H;
+    int n, B, H;
+    long rb, rt;
     BwdJob j[kMaxJobs];
 };
 
@@ -157,41 +175,50 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const bool have_next = J.t_next >= 0;
 
-    if (J.t_next >= 0) {  // dh_t += dah_{t_next} W_hh   (K = 3H)
+    const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B && u < H;
+    const long row = live ? (long)b * P.rb + (long)J.t * P.rt : 0;
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f, z_next = 0.f, dh_prev = 0.f;
+    if (live) {  // epilogue operands first (see the forward kernel)
+        dh = J.dh_out[(long)b * J.ds_b + (long)J.t * J.ds_t + u];
+        const float* s = J.stash + row * 5 * H;
+        r = s[u]; z = s[H + u]; n = s[2 * H + u]; q = s[3 * H + u]; hp = s[4 * H + u];
+        if (have_next) {
+            z_next = J.stash[((long)b * P.rb + (long)J.t_next * P.rt) * 5 * H + H + u];
+            dh_prev = J.dh_pong[(long)b * H + u];
+        }
+    }
+
+    if (have_next) {  // dh_t += dah_{t_next} W_hh   (K = 3H)
         const int kslice = ((H3 + 63) / 64) * 16;
         const int kbeg = wave * kslice, kend = min(H3, kbeg + kslice);
         const int brow = min(b0 + i, B - 1);
         const int urow = min(u0 + i, H - 1);
-        const float* a_row = J.dah + ((long)brow * P.T + J.t_next) * H3;
+        const float* a_row = J.dah + ((long)brow * P.rb + (long)J.t_next * P.rt) * H3;
         const float* b_rows[1] = {J.w_hh_t + (long)urow * H3};
         f32x4 acc[1];
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         smallm_mfma<1>(a_row, b_rows, kbeg, kend, H3, acc, g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][(g * 4 + r) * 16 + i] = acc[0][r];
+        for (int rr = 0; rr < 4; ++rr) red[wave][(g * 4 + rr) * 16 + i] = acc[0][rr];
     }
     __syncthreads();
-
-    const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
-    const int b = b0 + bi, u = u0 + uj;
-    if (b >= B || u >= H) return;
-    float dh = J.dh_out[(long)b * J.hs_b + (long)J.t * J.hs_t + u];
-    if (J.t_next >= 0) {
+    if (!live) return;
+    if (have_next) {
         dh += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        const float z_next = J.stash[((long)b * P.T + J.t_next) * 5 * H + H + u];
-        dh += J.dh_pong[(long)b * H + u] * z_next;
+        dh += dh_prev * z_next;
     }
     J.dh_ping[(long)b * H + u] = dh;
-    const float* s = J.stash + ((long)b * P.T + J.t) * 5 * H;
-    const float r = s[u], z = s[H + u], n = s[2 * H + u], q = s[3 * H + u], hp = s[4 * H + u];
     const float dn = dh * (1.0f - z);
     const float dz = dh * (hp - n);
     const float dpn = dn * (1.0f - n * n);
     const float dpr = dpn * q * r * (1.0f - r);
     const float dpz = dz * z * (1.0f - z);
-    float* di = J.dai + ((long)b * P.T + J.t) * H3;
-    float* dhh = J.dah + ((long)b * P.T + J.t) * H3;
+    float* di = J.dai + row * H3;
+    float* dhh = J.dah + row * H3;
     di[u] = dpr; di[H + u] = dpz; di[2 * H + u] = dpn;
     dhh[u] = dpr; dhh[H + u] = dpz; dhh[2 * H + u] = dpn * r;
 }
@@ -209,23 +236,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (c0 + k < C && r0 + tx < R) out[(long)(c0 + k) * R + r0 + tx] = tile[tx][k];
 }
 
-// out[n] (+)= sum_m a[m * lda + n]: block = 32 columns x 8 row-lanes, fixed reduction order (deterministic)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, long lda, int M, int N,
-                                                     float* __restrict__ out, int accumulate) {
-    __shared__ float red[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int n = blockIdx.x * 32 + tx;
-    float s = 0.f;
-    if (n < N)
-        for (int m = ty; m < M; m += 8) s += a[(long)m * lda + n];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && n < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][tx];
-        out[n] = accumulate ? out[n] + t : t;
+// Column sums in two deterministic stages: grid (N/64, R) blocks each reduce a row range of 64 columns into
+// part[r][n]; the second kernel adds the R partials in order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, long lda, int M, int N,
+                                                             int rows_per, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        int m = m0 + ty;
+        for (; m + 4 < m1; m += 8) {  // two independent accumulators: loads in flight
+            s0 += a[(long)m * lda + n];
+            s1 += a[(long)(m + 4) * lda + n];
+        }
+        if (m < m1) s0 += a[(long)m * lda + n];
     }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int R, int N,
+                                                           float* __restrict__ out, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += part[(long)r * N + n];
+    out[n] = accumulate ? out[n] + s : s;
 }
 
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, long lda,
@@ -237,17 +276,26 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
     y[(long)r * ldy + c] = a[(long)r * lda + c] + b[(long)r * ldb + c];
 }
 
+int colsum_parts(int M) {
+    int r = (M + 127) / 128;
+    return r > 256 ? 256 : (r < 1 ? 1 : r);
+}
+
+bool aligned4(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------ host
+// One direction of one layer, batch-major (B, T, .) arrays: the building-block entry points.
 extern "C" ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const float* b_hh, float* h_out, long hs_b,
                                   long hs_t, float* stash, int B, int T, int H, int reverse, void* stream_) {
+    SA_CLEAR_ERR();
     if (!ai || !w_hh || !b_hh || !h_out || B <= 0 || T <= 0 || H <= 0) return CTC_STATUS_INVALID_VALUE;
-    if ((H & 3) || (hs_b & 3) || (hs_t & 3) || ((uintptr_t)h_out & 15) || ((uintptr_t)w_hh & 15))
+    if ((H & 3) || (hs_b & 3) || (hs_t & 3) || !aligned4(h_out) || !aligned4(w_hh))
         return CTC_STATUS_INVALID_VALUE;  // 16-byte fragment loads need 4-float alignment
     hipStream_t stream = (hipStream_t)stream_;
     FwdJobs P;
-    P.n = 1; P.B = B; P.T = T; P.H = H;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1;
     FwdJob& J = P.j[0];
     J.ai = ai; J.w_hh = w_hh; J.b_hh = b_hh; J.h_out = h_out; J.stash = stash; J.hs_b = hs_b; J.hs_t = hs_t;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -269,9 +317,11 @@ extern "C" size_t sa_gru_bwd_workspace_bytes(int B, int T, int H) {
 extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, const float* h_out, const float* stash,
                                   const float* w_hh, float* dai, float* dah, int B, int T, int H, int reverse,
                                   void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!dh_out || !h_out || !stash || !w_hh || !dai || !dah || !workspace || B <= 0 || T <= 0 || H <= 0)
+    SA_CLEAR_ERR();
+    (void)h_out;  // h_{t-1} is read from the stash
+    if (!dh_out || !stash || !w_hh || !dai || !dah || !workspace || B <= 0 || T <= 0 || H <= 0)
         return CTC_STATUS_INVALID_VALUE;
-    if ((H & 3) || ((uintptr_t)dah & 15) || workspace_bytes < sa_gru_bwd_workspace_bytes(B, T, H))
+    if ((H & 3) || !aligned4(dah) || workspace_bytes < sa_gru_bwd_workspace_bytes(B, T, H))
         return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     float* dh0 = (float*)workspace;
@@ -280,16 +330,15 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
     hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream, w_hh, w_t,
                        3 * H, H);
     BwdJobs P;
-    P.n = 1; P.B = B; P.T = T; P.H = H;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1;
     BwdJob& J = P.j[0];
-    J.dh_out = dh_out; J.h_out = h_out; J.stash = stash; J.w_hh_t = w_t; J.dai = dai; J.dah = dah;
-    J.hs_b = hs_b; J.hs_t = hs_t;
+    J.dh_out = dh_out; J.stash = stash; J.w_hh_t = w_t; J.dai = dai; J.dah = dah;
+    J.ds_b = hs_b; J.ds_t = hs_t;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     for (int s = 0; s < T; ++s) {
         // forward-in-time layers are unwound from t = T-1 down to 0; reverse layers from t = 0 up to T-1
         J.t = reverse ? s : T - 1 - s;
         J.t_next = s == 0 ? -1 : (reverse ? J.t - 1 : J.t + 1);
-        J.t_prev = reverse ? (J.t + 1 < T ? J.t + 1 : -1) : (J.t - 1);
         J.dh_ping = (s & 1) ? dh1 : dh0;
         J.dh_pong = (s & 1) ? dh0 : dh1;
         hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, stream, P);
@@ -298,17 +347,231 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
     return CTC_STATUS_SUCCESS;
 }
 
+// ------------------------------------------------------------------------------------------------- the layer stack
+// Time-major arrays throughout: x (T, B, I0); h_out[l] (T, B, D*H); ai / stash / dai / dah [l*D+d] (T, B, .).
+static size_t stack_ai_bytes(int B, int T, int H) { return sa_align_up((size_t)T * B * 3 * H * sizeof(float), 256); }
+
+extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, int H, int I0) {
+    if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
+    return (size_t)L * D * stack_ai_bytes(B, T, H);
+}
+
+extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
+                                        const float* const* w_hh, const float* const* b_hh, float* const* h_out,
+                                        float* const* stash, int L, int D, int B, int T, int H, int chunk,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
+    if (!x || !w_ih || !b_ih || !w_hh || !b_hh || !h_out || !workspace) return CTC_STATUS_INVALID_VALUE;
+    if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
+        return CTC_STATUS_INVALID_VALUE;
+    if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (chunk <= 0) chunk = 32;
+    auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
+    const long DH = (long)D * H;
+    dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
+    ctcStatus_t st;
+
+    auto make_job = [&](int l, int d, int t, int t_prev) {
+        FwdJob J;
+        J.ai = ai_of(l, d); J.w_hh = w_hh[l * D + d]; J.b_hh = b_hh[l * D + d];
+        J.h_out = h_out[l] + (long)d * H; J.stash = stash ? stash[l * D + d] : nullptr;
+        J.hs_b = DH; J.hs_t = (long)B * DH; J.t = t; J.t_prev = t_prev;
+        return J;
+    };
+    FwdJobs P;
+    P.B = B; P.H = H; P.rb = 1; P.rt = B;
+
+    if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
+                   // the two directions of a layer share every launch
+        for (int l = 0; l < L; ++l) {
+            const float* in = l == 0 ? x : h_out[l - 1];
+            const int I = l == 0 ? I0 : 2 * H;
+            for (int d = 0; d < 2; ++d) {
+                st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I, 1.f, in, I, w_ih[l * 2 + d], I, 0.f, ai_of(l, d), 3 * H,
+                                      b_ih[l * 2 + d], nullptr, nullptr, 0, stream);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
+            P.n = 2; grid.z = 2;
+            for (int s = 0; s < T; ++s) {
+                P.j[0] = make_job(l, 0, s, s == 0 ? -1 : s - 1);
+                P.j[1] = make_job(l, 1, T - 1 - s, s == 0 ? -1 : T - s);
+                hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, stream, P);
+            }
+        }
+        SA_CHECK_LAUNCH();
+        return CTC_STATUS_SUCCESS;
+    }
+
+    // unidirectional: chunked layer wavefront.  Layer 0's input projection for all t up front.
+    st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I0, 1.f, x, I0, w_ih[0], I0, 0.f, ai_of(0, 0), 3 * H, b_ih[0], nullptr,
+                          nullptr, 0, stream);
+    if (st != CTC_STATUS_SUCCESS) return st;
+    const int nch = (T + chunk - 1) / chunk;
+    for (int w = 0; w < nch + L - 1; ++w) {
+        // input projections of the chunk each upper layer is about to process (its lower layer finished it last wave)
+        for (int l = 1; l < L; ++l) {
+            const int c = w - l;
+            if (c < 0 || c >= nch) continue;
+            const int t0 = c * chunk, t1 = min(T, t0 + chunk);
+            st = sa_gemm_f32_impl(0, 1, (t1 - t0) * B, 3 * H, H, 1.f, h_out[l - 1] + (long)t0 * B * H, H, w_ih[l], H,
+                                  0.f, ai_of(l, 0) + (long)t0 * B * 3 * H, 3 * H, b_ih[l], nullptr, nullptr, 0, stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+        }
+        for (int s = 0; s < chunk; ++s) {
+            int n = 0;
+            for (int l = 0; l < L; ++l) {
+                const int c = w - l;
+                if (c < 0 || c >= nch) continue;
+                const int t = c * chunk + s;
+                if (t >= T) continue;
+                P.j[n++] = make_job(l, 0, t, t == 0 ? -1 : t - 1);
+            }
+            if (n == 0) continue;
+            P.n = n; grid.z = n;
+            hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, stream, P);
+        }
+    }
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, int H, int I0) {
+    if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
+    const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +      // dh ping-pong
+                           sa_align_up((size_t)3 * H * H * sizeof(float), 256);       // W_hh^T
+    const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
+    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid;
+}
+
+// dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d] (T, B, 3H) for every layer and
+// direction, and dx (T, B, I0) = gradient wrt the stack input (may be NULL).
+extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, const float* const* w_ih,
+                                        const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
+                                        int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
+    if (!dh_top || !stash || !w_ih || !w_hh || !dai || !dah || !workspace) return CTC_STATUS_INVALID_VALUE;
+    if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
+        return CTC_STATUS_INVALID_VALUE;
+    if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (chunk <= 0) chunk = 32;
+    const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
+                           sa_align_up((size_t)3 * H * H * sizeof(float), 256);
+    const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
+    char* ws = (char*)workspace;
+    auto dh_buf = [&](int l, int d, int which) {
+        return (float*)(ws + (size_t)(l * D + d) * per_dir) + (size_t)which * B * H;
+    };
+    auto wt_of = [&](int l, int d) {
+        return (float*)(ws + (size_t)(l * D + d) * per_dir + sa_align_up((size_t)2 * B * H * sizeof(float), 256));
+    };
+    auto mid_of = [&](int l) { return (float*)(ws + (size_t)L * D * per_dir + (size_t)l * mid_bytes); };  // l < L-1
+    const long DH = (long)D * H;
+    for (int l = 0; l < L; ++l)
+        for (int d = 0; d < D; ++d)
+            hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream,
+                               w_hh[l * D + d], wt_of(l, d), 3 * H, H);
+    dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
+    BwdJobs P;
+    P.B = B; P.H = H; P.rb = 1; P.rt = B;
+    ctcStatus_t st;
+    // step counter per (layer, dir) selects the ping-pong buffer
+    auto make_job = [&](int l, int d, int t, int t_next, int step) {
+        BwdJob J;
+        const float* dho = (l == L - 1) ? dh_top : mid_of(l);
+        J.dh_out = dho + (long)d * H; J.ds_b = DH; J.ds_t = (long)B * DH;
+        J.stash = stash[l * D + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * D + d]; J.dah = dah[l * D + d];
+        J.dh_ping = dh_buf(l, d, step & 1); J.dh_pong = dh_buf(l, d, (step & 1) ^ 1);
+        J.t = t; J.t_next = t_next;
+        return J;
+    };
+
+    if (D == 2) {
+        for (int l = L - 1; l >= 0; --l) {
+            P.n = 2; grid.z = 2;
+            for (int s = 0; s < T; ++s) {
+                P.j[0] = make_job(l, 0, T - 1 - s, s == 0 ? -1 : T - s, s);      // forward-in-time direction unwinds
+                P.j[1] = make_job(l, 1, s, s == 0 ? -1 : s - 1, s);              // reverse direction unwinds forward
+                hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, stream, P);
+            }
+            // gradient wrt this layer's input = sum over directions of dai W_ih
+            float* din = l > 0 ? mid_of(l - 1) : dx;
+            const int I = l > 0 ? 2 * H : I0;
+            if (din)
+                for (int d = 0; d < 2; ++d) {
+                    st = sa_gemm_f32_impl(0, 0, T * B, I, 3 * H, 1.f, dai[l * 2 + d], 3 * H, w_ih[l * 2 + d], I,
+                                          d ? 1.f : 0.f, din, I, nullptr, nullptr, nullptr, 0, stream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
+        }
+        SA_CHECK_LAUNCH();
+        return CTC_STATUS_SUCCESS;
+    }
+
+    // unidirectional: the wavefront runs top layer first, time chunks from the end
+    const int nch = (T + chunk - 1) / chunk;
+    for (int w = 0; w < nch + L - 1; ++w) {
+        // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
+        for (int l = L - 2; l >= 0; --l) {
+            const int cc = w - (L - 1 - l);
+            if (cc < 0 || cc >= nch) continue;
+            const int c = nch - 1 - cc;
+            const int t0 = c * chunk, t1 = min(T, t0 + chunk);
+            st = sa_gemm_f32_impl(0, 0, (t1 - t0) * B, H, 3 * H, 1.f, dai[l + 1] + (long)t0 * B * 3 * H, 3 * H,
+                                  w_ih[l + 1], H, 0.f, mid_of(l) + (long)t0 * B * H, H, nullptr, nullptr, nullptr, 0,
+                                  stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+        }
+        for (int s = 0; s < chunk; ++s) {
+            int n = 0;
+            for (int l = L - 1; l >= 0; --l) {
+                const int cc = w - (L - 1 - l);
+                if (cc < 0 || cc >= nch) continue;
+                const int c = nch - 1 - cc;
+                const int t = c * chunk + (chunk - 1 - s);
+                if (t >= T) continue;
+                P.j[n++] = make_job(l, 0, t, t == T - 1 ? -1 : t + 1, T - 1 - t);
+            }
+            if (n == 0) continue;
+            P.n = n; grid.z = n;
+            hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, stream, P);
+        }
+    }
+    SA_CHECK_LAUNCH();
+    if (dx) {
+        st = sa_gemm_f32_impl(0, 0, T * B, I0, 3 * H, 1.f, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, nullptr,
+                              nullptr, 0, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+    }
+    return CTC_STATUS_SUCCESS;
+}
+
+extern "C" size_t sa_colsum_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)colsum_parts(M) * N * sizeof(float);
+}
+
 extern "C" ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, float* out, int accumulate,
-                                     void* stream_) {
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
     if (!a || !out || M < 0 || N <= 0) return CTC_STATUS_INVALID_VALUE;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream_, a, lda, M, N, out,
-                       accumulate);
+    const int R = colsum_parts(M > 0 ? M : 1);
+    if (!workspace || workspace_bytes < (size_t)R * N * sizeof(float)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int rows_per = (M + R - 1) / R;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, R), dim3(256), 0, stream, a, lda, M, N,
+                       rows_per > 0 ? rows_per : 1, (float*)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, R, N,
+                       out, accumulate);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
 
 extern "C" ctcStatus_t sa_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* y, long ldy,
                                        int rows, int cols, void* stream_) {
+    SA_CLEAR_ERR();
     if (!a || !b || !y || rows < 0 || cols < 0) return CTC_STATUS_INVALID_VALUE;
     const long total = (long)rows * cols;
     if (total == 0) return CTC_STATUS_SUCCESS;

@@ -13,3 +13,4 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
                              const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
                              const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes, hipStream_t stream);
 extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K);
+extern "C" size_t sa_colsum_workspace_bytes(int M, int N);

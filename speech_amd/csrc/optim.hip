@@ -70,6 +70,7 @@ extern "C" size_t sa_sgd_workspace_bytes(size_t n) { (void)n; return kMaxPartial
 extern "C" ctcStatus_t sa_clip_sgd_step(float* params, float* grads, float* momentum_buf, size_t n, float lr,
                                         float momentum, float max_norm, float grad_scale, float* d_norm_out,
                                         void* workspace, size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
     if (!params || !grads || !workspace || workspace_bytes < sa_sgd_workspace_bytes(n)) return CTC_STATUS_INVALID_VALUE;
     if (n == 0) return CTC_STATUS_SUCCESS;
     hipStream_t stream = (hipStream_t)stream_;

@@ -25,7 +25,36 @@ def _host_i32(v):
     return np.asarray(v, np.int32).reshape(-1)
 
 
-def ctc_loss_raw(acts, labels, act_lens, label_lens, blank=None, batch_first=True, want_grad=True):
+class CTCLabels:
+    """Labels / lengths of one batch, validated on the host once and staged on the device.  CTCLoss accepts this in
+    place of the `labels` tensor (then act_lens / label_lens are ignored) so that a training loop whose labels are
+    already resident issues no host->device copy per step."""
+
+    def __init__(self, labels, act_lens, label_lens, device):
+        lab_h, alen_h, llen_h = _host_i32(labels), _host_i32(act_lens), _host_i32(label_lens)
+        self.B = alen_h.shape[0]
+        if llen_h.shape[0] != self.B or lab_h.shape[0] != int(llen_h.sum()):
+            raise _lib.SpeechAmdError("CTCLoss: label / length tensors do not match the batch")
+        if alen_h.min() < 0 or llen_h.min() < 0:
+            raise _lib.SpeechAmdError("CTCLoss: bad lengths")
+        self.lab_h, self.alen_h = lab_h, alen_h
+        self.max_T, self.max_L = max(int(alen_h.max()), 1), int(llen_h.max())
+        ints = torch.from_numpy(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)])).to(device)
+        self.d_alen, self.d_llen, self.d_lab = ints[:self.B], ints[self.B:2 * self.B], ints[2 * self.B:]
+        self._checked = None
+
+    def check(self, B, T, K, blank):
+        key = (B, T, K, blank)
+        if self._checked == key:
+            return
+        if self.B != B or int(self.alen_h.max()) > T:
+            raise _lib.SpeechAmdError("CTCLoss: label / length tensors do not match the batch")
+        if self.lab_h.size and (self.lab_h.min() < 0 or self.lab_h.max() >= K or (self.lab_h == blank).any()):
+            raise _lib.SpeechAmdError("CTCLoss: labels must be in [0, %d) and differ from blank=%d" % (K, blank))
+        self._checked = key
+
+
+def ctc_loss_raw(acts, labels, act_lens=None, label_lens=None, blank=None, batch_first=True, want_grad=True):
     """Un-reduced face of the HIP kernels: returns (costs (B,), grads like acts or None), both on the GPU.
     costs[b] = -log p(labels_b | acts_b);  grads = d costs[b] / d acts (no batch scaling)."""
     _lib.require_cuda(acts, "acts")
@@ -33,32 +62,28 @@ def ctc_loss_raw(acts, labels, act_lens, label_lens, blank=None, batch_first=Tru
         raise _lib.SpeechAmdError("acts must be a float32 (B, T, V) tensor")
     L = _lib.lib()
     a = acts.detach()
-    if not a.is_contiguous():
-        a = a.contiguous()
+    if not (a.is_contiguous() or (a.stride(2) == 1 and a.transpose(0, 1).is_contiguous())):
+        a = a.contiguous()  # anything but a packed (B,T,V) / (T,B,V) buffer is repacked
     if batch_first:
         B, T, K = a.shape
-        st, sb = K, T * K
+        st, sb = a.stride(1), a.stride(0)
     else:
         T, B, K = a.shape
-        st, sb = B * K, K
+        st, sb = a.stride(0), a.stride(1)
     if blank is None:
         blank = K - 1
     dev = a.device
-    lab_h, alen_h, llen_h = _host_i32(labels), _host_i32(act_lens), _host_i32(label_lens)
-    if alen_h.shape[0] != B or llen_h.shape[0] != B or lab_h.shape[0] != int(llen_h.sum()):
-        raise _lib.SpeechAmdError("CTCLoss: label / length tensors do not match the batch")
-    if lab_h.size and (lab_h.min() < 0 or lab_h.max() >= K or (lab_h == blank).any()):
-        raise _lib.SpeechAmdError("CTCLoss: labels must be in [0, %d) and differ from blank=%d" % (K, blank))
-    if alen_h.min() < 0 or alen_h.max() > T or llen_h.min() < 0:
-        raise _lib.SpeechAmdError("CTCLoss: bad lengths")
-    max_T, max_L = max(int(alen_h.max()), 1), int(llen_h.max())
-    ints = torch.from_numpy(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)])).to(dev)
-    d_alen, d_llen, d_lab = ints[:B], ints[B:2 * B], ints[2 * B:]
+    prep = labels if isinstance(labels, CTCLabels) else CTCLabels(labels, act_lens, label_lens, dev)
+    prep.check(B, T, K, blank)
+    max_T, max_L = prep.max_T, prep.max_L
+    d_alen, d_llen, d_lab = prep.d_alen, prep.d_llen, prep.d_lab
     costs = torch.empty(B, dtype=torch.float32, device=dev)
     grads = None
     if want_grad:
         # rows beyond every utterance's length are never visited by the kernels
-        grads = torch.zeros_like(a) if max_T < T else torch.empty_like(a)
+        grads = torch.empty_strided(a.shape, a.stride(), dtype=torch.float32, device=dev)  # same layout as acts
+        if max_T < T:
+            grads.zero_()
     nbytes = L.sa_ctc_workspace_bytes(max_T, max_L, K, B)
     ws = _lib.WORKSPACE.get(nbytes, dev, "ctc")
     _lib.check(L.sa_ctc_loss(_lib.ptr(a), _lib.ptr(grads), st, sb, _lib.ptr(d_lab), _lib.ptr(d_llen),

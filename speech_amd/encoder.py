@@ -5,8 +5,13 @@ ctc_model.py:25-32 (CTC.forward_impl) run through torch.nn / cuDNN, plus the bac
 reference (train.py:30).  One torch.autograd.Function covers the whole network, so the backward is an explicit,
 fixed sequence of kernels writing every parameter gradient straight into its slot (no per-op autograd graph).
 
+Inside the encoder every activation is TIME-MAJOR (T', B, .): the last conv's GEMM epilogue scatters straight into
+that layout, a time chunk of any layer is then a contiguous row range (what the GRU layer wavefront needs), and the
+logits come out as (T', B, V+1) -- warp-ctc's native layout -- and are handed to the caller as a (B, T', V+1) view.
+
 Every tensor op below is a libspeech_amd.so call through speech_amd.ops; torch only allocates.
-Dropout (config["dropout"] != 0, training mode) multiplies by a torch-generated Bernoulli mask between kernels.
+Dropout (config["dropout"] != 0, training mode) multiplies by a torch-generated Bernoulli mask between kernels; the
+GRU stack is then run one layer per call so the mask can sit between layers (nn.GRU's inter-layer dropout).
 """
 import torch
 
@@ -30,6 +35,7 @@ class EncoderPlan:
             f = ops.conv_out_size(f, w, s)
         self.conv_out_dim = self.conv_cfg[-1][0] * f
         self.input_dim = input_dim
+        self.chunk = 0  # time steps per wavefront chunk (0: library default)
 
     def time_out(self, t):
         for out_c, h, w, s in self.conv_cfg:
@@ -42,127 +48,113 @@ def _drop_mask(t, p):
 
 
 class EncoderFunction(torch.autograd.Function):
-    """logits = fc(encode(x)).  params: flat list [conv w, conv b, ..., per (layer, dir): w_ih, w_hh, b_ih, b_hh, ...,
-    fc w, fc b] in that order."""
+    """logits = fc(encode(x)).  params: [conv w, conv b, ..., per (layer, dir): w_ih, w_hh, b_ih, b_hh, ..., fc w, fc b]."""
 
     @staticmethod
     def forward(ctx, plan, training, x, *params):
         P = list(params)
         nconv = len(plan.conv_cfg)
+        H, D, L = plan.H, plan.D, plan.layers
         conv_p = [(P[2 * i], P[2 * i + 1]) for i in range(nconv)]
         off = 2 * nconv
-        gru_p = []
-        for l in range(plan.layers):
-            row = []
-            for d in range(plan.D):
-                row.append(tuple(P[off:off + 4]))  # w_ih, w_hh, b_ih, b_hh
-                off += 4
-            gru_p.append(row)
-        fc_w, fc_b = P[off], P[off + 1]
+        w_ih = [P[off + 4 * k] for k in range(L * D)]
+        w_hh = [P[off + 4 * k + 1] for k in range(L * D)]
+        b_ih = [P[off + 4 * k + 2] for k in range(L * D)]
+        b_hh = [P[off + 4 * k + 3] for k in range(L * D)]
+        fc_w, fc_b = P[off + 4 * L * D], P[off + 4 * L * D + 1]
         need_grad = training and any(ctx.needs_input_grad[3:])
         p_drop = plan.dropout if training else 0.0
         B, T, F = x.shape
-        H, D = plan.H, plan.D
 
-        # conv stack: the last conv writes the GRU-ready (B, T', C*F') channel-major layout (model.py:66-71)
+        # conv stack; the last conv writes time-major channel-major features (T', B, C*F') (model.py:66-71)
         a = x.contiguous().view(B, 1, T, F)
         conv_saved = []
         for i, ((w, b), (out_c, kh, kw, s)) in enumerate(zip(conv_p, plan.conv_cfg)):
-            last = i == nconv - 1
-            y, ys = ops.conv2d_relu_fwd(a, w, b, s, feature_layout=last)
+            y, ys = ops.conv2d_relu_fwd(a, w, b, s, "tbf" if i == nconv - 1 else "nchw")
             mask = None
             if p_drop:
                 mask = _drop_mask(y, p_drop)
                 y = y * mask
             conv_saved.append((a, y, ys, mask))
             a = y
-        feat = a  # (B, T', conv_out)
-        Tp = feat.shape[1]
+        feat = a  # (T', B, conv_out)
+        Tp = feat.shape[0]
 
-        # GRU stack
+        # GRU stack: one wavefront call for all layers, or one call per layer when dropout masks sit in between
+        groups = [list(range(L))] if not p_drop else [[l] for l in range(L)]
         inp = feat
         gru_saved = []
-        for l in range(plan.layers):
-            hbuf = torch.empty(B, Tp, D * H, dtype=torch.float32, device=x.device)
-            stashes = []
-            for d in range(D):
-                w_ih, w_hh, b_ih, b_hh = gru_p[l][d]
-                ai = ops.gemm(inp.view(B * Tp, inp.shape[2]), w_ih, trans_b=True, bias=b_ih).view(B, Tp, 3 * H)
-                stash = torch.empty(B, Tp, 5 * H, dtype=torch.float32, device=x.device) if need_grad else None
-                ops.gru_fwd(ai, w_hh, b_hh, hbuf[:, :, d * H:(d + 1) * H], stash, reverse=(d == 1))
-                stashes.append(stash)
+        for grp in groups:
+            sel = [l * D + d for l in grp for d in range(D)]
+            h_out, stash = ops.gru_stack_fwd(inp, [w_ih[k] for k in sel], [b_ih[k] for k in sel],
+                                             [w_hh[k] for k in sel], [b_hh[k] for k in sel], len(grp), D, H,
+                                             want_stash=need_grad, chunk=plan.chunk)
+            top = h_out[-1]
             mask = None
-            out = hbuf
-            if p_drop and l + 1 < plan.layers:  # nn.GRU: dropout on every layer's output except the last
-                mask = _drop_mask(hbuf, p_drop)
-                out = hbuf * mask
-            gru_saved.append((inp, hbuf, stashes, mask))
-            inp = out
-        if D == 2:  # model.py:75-77
-            enc = ops.add_rows(inp.view(B * Tp, 2 * H)[:, :H], inp.view(B * Tp, 2 * H)[:, H:])
-        else:
-            enc = inp.view(B * Tp, H)
-        logits = ops.gemm(enc, fc_w, trans_b=True, bias=fc_b).view(B, Tp, fc_w.shape[0])
+            if p_drop and grp[-1] + 1 < L:  # nn.GRU: dropout on every layer's output except the last
+                mask = _drop_mask(top, p_drop)
+                top = top * mask
+            gru_saved.append((grp, inp, h_out, stash, mask))
+            inp = top
+        top2 = inp.view(Tp * B, D * H)
+        enc = ops.add_rows(top2[:, :H], top2[:, H:]) if D == 2 else top2  # model.py:75-77
+        logits_tm = ops.gemm(enc, fc_w, trans_b=True, bias=fc_b).view(Tp, B, fc_w.shape[0])
 
         if need_grad:
+            # parameters re-homed by Model.flatten_parameters_() carry a `_grad_slot` view of the flat gradient
+            # buffer: backward writes each gradient there and hands the view to autograd
+            ctx.slots = [getattr(p, "_grad_slot", None) for p in params]
             ctx.plan = plan
-            ctx.conv_p, ctx.gru_p, ctx.fc_w = conv_p, gru_p, fc_w
+            ctx.conv_p, ctx.w_ih, ctx.w_hh, ctx.fc_w = conv_p, w_ih, w_hh, fc_w
             ctx.conv_saved, ctx.gru_saved, ctx.enc = conv_saved, gru_saved, enc
             ctx.dims = (B, Tp)
-        return logits
+        return logits_tm.transpose(0, 1)  # (B, T', V+1) view of the time-major buffer
 
     @staticmethod
     def backward(ctx, dlogits):
         plan = ctx.plan
         B, Tp = ctx.dims
-        H, D = plan.H, plan.D
-        dl = dlogits.contiguous().view(B * Tp, -1)
-        grads_fc = [ops.gemm(dl, ctx.enc, trans_a=True), ops.colsum(dl)]
-        denc = ops.gemm(dl, ctx.fc_w)  # (B*T', H)
-        # gradient wrt the top layer's (B, T', D*H) output: both directions receive denc (model.py:75-77)
-        dout = denc.view(B, Tp, H)
-        dout_views = [dout, dout] if D == 2 else [dout]
-        grads_gru = [None] * plan.layers
-        dai = torch.empty(B, Tp, 3 * H, dtype=torch.float32, device=dl.device)
-        dah = torch.empty(B, Tp, 3 * H, dtype=torch.float32, device=dl.device)
-        for l in range(plan.layers - 1, -1, -1):
-            inp, hbuf, stashes, mask = ctx.gru_saved[l]
-            I = inp.shape[2]
-            dinp = torch.empty(B * Tp, I, dtype=torch.float32, device=dl.device)
-            row = []
-            for d in range(D):
-                w_ih, w_hh, b_ih, b_hh = ctx.gru_p[l][d]
-                stash = stashes[d]
-                ops.gru_bwd(dout_views[d], hbuf[:, :, d * H:(d + 1) * H], stash, w_hh, dai, dah, reverse=(d == 1))
-                dai2, dah2 = dai.view(B * Tp, 3 * H), dah.view(B * Tp, 3 * H)
-                g_wih = ops.gemm(dai2, inp.view(B * Tp, I), trans_a=True)
-                g_whh = ops.gemm(dah2, stash.view(B * Tp, 5 * H)[:, 4 * H:], trans_a=True)
-                g_bih, g_bhh = ops.colsum(dai2), ops.colsum(dah2)
-                ops.gemm(dai2, w_ih, out=dinp, beta=(1.0 if d == 1 else 0.0))
-                row.append((g_wih, g_whh, g_bih, g_bhh))
-            grads_gru[l] = row
-            if l > 0:
-                prev_mask = ctx.gru_saved[l - 1][3]
-                dprev = dinp.view(B, Tp, I)
-                if prev_mask is not None:
-                    dprev = dprev * prev_mask
-                dout_views = [dprev[:, :, d * H:(d + 1) * H] for d in range(D)]
+        H, D, L = plan.H, plan.D, plan.layers
+        nconv = len(plan.conv_cfg)
+        slots = ctx.slots
+        dl = dlogits.transpose(0, 1).contiguous().view(Tp * B, -1)  # no copy when it is the CTC gradient
+        fc_i = 2 * nconv + 4 * L * D
+        grads = [None] * (fc_i + 2)
+        grads[fc_i] = ops.gemm(dl, ctx.enc, trans_a=True, out=slots[fc_i])
+        grads[fc_i + 1] = ops.colsum(dl, out=slots[fc_i + 1])
+        denc = ops.gemm(dl, ctx.fc_w)  # (T'*B, H)
+        # both directions of the top layer receive denc (model.py:75-77)
+        dtop = torch.cat([denc, denc], dim=1).view(Tp, B, 2 * H) if D == 2 else denc.view(Tp, B, H)
+        for grp, inp, h_out, stash, mask in reversed(ctx.gru_saved):
+            if mask is not None:
+                dtop = dtop * mask
+            sel = [l * D + d for l in grp for d in range(D)]
+            I0 = inp.shape[2]
+            dai, dah, dx = ops.gru_stack_bwd(dtop.contiguous(), stash, [ctx.w_ih[k] for k in sel],
+                                             [ctx.w_hh[k] for k in sel], len(grp), D, H, I0, want_dx=True,
+                                             chunk=plan.chunk)
+            for j, l in enumerate(grp):
+                lay_in = inp if j == 0 else h_out[j - 1]
+                lay_in2 = lay_in.view(Tp * B, lay_in.shape[2])
+                for d in range(D):
+                    k = j * D + d
+                    gi = 2 * nconv + 4 * (l * D + d)
+                    dai2, dah2 = dai[k].view(Tp * B, 3 * H), dah[k].view(Tp * B, 3 * H)
+                    grads[gi] = ops.gemm(dai2, lay_in2, trans_a=True, out=slots[gi])
+                    grads[gi + 1] = ops.gemm(dah2, stash[k].view(Tp * B, 5 * H)[:, 4 * H:], trans_a=True,
+                                             out=slots[gi + 1])
+                    grads[gi + 2] = ops.colsum(dai2, out=slots[gi + 2])
+                    grads[gi + 3] = ops.colsum(dah2, out=slots[gi + 3])
+            dtop = dx
         # conv stack
-        dy = dinp.view(B, Tp, -1)
-        grads_conv = [None] * len(plan.conv_cfg)
-        for i in range(len(plan.conv_cfg) - 1, -1, -1):
+        dy = dtop
+        for i in range(nconv - 1, -1, -1):
             a, y, ys, mask = ctx.conv_saved[i]
             if mask is not None:
                 dy = dy * mask
             s = plan.conv_cfg[i][3]
-            dx, dw, db = ops.conv2d_relu_bwd(a, ctx.conv_p[i][0], y, dy.contiguous(), ys, s, need_dx=(i > 0))
-            grads_conv[i] = (dw, db)
+            dx, dw, db = ops.conv2d_relu_bwd(a, ctx.conv_p[i][0], y, dy.contiguous(), ys, s, need_dx=(i > 0),
+                                             dw=slots[2 * i], db=slots[2 * i + 1])
+            grads[2 * i], grads[2 * i + 1] = dw, db
             dy = dx
-        flat = []
-        for dw, db in grads_conv:
-            flat += [dw, db]
-        for row in grads_gru:
-            for g in row:
-                flat += list(g)
-        flat += grads_fc
-        return (None, None, None) + tuple(flat)
+        return (None, None, None) + tuple(grads)

@@ -108,8 +108,10 @@ class Model(nn.Module):
         return self._run(x, eye, zero)
 
     def flatten_parameters_(self):
-        """Re-home every parameter (and its .grad) into ONE flat fp32 buffer each: the fused clip+SGD step and the
-        single RCCL all-reduce both operate on these.  Returns (flat_params, flat_grads)."""
+        """Re-home every parameter into ONE flat fp32 buffer and give each a slot in ONE flat gradient buffer: the
+        fused clip+SGD step and the single RCCL all-reduce both operate on these.  Call after .cuda().
+        Per step: p.grad = None for all p (model.zero_grad(set_to_none=True)); backward then fills every slot.
+        Returns (flat_params, flat_grads)."""
         ps = [p for p in self.parameters()]
         n = sum(p.numel() for p in ps)
         dev = ps[0].device
@@ -120,7 +122,8 @@ class Model(nn.Module):
             k = p.numel()
             flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = flat_p[off:off + k].view(p.shape)
-            p.grad = flat_g[off:off + k].view(p.shape)
+            p._grad_slot = flat_g[off:off + k].view(p.shape)  # EncoderFunction.backward writes gradients here
+            p.grad = None
             off += k
         self._flat = (flat_p, flat_g)
         return self._flat

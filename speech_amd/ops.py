@@ -2,12 +2,52 @@
 
 torch supplies device memory and the current stream; every FLOP is done by libspeech_amd.so.  Nothing here has a
 CPU path: CPU tensors raise SpeechAmdError."""
+import ctypes
 import math
 
 import torch
 
 from . import _lib
 from ._lib import WORKSPACE, check, cur_stream, ptr
+
+
+class Profile:
+    """Optional HIP-event timing of op calls on the current stream (bench.py's live roofline measurement).
+    Usage: ops.PROFILE = ops.Profile(); ...run...; torch.cuda.synchronize(); ops.PROFILE.summary()"""
+
+    def __init__(self):
+        self.spans = []  # (name, start_event, end_event, launches, work)
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, n, work in self.spans:
+            d = out.setdefault(name, {"ms": 0.0, "calls": 0, "launches": 0, "work": 0.0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["calls"] += 1
+            d["launches"] += n
+            d["work"] += work
+        return out
+
+
+PROFILE = None
+
+
+class _span:
+    def __init__(self, name, launches=1, work=0.0):
+        self.name, self.launches, self.work = name, launches, work
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.spans.append((self.name, self.e0, self.e1, self.launches, self.work))
+        return False
 
 
 def _f32(t, name):
@@ -31,9 +71,10 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, alpha=1.0, bet
     L = _lib.lib()
     nbytes = L.sa_gemm_workspace_bytes(M, N, K)
     ws = WORKSPACE.get(nbytes, a.device, "gemm") if nbytes else None
-    check(L.sa_gemm_f32(int(trans_a), int(trans_b), M, N, K, alpha, ptr(a), a.stride(0), ptr(b), b.stride(0), beta,
-                        ptr(out), out.stride(0), ptr(bias), ptr(ws), ws.numel() if ws is not None else 0,
-                        cur_stream()), "sa_gemm_f32")
+    with _span("gemm", 1, 2.0 * M * N * K):
+        check(L.sa_gemm_f32(int(trans_a), int(trans_b), M, N, K, alpha, ptr(a), a.stride(0), ptr(b), b.stride(0),
+                            beta, ptr(out), out.stride(0), ptr(bias), ptr(ws), ws.numel() if ws is not None else 0,
+                            cur_stream()), "sa_gemm_f32")
     return out
 
 
@@ -41,9 +82,12 @@ def conv_out_size(n, k, s):
     return int(math.ceil((n - k + 1) / s))
 
 
-def conv2d_relu_fwd(x, w, bias, s, feature_layout):
-    """x (B,C,T,F) contiguous -> relu(conv(x)).  feature_layout: return (B, T', O*F') channel-major features
-    (model.py:66-71) instead of NCHW."""
+def conv2d_relu_fwd(x, w, bias, s, layout="nchw"):
+    """x (B,C,T,F) contiguous -> relu(conv(x)) in one of three output layouts:
+      "nchw": (B, O, T', F')              (input of a following conv)
+      "btf" : (B, T', O*F') channel-major features, batch-major   (model.py:66-71)
+      "tbf" : (T', B, O*F') the same features time-major          (what the GRU stack consumes)
+    Returns (y, (ys_b, ys_c, ys_t)) with y[b*ys_b + c*ys_c + t*ys_t + f]."""
     _f32(x, "x"), _f32(w, "w"), _f32(bias, "bias")
     assert x.is_contiguous() and w.is_contiguous()
     B, C, T, F = x.shape
@@ -52,32 +96,40 @@ def conv2d_relu_fwd(x, w, bias, s, feature_layout):
     To, Fo = conv_out_size(T, kh, s), conv_out_size(F, kw, s)
     if To <= 0 or Fo <= 0:
         raise _lib.SpeechAmdError("convolution output is empty")
-    if feature_layout:
+    if layout == "btf":
         y = torch.empty(B, To, O * Fo, dtype=torch.float32, device=x.device)
         ys = (To * O * Fo, Fo, O * Fo)
+    elif layout == "tbf":
+        y = torch.empty(To, B, O * Fo, dtype=torch.float32, device=x.device)
+        ys = (O * Fo, Fo, B * O * Fo)
     else:
         y = torch.empty(B, O, To, Fo, dtype=torch.float32, device=x.device)
         ys = (O * To * Fo, To * Fo, Fo)
     L = _lib.lib()
     nbytes = L.sa_conv2d_fwd_workspace_bytes(B, C, T, F, O, kh, kw, s)
     ws = WORKSPACE.get(nbytes, x.device, "conv")
-    check(L.sa_conv2d_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1], ys[2],
-                               ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
+    with _span("conv_fwd", 2, 2.0 * B * To * Fo * O * C * kh * kw):
+        check(L.sa_conv2d_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1], ys[2],
+                                   ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
     return y, ys
 
 
-def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx):
+def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None):
     """Gradients of relu(conv(x)): returns (dx or None, dw, dbias).  y / dy share the strides `ys`."""
     B, C, T, F = x.shape
     O, _, kh, kw = w.shape
-    dw = torch.empty_like(w)
-    db = torch.empty(O, dtype=torch.float32, device=x.device)
+    if dw is None:
+        dw = torch.empty_like(w)
+    if db is None:
+        db = torch.empty(O, dtype=torch.float32, device=x.device)
+    assert dw.is_contiguous() and dw.shape == w.shape
     dx = torch.empty_like(x) if need_dx else None
     L = _lib.lib()
     nbytes = L.sa_conv2d_bwd_workspace_bytes(B, C, T, F, O, kh, kw, s)
     ws = WORKSPACE.get(nbytes, x.device, "conv")
-    check(L.sa_conv2d_relu_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), B, C, T, F, O, kh, kw, s,
-                               ys[0], ys[1], ys[2], ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_bwd")
+    with _span("conv_bwd", 5, 0.0):
+        check(L.sa_conv2d_relu_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), B, C, T, F, O, kh, kw,
+                                   s, ys[0], ys[1], ys[2], ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_bwd")
     return dx, dw, db
 
 
@@ -86,8 +138,11 @@ def gru_fwd(ai, w_hh, b_hh, h_out, stash, reverse):
     B, T, H3 = ai.shape
     H = H3 // 3
     assert ai.is_contiguous() and w_hh.is_contiguous() and h_out.shape == (B, T, H) and h_out.stride(2) == 1
-    check(_lib.lib().sa_gru_fwd(ptr(ai), ptr(w_hh), ptr(b_hh), ptr(h_out), h_out.stride(0), h_out.stride(1),
-                                ptr(stash), B, T, H, int(reverse), cur_stream()), "sa_gru_fwd")
+    # algorithmic bytes per step launch (W_hh resident on chip): ai 3H + h_prev H + h H (+ stash 5H), fp32
+    nbytes = 4.0 * B * H * (5 + (5 if stash is not None else 0))
+    with _span("gru_fwd_step", T, nbytes * T):
+        check(_lib.lib().sa_gru_fwd(ptr(ai), ptr(w_hh), ptr(b_hh), ptr(h_out), h_out.stride(0), h_out.stride(1),
+                                    ptr(stash), B, T, H, int(reverse), cur_stream()), "sa_gru_fwd")
 
 
 def gru_bwd(dh_out, h_out, stash, w_hh, dai, dah, reverse):
@@ -97,8 +152,11 @@ def gru_bwd(dh_out, h_out, stash, w_hh, dai, dah, reverse):
     L = _lib.lib()
     nbytes = L.sa_gru_bwd_workspace_bytes(B, T, H)
     ws = WORKSPACE.get(nbytes, dh_out.device, "gru")
-    check(L.sa_gru_bwd(ptr(dh_out), dh_out.stride(0), dh_out.stride(1), ptr(h_out), ptr(stash), ptr(w_hh), ptr(dai),
-                       ptr(dah), B, T, H, int(reverse), ptr(ws), ws.numel(), cur_stream()), "sa_gru_bwd")
+    # algorithmic bytes per step launch: read dah 3H + stash 5H + dh_out H + dh H, write dai 3H + dah 3H + dh H
+    with _span("gru_bwd_step", T, 4.0 * B * H * 17 * T):
+        check(L.sa_gru_bwd(ptr(dh_out), dh_out.stride(0), dh_out.stride(1), ptr(h_out), ptr(stash), ptr(w_hh),
+                           ptr(dai), ptr(dah), B, T, H, int(reverse), ptr(ws), ws.numel(), cur_stream()),
+              "sa_gru_bwd")
 
 
 def colsum(a, out=None, accumulate=False):
@@ -107,9 +165,57 @@ def colsum(a, out=None, accumulate=False):
     M, N = a.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=a.device)
-    check(_lib.lib().sa_colsum_f32(ptr(a), a.stride(0), M, N, ptr(out), int(accumulate), cur_stream()),
-          "sa_colsum_f32")
+    L = _lib.lib()
+    ws = WORKSPACE.get(L.sa_colsum_workspace_bytes(M, N), a.device, "colsum")
+    with _span("colsum", 2, 4.0 * M * N):
+        check(L.sa_colsum_f32(ptr(a), a.stride(0), M, N, ptr(out), int(accumulate), ptr(ws), ws.numel(),
+                              cur_stream()), "sa_colsum_f32")
     return out
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+    return arr
+
+
+def gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash, chunk=0):
+    """x (T, B, I0) time-major.  Parameter lists hold L*D tensors (index l*D + d).  Returns (h_out list of L
+    (T, B, D*H) tensors, stash list of L*D (T, B, 5H) tensors or None)."""
+    _f32(x, "x")
+    assert x.is_contiguous()
+    T, B, I0 = x.shape
+    dev = x.device
+    h_out = [torch.empty(T, B, D * H, dtype=torch.float32, device=dev) for _ in range(L)]
+    stash = [torch.empty(T, B, 5 * H, dtype=torch.float32, device=dev) for _ in range(L * D)] if want_stash else None
+    lib = _lib.lib()
+    ws = WORKSPACE.get(lib.sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0), dev, "gru_stack")
+    launches = (T + L - 1 if D == 1 else L * T)
+    nbytes = 4.0 * B * H * (5 + (5 if want_stash else 0)) * T * L * D
+    with _span("gru_fwd_stack", launches, nbytes):
+        check(lib.sa_gru_stack_fwd(ptr(x), I0, _ptr_array(w_ih), _ptr_array(b_ih), _ptr_array(w_hh),
+                                   _ptr_array(b_hh), _ptr_array(h_out), _ptr_array(stash) if stash else None, L, D, B,
+                                   T, H, chunk, ptr(ws), ws.numel(), cur_stream()), "sa_gru_stack_fwd")
+    return h_out, stash
+
+
+def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0):
+    """dh_top (T, B, D*H).  Returns (dai list, dah list of L*D (T, B, 3H) tensors, dx (T, B, I0) or None)."""
+    T, B, _ = dh_top.shape
+    dev = dh_top.device
+    assert dh_top.is_contiguous()
+    dai = [torch.empty(T, B, 3 * H, dtype=torch.float32, device=dev) for _ in range(L * D)]
+    dah = [torch.empty(T, B, 3 * H, dtype=torch.float32, device=dev) for _ in range(L * D)]
+    dx = torch.empty(T, B, I0, dtype=torch.float32, device=dev) if want_dx else None
+    lib = _lib.lib()
+    ws = WORKSPACE.get(lib.sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0), dev, "gru_stack_bwd")
+    launches = (T + L - 1 if D == 1 else L * T)
+    with _span("gru_bwd_stack", launches, 4.0 * B * H * 17 * T * L * D):
+        check(lib.sa_gru_stack_bwd(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
+                                   _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk, ptr(ws),
+                                   ws.numel(), cur_stream()), "sa_gru_stack_bwd")
+    return dai, dah, dx
 
 
 def add_rows(a, b, out=None):

@@ -81,7 +81,7 @@ def test_conv_relu_fwd_bwd(B, C, T, F, O, kh, kw, s, feature_layout):
     w = rng.randn(O, C, kh, kw) / np.sqrt(C * kh * kw)
     b = rng.randn(O) * 0.1
     y_ref, cols = E.conv_relu_fwd(x, w, b, s)
-    y, ys = ops.conv2d_relu_fwd(dev(x), dev(w), dev(b), s, feature_layout)
+    y, ys = ops.conv2d_relu_fwd(dev(x), dev(w), dev(b), s, "btf" if feature_layout else "nchw")
     Bo, Oo, To, Fo = y_ref.shape
     y_nchw = y.view(B, To, O, Fo).permute(0, 2, 1, 3) if feature_layout else y
     close(y_nchw, y_ref, rtol=1e-5, atol_scale=2e-6)
@@ -179,3 +179,61 @@ def test_clip_sgd_step(momentum, gscale):
         close(p, P["p"], rtol=1e-5, atol_scale=1e-6)
     if gscale > 1:
         assert total > 200.0  # the clip branch was exercised
+
+
+# ------------------------------------------------------------------------------------------- the GRU stack (wavefront)
+@pytest.mark.parametrize("L,D,B,T,I0,H,chunk", [(4, 1, 5, 23, 12, 16, 5), (3, 1, 32, 9, 40, 64, 4), (2, 2, 3, 11, 10, 24, 0),
+                                              (1, 1, 2, 7, 6, 8, 32), (4, 1, 2, 40, 8, 16, 0)])
+def test_gru_stack_matches_oracle(L, D, B, T, I0, H, chunk):
+    """sa_gru_stack_fwd/bwd (chunked layer wavefront for D=1, paired directions for D=2) vs the per-layer oracle."""
+    from speech_amd import ops
+    rng = np.random.RandomState(L * 100 + T)
+    k = 1.0 / np.sqrt(H)
+    x = rng.randn(B, T, I0)
+    P = []
+    for l in range(L):
+        I = I0 if l == 0 else D * H
+        for d in range(D):
+            P.append((rng.uniform(-k, k, (3 * H, I)), rng.uniform(-k, k, (3 * H, H)), rng.uniform(-k, k, 3 * H),
+                      rng.uniform(-k, k, 3 * H)))
+    # oracle forward
+    inp, caches = x, []
+    for l in range(L):
+        outs, cs = [], []
+        for d in range(D):
+            Wih, Whh, bih, bhh = P[l * D + d]
+            hs, c = E.gru_dir_fwd(inp, Wih, Whh, bih, bhh, d == 1)
+            outs.append(hs), cs.append(c)
+        caches.append(cs)
+        inp = np.concatenate(outs, axis=2)
+    top_ref = inp
+    x_tm = dev(x.transpose(1, 0, 2))
+    w_ih, w_hh = [dev(p[0]) for p in P], [dev(p[1]) for p in P]
+    b_ih, b_hh = [dev(p[2]) for p in P], [dev(p[3]) for p in P]
+    h_out, stash = ops.gru_stack_fwd(x_tm, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=True, chunk=chunk)
+    close(h_out[-1].transpose(0, 1), top_ref, rtol=5e-5, atol_scale=5e-6)
+    h_inf, none = ops.gru_stack_fwd(x_tm, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=False, chunk=chunk)
+    assert none is None and torch.equal(h_inf[-1], h_out[-1])
+    # oracle backward
+    dtop = rng.randn(B, T, D * H)
+    dout, want = dtop, {}
+    for l in range(L - 1, -1, -1):
+        dins = []
+        for d in range(D):
+            Wih, Whh, _, _ = P[l * D + d]
+            dx, dWih, dWhh, dbih, dbhh = E.gru_dir_bwd(dout[:, :, d * H:(d + 1) * H], caches[l][d], Wih, Whh)
+            want[(l, d)] = (dWih, dWhh, dbih, dbhh)
+            dins.append(dx)
+        dout = dins[0] + dins[1] if D == 2 else dins[0]
+    dai, dah, dx = ops.gru_stack_bwd(dev(dtop.transpose(1, 0, 2)), stash, w_ih, w_hh, L, D, H, I0, chunk=chunk)
+    tol = dict(rtol=1e-4, atol_scale=5e-5)
+    close(dx.transpose(0, 1), dout, **tol)
+    for l in range(L):
+        lay_in = x_tm if l == 0 else h_out[l - 1]
+        for d in range(D):
+            kk = l * D + d
+            a2, h2 = dai[kk].view(T * B, 3 * H), dah[kk].view(T * B, 3 * H)
+            close(ops.gemm(a2, lay_in.view(T * B, -1), trans_a=True), want[(l, d)][0], **tol)
+            close(ops.gemm(h2, stash[kk].view(T * B, 5 * H)[:, 4 * H:], trans_a=True), want[(l, d)][1], **tol)
+            close(ops.colsum(a2), want[(l, d)][2], **tol)
+            close(ops.colsum(h2), want[(l, d)][3], **tol)

@@ -113,3 +113,32 @@ def test_clip_and_sgd_matches_torch():
     assert abs(total - float(norm)) < 1e-9 * total and total > 200
     for k in P:
         np.testing.assert_allclose(newP[k], tp[k].detach().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_torch_ref_port_matches_reference_fixture(golden_dir, name):
+    """oracle/torch_ref.py (the timed CPU baseline) reproduces the live reference's logits bit-for-bit class."""
+    from oracle.torch_ref import TorchRefCTC
+    F, V, cfg = CFGS[name]
+    z, P = load_case(golden_dir, name)
+    m = TorchRefCTC(F, V, cfg)
+    m.load_state_dict({k: torch.tensor(v) for k, v in P.items()})
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.tensor(z["x"]))
+    np.testing.assert_allclose(out.numpy(), z["logits"], rtol=1e-5, atol=1e-6)
+
+
+def test_torch_ref_train_step_runs_and_decreases_loss():
+    from oracle.torch_ref import TorchRefCTC, train_step
+    F, V, cfg = CFGS["encoder_tiny"]
+    torch.manual_seed(0)
+    m = TorchRefCTC(F, V, cfg)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    rng = np.random.RandomState(0)
+    x = torch.tensor(rng.randn(2, 60, F).astype(np.float32))
+    labs = rng.randint(0, V, 10).astype(np.int32)
+    l0, _ = train_step(m, opt, x, labs, np.array([5, 5], np.int32))
+    for _ in range(5):
+        l1, gn = train_step(m, opt, x, labs, np.array([5, 5], np.int32))
+    assert np.isfinite(l1) and l1 < l0 and gn > 0
