@@ -22,11 +22,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDT = 132;  // LDS row pitch in floats (128 + 4): keeps 16-byte alignment, spreads transposed writes
 
+constexpr int kMaxGroup = 8;
+
 struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    const float* bias;
+    // a group of up to 8 problems of identical shape shares one launch (blockIdx.z = problem * splits + split):
+    // the per-chunk input projections of all layers of the GRU wavefront
+    int nprob, splits;
+    const float* Ag[kMaxGroup];
+    const float* Bg[kMaxGroup];
+    float* Cg[kMaxGroup];
+    const float* biasg[kMaxGroup];
     long lda, ldb, ldc;
     int M, N, K;
     float alpha, beta;
@@ -38,7 +43,7 @@ struct GemmArgs {
     int m_inner, m_mid;
     long s_outer, s_mid, col_stride;
     int relu;
-    float* partial;   // split-K workspace [splits][M][N] or null
+    float* partial;   // split-K workspace [nprob][splits][M][N] or null
 };
 
 __device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
@@ -120,7 +125,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    const int prob = blockIdx.z / g.splits, split = blockIdx.z - prob * g.splits;
+    const float* __restrict__ gA = g.Ag[prob];
+    const float* __restrict__ gB = g.Bg[prob];
+    const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int ntiles = (kend - kbeg + BK - 1) / BK;
 
@@ -134,8 +142,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     float4 ra[2], rb[2];
     if (ntiles > 0) {
-        load_tile<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
-        load_tile<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+        load_tile<!TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+        load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
         store_tile<!TA>(As(0), tid, ra);
         store_tile<TB>(Bs(0), tid, rb);
     }
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const bool more = it + 1 < ntiles;
         if (more) {  // issue the next tile's global loads before this tile's MFMAs
             const int k0 = kbeg + (it + 1) * BK;
-            load_tile<!TA>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-            load_tile<TB>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+            load_tile<!TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+            load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
         }
         const float* a_s = As(cur) + (lane >> 5) * LDT + wm * 64 + (lane & 31);
         const float* b_s = Bs(cur) + (lane >> 5) * LDT + wn * 64 + (lane & 31);
@@ -170,7 +178,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 
     // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const bool split = g.partial != nullptr;
+    const bool splitk = g.partial != nullptr;
+    float* __restrict__ gC = g.Cg[prob];
+    const float* __restrict__ gbias = g.biasg[prob];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -178,16 +188,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
             if (col >= g.N) continue;
             float bv = 0.f;
-            if (!split && g.bias) bv = g.bias[col];
+            if (!splitk && gbias) bv = gbias[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= g.M) continue;
-                if (split) {
+                if (splitk) {
                     g.partial[((long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
                 } else {
-                    float* c = g.m_inner > 0 ? g.C + remap_row(g, row) + col * g.col_stride
-                                             : g.C + (long)row * g.ldc + col;
+                    float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride
+                                             : gC + (long)row * g.ldc + col;
                     float v = g.alpha * acc[i][j][r] + bv;
                     if (g.beta != 0.f) v += g.beta * *c;
                     if (g.relu) v = fmaxf(v, 0.f);
@@ -203,17 +213,21 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
     const long total = (long)g.M * g.N;
     if (idx >= total) return;
     const int row = (int)(idx / g.N), col = (int)(idx % g.N);
+    const int prob = blockIdx.y;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += g.partial[(long)z * total + idx];  // fixed order: deterministic
-    float* c = g.m_inner > 0 ? g.C + remap_row(g, row) + col * g.col_stride : g.C + (long)row * g.ldc + col;
-    float v = g.alpha * s + (g.bias ? g.bias[col] : 0.f);
+    for (int z = 0; z < splits; ++z)
+        s += g.partial[((long)prob * splits + z) * total + idx];  // fixed order: deterministic
+    float* gC = g.Cg[prob];
+    const float* gbias = g.biasg[prob];
+    float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride : gC + (long)row * g.ldc + col;
+    float v = g.alpha * s + (gbias ? gbias[col] : 0.f);
     if (g.beta != 0.f) v += g.beta * *c;
     if (g.relu) v = fmaxf(v, 0.f);
     *c = v;
 }
 
-int choose_splits(int M, int N, int K) {
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+int choose_splits(int M, int N, int K, int nprob = 1) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nprob;
     if (tiles >= 192 || K < 8 * BK) return 1;
     int s = (int)((512 + tiles - 1) / tiles);       // aim for ~2 blocks per CU
     const int max_by_k = K / (4 * BK);              // at least 4 K-tiles per split
@@ -224,30 +238,35 @@ int choose_splits(int M, int N, int K) {
 
 }  // namespace
 
-ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
-                             const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
-                             const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes,
-                             hipStream_t stream) {
+ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
+                                   const float* const* A, long lda, const float* const* B, long ldb, float beta,
+                                   float* const* C, long ldc, const float* const* bias, const SaGemmEpilogue* ep,
+                                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
     SA_CLEAR_ERR();
-    if (M < 0 || N < 0 || K < 0) return CTC_STATUS_INVALID_VALUE;
+    if (M < 0 || N < 0 || K < 0 || nprob < 1 || nprob > kMaxGroup) return CTC_STATUS_INVALID_VALUE;
     if (M == 0 || N == 0) return CTC_STATUS_SUCCESS;
-    if (!A || !B || !C) return CTC_STATUS_INVALID_VALUE;
     GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.nprob = nprob;
+    g.vecA = (lda & 3) == 0;
+    g.vecB = (ldb & 3) == 0;
+    for (int p = 0; p < nprob; ++p) {
+        if (!A[p] || !B[p] || !C[p]) return CTC_STATUS_INVALID_VALUE;
+        g.Ag[p] = A[p]; g.Bg[p] = B[p]; g.Cg[p] = C[p]; g.biasg[p] = bias ? bias[p] : nullptr;
+        g.vecA = g.vecA && (((uintptr_t)A[p] & 15) == 0);
+        g.vecB = g.vecB && (((uintptr_t)B[p] & 15) == 0);
+    }
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
-    g.vecA = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
-    g.vecB = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
     g.m_inner = ep ? ep->m_inner : 0;
     g.m_mid = ep ? ep->m_mid : 1;
     g.s_outer = ep ? ep->s_outer : 0;
     g.s_mid = ep ? ep->s_mid : 0;
     g.col_stride = ep ? ep->col_stride : 1;
     g.relu = ep ? ep->relu : 0;
-    int splits = choose_splits(M, N, K);
+    int splits = choose_splits(M, N, K, nprob);
     if (splits > 1) {
-        const size_t need = (size_t)splits * M * N * sizeof(float);
+        const size_t need = (size_t)nprob * splits * M * N * sizeof(float);
         if (!workspace || workspace_bytes < need) splits = 1;  // no room: fall back to one pass (still correct)
     }
     int kps = (K + splits - 1) / splits;
@@ -255,8 +274,9 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
     if (kps < BK) kps = BK;
     splits = K > 0 ? (K + kps - 1) / kps : 1;
     g.k_per_split = kps;
+    g.splits = splits;
     g.partial = splits > 1 ? (float*)workspace : nullptr;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
     if (trans_a) {
         if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, g);
@@ -267,11 +287,25 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
     SA_CHECK_LAUNCH();
     if (splits > 1) {
         const long total = (long)M * N;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, g,
-                           splits);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), nprob), dim3(256), 0,
+                           stream, g, splits);
         SA_CHECK_LAUNCH();
     }
     return CTC_STATUS_SUCCESS;
+}
+
+size_t sa_gemm_group_workspace_bytes(int nprob, int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || nprob <= 0) return 0;
+    const int s = choose_splits(M, N, K, nprob);
+    return s > 1 ? (size_t)nprob * s * M * N * sizeof(float) : 0;
+}
+
+ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
+                             const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                             const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
+    return sa_gemm_f32_group_impl(1, trans_a, trans_b, M, N, K, alpha, &A, lda, &B, ldb, beta, &C, ldc, &bias, ep,
+                                  workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) {

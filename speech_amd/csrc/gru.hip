@@ -19,6 +19,8 @@
 //   forward : 3 gate tiles (r, z, n rows of W_hh) x K = H
 //   backward: 1 tile of dh_{t-1} = dah_t W_hh (rows of W_hh^T, transposed once per call) x K = 3H, then the gate
 //             gradients of step t-1 in the epilogue (they become the next launch's A operand).
+#include <stdlib.h>
+
 #include "common.h"
 #include "internal.h"
 
@@ -33,40 +35,52 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // acc[n] += A_tile(16 x kslice) * B_tile_n(16 x kslice)^T over this wave's K slice.
 // 16x16x4 f32 operand layout: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; each lane loads
 // 4 consecutive k (one float4) from its row and feeds 4 MFMAs, the four 16-lane groups cover 16 consecutive k.
-template <int NT>
+// The loop is a dependent-latency problem (L2 round trip ~0.5 us per trip if loads and MFMAs alternate), so operands
+// are fetched U iterations at a time -- U * (1 + NT) independent 16-byte loads in flight -- before their MFMAs issue.
+template <int NT, int U>
 __device__ __forceinline__ void smallm_mfma(const float* __restrict__ a_row, const float* const (&b_row)[NT],
                                             int kbeg, int kend, int K, f32x4 (&acc)[NT], int g) {
-    for (int kk = kbeg; kk < kend; kk += 16) {  // wave-uniform trip count (MFMA must not sit in divergent flow)
-        const int k = kk + 4 * g;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 b[NT];
-        if (k + 3 < K) {
-            a = *reinterpret_cast<const float4*>(a_row + k);
+    for (int kk0 = kbeg; kk0 < kend; kk0 += 16 * U) {  // wave-uniform trip counts (MFMA must not sit in divergent flow)
+        float4 a[U];
+        float4 b[U][NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const float4*>(b_row[n] + k);
-        } else {
+        for (int it = 0; it < U; ++it) {
+            const int k = kk0 + 16 * it + 4 * g;
+            a[it] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k + 0 < K) { a.x = a_row[k];
+            for (int n = 0; n < NT; ++n) b[it][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk0 + 16 * it < kend) {
+                if (k + 3 < K) {
+                    a[it] = *reinterpret_cast<const float4*>(a_row + k);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) b[n].x = b_row[n][k]; }
-            if (k + 1 < K) { a.y = a_row[k + 1];
+                    for (int n = 0; n < NT; ++n) b[it][n] = *reinterpret_cast<const float4*>(b_row[n] + k);
+                } else {
+                    if (k + 0 < K) { a[it].x = a_row[k];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) b[n].y = b_row[n][k + 1]; }
-            if (k + 2 < K) { a.z = a_row[k + 2];
+                        for (int n = 0; n < NT; ++n) b[it][n].x = b_row[n][k]; }
+                    if (k + 1 < K) { a[it].y = a_row[k + 1];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) b[n].z = b_row[n][k + 2]; }
+                        for (int n = 0; n < NT; ++n) b[it][n].y = b_row[n][k + 1]; }
+                    if (k + 2 < K) { a[it].z = a_row[k + 2];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) b[it][n].z = b_row[n][k + 2]; }
+                }
+            }
         }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[n].x, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[n].y, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[n].z, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[n].w, acc[n], 0, 0, 0);
+        for (int it = 0; it < U; ++it) {
+            if (kk0 + 16 * it < kend) {  // wave-uniform
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, b[it][n].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, b[it][n].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, b[it][n].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, b[it][n].w, acc[n], 0, 0, 0);
+                }
+            }
         }
     }
 }
-
 
 // Row-structured arrays (ai, stash, dai, dah) address row (b, t) as  b * rb + t * rt  (time-major: rb = 1, rt = B;
 // batch-major: rb = T, rt = 1).
@@ -82,6 +96,7 @@ struct FwdJob {
 };
 struct FwdJobs {
     int n, B, H;
+    int dbg;  // ablation switches for tools/gru_step_bench.py (0 in production): 1 = no W loads, 2 = no h loads
     long rb, rt;
     FwdJob j[kMaxJobs];
 };
@@ -116,10 +131,12 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
         const float* a_row = J.h_out + (long)brow * J.hs_b + (long)J.t_prev * J.hs_t;
         const float* b_rows[3] = {J.w_hh + (long)urow * H, J.w_hh + (long)(H + urow) * H,
                                   J.w_hh + (long)(2 * H + urow) * H};
+        if (P.dbg & 1) { b_rows[0] = J.w_hh; b_rows[1] = J.w_hh; b_rows[2] = J.w_hh; }  // every lane: one 2 KB row
+        if (P.dbg & 2) a_row = J.h_out;
         f32x4 acc[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        smallm_mfma<3>(a_row, b_rows, kbeg, kend, H, acc, g);
+        smallm_mfma<3, 8>(a_row, b_rows, kbeg, kend, H, acc, g);
         // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
         for (int n = 0; n < 3; ++n)
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
         const float* b_rows[1] = {J.w_hh_t + (long)urow * H3};
         f32x4 acc[1];
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        smallm_mfma<1>(a_row, b_rows, kbeg, kend, H3, acc, g);
+        smallm_mfma<1, 12>(a_row, b_rows, kbeg, kend, H3, acc, g);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) red[wave][(g * 4 + rr) * 16 + i] = acc[0][rr];
     }
@@ -295,7 +312,7 @@ extern "C" ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const floa
         return CTC_STATUS_INVALID_VALUE;  // 16-byte fragment loads need 4-float alignment
     hipStream_t stream = (hipStream_t)stream_;
     FwdJobs P;
-    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.dbg = 0;
     FwdJob& J = P.j[0];
     J.ai = ai; J.w_hh = w_hh; J.b_hh = b_hh; J.h_out = h_out; J.stash = stash; J.hs_b = hs_b; J.hs_t = hs_t;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -351,9 +368,23 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
 // Time-major arrays throughout: x (T, B, I0); h_out[l] (T, B, D*H); ai / stash / dai / dah [l*D+d] (T, B, .).
 static size_t stack_ai_bytes(int B, int T, int H) { return sa_align_up((size_t)T * B * 3 * H * sizeof(float), 256); }
 
+static int clamp_chunk(int chunk, int T) {
+    if (chunk <= 0) chunk = 32;
+    return chunk > T ? T : chunk;
+}
+static size_t stack_gemm_ws(int L, int B, int T, int H, int chunk, bool fwd) {
+    // split-K workspace of the grouped per-chunk projections (up to L-1 problems per launch)
+    const int c = clamp_chunk(chunk, T);
+    const size_t w = fwd ? sa_gemm_group_workspace_bytes(L > 1 ? L - 1 : 1, c * B, 3 * H, H)
+                         : sa_gemm_group_workspace_bytes(L > 1 ? L - 1 : 1, c * B, H, 3 * H);
+    return sa_align_up(w, 256);
+}
+
 extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, int H, int I0) {
     if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
-    return (size_t)L * D * stack_ai_bytes(B, T, H);
+    size_t gw = 0;
+    for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, true); if (w > gw) gw = w; }
+    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw;
 }
 
 extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
@@ -366,8 +397,10 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (chunk <= 0) chunk = 32;
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
+    char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
+    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H);
     const long DH = (long)D * H;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     ctcStatus_t st;
@@ -381,6 +414,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     };
     FwdJobs P;
     P.B = B; P.H = H; P.rb = 1; P.rt = B;
+    { const char* e = getenv("SA_GRU_DBG"); P.dbg = e ? atoi(e) : 0; }
 
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
                    // the two directions of a layer share every launch
@@ -409,14 +443,30 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (st != CTC_STATUS_SUCCESS) return st;
     const int nch = (T + chunk - 1) / chunk;
     for (int w = 0; w < nch + L - 1; ++w) {
-        // input projections of the chunk each upper layer is about to process (its lower layer finished it last wave)
-        for (int l = 1; l < L; ++l) {
-            const int c = w - l;
-            if (c < 0 || c >= nch) continue;
-            const int t0 = c * chunk, t1 = min(T, t0 + chunk);
-            st = sa_gemm_f32_impl(0, 1, (t1 - t0) * B, 3 * H, H, 1.f, h_out[l - 1] + (long)t0 * B * H, H, w_ih[l], H,
-                                  0.f, ai_of(l, 0) + (long)t0 * B * 3 * H, 3 * H, b_ih[l], nullptr, nullptr, 0, stream);
-            if (st != CTC_STATUS_SUCCESS) return st;
+        // input projections of the chunk each upper layer is about to process (its lower layer finished it last
+        // wave): full chunks of all layers go out as ONE grouped GEMM launch, a ragged last chunk on its own
+        {
+            const float* gA[kMaxJobs]; const float* gB[kMaxJobs]; float* gC[kMaxJobs]; const float* gb[kMaxJobs];
+            int ng = 0;
+            for (int l = 1; l < L; ++l) {
+                const int c = w - l;
+                if (c < 0 || c >= nch) continue;
+                const int t0 = c * chunk, t1 = min(T, t0 + chunk);
+                const float* Ap = h_out[l - 1] + (long)t0 * B * H;
+                float* Cp = ai_of(l, 0) + (long)t0 * B * 3 * H;
+                if (t1 - t0 == chunk) {
+                    gA[ng] = Ap; gB[ng] = w_ih[l]; gC[ng] = Cp; gb[ng] = b_ih[l]; ++ng;
+                } else {
+                    st = sa_gemm_f32_impl(0, 1, (t1 - t0) * B, 3 * H, H, 1.f, Ap, H, w_ih[l], H, 0.f, Cp, 3 * H,
+                                          b_ih[l], nullptr, gws, gws_bytes, stream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
+            }
+            if (ng > 0) {
+                st = sa_gemm_f32_group_impl(ng, 0, 1, chunk * B, 3 * H, H, 1.f, gA, H, gB, H, 0.f, gC, 3 * H, gb,
+                                            nullptr, gws, gws_bytes, stream);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
         }
         for (int s = 0; s < chunk; ++s) {
             int n = 0;
@@ -441,7 +491,9 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +      // dh ping-pong
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);       // W_hh^T
     const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
-    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid;
+    size_t gw = 0;
+    for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
+    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw;
 }
 
 // dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d] (T, B, 3H) for every layer and
@@ -456,11 +508,14 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (chunk <= 0) chunk = 32;
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
     const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
     char* ws = (char*)workspace;
+    const size_t fixed_bytes = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
+    char* gws = ws + fixed_bytes;
+    const size_t gws_bytes = workspace_bytes - fixed_bytes;
     auto dh_buf = [&](int l, int d, int which) {
         return (float*)(ws + (size_t)(l * D + d) * per_dir) + (size_t)which * B * H;
     };
@@ -514,15 +569,29 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     const int nch = (T + chunk - 1) / chunk;
     for (int w = 0; w < nch + L - 1; ++w) {
         // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
-        for (int l = L - 2; l >= 0; --l) {
-            const int cc = w - (L - 1 - l);
-            if (cc < 0 || cc >= nch) continue;
-            const int c = nch - 1 - cc;
-            const int t0 = c * chunk, t1 = min(T, t0 + chunk);
-            st = sa_gemm_f32_impl(0, 0, (t1 - t0) * B, H, 3 * H, 1.f, dai[l + 1] + (long)t0 * B * 3 * H, 3 * H,
-                                  w_ih[l + 1], H, 0.f, mid_of(l) + (long)t0 * B * H, H, nullptr, nullptr, nullptr, 0,
-                                  stream);
-            if (st != CTC_STATUS_SUCCESS) return st;
+        {
+            const float* gA[kMaxJobs]; const float* gB[kMaxJobs]; float* gC[kMaxJobs];
+            int ng = 0;
+            for (int l = L - 2; l >= 0; --l) {
+                const int cc = w - (L - 1 - l);
+                if (cc < 0 || cc >= nch) continue;
+                const int c = nch - 1 - cc;
+                const int t0 = c * chunk, t1 = min(T, t0 + chunk);
+                const float* Ap = dai[l + 1] + (long)t0 * B * 3 * H;
+                float* Cp = mid_of(l) + (long)t0 * B * H;
+                if (t1 - t0 == chunk) {
+                    gA[ng] = Ap; gB[ng] = w_ih[l + 1]; gC[ng] = Cp; ++ng;
+                } else {
+                    st = sa_gemm_f32_impl(0, 0, (t1 - t0) * B, H, 3 * H, 1.f, Ap, 3 * H, w_ih[l + 1], H, 0.f, Cp, H,
+                                          nullptr, nullptr, gws, gws_bytes, stream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
+            }
+            if (ng > 0) {
+                st = sa_gemm_f32_group_impl(ng, 0, 0, chunk * B, H, 3 * H, 1.f, gA, 3 * H, gB, H, 0.f, gC, H, nullptr,
+                                            nullptr, gws, gws_bytes, stream);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
         }
         for (int s = 0; s < chunk; ++s) {
             int n = 0;

@@ -13,4 +13,10 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
                              const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
                              const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes, hipStream_t stream);
 extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K);
+// nprob (<= 8) problems of identical shape in one launch; array arguments are host arrays of device pointers
+ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
+                                   const float* const* A, long lda, const float* const* B, long ldb, float beta,
+                                   float* const* C, long ldc, const float* const* bias, const SaGemmEpilogue* ep,
+                                   void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t sa_gemm_group_workspace_bytes(int nprob, int M, int N, int K);
 extern "C" size_t sa_colsum_workspace_bytes(int M, int N);

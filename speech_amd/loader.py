@@ -1,0 +1,155 @@
+"""speech_amd.loader -- the reference's data-loading API (/root/reference/speech/loader.py) for the drop-in drivers.
+
+Host-side, I/O-bound code: nothing here is on the measured hot path, it exists so that
+train.py / eval.py keep working against the same JSON-lines datasets and the same batch format
+    batch = (inputs: tuple of float32 [T_i, F] arrays, labels: tuple of int lists)
+Differences from the reference, all supersets:
+  * the collate function returns a real tuple, not a one-shot zip iterator (loader.py:148 breaks eval_dev in py3);
+  * wave files are read with scipy.io.wavfile when `soundfile` is not installed;
+  * the character map is built from a SORTED set, so label ids do not depend on PYTHONHASHSEED.
+"""
+import json
+import random
+
+import numpy as np
+import scipy.signal
+import torch.utils.data as tud
+
+
+def array_from_wave(file_name):
+    """speech/utils/wave.py:8-10: (int16 samples, sample rate)."""
+    try:
+        import soundfile
+        audio, samp_rate = soundfile.read(file_name, dtype="int16")
+        return audio, samp_rate
+    except ImportError:
+        import scipy.io.wavfile
+        samp_rate, audio = scipy.io.wavfile.read(file_name)
+        return audio, samp_rate
+
+
+def wav_duration(file_name):
+    audio, samp_rate = array_from_wave(file_name)
+    return audio.shape[0] / samp_rate
+
+
+def log_specgram(audio, sample_rate, window_size=20, step_size=10, eps=1e-10):
+    """loader.py:156-166: log power spectrogram, Hann window of window_size ms, hop step_size ms -> (frames, bins)."""
+    nperseg = int(window_size * sample_rate / 1e3)
+    noverlap = int(step_size * sample_rate / 1e3)
+    _, _, spec = scipy.signal.spectrogram(audio, fs=sample_rate, window="hann", nperseg=nperseg, noverlap=noverlap,
+                                          detrend=False)
+    return np.log(spec.T.astype(np.float32) + eps)
+
+
+def log_specgram_from_file(audio_file):
+    audio, sr = array_from_wave(audio_file)
+    return log_specgram(audio, sr)
+
+
+def read_data_json(data_json):
+    with open(data_json) as fid:
+        return [json.loads(line) for line in fid]
+
+
+def compute_mean_std(audio_files):
+    feats = np.vstack([log_specgram_from_file(af) for af in audio_files])
+    return np.mean(feats, axis=0), np.std(feats, axis=0)
+
+
+class Preprocessor:
+    END = "</s>"
+    START = "<s>"
+
+    def __init__(self, data_json, max_samples=100, start_and_end=True):
+        """Feature statistics from up to max_samples files and the character <-> int maps (loader.py:15-45)."""
+        data = read_data_json(data_json)
+        audio_files = [d["audio"] for d in data]
+        random.shuffle(audio_files)
+        self.mean, self.std = compute_mean_std(audio_files[:max_samples])
+        self._input_dim = self.mean.shape[0]
+        chars = sorted(set(t for d in data for t in d["text"]))
+        if start_and_end:
+            chars.extend([self.END, self.START])  # START last: easy to exclude from a model's output classes
+        self.start_and_end = start_and_end
+        self.int_to_char = dict(enumerate(chars))
+        self.char_to_int = {v: k for k, v in self.int_to_char.items()}
+
+    def encode(self, text):
+        text = list(text)
+        if self.start_and_end:
+            text = [self.START] + text + [self.END]
+        return [self.char_to_int[t] for t in text]
+
+    def decode(self, seq):
+        text = [self.int_to_char[int(s)] for s in seq]
+        if not self.start_and_end:
+            return text
+        s = 1 if text and text[0] == self.START else 0
+        e = text.index(self.END) if text and text[-1] == self.END else len(text)
+        return text[s:e]
+
+    def preprocess(self, wave_file, text):
+        inputs = (log_specgram_from_file(wave_file) - self.mean) / self.std
+        return inputs, self.encode(text)
+
+    @property
+    def input_dim(self):
+        return self._input_dim
+
+    @property
+    def vocab_size(self):
+        return len(self.int_to_char)
+
+
+class AudioDataset(tud.Dataset):
+    """Examples bucketed by transcript length (bucket width 4), each bucket sorted by (duration, length)
+    (loader.py:87-117), so that consecutive batches hold utterances of similar length."""
+
+    def __init__(self, data_json, preproc, batch_size):
+        data = read_data_json(data_json)
+        self.preproc = preproc
+        bucket_diff = 4
+        num_buckets = max(max(len(x["text"]) for x in data) // bucket_diff, 1)
+        buckets = [[] for _ in range(num_buckets)]
+        for d in data:
+            buckets[min(len(d["text"]) // bucket_diff, num_buckets - 1)].append(d)
+        for b in buckets:
+            b.sort(key=lambda x: (round(x["duration"], 1), len(x["text"])))
+        self.data = [d for b in buckets for d in b]
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        datum = self.data[idx]
+        return self.preproc.preprocess(datum["audio"], datum["text"])
+
+
+class BatchRandomSampler(tud.sampler.Sampler):
+    """Consecutive batches, visited in random order without replacement (loader.py:120-137).  The shuffle uses
+    Python's `random`, which train.py seeds from the config: every data-parallel rank draws the same order."""
+
+    def __init__(self, data_source, batch_size):
+        it_end = len(data_source) - batch_size + 1
+        self.batches = [range(i, i + batch_size) for i in range(0, it_end, batch_size)]
+        self.data_source = data_source
+
+    def __iter__(self):
+        random.shuffle(self.batches)
+        return (i for b in self.batches for i in b)
+
+    def __len__(self):
+        return len(self.data_source)
+
+
+def _collate(batch):
+    inputs, labels = zip(*batch)
+    return inputs, labels
+
+
+def make_loader(dataset_json, preproc, batch_size, num_workers=4):
+    dataset = AudioDataset(dataset_json, preproc, batch_size)
+    sampler = BatchRandomSampler(dataset, batch_size)
+    return tud.DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+                          collate_fn=_collate, drop_last=True)

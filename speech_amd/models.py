@@ -30,6 +30,7 @@ class Model(nn.Module):
     def __init__(self, input_dim, config):
         super().__init__()
         self.input_dim = input_dim
+        self._ctor_args = (input_dim, config)
         encoder_cfg = config["encoder"]
         convs = []
         in_c = 1
@@ -173,6 +174,7 @@ def zero_pad_concat(inputs):
 class CTC(Model):
     def __init__(self, freq_dim, output_dim, config):
         super().__init__(freq_dim, config)
+        self._ctor_args = (freq_dim, output_dim, config)
         # include the blank token (ctc_model.py:17-19): blank is the LAST class
         self.blank = output_dim
         self.fc = LinearND(self.encoder_dim, output_dim + 1)

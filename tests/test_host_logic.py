@@ -1,0 +1,98 @@
+"""Host-side logic that needs no GPU: the loader / io / score mirrors of the reference API, the import-path shims,
+collate / conv_out_size of the model classes, and that a CPU model refuses to compute."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.io.wavfile
+import torch
+
+
+@pytest.fixture()
+def tiny_dataset(tmp_path):
+    """Two synthetic 16 kHz wavs and an 8-line JSON-lines file (the shape of /root/reference/tests/test.json)."""
+    rng = np.random.RandomState(0)
+    files = []
+    for i, n in enumerate([17622, 25130]):
+        t = np.arange(n) / 16000.0
+        audio = (3000 * np.sin(2 * np.pi * (200 + 150 * i) * t) + 300 * rng.randn(n)).astype(np.int16)
+        path = str(tmp_path / ("utt%d.wav" % i))
+        scipy.io.wavfile.write(path, 16000, audio)
+        files.append((path, n / 16000.0))
+    lines = []
+    for k in range(8):
+        path, dur = files[k % 2]
+        lines.append({"text": list("hello world" if k % 2 == 0 else "hello hi"), "duration": dur, "audio": path})
+    js = str(tmp_path / "data.json")
+    with open(js, "w") as fid:
+        for l in lines:
+            fid.write(json.dumps(l) + "\n")
+    return js
+
+
+def test_loader_surface(tiny_dataset):
+    # mirrors /root/reference/tests/loader_test.py:5-35
+    import speech.loader as loader
+    preproc = loader.Preprocessor(tiny_dataset)
+    assert preproc.vocab_size == 11  # 9 characters + </s> + <s>
+    assert preproc.int_to_char[preproc.vocab_size - 1] == preproc.START
+    assert preproc.input_dim == 161  # 20 ms window at 16 kHz -> 320 // 2 + 1 bins
+    ldr = loader.make_loader(tiny_dataset, preproc, batch_size=2, num_workers=0)
+    n = 0
+    for inputs, labels in ldr:
+        assert inputs[0].shape == inputs[1].shape and inputs[0].shape[1] == preproc.input_dim
+        assert inputs[0].dtype == np.float32 and len(labels) == 2
+        n += len(inputs)
+        _ = (inputs, labels)[1]  # a materialised tuple: indexable and re-iterable (reference App. C defect)
+    assert n == 8
+    text = preproc.decode(preproc.encode("hello"))
+    assert "".join(text) == "hello"
+
+
+def test_io_and_score_round_trip(tiny_dataset, tmp_path):
+    # mirrors /root/reference/tests/io_test.py:8-31
+    import speech
+    import speech.loader as loader
+    from speech.models import CTC
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 32, 2]], "rnn": {"dim": 16, "bidirectional": False, "layers": 1}}}
+    preproc = loader.Preprocessor(tiny_dataset)
+    model = CTC(preproc.input_dim, preproc.vocab_size, cfg)
+    speech.save(model, preproc, str(tmp_path / "ckpt"), tag="best")
+    m2, p2 = speech.load(str(tmp_path / "ckpt"), tag="best")
+    for attr in ("mean", "std", "int_to_char", "char_to_int"):
+        assert hasattr(p2, attr)
+    assert set(m2.state_dict().keys()) == set(model.state_dict().keys())
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+    assert hasattr(m2, "encoder_dim") and not m2.is_cuda
+    assert speech.compute_cer([("abc", "abc"), ("abcd", "abxd")]) == 1 / 7
+
+
+def test_model_host_methods_and_cpu_refusal():
+    from speech_amd import _lib
+    from speech_amd.models import CTC, zero_pad_concat
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 16, "bidirectional": False, "layers": 1}}}
+    model = CTC(40, 10, cfg)
+    assert model.conv_out_size(100, 0) == 48 and model.conv_out_size(40, 1) == 5 and model.blank == 10
+    assert sorted(model.state_dict()) == sorted(["conv.0.weight", "conv.0.bias", "rnn.weight_ih_l0", "rnn.weight_hh_l0",
+                                                 "rnn.bias_ih_l0", "rnn.bias_hh_l0", "fc.fc.weight", "fc.fc.bias"])
+    inputs = (np.ones((7, 40)), np.ones((5, 40)))
+    x, y, x_lens, y_lens = model.collate(inputs, ([1, 2, 3], [4]))
+    assert x.shape == (2, 7, 40) and x.dtype == torch.float32 and float(x[1, 5:].abs().sum()) == 0
+    assert y.tolist() == [1, 2, 3, 4] and y_lens.tolist() == [3, 1]
+    assert x_lens.tolist() == [model.conv_out_size(7, 0)] * 2  # ctc_model.py:43-45: padded length for everyone
+    assert zero_pad_concat(inputs).shape == (2, 7, 40)
+    assert CTC.max_decode([1, 2, 2, 0, 0, 0, 2, 1], 0) == [1, 2, 2, 1] and CTC.max_decode([0, 0, 0], 0) == []
+    with pytest.raises(_lib.SpeechAmdError):
+        model.loss((tuple(np.random.randn(100, 40) for _ in range(2)), ([1, 2], [3])))  # CPU model: no fallback
+
+
+def test_import_shims_match_reference_paths():
+    import functions.ctc as ctc
+    import speech
+    import speech.models as models
+    from speech_amd.ctc import CTCLoss
+    assert ctc.CTCLoss is CTCLoss and hasattr(models, "CTC") and hasattr(models, "Model")
+    assert callable(speech.save) and callable(speech.load) and callable(speech.compute_cer)
+    assert ctc.CTCLoss().blank is None  # no-arg constructor, as ctc_model.py:38 uses it
