@@ -148,12 +148,15 @@ ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, const float* h
  * (d = 1: the reverse direction), in nn.GRU's layouts.  Includes the input projections (MFMA GEMMs).
  * Unidirectional stacks run as a chunked layer wavefront (`chunk` time steps per chunk, <= 0: default): layer l
  * processes chunk c while layer l+1 processes chunk c-1, up to L layer-steps per launch.  Bidirectional stacks run
- * layer by layer with both directions sharing each launch.  L <= 8. */
+ * layer by layer with both directions sharing each launch.  L <= 8.
+ * aux_streams (n_aux >= 0 extra hipStream_t handles, may be NULL): a step launch is a latency chain that leaves the
+ * chip idle, so the batch is cut into 1 + n_aux independent groups of rows whose step kernels run concurrently, one
+ * group per stream; the groups rejoin `stream` (event wait) once per wavefront wave and at the end of the call. */
 size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, int H, int I0);
 ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
                              const float* const* w_hh, const float* const* b_hh, float* const* h_out,
                              float* const* stash, int L, int D, int B, int T, int H, int chunk, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             size_t workspace_bytes, void* stream, void* const* aux_streams, int n_aux);
 
 /* Backward through the stack.  dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d]
  * (T, B, 3H) (gradients wrt the i2h / h2h pre-activations of every layer and direction: the weight and bias gradients
@@ -163,7 +166,7 @@ size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, int H, int I
 ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, const float* const* w_ih,
                              const float* const* w_hh, float* const* dai, float* const* dah, float* dx, int I0, int L,
                              int D, int B, int T, int H, int chunk, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             void* stream, void* const* aux_streams, int n_aux);
 
 /* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients; two deterministic stages through `workspace`. */
 size_t sa_colsum_workspace_bytes(int M, int N);

@@ -227,13 +227,25 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
 }
 
 int choose_splits(int M, int N, int K, int nprob = 1) {
+    // Blocks of this kernel sit 2-3 per CU and share each SIMD's matrix pipe, so the launch is balanced when the block
+    // count is just under a multiple of the CU count: pick the split (>= 4 K-tiles each) whose tiles * split fills
+    // 256 / 512 / 768 slots best, preferring fewer splits on ties (less partial-sum traffic).
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nprob;
     if (tiles >= 192 || K < 8 * BK) return 1;
-    int s = (int)((512 + tiles - 1) / tiles);       // aim for ~2 blocks per CU
-    const int max_by_k = K / (4 * BK);              // at least 4 K-tiles per split
-    if (s > max_by_k) s = max_by_k;
-    if (s > 128) s = 128;
-    return s < 1 ? 1 : s;
+    int max_s = K / (4 * BK);
+    if (max_s > 128) max_s = 128;
+    if (max_s < 1) return 1;
+    int best = 1;
+    double best_score = 0.0;
+    for (int s = 1; s <= max_s; ++s) {
+        const long blocks = tiles * s;
+        if (blocks > 768) break;
+        const long slots = ((blocks + 255) / 256) * 256;
+        double score = (double)blocks / (double)slots;          // fill of the last round
+        score *= blocks >= 512 ? 1.0 : (blocks >= 256 ? 0.92 : 0.5 * blocks / 256.0 + 0.3);  // want >= 2 blocks per CU
+        if (score > best_score + 0.02) { best_score = score; best = s; }
+    }
+    return best;
 }
 
 }  // namespace

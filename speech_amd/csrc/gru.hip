@@ -96,6 +96,8 @@ struct FwdJob {
 };
 struct FwdJobs {
     int n, B, H;
+    int bt0;        // first batch tile handled by this launch (blockIdx.y is relative to it)
+    int tile_rows;  // batch rows owned by a block: 16, or 8 / 4 when the batch is cut into more concurrent chains
     int dbg;  // ablation switches for tools/gru_step_bench.py (0 in production): 1 = no W loads, 2 = no h loads
     long rb, rt;
     FwdJob j[kMaxJobs];
@@ -107,13 +109,13 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
     const int H = P.H, B = P.B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int u0 = blockIdx.x * 16, b0 = (blockIdx.y + P.bt0) * P.tile_rows;
     const bool first = J.t_prev < 0;
 
     // epilogue operands first: their latency overlaps the operand fetch + MFMA phase
     const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
     const int b = b0 + bi, u = u0 + uj;
-    const bool live = b < B && u < H;
+    const bool live = b < B && u < H && bi < P.tile_rows;
     float e_ai_r = 0.f, e_ai_z = 0.f, e_ai_n = 0.f, e_br = 0.f, e_bz = 0.f, e_bn = 0.f, hp = 0.f;
     const long row = live ? (long)b * P.rb + (long)J.t * P.rt : 0;
     if (live) {
@@ -166,6 +168,163 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
     }
 }
 
+// -------------------------------------------------------------------------------------- persistent forward chunk
+// One launch runs `nsteps` consecutive time steps of up to 8 layer-jobs.  Block (unit tile u, batch tile bt, job)
+// keeps its 3 x 16 rows of W_hh in LDS for the whole chunk (the step kernels re-stream them from a cold L2 on every
+// launch) and carries its own h values in registers.  What must cross CUs every step is the h_{t} slice each block
+// produces: it is published with write-through (sc1) stores, then one relaxed agent-scope counter per
+// (job, batch tile) group is bumped; consumers poll that counter from one lane and read h_{t-1} with sc1
+// (L1-bypassing) 16-byte buffer loads -- the R1 hand-off recipe of the CDNA guide, placement independent.
+// All blocks must be co-resident: grid <= #CUs and ~110 KB of LDS force one block per CU; spins are bounded.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct PFwdJob {
+    const float* ai;
+    const float* w_hh;
+    const float* b_hh;
+    float* h_out;
+    float* stash;
+    unsigned* counters;  // one per batch tile; monotonic over the whole stack call
+    long hs_b, hs_t;
+    int t0, nsteps;
+    unsigned base;       // arrivals per counter before this launch
+};
+struct PFwdJobs {
+    int n, B, H;
+    long rb, rt;
+    unsigned* err;
+    unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
+    PFwdJob j[kMaxJobs];
+};
+
+__global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    const PFwdJob& J = P.j[blockIdx.z];
+    const int H = P.H, B = P.B;
+    const int LDW = H + 4;                       // padded row pitch: 16-byte aligned, spreads the fragment reads
+    float* Wl = psm;                             // [48][LDW]: rows u0.., H+u0.., 2H+u0.. of W_hh
+    float* red = psm + 48 * LDW;                 // [4][3][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ntile_u = gridDim.x;
+    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+
+    // W_hh slice -> LDS, once per launch
+    for (int idx = tid; idx < 48 * (H / 4); idx += 256) {
+        const int r = idx / (H / 4), c4 = idx - r * (H / 4);
+        const int grow = (r >> 4) * H + u0 + (r & 15);
+        *reinterpret_cast<float4*>(&Wl[r * LDW + 4 * c4]) =
+            *reinterpret_cast<const float4*>(J.w_hh + (long)grow * H + 4 * c4);
+    }
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    const float e_br = J.b_hh[u], e_bz = J.b_hh[H + u], e_bn = J.b_hh[2 * H + u];
+    float hp = 0.f;
+    if (live && J.t0 > 0) hp = J.h_out[(long)b * J.hs_b + (long)(J.t0 - 1) * J.hs_t + u];
+    unsigned* counter = J.counters + blockIdx.y;
+    const int kslice = H / 4, kbeg = wave * kslice;  // H % 64 == 0 (checked by the host)
+    const int brow = min(b0 + i, B - 1);
+    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)J.h_out, 0, 0x7fffffff, 0x00020000);
+    bool dead = false;
+    __syncthreads();
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
+    const bool timed = P.timing != nullptr && tid == 0;
+    if (timed) tprev = wall_clock64();
+#define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
+
+    for (int s = 0; s < J.nsteps; ++s) {
+        const int t = J.t0 + s;
+        const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
+        float e_ai_r = 0.f, e_ai_z = 0.f, e_ai_n = 0.f;
+        if (live) {
+            const float* ai = J.ai + row * 3 * H;
+            e_ai_r = ai[u]; e_ai_z = ai[H + u]; e_ai_n = ai[2 * H + u];
+        }
+        if (s > 0) {  // every unit tile of this (job, batch tile) must have published h_{t-1}
+            if (tid == 0 && !dead) {
+                const unsigned need = J.base + (unsigned)ntile_u * (unsigned)s;
+                int spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) { dead = true; atomicExch(P.err, 1u); break; }
+                }
+            }
+            __syncthreads();
+        }
+        SA_TICK(0)
+        if (t > 0) {
+            f32x4 acc[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int abase = (int)(((long)brow * J.hs_b + (long)(t - 1) * J.hs_t) * 4);  // byte offset of the h row
+            for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 128) {
+                f32x4v a[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int k = kk0 + 16 * it + 4 * g;
+                    a[it] = kk0 + 16 * it < kbeg + kslice
+                                ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
+                                : f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    if (kk0 + 16 * it < kbeg + kslice) {
+                        const int k = kk0 + 16 * it + 4 * g;
+#pragma unroll
+                        for (int n = 0; n < 3; ++n) {
+                            const float4 w = *reinterpret_cast<const float4*>(&Wl[(n * 16 + i) * LDW + k]);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, acc[n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * 3 + n) * 256 + (g * 4 + r) * 16 + i] = acc[n][r];
+        }
+        __syncthreads();
+        SA_TICK(1)
+        float sr = 0.f, sz = 0.f, sn = 0.f;
+        if (t > 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                sr += red[(w * 3 + 0) * 256 + tid];
+                sz += red[(w * 3 + 1) * 256 + tid];
+                sn += red[(w * 3 + 2) * 256 + tid];
+            }
+        }
+        if (live) {
+            const float r = sigmoidf_(e_ai_r + sr + e_br);
+            const float z = sigmoidf_(e_ai_z + sz + e_bz);
+            const float q = sn + e_bn;
+            const float n = tanhf(e_ai_n + r * q);
+            const float h = (1.0f - z) * n + z * hp;
+            __hip_atomic_store(J.h_out + (long)b * J.hs_b + (long)t * J.hs_t + u, h, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);  // write-through: visible to every CU once acknowledged
+            if (J.stash) {
+                float* st = J.stash + row * 5 * H;
+                st[u] = r; st[H + u] = z; st[2 * H + u] = n; st[3 * H + u] = q; st[4 * H + u] = hp;
+            }
+            hp = h;
+        }
+        SA_TICK(2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the flag
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SA_TICK(3)
+    }
+    if (timed) {
+        unsigned long long* o = P.timing + 4 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
+    }
+#undef SA_TICK
+}
+
 // ----------------------------------------------------------------------------------------------------- backward step
 struct BwdJob {
     const float* dh_out;  // gradient wrt h_out, [b * ds_b + t * ds_t + j]
@@ -181,6 +340,7 @@ struct BwdJob {
 };
 struct BwdJobs {
     int n, B, H;
+    int bt0, tile_rows;
     long rb, rt;
     BwdJob j[kMaxJobs];
 };
@@ -191,12 +351,12 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
     const int H = P.H, B = P.B, H3 = 3 * P.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int u0 = blockIdx.x * 16, b0 = (blockIdx.y + P.bt0) * P.tile_rows;
     const bool have_next = J.t_next >= 0;
 
     const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
     const int b = b0 + bi, u = u0 + uj;
-    const bool live = b < B && u < H;
+    const bool live = b < B && u < H && bi < P.tile_rows;
     const long row = live ? (long)b * P.rb + (long)J.t * P.rt : 0;
     float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f, z_next = 0.f, dh_prev = 0.f;
     if (live) {  // epilogue operands first (see the forward kernel)
@@ -275,13 +435,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (ty == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
+// 16 lanes per column add the R partials in a fixed tree (deterministic), 16 columns per block
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int R, int N,
                                                            float* __restrict__ out, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    const int n = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += part[(long)r * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int r = j; r < R; r += 16) s += part[(long)r * N + n];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (n < N && j == 0) out[n] = accumulate ? out[n] + s : s;
 }
 
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, long lda,
@@ -312,7 +476,7 @@ extern "C" ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const floa
         return CTC_STATUS_INVALID_VALUE;  // 16-byte fragment loads need 4-float alignment
     hipStream_t stream = (hipStream_t)stream_;
     FwdJobs P;
-    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.dbg = 0;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.dbg = 0; P.bt0 = 0; P.tile_rows = 16;
     FwdJob& J = P.j[0];
     J.ai = ai; J.w_hh = w_hh; J.b_hh = b_hh; J.h_out = h_out; J.stash = stash; J.hs_b = hs_b; J.hs_t = hs_t;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -347,7 +511,7 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
     hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream, w_hh, w_t,
                        3 * H, H);
     BwdJobs P;
-    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.bt0 = 0; P.tile_rows = 16;
     BwdJob& J = P.j[0];
     J.dh_out = dh_out; J.stash = stash; J.w_hh_t = w_t; J.dai = dai; J.dah = dah;
     J.ds_b = hs_b; J.ds_t = hs_t;
@@ -365,11 +529,84 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
 }
 
 // ------------------------------------------------------------------------------------------------- the layer stack
+// A step launch is a dependent-latency chain that leaves the chip mostly idle (profiles/r01_pmc_gru_step_kernels.txt:
+// >60 % of wave cycles in s_waitcnt), so the batch is cut into independent groups of rows ("chains"), each advanced on
+// its own HIP stream: their step kernels overlap on the GPU.  Stream 0 is the caller's (it also runs the GEMMs); the
+// chains join it once per wavefront wave through events.
+constexpr int kMaxChains = 8;
+
+struct Chains {
+    int n = 1;
+    int tile_rows = 16;
+    hipStream_t s[kMaxChains];
+    int bt0[kMaxChains], nbt[kMaxChains];
+    hipEvent_t ev_main = nullptr, ev_sub[kMaxChains];
+    bool ok = true;
+
+    Chains(hipStream_t main, void* const* aux, int n_aux, int B) {
+        s[0] = main;
+        int want = 1 + (aux ? n_aux : 0);
+        if (want > kMaxChains) want = kMaxChains;
+        tile_rows = 16;
+        while (tile_rows > 4 && (B + tile_rows - 1) / tile_rows < want) tile_rows >>= 1;
+        const int tiles = (B + tile_rows - 1) / tile_rows;
+        n = want < tiles ? want : tiles;
+        for (int c = 1; c < n; ++c) s[c] = (hipStream_t)aux[c - 1];
+        for (int c = 0, t = 0; c < n; ++c) {
+            const int cnt = tiles / n + (c < tiles % n ? 1 : 0);
+            bt0[c] = t; nbt[c] = cnt; t += cnt;
+        }
+        for (int c = 0; c < kMaxChains; ++c) ev_sub[c] = nullptr;
+        if (n > 1) {
+            ok = hipEventCreateWithFlags(&ev_main, hipEventDisableTiming) == hipSuccess;
+            for (int c = 1; c < n && ok; ++c) ok = hipEventCreateWithFlags(&ev_sub[c], hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    ~Chains() {
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        for (int c = 0; c < kMaxChains; ++c)
+            if (ev_sub[c]) (void)hipEventDestroy(ev_sub[c]);
+    }
+    void fork() {  // side chains wait for everything enqueued on the main stream so far
+        if (n < 2) return;
+        (void)hipEventRecord(ev_main, s[0]);
+        for (int c = 1; c < n; ++c) (void)hipStreamWaitEvent(s[c], ev_main, 0);
+    }
+    void join() {  // the main stream waits for the side chains
+        for (int c = 1; c < n; ++c) {
+            (void)hipEventRecord(ev_sub[c], s[c]);
+            (void)hipStreamWaitEvent(s[0], ev_sub[c], 0);
+        }
+    }
+};
 // Time-major arrays throughout: x (T, B, I0); h_out[l] (T, B, D*H); ai / stash / dai / dah [l*D+d] (T, B, .).
 static size_t stack_ai_bytes(int B, int T, int H) { return sa_align_up((size_t)T * B * 3 * H * sizeof(float), 256); }
 
+constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
+
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            cus = n;
+        if (cus <= 0) cus = 1;
+    }
+    return cus;
+}
+
+// Opt-in experiment (SA_GRU_PERSIST=1).  Measured on MI355X at S-LIBRI (tools/gru_persist_check.py,
+// tools/gru_persist_timing.py): bit-identical to the step kernels but 8.1 ms vs 7.0 ms per stack forward -- an
+// in-kernel step costs ~10 us (4.9 us waiting for the group's publish, 2.7 us reading the fresh 32 KB h rows with
+// sc1 loads, 1.3 us MFMA, 1 us epilogue + drain), i.e. the all-to-all seam is as expensive as the kernel boundary.
+static bool persist_enabled() {
+    const char* e = getenv("SA_GRU_PERSIST");
+    return e && e[0] == '1';
+}
+
 static int clamp_chunk(int chunk, int T) {
-    if (chunk <= 0) chunk = 32;
+    if (chunk <= 0) chunk = 16;  // measured on MI355X at S-LIBRI: 16 -> 19.6 ms/step, 32 -> 19.9, 8 -> 20.5
     return chunk > T ? T : chunk;
 }
 static size_t stack_gemm_ws(int L, int B, int T, int H, int chunk, bool fwd) {
@@ -384,13 +621,14 @@ extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, i
     if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, true); if (w > gw) gw = w; }
-    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw;
+    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + kSyncBytes;
 }
 
 extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
                                         const float* const* w_hh, const float* const* b_hh, float* const* h_out,
                                         float* const* stash, int L, int D, int B, int T, int H, int chunk,
-                                        void* workspace, size_t workspace_bytes, void* stream_) {
+                                        void* workspace, size_t workspace_bytes, void* stream_,
+                                        void* const* aux_streams, int n_aux) {
     SA_CLEAR_ERR();
     if (!x || !w_ih || !b_ih || !w_hh || !b_hh || !h_out || !workspace) return CTC_STATUS_INVALID_VALUE;
     if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
@@ -400,7 +638,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
-    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H);
+    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kSyncBytes;
+    unsigned* sync = (unsigned*)((char*)workspace + workspace_bytes - kSyncBytes);
     const long DH = (long)D * H;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     ctcStatus_t st;
@@ -413,7 +652,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         return J;
     };
     FwdJobs P;
-    P.B = B; P.H = H; P.rb = 1; P.rt = B;
+    P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16;
     { const char* e = getenv("SA_GRU_DBG"); P.dbg = e ? atoi(e) : 0; }
 
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
@@ -441,7 +680,22 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I0, 1.f, x, I0, w_ih[0], I0, 0.f, ai_of(0, 0), 3 * H, b_ih[0], nullptr,
                           nullptr, 0, stream);
     if (st != CTC_STATUS_SUCCESS) return st;
+    Chains ch(stream, aux_streams, n_aux, B);
+    if (!ch.ok) return CTC_STATUS_EXECUTION_FAILED;
+    P.tile_rows = ch.tile_rows;
     const int nch = (T + chunk - 1) / chunk;
+    // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
+    const int nbt = (B + 15) / 16, ntile_u = H / 16;
+    const size_t plds = ((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float);
+    const bool persist = persist_enabled() && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
+                         (long)L * ntile_u * nbt <= device_cus() && (size_t)(L * nbt + 1) * 4 <= kSyncBytes &&
+                         (long)T * B * H * 4 < 0x7fffffffL;
+    if (persist) {
+        if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+        if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)plds) != hipSuccess)
+            return CTC_STATUS_EXECUTION_FAILED;
+    }
     for (int w = 0; w < nch + L - 1; ++w) {
         // input projections of the chunk each upper layer is about to process (its lower layer finished it last
         // wave): full chunks of all layers go out as ONE grouped GEMM launch, a ragged last chunk on its own
@@ -468,6 +722,25 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 if (st != CTC_STATUS_SUCCESS) return st;
             }
         }
+        if (persist) {  // ONE launch runs the whole chunk of every active layer
+            PFwdJobs Q;
+            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + L * nbt;
+            Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;  // 3 KB of the sync page
+            int n = 0;
+            for (int l = 0; l < L; ++l) {
+                const int c = w - l;
+                if (c < 0 || c >= nch) continue;
+                PFwdJob& J = Q.j[n++];
+                J.ai = ai_of(l, 0); J.w_hh = w_hh[l]; J.b_hh = b_hh[l]; J.h_out = h_out[l];
+                J.stash = stash ? stash[l] : nullptr; J.counters = sync + l * nbt;
+                J.hs_b = H; J.hs_t = (long)B * H; J.t0 = c * chunk; J.nsteps = min(chunk, T - J.t0);
+                J.base = (unsigned)ntile_u * (unsigned)J.t0;
+            }
+            Q.n = n;
+            hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
+            continue;
+        }
+        ch.fork();
         for (int s = 0; s < chunk; ++s) {
             int n = 0;
             for (int l = 0; l < L; ++l) {
@@ -479,8 +752,12 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
             if (n == 0) continue;
             P.n = n; grid.z = n;
-            hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, stream, P);
+            for (int k = 0; k < ch.n; ++k) {
+                P.bt0 = ch.bt0[k]; grid.y = ch.nbt[k];
+                hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, ch.s[k], P);
+            }
         }
+        ch.join();
     }
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
@@ -501,7 +778,7 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
 extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, const float* const* w_ih,
                                         const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
                                         int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
-                                        size_t workspace_bytes, void* stream_) {
+                                        size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux) {
     SA_CLEAR_ERR();
     if (!dh_top || !stash || !w_ih || !w_hh || !dai || !dah || !workspace) return CTC_STATUS_INVALID_VALUE;
     if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
@@ -530,7 +807,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                                w_hh[l * D + d], wt_of(l, d), 3 * H, H);
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     BwdJobs P;
-    P.B = B; P.H = H; P.rb = 1; P.rt = B;
+    P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16;
     ctcStatus_t st;
     // step counter per (layer, dir) selects the ping-pong buffer
     auto make_job = [&](int l, int d, int t, int t_next, int step) {
@@ -566,6 +843,9 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     }
 
     // unidirectional: the wavefront runs top layer first, time chunks from the end
+    Chains ch(stream, aux_streams, n_aux, B);
+    if (!ch.ok) return CTC_STATUS_EXECUTION_FAILED;
+    P.tile_rows = ch.tile_rows;
     const int nch = (T + chunk - 1) / chunk;
     for (int w = 0; w < nch + L - 1; ++w) {
         // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
@@ -593,6 +873,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                 if (st != CTC_STATUS_SUCCESS) return st;
             }
         }
+        ch.fork();
         for (int s = 0; s < chunk; ++s) {
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
@@ -605,8 +886,12 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
             }
             if (n == 0) continue;
             P.n = n; grid.z = n;
-            hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, stream, P);
+            for (int k = 0; k < ch.n; ++k) {
+                P.bt0 = ch.bt0[k]; grid.y = ch.nbt[k];
+                hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, ch.s[k], P);
+            }
         }
+        ch.join();
     }
     SA_CHECK_LAUNCH();
     if (dx) {
@@ -632,7 +917,7 @@ extern "C" ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, flo
     const int rows_per = (M + R - 1) / R;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, R), dim3(256), 0, stream, a, lda, M, N,
                        rows_per > 0 ? rows_per : 1, (float*)workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, R, N,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)workspace, R, N,
                        out, accumulate);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;

@@ -13,6 +13,8 @@ Every tensor op below is a libspeech_amd.so call through speech_amd.ops; torch o
 Dropout (config["dropout"] != 0, training mode) multiplies by a torch-generated Bernoulli mask between kernels; the
 GRU stack is then run one layer per call so the mask can sit between layers (nn.GRU's inter-layer dropout).
 """
+import os
+
 import torch
 
 from . import ops
@@ -35,7 +37,7 @@ class EncoderPlan:
             f = ops.conv_out_size(f, w, s)
         self.conv_out_dim = self.conv_cfg[-1][0] * f
         self.input_dim = input_dim
-        self.chunk = 0  # time steps per wavefront chunk (0: library default)
+        self.chunk = int(os.environ.get("SA_GRU_CHUNK", "0"))  # time steps per wavefront chunk (0: library default)
 
     def time_out(self, t):
         for out_c, h, w, s in self.conv_cfg:
