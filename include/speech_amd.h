@@ -168,6 +168,14 @@ ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, con
                              int D, int B, int T, int H, int chunk, void* workspace, size_t workspace_bytes,
                              void* stream, void* const* aux_streams, int n_aux);
 
+/* Opt-in launch profiler for the stack entry points (bench.py): after sa_gru_profile_configure(1), block 0 of every
+ * step launch stamps the 100 MHz wall clock at entry and exit into a device ring (16 K launches).
+ * sa_gru_profile_read(kind, &interval_us, &kernel_us) (kind 0 = forward, 1 = backward step kernel; SYNC) returns the
+ * number of full-width launches averaged, their mean entry-to-entry interval and mean entry-to-exit time, and resets.
+ * configure(0) switches it off (the default).  The library's only process-global state. */
+void sa_gru_profile_configure(int enable);
+int sa_gru_profile_read(int kind, float* avg_interval_us, float* avg_kernel_us);
+
 /* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients; two deterministic stages through `workspace`. */
 size_t sa_colsum_workspace_bytes(int M, int N);
 ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, float* out, int accumulate, void* workspace,

@@ -59,6 +59,8 @@ SIGNATURES = {
                                                                                          c_void_p, c_int]),
     "sa_gru_stack_bwd_workspace_bytes": (c_size_t, [c_int] * 6),
     "sa_gru_stack_bwd": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
+    "sa_gru_profile_configure": (None, [c_int]),
+    "sa_gru_profile_read": (c_int, [c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "sa_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),

@@ -4,7 +4,7 @@
 //
 //   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ beta * C)
 //
-// Tiling (CDNA4): 128x128 block tile, BK = 16, 256 threads = 4 waves as 2x2, each wave a 64x64 sub-tile =
+// Tiling (CDNA4): 128x128 block tile, BK = 32, 256 threads = 4 waves as 2x2, each wave a 64x64 sub-tile =
 // 2x2 MFMA 32x32 tiles (4 x 16 accumulator VGPRs).  Operand tiles are staged in LDS k-major ([k][m], [k][n]):
 // an MFMA fragment read is then 32 consecutive floats per half-wave (conflict-free ds_read_b32).  An operand that
 // is k-contiguous in memory (A of an NT product, nn.Linear weights) is transposed on the way into LDS; an operand
@@ -19,7 +19,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = 132;  // LDS row pitch in floats (128 + 4): keeps 16-byte alignment, spreads transposed writes
 
 constexpr int kMaxGroup = 8;
@@ -51,18 +51,27 @@ __device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
     return (long)(q / g.m_mid) * g.s_outer + (long)(q % g.m_mid) * g.s_mid + (row % g.m_inner);
 }
 
-// Load this thread's slice of one operand tile into registers.
-// KCONTIG: memory is [rows][k] (k contiguous)  -> 2 x float4: row = tid/4 + 64p, k = 4*(tid%4)
-// else:    memory is [k][cols] (cols contiguous) -> 2 x float4: k = tid/32 + 8p, col = 4*(tid%32)
-template <bool KCONTIG>
+// Load this thread's slice of one operand tile (128 x BK) into registers: NL = 4 float4 per thread.
+// KCONTIG: memory is [rows][k] (k contiguous)  -> row = tid/8 + 32p, k = 4*(tid%8)      (128 B per row: full lines)
+// else:    memory is [k][cols] (cols contiguous) -> k = tid/32 + 8p, col = 4*(tid%32)
+// FAST: the block's tile is interior, K-tiles are full and 16-byte loads are legal: no guards, no branches.
+constexpr int NL = 4;
+template <bool KCONTIG, bool FAST>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int r0, int R, int k0, int kend,
-                                          int vec, int tid, float4 v[2]) {
+                                          int vec, int tid, float4 (&v)[NL]) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NL; ++p) {
+        if (FAST) {
+            if (KCONTIG)
+                v[p] = *reinterpret_cast<const float4*>(P + (long)(r0 + (tid >> 3) + 32 * p) * ld + k0 + 4 * (tid & 7));
+            else
+                v[p] = *reinterpret_cast<const float4*>(P + (long)(k0 + (tid >> 5) + 8 * p) * ld + r0 + 4 * (tid & 31));
+            continue;
+        }
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KCONTIG) {
-            const int row = r0 + (tid >> 2) + 64 * p;
-            const int k = k0 + 4 * (tid & 3);
+            const int row = r0 + (tid >> 3) + 32 * p;
+            const int k = k0 + 4 * (tid & 7);
             if (row < R) {
                 const float* q = P + (long)row * ld + k;
                 if (vec && k + 3 < kend) {
@@ -94,12 +103,12 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
 }
 
 template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ S /* [BK][LDT] */, int tid, const float4 v[2]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ S /* [BK][LDT] */, int tid, const float4 (&v)[NL]) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NL; ++p) {
         if (KCONTIG) {
-            const int row = (tid >> 2) + 64 * p;
-            const int k = 4 * (tid & 3);
+            const int row = (tid >> 3) + 32 * p;
+            const int k = 4 * (tid & 7);
             S[(k + 0) * LDT + row] = v[p].x;
             S[(k + 1) * LDT + row] = v[p].y;
             S[(k + 2) * LDT + row] = v[p].z;
@@ -112,14 +121,73 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S /* [BK][LDT] */
     }
 }
 
+// 32 MFMAs of one K tile.  Fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued.
+__device__ __forceinline__ void mma_tile(const float* __restrict__ a_s, const float* __restrict__ b_s,
+                                         f32x16 (&acc)[2][2]) {
+    float a0 = a_s[0], a1 = a_s[32], b0 = b_s[0], b1 = b_s[32];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        if (ks + 1 < BK / 2) {
+            na0 = a_s[(2 * ks + 2) * LDT]; na1 = a_s[(2 * ks + 2) * LDT + 32];
+            nb0 = b_s[(2 * ks + 2) * LDT]; nb1 = b_s[(2 * ks + 2) * LDT + 32];
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+}
+
+// The K loop: register-staged, double-buffered LDS, one barrier per K tile.  The next tile's global loads are issued
+// before this tile's 64 MFMAs per wave (4096 matrix-pipe cycles ~ 1.8 us: a block that sits alone on its CU -- the
+// small per-chunk GEMMs of the GRU wavefront -- still covers an L2/HBM round trip with them).
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __restrict__ gA,
+                                              const float* __restrict__ gB, float* smem, int m0, int n0, int kbeg,
+                                              int kend, int tid, bool fast, f32x16 (&acc)[2][2]) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    auto As = [&](int i) { return smem + i * (BK * LDT); };
+    auto Bs = [&](int i) { return smem + (2 + i) * (BK * LDT); };
+    const int frag = (lane >> 5) * LDT + (lane & 31);
+    float4 ra[NL], rb[NL];
+    auto load = [&](int tile) {
+        const int k0 = kbeg + tile * BK;
+        if (fast) {  // block-uniform: only the loads differ
+            load_tile<!TA, true>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+            load_tile<TB, true>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+        } else {
+            load_tile<!TA, false>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+            load_tile<TB, false>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+        }
+    };
+    if (ntiles > 0) {
+        load(0);
+        store_tile<!TA>(As(0), tid, ra);
+        store_tile<TB>(Bs(0), tid, rb);
+    }
+    __syncthreads();
+    for (int it = 0; it < ntiles; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < ntiles;
+        if (more) load(it + 1);
+        mma_tile(As(cur) + frag + wm * 64, Bs(cur) + frag + wn * 64, acc);
+        if (more) {
+            store_tile<!TA>(As(cur ^ 1), tid, ra);
+            store_tile<TB>(Bs(cur ^ 1), tid, rb);
+        }
+        __syncthreads();
+    }
+}
+
 // TA: A is stored (K, M) (m-contiguous);  !TA: A is stored (M, K) (k-contiguous)
 // TB: B is stored (N, K) (k-contiguous);  !TB: B is stored (K, N) (n-contiguous)
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
-    auto As = [&](int i) { return smem + i * (BK * LDT); };
-    auto Bs = [&](int i) { return smem + (2 + i) * (BK * LDT); };
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -130,7 +198,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const float* __restrict__ gB = g.Bg[prob];
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -140,42 +207,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[2], rb[2];
-    if (ntiles > 0) {
-        load_tile<!TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
-        load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
-        store_tile<!TA>(As(0), tid, ra);
-        store_tile<TB>(Bs(0), tid, rb);
-    }
-    __syncthreads();
-
-    for (int it = 0; it < ntiles; ++it) {
-        const int cur = it & 1;
-        const bool more = it + 1 < ntiles;
-        if (more) {  // issue the next tile's global loads before this tile's MFMAs
-            const int k0 = kbeg + (it + 1) * BK;
-            load_tile<!TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-            load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-        }
-        const float* a_s = As(cur) + (lane >> 5) * LDT + wm * 64 + (lane & 31);
-        const float* b_s = Bs(cur) + (lane >> 5) * LDT + wn * 64 + (lane & 31);
-#pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const float a0 = a_s[(2 * ks) * LDT];
-            const float a1 = a_s[(2 * ks) * LDT + 32];
-            const float b0 = b_s[(2 * ks) * LDT];
-            const float b1 = b_s[(2 * ks) * LDT + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (more) {
-            store_tile<!TA>(As(cur ^ 1), tid, ra);
-            store_tile<TB>(Bs(cur ^ 1), tid, rb);
-        }
-        __syncthreads();
-    }
+    const bool fast = g.vecA && g.vecB && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
+    gemm_mainloop<TA, TB>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, fast, acc);
 
     // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool splitk = g.partial != nullptr;

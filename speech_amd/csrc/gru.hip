@@ -98,6 +98,7 @@ struct FwdJobs {
     int n, B, H;
     int bt0;        // first batch tile handled by this launch (blockIdx.y is relative to it)
     int tile_rows;  // batch rows owned by a block: 16, or 8 / 4 when the batch is cut into more concurrent chains
+    unsigned long long* stamp;  // profiling: block (0,0,0) writes wall_clock64() at entry / exit (null: off)
     int dbg;  // ablation switches for tools/gru_step_bench.py (0 in production): 1 = no W loads, 2 = no h loads
     long rb, rt;
     FwdJob j[kMaxJobs];
@@ -111,6 +112,8 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
     const int i = lane & 15, g = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = (blockIdx.y + P.bt0) * P.tile_rows;
     const bool first = J.t_prev < 0;
+    const bool stamper = P.stamp && threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
 
     // epilogue operands first: their latency overlaps the operand fetch + MFMA phase
     const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
             for (int r = 0; r < 4; ++r) red[wave][n][(g * 4 + r) * 16 + i] = acc[n][r];
     }
     __syncthreads();
-    if (!live) return;
+    if (!live) { if (stamper) P.stamp[1] = wall_clock64(); return; }
     float sr = 0.f, sz = 0.f, sn = 0.f;
     if (!first) {
 #pragma unroll
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
         float* s = J.stash + row * 5 * H;
         s[u] = r; s[H + u] = z; s[2 * H + u] = n; s[3 * H + u] = q; s[4 * H + u] = hp;
     }
+    if (stamper) P.stamp[1] = wall_clock64();
 }
 
 // -------------------------------------------------------------------------------------- persistent forward chunk
@@ -341,6 +345,7 @@ struct BwdJob {
 struct BwdJobs {
     int n, B, H;
     int bt0, tile_rows;
+    unsigned long long* stamp;
     long rb, rt;
     BwdJob j[kMaxJobs];
 };
@@ -353,6 +358,8 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
     const int i = lane & 15, g = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = (blockIdx.y + P.bt0) * P.tile_rows;
     const bool have_next = J.t_next >= 0;
+    const bool stamper = P.stamp && threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
 
     const int bi = threadIdx.x >> 4, uj = threadIdx.x & 15;
     const int b = b0 + bi, u = u0 + uj;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
         for (int rr = 0; rr < 4; ++rr) red[wave][(g * 4 + rr) * 16 + i] = acc[0][rr];
     }
     __syncthreads();
-    if (!live) return;
+    if (!live) { if (stamper) P.stamp[1] = wall_clock64(); return; }
     if (have_next) {
         dh += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         dh += dh_prev * z_next;
@@ -398,6 +405,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
     float* dhh = J.dah + row * H3;
     di[u] = dpr; di[H + u] = dpz; di[2 * H + u] = dpn;
     dhh[u] = dpr; dhh[H + u] = dpz; dhh[2 * H + u] = dpn * r;
+    if (stamper) P.stamp[1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------- small helpers
@@ -476,7 +484,7 @@ extern "C" ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const floa
         return CTC_STATUS_INVALID_VALUE;  // 16-byte fragment loads need 4-float alignment
     hipStream_t stream = (hipStream_t)stream_;
     FwdJobs P;
-    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.dbg = 0; P.bt0 = 0; P.tile_rows = 16;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.dbg = 0; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
     FwdJob& J = P.j[0];
     J.ai = ai; J.w_hh = w_hh; J.b_hh = b_hh; J.h_out = h_out; J.stash = stash; J.hs_b = hs_b; J.hs_t = hs_t;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -511,7 +519,7 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
     hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream, w_hh, w_t,
                        3 * H, H);
     BwdJobs P;
-    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.bt0 = 0; P.tile_rows = 16;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
     BwdJob& J = P.j[0];
     J.dh_out = dh_out; J.stash = stash; J.w_hh_t = w_t; J.dai = dai; J.dah = dah;
     J.ds_b = hs_b; J.ds_t = hs_t;
@@ -581,6 +589,65 @@ struct Chains {
 };
 // Time-major arrays throughout: x (T, B, I0); h_out[l] (T, B, D*H); ai / stash / dai / dah [l*D+d] (T, B, .).
 static size_t stack_ai_bytes(int B, int T, int H) { return sa_align_up((size_t)T * B * 3 * H * sizeof(float), 256); }
+
+// ---- opt-in launch profiler (bench.py's live roofline measurement).  When enabled, thread 0 of block (0,0,0) of
+// every step launch of the stack entry points writes the 100 MHz wall clock at kernel entry and exit into a device
+// ring; sa_gru_profile_read() copies the ring back and averages (a) entry-to-exit of that block = kernel time and
+// (b) entry-to-entry of consecutive full-width launches = the per-launch interval including the dispatch gap.
+// HIP events around single launches perturb the stream by several microseconds each, device stamps do not.
+// This is the library's only process-global state and is off by default.
+namespace {
+struct StepProfiler {
+    static constexpr int kRing = 1 << 14;
+    bool on = false;
+    unsigned long long* ring[2] = {nullptr, nullptr};   // device: [kRing][2] per kind
+    unsigned char* full[2] = {nullptr, nullptr};        // host: launch was full width (L jobs)
+    long count[2] = {0, 0};
+    // flags: bit 0 = full width (L jobs), bit 1 = directly follows another step launch (no GEMM in between)
+    unsigned long long* slot(int kind, bool full_width, bool follows_step) {
+        if (!on || count[kind] >= kRing) return nullptr;
+        full[kind][count[kind]] = (full_width ? 1 : 0) | (follows_step ? 2 : 0);
+        return ring[kind] + 2 * (count[kind]++);
+    }
+};
+StepProfiler g_prof;
+}  // namespace
+
+extern "C" void sa_gru_profile_configure(int enable) {
+    if (enable && !g_prof.ring[0]) {
+        for (int k = 0; k < 2; ++k) {
+            if (hipMalloc((void**)&g_prof.ring[k], sizeof(unsigned long long) * 2 * StepProfiler::kRing) != hipSuccess)
+                return;
+            g_prof.full[k] = (unsigned char*)malloc(StepProfiler::kRing);
+        }
+    }
+    g_prof.on = enable != 0 && g_prof.ring[0] && g_prof.ring[1];
+    g_prof.count[0] = g_prof.count[1] = 0;
+}
+
+// kind 0 = forward step kernel, 1 = backward.  Returns the number of launches averaged.
+extern "C" int sa_gru_profile_read(int kind, float* avg_interval_us, float* avg_kernel_us) {
+    if (kind < 0 || kind > 1 || !avg_interval_us || !avg_kernel_us || !g_prof.ring[kind]) return 0;
+    const long n = g_prof.count[kind];
+    g_prof.count[kind] = 0;
+    if (n < 2) return 0;
+    unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * 2 * n);
+    if (hipMemcpy(h, g_prof.ring[kind], sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) {
+        free(h);
+        return 0;
+    }
+    double ti = 0.0, tk = 0.0;
+    long ni = 0, nk = 0;
+    for (long i = 0; i < n; ++i) {
+        if (!(g_prof.full[kind][i] & 1)) continue;
+        tk += (double)(h[2 * i + 1] - h[2 * i]); ++nk;
+        if (i + 1 < n && g_prof.full[kind][i + 1] == 3) { ti += (double)(h[2 * i + 2] - h[2 * i]); ++ni; }
+    }
+    free(h);
+    *avg_kernel_us = nk ? (float)(tk / nk * 0.01) : 0.f;      // 100 MHz ticks -> us
+    *avg_interval_us = ni ? (float)(ti / ni * 0.01) : 0.f;
+    return (int)nk;
+}
 
 constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
 
@@ -652,7 +719,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         return J;
     };
     FwdJobs P;
-    P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16;
+    P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
     { const char* e = getenv("SA_GRU_DBG"); P.dbg = e ? atoi(e) : 0; }
 
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
@@ -754,6 +821,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             P.n = n; grid.z = n;
             for (int k = 0; k < ch.n; ++k) {
                 P.bt0 = ch.bt0[k]; grid.y = ch.nbt[k];
+                P.stamp = k == 0 ? g_prof.slot(0, n == L, s > 0) : nullptr;
                 hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, ch.s[k], P);
             }
         }
@@ -807,7 +875,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                                w_hh[l * D + d], wt_of(l, d), 3 * H, H);
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     BwdJobs P;
-    P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16;
+    P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
     ctcStatus_t st;
     // step counter per (layer, dir) selects the ping-pong buffer
     auto make_job = [&](int l, int d, int t, int t_next, int step) {
@@ -888,6 +956,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
             P.n = n; grid.z = n;
             for (int k = 0; k < ch.n; ++k) {
                 P.bt0 = ch.bt0[k]; grid.y = ch.nbt[k];
+                P.stamp = k == 0 ? g_prof.slot(1, n == L, s > 0) : nullptr;
                 hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, ch.s[k], P);
             }
         }

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "speech_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(?:ctcStatus_t|size_t|int|const char\s*\*)\s+([a-zA-Z_][a-zA-Z0-9_]*)\s*\(", src)
+    names = re.findall(r"\b(?:ctcStatus_t|size_t|int|void|const char\s*\*)\s+([a-zA-Z_][a-zA-Z0-9_]*)\s*\(", src)
     return sorted(set(names))
 
 
