@@ -113,24 +113,34 @@ def gpu_leg(args, world, rank, local):
     return res
 
 
-def cpu_baseline(steps=2):
+CPU_THREADS = 16  # best of {8, 16, 32, 64, 128} on the GPU box's 256 host threads (tools/cpu_baseline_threads.py:
+                  # 2.22, 1.84, 3.21, 7.87, 19.98 s/step) -- torch's default of 128 oversubscribes the small GRU GEMMs
+
+
+def cpu_baseline(steps=4):
     """The reference's CPU path restated (oracle/torch_ref.py: the same torch.nn CPU modules + C CTC restatement),
     timed on this box's host cores on a bounded sample: `steps` full B=32 train steps after one warm-up."""
     from oracle.torch_ref import TorchRefCTC, train_step
-    torch.manual_seed(2017)
-    model = TorchRefCTC(F, V, S_LIBRI)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.0)
-    x_h, lab_h = synthetic(0)
-    x = torch.from_numpy(x_h)
-    ll = np.full(B, L, np.int32)
-    train_step(model, opt, x, lab_h, ll)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss, _ = train_step(model, opt, x, lab_h, ll)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": B / dt, "unit": "utt/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d full train steps (B=32, T=1000) of oracle/torch_ref.py after 1 warm-up; %.2f s/step"
-                      % (steps, dt), "loss": loss}
+    threads = min(CPU_THREADS, os.cpu_count() or CPU_THREADS)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(2017)
+        model = TorchRefCTC(F, V, S_LIBRI)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.0)
+        x_h, lab_h = synthetic(0)
+        x = torch.from_numpy(x_h)
+        ll = np.full(B, L, np.int32)
+        train_step(model, opt, x, lab_h, ll, threads=threads)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = train_step(model, opt, x, lab_h, ll, threads=threads)
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": B / dt, "unit": "utt/s", "cores": threads, "kind": "port",
+            "sample": "%d full train steps (B=32, T=1000) of oracle/torch_ref.py after 1 warm-up on %d threads; "
+                      "%.2f s/step" % (steps, threads, dt), "loss": loss}
 
 
 def roofline(prof, step_us, steps):
@@ -139,6 +149,10 @@ def roofline(prof, step_us, steps):
     timed region, from device-side clock stamps (HIP events around single launches perturb the stream by several us);
     work = the algorithmic bytes one launch moves (17*B*H*4 per layer-step x 4 layer-jobs)."""
     out = {}
+    try:  # HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json documents how they were taken)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    except Exception:
+        traffic = {}
     for name, per_job in (("gru_bwd_step_kernel", 17), ("gru_fwd_step_kernel", 10)):
         us, kern_us, n = step_us.get(name, (0.0, 0.0, 0))
         if n == 0 or us <= 0:
@@ -146,7 +160,8 @@ def roofline(prof, step_us, steps):
         nbytes = 4.0 * B * 512 * per_job * 4  # 4 layer-jobs per launch, B x H fp32 elements each
         ach = nbytes / (us * 1e-6) / 1e9
         out[name] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": us, "block0_kernel_us": kern_us,
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name, {}).get("bytes_per_launch"),
+                     "avg_launch_us": us, "block0_kernel_us": kern_us,
                      "samples": n, "bytes_per_launch": nbytes}
     g = prof.get("gemm")
     gemm = None
