@@ -112,18 +112,20 @@ ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alp
  * x (B, in_c, T, F) NCHW contiguous; w (out_c, in_c, kh, kw); y written with caller-given strides so the last conv
  * can emit the GRU-ready (B, T', out_c * F') layout of model.py:66-71 directly:
  *     y[b * ys_b + c * ys_c + t * ys_t + f].
- * workspace >= sa_conv2d_fwd_workspace_bytes() holds the im2col matrix. */
+ * workspace >= sa_conv2d_fwd_workspace_bytes() holds the im2col matrix; if keep_cols != NULL the im2col matrix
+ * ((B*T'*F') x (in_c*kh*kw) floats) is written there instead, for sa_conv2d_relu_bwd(fwd_cols) to reuse. */
 size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s);
 ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in_c, int T,
                                int F, int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               float* keep_cols /* or NULL */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above: dy (same strides as y), y (to mask the ReLU) -> dw (+=0: overwritten), dbias, and dx
  * (NCHW, overwritten) unless dx == NULL.  workspace >= sa_conv2d_bwd_workspace_bytes(). */
 size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s);
 ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                                float* dbias, int B, int in_c, int T, int F, int out_c, int kh, int kw, int s,
-                               long ys_b, long ys_c, long ys_t, void* workspace, size_t workspace_bytes, void* stream);
+                               long ys_b, long ys_c, long ys_t, const float* fwd_cols /* or NULL */, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* One direction of one nn.GRU layer (model.py:35-39,73; equations SURVEY.md App. B; gate order [r; z; n]).
  *   ai   (B, T, 3H): input pre-activations x W_ih^T + b_ih (from sa_gemm_f32), batch-first.

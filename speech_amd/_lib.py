@@ -46,9 +46,10 @@ SIGNATURES = {
                             c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sa_conv2d_fwd_workspace_bytes": (c_size_t, [c_int] * 8),
     "sa_conv2d_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_long, c_long, c_long, c_void_p, c_size_t, c_void_p]),
+                                   c_int, c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sa_conv2d_bwd_workspace_bytes": (c_size_t, [c_int] * 8),
-    "sa_conv2d_relu_bwd": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_long] * 3 + [c_void_p, c_size_t, c_void_p]),
+    "sa_conv2d_relu_bwd": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_long] * 3 + [c_void_p, c_void_p, c_size_t,
+                                                                                c_void_p]),
     "sa_gru_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int,
                            c_int, c_void_p]),
     "sa_gru_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

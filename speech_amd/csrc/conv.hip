@@ -73,6 +73,87 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
     }
 }
 
+// dW[o][k] = sum_pos dyp[pos][o] * cols[pos][k] for small O*K (the first conv: 32 x 160): an outer-product reduction
+// over ~4e5 positions.  As a GEMM it has M = O = 32 of a 128-row tile (75 % of the MFMAs wasted) and needs a 128-way
+// split-K; here each block reduces a slab of positions with the O*K accumulators register-tiled over its threads
+// (thread = 4 output channels x up to 8 taps: 4 + 8 LDS operand reads feed 32 FMAs), then a second kernel adds the
+// per-block partials in fixed order.
+constexpr int kDwTO = 4;       // output channels per thread
+constexpr int kDwTK = 8;       // taps per thread (strided by the number of tap groups)
+constexpr int kDwPosTile = 32; // positions staged per LDS tile
+
+__host__ __device__ inline bool conv_dw_fits(int O, int K) {
+    const int nog = (O + kDwTO - 1) / kDwTO;
+    if (nog > 256 || (O % kDwTO) != 0) return false;
+    const int nkg = 256 / nog;
+    return nkg >= 1 && (long)nkg * kDwTK >= K;
+}
+
+__global__ __launch_bounds__(256) void conv_dw_partial_kernel(const float* __restrict__ dyp,
+                                                              const float* __restrict__ cols, long npos, int O, int K,
+                                                              int pos_per_block, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_dy = sm;                      // [kDwPosTile][O]
+    float* s_co = sm + kDwPosTile * O;     // [kDwPosTile][K]
+    const int tid = threadIdx.x;
+    const int nog = O / kDwTO, nkg = 256 / nog;
+    const int og = tid / nkg, kg = tid - og * nkg;
+    const bool worker = og < nog;
+    float acc[kDwTO][kDwTK];
+#pragma unroll
+    for (int i = 0; i < kDwTO; ++i)
+#pragma unroll
+        for (int j = 0; j < kDwTK; ++j) acc[i][j] = 0.f;
+    const long p0 = (long)blockIdx.x * pos_per_block;
+    const long p1 = min(npos, p0 + pos_per_block);
+    for (long pt = p0; pt < p1; pt += kDwPosTile) {
+        const int np = (int)min((long)kDwPosTile, p1 - pt);
+        __syncthreads();
+        for (int i = tid; i < np * O; i += 256) s_dy[i] = dyp[pt * O + i];
+        for (int i = tid; i < np * K; i += 256) s_co[i] = cols[pt * K + i];
+        __syncthreads();
+        if (!worker) continue;
+        for (int p = 0; p < np; ++p) {
+            const float4 d = *reinterpret_cast<const float4*>(&s_dy[p * O + og * kDwTO]);
+            float c[kDwTK];
+#pragma unroll
+            for (int j = 0; j < kDwTK; ++j) {
+                const int k = kg + j * nkg;
+                c[j] = k < K ? s_co[p * K + k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < kDwTK; ++j) {
+                acc[0][j] = fmaf(d.x, c[j], acc[0][j]);
+                acc[1][j] = fmaf(d.y, c[j], acc[1][j]);
+                acc[2][j] = fmaf(d.z, c[j], acc[2][j]);
+                acc[3][j] = fmaf(d.w, c[j], acc[3][j]);
+            }
+        }
+    }
+    if (!worker) return;
+    float* out = part + (long)blockIdx.x * O * K;
+#pragma unroll
+    for (int i = 0; i < kDwTO; ++i)
+#pragma unroll
+        for (int j = 0; j < kDwTK; ++j) {
+            const int k = kg + j * nkg;
+            if (k < K) out[(og * kDwTO + i) * K + k] = acc[i][j];
+        }
+}
+
+__global__ __launch_bounds__(256) void conv_dw_final_kernel(const float* __restrict__ part, int nblocks, int OK,
+                                                            float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= OK) return;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 1 < nblocks; b += 2) { s0 += part[(long)b * OK + idx]; s1 += part[(long)(b + 1) * OK + idx]; }
+    if (b < nblocks) s0 += part[(long)b * OK + idx];
+    dw[idx] = s0 + s1;
+}
+
+constexpr int kDwBlocks = 512;
+
 bool make_geom(ConvGeom* g, int B, int C, int T, int F, int O, int kh, int kw, int s) {
     if (B <= 0 || C <= 0 || T <= 0 || F <= 0 || O <= 0 || kh <= 0 || kw <= 0 || s <= 0) return false;
     g->B = B; g->C = C; g->T = T; g->F = F; g->O = O; g->kh = kh; g->kw = kw; g->s = s;
@@ -97,8 +178,8 @@ extern "C" size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, i
 
 extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                                           int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
-                                          long ys_c, long ys_t, void* workspace, size_t workspace_bytes,
-                                          void* stream_) {
+                                          long ys_c, long ys_t, float* keep_cols, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
     SA_CLEAR_ERR();
     ConvGeom g;
     if (!x || !w || !bias || !y || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
@@ -106,7 +187,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
     if (workspace_bytes < sa_conv2d_fwd_workspace_bytes(B, in_c, T, F, out_c, kh, kw, s)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     const long npos = (long)g.B * g.To * g.Fo;
-    float* cols = (float*)workspace;
+    float* cols = keep_cols ? keep_cols : (float*)workspace;  // keep_cols: caller-owned (npos x K) buffer reused by bwd
     char* gws = (char*)workspace + sa_align_up((size_t)npos * g.K * sizeof(float), 256);
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
     SA_CHECK_LAUNCH();
@@ -125,6 +206,8 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
     if (gw2 > gw) gw = gw2;
     const size_t gw3 = sa_colsum_workspace_bytes((int)npos, g.O);
     if (gw3 > gw) gw = gw3;
+    const size_t gw4 = (size_t)kDwBlocks * g.O * g.K * sizeof(float);  // conv_dw_partial_kernel
+    if (conv_dw_fits(g.O, g.K) && gw4 > gw) gw = gw4;
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +   // cols, reused for dcols
            sa_align_up((size_t)npos * g.O * sizeof(float), 256) +   // dyp
            sa_align_up(gw, 256);
@@ -132,8 +215,8 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
 
 extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
                                           float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh,
-                                          int kw, int s, long ys_b, long ys_c, long ys_t, void* workspace,
-                                          size_t workspace_bytes, void* stream_) {
+                                          int kw, int s, long ys_b, long ys_c, long ys_t, const float* fwd_cols,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
     SA_CLEAR_ERR();
     ConvGeom g;
     if (!x || !w || !y || !dy || !dw || !dbias || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
@@ -145,14 +228,32 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
     float* dyp = (float*)((char*)cols + sa_align_up((size_t)npos * g.K * sizeof(float), 256));
     char* gws = (char*)dyp + sa_align_up((size_t)npos * g.O * sizeof(float), 256);
     const size_t gws_bytes = workspace_bytes - (size_t)(gws - (char*)workspace);
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
+    if (fwd_cols && !dx) {
+        cols = const_cast<float*>(fwd_cols);  // the forward pass's im2col matrix, kept by the caller (read only here)
+    } else {
+        hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
+    }
     hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, dyp, g, ys_b,
                        ys_c, ys_t);
     SA_CHECK_LAUNCH();
     // dW[o, k] = sum_pos dyp[pos, o] * cols[pos, k]
-    ctcStatus_t st = sa_gemm_f32_impl(1, 0, g.O, g.K, (int)npos, 1.0f, dyp, g.O, cols, g.K, 0.f, dw, g.K, nullptr,
-                                      nullptr, gws, gws_bytes, stream);
-    if (st != CTC_STATUS_SUCCESS) return st;
+    ctcStatus_t st;
+    const int OK = g.O * g.K;
+    if (conv_dw_fits(g.O, g.K) && gws_bytes >= (size_t)kDwBlocks * OK * sizeof(float)) {
+        int nb = (int)min((long)kDwBlocks, (npos + kDwPosTile - 1) / kDwPosTile);
+        int ppb = (int)((npos + nb - 1) / nb);
+        ppb = (ppb + kDwPosTile - 1) / kDwPosTile * kDwPosTile;
+        nb = (int)((npos + ppb - 1) / ppb);
+        hipLaunchKernelGGL(conv_dw_partial_kernel, dim3(nb), dim3(256), (size_t)kDwPosTile * (g.O + g.K) * sizeof(float),
+                           stream, dyp, cols, npos, g.O, g.K, ppb, (float*)gws);
+        hipLaunchKernelGGL(conv_dw_final_kernel, dim3((OK + 255) / 256), dim3(256), 0, stream, (const float*)gws, nb,
+                           OK, dw);
+        SA_CHECK_LAUNCH();
+    } else {
+        st = sa_gemm_f32_impl(1, 0, g.O, g.K, (int)npos, 1.0f, dyp, g.O, cols, g.K, 0.f, dw, g.K, nullptr, nullptr,
+                              gws, gws_bytes, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+    }
     st = sa_colsum_f32(dyp, g.O, (int)npos, g.O, dbias, 0, gws, gws_bytes, stream_);
     if (st != CTC_STATUS_SUCCESS) return st;
     if (dx) {

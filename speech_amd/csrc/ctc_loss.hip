@@ -26,6 +26,8 @@
 // log(0) is the finite sentinel SA_NEG, so no inf/NaN guards sit on the dependent chain.
 // HIPCC_FLAGS: -fno-honor-nans
 // (no NaN is ever an operand here -- log(0) is the finite SA_NEG -- so fmaxf/fminf need no canonicalising v_max.)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -96,6 +98,7 @@ struct AbArgs {
     float* goffs;         // [B][2][nchunks][nbatch]
     float* logp2_out;     // [B][2]: log2 p = hat + offset
     float* costs;         // [B]
+    unsigned long long* dbg;  // debug (SA_CTC_DBG): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
 };
 
 // One (direction, chunk) wave over all T steps.  DIR 0 = alpha (time forward), 1 = beta (time backward).
@@ -165,11 +168,24 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
     };
     load_emissions(0, el, eb);
 
+    // One time step of this wave's 64 state pairs.  Both updates share ONE pivot m = max3(L, B, n): the three exp2 and
+    // the two log2 are then mutually independent (dependent chain: dpp -> max3 -> sub -> exp2 -> add -> log2 -> add),
+    // instead of two back-to-back log-sum-exp chains.  A sum can flush to 0 only when its own operands sit more than
+    // 126 log2-units below the pivot; it is then replaced by the larger operand (exact for the unreachable sentinel,
+    // so infeasible alignments stay infeasible; otherwise an error below 2^-126 of the neighbouring state's mass).
     auto do_step = [&](float e_l_raw, float e_b_, float h, int r) {
         const float n = DIR == 0 ? sa_wave_shr1(Lst, h) : sa_wave_shl1(Lst, h);
         const float e_lv = own_ok ? e_l_raw : SA_NEG;
-        const float nB = e_b_ + lse2_1p(Bst, n);
-        const float nL = e_lv + lse3_1p(Lst, Bst, skip ? n : SA_NEG);
+        const float mLB = fmaxf(Lst, Bst);
+        const float mBn = fmaxf(Bst, n);
+        const float m = fmaxf(mLB, n);
+        const float xL = sa_exp2(Lst - m);
+        const float xB = sa_exp2(Bst - m);
+        const float xn = sa_exp2(n - m);
+        const float sB = xB + xn;
+        const float sL = xL + xB + (skip ? xn : 0.f);
+        const float nB = e_b_ + (sB > 0.f ? m + sa_log2(sB) : mBn);
+        const float nL = e_lv + (sL > 0.f ? m + sa_log2(sL) : mLB);
         Bst = nB;
         Lst = nL;
         if (WITH_BETA) {
@@ -183,6 +199,9 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
 
     int avail = 0;  // producer progress last seen
     int bi = 0;     // batch index
+    const bool dbg_me = A.dbg != nullptr && b == 0 && DIR == 0 && chunk == 0 && lane == 0;
+    unsigned long long c0 = 0, w0 = 0;
+    if (dbg_me) { c0 = clock64(); w0 = wall_clock64(); }
     for (int r0 = 0; r0 < T; r0 += kU, ++bi) {
         // (1) every kRenorm batches: subtract the integer part of the wave maximum (exact in fp32), carry it in `off`
         if ((bi & (kRenorm - 1)) == 0) {
@@ -239,6 +258,7 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
         for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
     }
 
+    if (dbg_me) { A.dbg[0] = clock64() - c0; A.dbg[1] = wall_clock64() - w0; A.dbg[2] = (unsigned long long)T; }
     if (DIR == 0) {
         if (j == L) { sh->fin[0] = Bst; sh->fin[1] = off; }
         if (j == L - 1) { sh->fin[2] = Lst; sh->fin[3] = off; }
@@ -448,6 +468,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.goffs = (float*)(ws + o_goffs);
     A.logp2_out = (float*)(ws + o_lp);
     A.costs = d_costs;
+    A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
     {  // K_A
         const int G = K <= 16 ? 16 : (K <= 32 ? 32 : 64);

@@ -72,12 +72,16 @@ class EncoderFunction(torch.autograd.Function):
         a = x.contiguous().view(B, 1, T, F)
         conv_saved = []
         for i, ((w, b), (out_c, kh, kw, s)) in enumerate(zip(conv_p, plan.conv_cfg)):
-            y, ys = ops.conv2d_relu_fwd(a, w, b, s, "tbf" if i == nconv - 1 else "nchw")
+            # the first conv keeps its im2col matrix for the backward pass (no dx there, so it is read-only)
+            keep = need_grad and i == 0
+            res = ops.conv2d_relu_fwd(a, w, b, s, "tbf" if i == nconv - 1 else "nchw", keep_cols=keep)
+            y, ys = res[0], res[1]
+            cols = res[2] if keep else None
             mask = None
             if p_drop:
                 mask = _drop_mask(y, p_drop)
                 y = y * mask
-            conv_saved.append((a, y, ys, mask))
+            conv_saved.append((a, y, ys, mask, cols))
             a = y
         feat = a  # (T', B, conv_out)
         Tp = feat.shape[0]
@@ -151,12 +155,12 @@ class EncoderFunction(torch.autograd.Function):
         # conv stack
         dy = dtop
         for i in range(nconv - 1, -1, -1):
-            a, y, ys, mask = ctx.conv_saved[i]
+            a, y, ys, mask, cols = ctx.conv_saved[i]
             if mask is not None:
                 dy = dy * mask
             s = plan.conv_cfg[i][3]
             dx, dw, db = ops.conv2d_relu_bwd(a, ctx.conv_p[i][0], y, dy.contiguous(), ys, s, need_dx=(i > 0),
-                                             dw=slots[2 * i], db=slots[2 * i + 1])
+                                             dw=slots[2 * i], db=slots[2 * i + 1], cols=cols)
             grads[2 * i], grads[2 * i + 1] = dw, db
             dy = dx
         return (None, None, None) + tuple(grads)

@@ -82,12 +82,13 @@ def conv_out_size(n, k, s):
     return int(math.ceil((n - k + 1) / s))
 
 
-def conv2d_relu_fwd(x, w, bias, s, layout="nchw"):
+def conv2d_relu_fwd(x, w, bias, s, layout="nchw", keep_cols=False):
     """x (B,C,T,F) contiguous -> relu(conv(x)) in one of three output layouts:
       "nchw": (B, O, T', F')              (input of a following conv)
       "btf" : (B, T', O*F') channel-major features, batch-major   (model.py:66-71)
       "tbf" : (T', B, O*F') the same features time-major          (what the GRU stack consumes)
-    Returns (y, (ys_b, ys_c, ys_t)) with y[b*ys_b + c*ys_c + t*ys_t + f]."""
+    Returns (y, (ys_b, ys_c, ys_t)) with y[b*ys_b + c*ys_c + t*ys_t + f]; with keep_cols also the im2col matrix
+    (a tensor the caller passes to conv2d_relu_bwd(cols=...) so that backward does not rebuild it)."""
     _f32(x, "x"), _f32(w, "w"), _f32(bias, "bias")
     assert x.is_contiguous() and w.is_contiguous()
     B, C, T, F = x.shape
@@ -108,13 +109,16 @@ def conv2d_relu_fwd(x, w, bias, s, layout="nchw"):
     L = _lib.lib()
     nbytes = L.sa_conv2d_fwd_workspace_bytes(B, C, T, F, O, kh, kw, s)
     ws = WORKSPACE.get(nbytes, x.device, "conv")
+    cols = torch.empty(B * To * Fo, C * kh * kw, dtype=torch.float32, device=x.device) if keep_cols else None
     with _span("conv_fwd", 2, 2.0 * B * To * Fo * O * C * kh * kw):
         check(L.sa_conv2d_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1], ys[2],
-                                   ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
+                                   ptr(cols), ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
+    if keep_cols:
+        return y, ys, cols
     return y, ys
 
 
-def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None):
+def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None, cols=None):
     """Gradients of relu(conv(x)): returns (dx or None, dw, dbias).  y / dy share the strides `ys`."""
     B, C, T, F = x.shape
     O, _, kh, kw = w.shape
@@ -129,7 +133,8 @@ def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None):
     ws = WORKSPACE.get(nbytes, x.device, "conv")
     with _span("conv_bwd", 5, 0.0):
         check(L.sa_conv2d_relu_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), B, C, T, F, O, kh, kw,
-                                   s, ys[0], ys[1], ys[2], ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_bwd")
+                                   s, ys[0], ys[1], ys[2], ptr(cols), ptr(ws), ws.numel(), cur_stream()),
+              "sa_conv2d_relu_bwd")
     return dx, dw, db
 
 
