@@ -49,3 +49,31 @@ def test_cpu_tensor_fails_loudly():
     with pytest.raises(_lib.SpeechAmdError):
         CTCLoss()(torch.zeros(2, 5, 4, requires_grad=True), torch.IntTensor([1, 2]), torch.IntTensor([5, 5]),
                   torch.IntTensor([1, 1]))
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under speech_amd/, speech/, functions/, train.py or eval.py may import,
+    load or execute it (bench.py may, in its cpu_baseline leg only)."""
+    import ast
+    offenders = []
+    files = [os.path.join(ROOT, f) for f in ("train.py", "eval.py")]
+    for pkg in ("speech_amd", "speech", "functions"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, pkg)):
+            files += [os.path.join(dp, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        src = open(f).read()
+        for node in ast.walk(ast.parse(src)):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                offenders.append(f)
+        if "libctc_ref" in src:
+            offenders.append(f)
+    for dp, _, fs in os.walk(os.path.join(ROOT, "speech_amd", "csrc")):
+        for f in fs:
+            if "oracle" in open(os.path.join(dp, f), errors="ignore").read():
+                offenders.append(os.path.join(dp, f))
+    assert not offenders, offenders
