@@ -197,6 +197,20 @@ ctcStatus_t sa_clip_sgd_step(float* params, float* grads, float* momentum_buf /*
                              float momentum, float max_norm, float grad_scale, float* d_norm_out, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * 6. Featuriser: the log power spectrogram of speech/loader.py:156-166
+ *    (scipy.signal.spectrogram, periodic Hann window of nperseg samples, hop = nperseg - noverlap, no detrend,
+ *    one-sided 'density' scaling, then log(x + eps)) and the per-bin normalisation (x - mean) / std of loader.py:67.
+ *    d_audio: int16 samples on the device; d_dft: the (nperseg, 2 * (nperseg/2+1)) windowed DFT matrix filled once by
+ *    sa_specgram_build_dft; d_mean / d_std: per-bin statistics or both NULL; out: (frames, nperseg/2+1) fp32.
+ * ----------------------------------------------------------------------------------------------------------------*/
+int sa_specgram_frames(int n, int nperseg, int hop);
+ctcStatus_t sa_specgram_build_dft(float* d_dft, int nperseg, void* stream);
+size_t sa_log_specgram_workspace_bytes(int n, int nperseg, int hop);
+ctcStatus_t sa_log_specgram(const short* d_audio, int n, int sample_rate, int nperseg, int hop, const float* d_dft,
+                            const float* d_mean, const float* d_std, float eps, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,9 +111,23 @@ def decoder_cases(ctc_decoder):
     np.savez_compressed(os.path.join(OUT, "decoder.npz"), **cases)
 
 
+def specgram_case():
+    """The reference's own log_specgram (speech/loader.py:156-166) on a seeded synthetic int16 signal."""
+    import speech.loader as ref_loader
+    rng = np.random.RandomState(2017)
+    n = 16000 + 377
+    t = np.arange(n) / 16000.0
+    audio = (4000 * np.sin(2 * np.pi * 440 * t) + 1500 * np.sin(2 * np.pi * 1234.5 * t) + 300 * rng.randn(n))
+    audio = audio.astype(np.int16)
+    feats = ref_loader.log_specgram(audio, 16000)
+    np.savez_compressed(os.path.join(OUT, "specgram.npz"), audio=audio, feats=feats, sample_rate=np.array(16000))
+    print("specgram", feats.shape, feats.dtype)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     models, ctc_decoder = import_reference()
+    specgram_case()
     sys.path.insert(0, os.path.join(REF, "tests"))
     import shared  # the reference's own test config (tests/shared.py:4-16)
     encoder_case(models, "encoder_tiny", 40, 10, shared.model_config, B=4, T=100, seed=2017)

@@ -65,6 +65,11 @@ SIGNATURES = {
     "sa_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "sa_specgram_frames": (c_int, [c_int, c_int, c_int]),
+    "sa_specgram_build_dft": (c_int, [c_void_p, c_int, c_void_p]),
+    "sa_log_specgram_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sa_log_specgram": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
     "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),
     "sa_clip_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),

@@ -99,7 +99,6 @@ struct FwdJobs {
     int bt0;        // first batch tile handled by this launch (blockIdx.y is relative to it)
     int tile_rows;  // batch rows owned by a block: 16, or 8 / 4 when the batch is cut into more concurrent chains
     unsigned long long* stamp;  // profiling: block (0,0,0) writes wall_clock64() at entry / exit (null: off)
-    int dbg;  // ablation switches for tools/gru_step_bench.py (0 in production): 1 = no W loads, 2 = no h loads
     long rb, rt;
     FwdJob j[kMaxJobs];
 };
@@ -136,8 +135,6 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(FwdJobs P) {
         const float* a_row = J.h_out + (long)brow * J.hs_b + (long)J.t_prev * J.hs_t;
         const float* b_rows[3] = {J.w_hh + (long)urow * H, J.w_hh + (long)(H + urow) * H,
                                   J.w_hh + (long)(2 * H + urow) * H};
-        if (P.dbg & 1) { b_rows[0] = J.w_hh; b_rows[1] = J.w_hh; b_rows[2] = J.w_hh; }  // every lane: one 2 KB row
-        if (P.dbg & 2) a_row = J.h_out;
         f32x4 acc[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -484,7 +481,7 @@ extern "C" ctcStatus_t sa_gru_fwd(const float* ai, const float* w_hh, const floa
         return CTC_STATUS_INVALID_VALUE;  // 16-byte fragment loads need 4-float alignment
     hipStream_t stream = (hipStream_t)stream_;
     FwdJobs P;
-    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.dbg = 0; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
+    P.n = 1; P.B = B; P.H = H; P.rb = T; P.rt = 1; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
     FwdJob& J = P.j[0];
     J.ai = ai; J.w_hh = w_hh; J.b_hh = b_hh; J.h_out = h_out; J.stash = stash; J.hs_b = hs_b; J.hs_t = hs_t;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -720,7 +717,6 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     };
     FwdJobs P;
     P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
-    { const char* e = getenv("SA_GRU_DBG"); P.dbg = e ? atoi(e) : 0; }
 
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
                    // the two directions of a layer share every launch

@@ -237,3 +237,55 @@ def test_gru_stack_matches_oracle(L, D, B, T, I0, H, chunk):
             close(ops.gemm(h2, stash[kk].view(T * B, 5 * H)[:, 4 * H:], trans_a=True), want[(l, d)][1], **tol)
             close(ops.colsum(a2), want[(l, d)][2], **tol)
             close(ops.colsum(h2), want[(l, d)][3], **tol)
+
+
+# ------------------------------------------------------------------- documented experimental paths stay bit-identical
+def _stack_case(L, B, T, I0, H):
+    torch.manual_seed(0)
+    x = torch.randn(T, B, I0, device="cuda")
+    k = 1.0 / H ** 0.5
+    w_ih = [torch.empty(3 * H, I0 if l == 0 else H, device="cuda").uniform_(-k, k) for l in range(L)]
+    w_hh = [torch.empty(3 * H, H, device="cuda").uniform_(-k, k) for l in range(L)]
+    b_ih = [torch.empty(3 * H, device="cuda").uniform_(-k, k) for l in range(L)]
+    b_hh = [torch.empty(3 * H, device="cuda").uniform_(-k, k) for l in range(L)]
+    return x, w_ih, b_ih, w_hh, b_hh
+
+
+def test_multi_stream_chains_are_bit_identical():
+    """ops.N_CHAINS > 1 (batch rows split over HIP streams; measured slower) must not change results."""
+    from speech_amd import ops
+    L, B, T, I0, H = 3, 32, 40, 24, 64
+    x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)
+    dtop = torch.randn(T, B, H, device="cuda")
+    outs = []
+    try:
+        for chains in (1, 2, 4):
+            ops.N_CHAINS = chains
+            h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True)
+            dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0)
+            torch.cuda.synchronize()
+            outs.append((h[-1].clone(), dx.clone(), dai[0].clone()))
+    finally:
+        ops.N_CHAINS = 1
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+
+
+def test_persistent_chunk_kernel_is_bit_identical():
+    """SA_GRU_PERSIST=1 (LDS-resident W_hh, in-kernel hand-offs; measured slower) vs the step kernels."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_blocks import _stack_case\nfrom speech_amd import ops\n"
+            "x, w_ih, b_ih, w_hh, b_hh = _stack_case(4, 32, 50, 40, 128)\n"
+            "h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, 4, 1, 128, want_stash=True)\n"
+            "torch.cuda.synchronize(); torch.save([t.cpu() for t in h + st], sys.argv[1])\n") % (root, root)
+    res = []
+    for mode in ("0", "1"):
+        out = "/tmp/sa_persist_%s.pt" % mode
+        env = dict(os.environ, SA_GRU_PERSIST=mode)
+        subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=120)
+        res.append(torch.load(out))
+    assert len(res[0]) == len(res[1]) and all(torch.equal(a, b) for a, b in zip(*res))
