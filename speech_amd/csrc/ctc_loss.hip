@@ -35,6 +35,7 @@ namespace {
 constexpr int kU = 8;          // steps per hand-off batch (producer lead, emission prefetch depth, renorm period)
 constexpr int kRenorm = 4;     // renormalise every kRenorm batches (32 steps): states drift <~ 200 log2 units between
 constexpr int kMaxChunks = 8;  // chunks per direction: labels up to 64 * 8 - 1 = 511 per utterance
+constexpr int kWideMinBatch = 512;  // from this many utterances per call the one-wave-per-utterance kernel (K_W) runs
 
 // ---------------------------------------------------------------------------------------------------------- K_A
 // grid (row blocks, B).  G lanes cooperate on one row (G = 16, 32 or 64); a wave handles 64 / G rows at a time.
@@ -64,6 +65,54 @@ __global__ __launch_bounds__(256) void ctc_logsoftmax2_kernel(const float* __res
     if (act) {
         float* o = ly2 + (long)b * ly_sb + (long)t * K;
         for (int k = gl; k < K; k += G) o[k] = fmaxf((a[k] - m) * SA_LOG2E - lz, SA_NEG);
+    }
+}
+
+// K_A for small alphabets (K <= 64, i.e. every character-level model of the reference): a workgroup stages 256 rows
+// in LDS with coalesced loads, then ONE LANE normalises ONE ROW out of LDS (row stride odd -> conflict-free) and the
+// tile is written back coalesced.  ~8 wave instructions per row instead of ~50 for the lane-group kernel above
+// (whose two butterfly reductions per row dominate at K = 29), which makes K_A HBM-bound at large B.
+__global__ __launch_bounds__(256) void ctc_logsoftmax2_rows_kernel(const float* __restrict__ acts, long st, long sb,
+                                                                   const int* __restrict__ in_lens, int K, long ly_sb,
+                                                                   float* __restrict__ ly2) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* tile = reinterpret_cast<float*>(smem_raw);  // [256][KS]
+    const int KS = K | 1;
+    const int b = blockIdx.y;
+    const int T = in_lens[b];
+    const int t0 = blockIdx.x * 256;
+    const int nrows = min(256, T - t0);
+    if (nrows <= 0) return;
+    const int n = nrows * K;
+    const int dr = 256 / K, dk = 256 - dr * K;  // idx += 256  ->  (row, k) += (dr, dk) with one carry
+    const float* src = acts + (long)b * sb + (long)t0 * st;
+    {
+        int r = threadIdx.x / K, k = threadIdx.x - r * K;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            tile[r * KS + k] = src[(long)r * st + k];
+            r += dr; k += dk;
+            if (k >= K) { k -= K; ++r; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nrows) {
+        float* row = tile + threadIdx.x * KS;
+        float m = -3.0e38f;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, row[k]);
+        float z = 0.f;
+        for (int k = 0; k < K; ++k) z += sa_exp2((row[k] - m) * SA_LOG2E);
+        const float lz = sa_log2(z);
+        for (int k = 0; k < K; ++k) row[k] = fmaxf((row[k] - m) * SA_LOG2E - lz, SA_NEG);
+    }
+    __syncthreads();
+    {
+        float* dst = ly2 + (long)b * ly_sb + (long)t0 * K;
+        int r = threadIdx.x / K, k = threadIdx.x - r * K;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            dst[i] = tile[r * KS + k];
+            r += dr; k += dk;
+            if (k >= K) { k -= K; ++r; }
+        }
     }
 }
 
@@ -399,6 +448,331 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- K_W
+// Throughput regime (several utterances per CU, e.g. SURVEY.md 8d "M-CTC at saturating B"): ONE WAVE per utterance.
+// K_B above spends a whole workgroup, ~120 KB of LDS and 4 HBM stash planes per utterance to cut the latency of one
+// lattice; with thousands of lattices the chip is instead bound by stash traffic and by how many lattices a CU can
+// hold.  Here lane i owns R CONTIGUOUS state pairs (R = 1, 2, 4, 8 for up to 63 / 127 / 255 / 511 labels): the R
+// pair updates of a step are independent (ILP inside the wave, one DPP for the lane boundary), there is no
+// cross-wave hand-off at all, and alpha then beta run back to back in the same wave.
+//   alpha pass  keeps only a CHECKPOINT of its states every KU steps (1/KU of a full alpha plane stash);
+//   beta pass   walks the batches of KU steps backwards: reloads the batch's checkpoint (prefetched one batch
+//               ahead), recomputes the batch's alpha states into registers -- bit-identical, the arithmetic and the
+//               renormalisation points are the same -- then runs its own KU steps, forming the occupancies on the
+//               fly (blank: DPP wave sum, labels: LDS float atomics into a K-entry row owned by the wave) and
+//               writing the gradient row itself.  No beta stash, no K_C.
+// A score-only alpha pass of 4096 utterances takes 0.48 ms, so recomputing alpha is cheaper than the 8.4 GB of HBM
+// traffic a full alpha stash costs.  Emission rows are staged KU rows at a time into a per-wave LDS ring with
+// coalesced loads issued a batch ahead.  ~4.5 KB of LDS per wave at K = 29: occupancy is VGPR-bound (4 waves / SIMD).
+struct WaveArgs {
+    const float* ly2;
+    const int* labels;
+    const int* label_lens;
+    const int* in_lens;
+    int K, T_max, blank, B, nren, nq, wave_lds_floats;
+    long ly_sb;
+    float* stash;  // [B][nq][2][64 * R]: alpha (blank, label) states at the start of every batch of KU steps
+    float* costs;
+    float* grads;
+    long st, sb;
+};
+
+template <int R>
+struct WaveCfg {
+    static constexpr int KU = R <= 4 ? 8 : 4;  // steps per batch (bounds the recomputed-alpha registers: 2 * KU * R)
+    static constexpr int NU = 8;                // staging registers: KU * K <= 64 * NU takes the SMALLK path
+};
+
+// Emission rows [tlo, tlo + nrows) of one utterance -> registers (issue) -> the wave's LDS ring (commit).
+// Every VMEM access in the T loops of this kernel is unconditional (clamped index, then a select): a branch around
+// a load or store makes the outstanding-operation count unknown to the compiler, which then waits for vmcnt(0) --
+// the HBM round trip of the previous step's stores -- before every later use of any loaded value.
+template <int R, bool SMALLK>
+struct RowStager {
+    static constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
+    const float* ly;
+    int K, lane;
+    float pv[NU];
+    __device__ __forceinline__ void issue(int tlo, int nrows) {
+        if (!SMALLK) return;
+        const int n = nrows * K;
+        const float* src = ly + (long)tlo * K;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pv[u] = src[min(lane + 64 * u, n - 1)];
+    }
+    __device__ __forceinline__ void commit(int tlo, int nrows, float* dst) {
+        if (SMALLK) {  // the ring buffers hold 64 * NU floats on this path: no bounds test
+#pragma unroll
+            for (int u = 0; u < NU; ++u) dst[lane + 64 * u] = pv[u];
+        } else {
+            const int n = nrows * K;
+            const float* src = ly + (long)tlo * K;
+            for (int i = lane; i < n; i += 64) dst[i] = src[i];
+        }
+    }
+    __device__ __forceinline__ int buf_floats() const { return SMALLK ? 64 * NU : KU * K; }
+};
+
+// One time step of a wave's 64 * R state pairs.  DIR 0: alpha pairs (blank_j, label_j), neighbour = label_{j-1};
+// DIR 1: beta pairs (label_{j-1}, blank_j), neighbour = label_j.  Same shared-pivot arithmetic as K_B's do_step.
+template <int R, int DIR>
+__device__ __forceinline__ void wave_step(float (&Bst)[R], float (&Lst)[R], const float (&el)[R], float eb,
+                                          const bool (&skip)[R]) {
+    const float edge = DIR == 0 ? sa_wave_shr1(Lst[R - 1], SA_NEG) : sa_wave_shl1(Lst[0], SA_NEG);
+    float nB[R], nL[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float n = DIR == 0 ? (r == 0 ? edge : Lst[r - 1]) : (r == R - 1 ? edge : Lst[r + 1]);
+        const float mLB = fmaxf(Lst[r], Bst[r]);
+        const float mBn = fmaxf(Bst[r], n);
+        const float m = fmaxf(mLB, n);
+        const float xL = sa_exp2(Lst[r] - m);
+        const float xB = sa_exp2(Bst[r] - m);
+        const float xn = sa_exp2(n - m);
+        const float sB = xB + xn;
+        const float sL = xL + xB + (skip[r] ? xn : 0.f);
+        nB[r] = eb + (sB > 0.f ? m + sa_log2(sB) : mBn);
+        nL[r] = el[r] + (sL > 0.f ? m + sa_log2(sL) : mLB);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Bst[r] = nB[r]; Lst[r] = nL[r]; }
+}
+
+template <int R>
+__device__ __forceinline__ float wave_renorm(float (&Bst)[R], float (&Lst)[R]) {  // exact: integer shift
+    float m = SA_NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = fmaxf(m, fmaxf(Bst[r], Lst[r]));
+    m = sa_wave_max_dpp(m);
+    const float d = m > SA_NEG_TEST ? __builtin_rintf(m) : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Bst[r] -= d; Lst[r] -= d; }
+    return d;
+}
+
+template <int R, bool WITH_GRAD, bool SMALLK>
+__device__ __forceinline__ void ctc_wave_alpha(const WaveArgs& A, int b, int lane, int L, int T, const int* lab,
+                                               float* ring, float* aoff, float* out_lp, float* out_off) {
+    constexpr int KU = WaveCfg<R>::KU, P = 64 * R;
+    const int K = A.K;
+    int own_lab[R];
+    bool own_ok[R], skip[R];
+    float Bst[R], Lst[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * R + r;
+        own_ok[r] = j < L;
+        own_lab[r] = own_ok[r] ? lab[j] : A.blank;
+        skip[r] = (j >= 1 && j <= L - 1) ? (lab[j] != lab[j - 1]) : false;
+        Bst[r] = j == 0 ? 0.0f : SA_NEG;
+        Lst[r] = SA_NEG;
+    }
+    float off = 0.f;
+    RowStager<R, SMALLK> stage;
+    stage.ly = A.ly2 + (long)b * A.ly_sb; stage.K = K; stage.lane = lane;
+    if (T > 0) {
+        stage.issue(0, min(KU, T));
+        stage.commit(0, min(KU, T), ring);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // everything loaded so far (labels, first rows) is waited for once, here
+
+    int q = 0;
+    for (int r0 = 0; r0 < T; r0 += KU, ++q) {
+        const float* cur = ring + (q & 1) * stage.buf_floats();
+        float* nxt = ring + ((q + 1) & 1) * stage.buf_floats();
+        if ((r0 & 31) == 0) {
+            off += wave_renorm<R>(Bst, Lst);
+            if (WITH_GRAD && lane == 0) aoff[r0 >> 5] = off;
+        }
+        if (WITH_GRAD) {
+            float* ck = A.stash + ((long)b * A.nq + q) * 2 * P + lane * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { ck[r] = Bst[r]; ck[P + r] = Lst[r]; }
+        }
+        const bool more = r0 + KU < T;
+        if (more) stage.issue(r0 + KU, min(KU, T - r0 - KU));
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            if (r0 + k < T) {
+                const float* rowp = cur + k * K;
+                const float eb = rowp[A.blank];
+                float el[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float v = rowp[own_lab[r]];  // own_lab is the blank where there is no label state
+                    el[r] = own_ok[r] ? v : SA_NEG;
+                }
+                wave_step<R, 0>(Bst, Lst, el, eb, skip);
+            }
+        }
+        if (more) stage.commit(r0 + KU, min(KU, T - r0 - KU), nxt);
+    }
+
+    float f0 = SA_NEG, f1 = SA_NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * R + r;
+        if (j == L) f0 = Bst[r];
+        if (j == L - 1) f1 = Lst[r];
+    }
+    f0 = sa_wave_max_dpp(f0);
+    f1 = sa_wave_max_dpp(f1);
+    *out_lp = lse2_1p(f0, f1);
+    *out_off = off;
+}
+
+template <int R, bool SMALLK>
+__device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane, int L, int T, const int* lab,
+                                              float* ring, float* occ, const float* aoff, float lp, float lpo) {
+    constexpr int KU = WaveCfg<R>::KU, P = 64 * R;
+    const int K = A.K;
+    int a_lab[R], b_lab[R];
+    bool a_ok[R], b_ok[R], skip[R], blank_ok[R];
+    float Bst[R], Lst[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * R + r;
+        a_ok[r] = j < L;
+        a_lab[r] = a_ok[r] ? lab[j] : A.blank;
+        b_ok[r] = j >= 1 && j - 1 < L;
+        b_lab[r] = b_ok[r] ? lab[j - 1] : A.blank;
+        skip[r] = (j >= 1 && j <= L - 1) ? (lab[j] != lab[j - 1]) : false;
+        blank_ok[r] = j <= L;
+        Bst[r] = j == L ? 0.0f : SA_NEG;
+        Lst[r] = SA_NEG;
+    }
+    float off = 0.f;
+    RowStager<R, SMALLK> stage;
+    stage.ly = A.ly2 + (long)b * A.ly_sb; stage.K = K; stage.lane = lane;
+    const float* ck_base = A.stash + (long)b * A.nq * 2 * P + lane * R;
+    const int q_last = (T - 1) / KU;
+    float cB[R], cL[R];  // checkpoint of the batch about to be processed
+    {
+        const int tlo = q_last * KU;
+        stage.issue(tlo, T - tlo);
+        stage.commit(tlo, T - tlo, ring);
+        const float* ck = ck_base + (long)q_last * 2 * P;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cB[r] = ck[r]; cL[r] = ck[P + r]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+
+    int bi = 0;
+    for (int q = q_last; q >= 0; --q, ++bi) {
+        const int tlo = q * KU;
+        const int nrows = min(KU, T - tlo);
+        const float* cur = ring + (bi & 1) * stage.buf_floats();
+        float* nxt = ring + ((bi + 1) & 1) * stage.buf_floats();
+        if ((bi & 3) == 0) off += wave_renorm<R>(Bst, Lst);
+        float aBs[R], aLs[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { aBs[r] = cB[r]; aLs[r] = cL[r]; }
+        if (q > 0) {  // the previous batch in time: rows and checkpoint, a batch ahead of their use
+            stage.issue(tlo - KU, KU);
+            const float* ck = ck_base + (long)(q - 1) * 2 * P;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { cB[r] = ck[r]; cL[r] = ck[P + r]; }
+        }
+        const float io = aoff[tlo >> 5] + off - lpo;  // alpha offset + beta offset - log2 p offset: integers, exact
+
+        // (1) recompute this batch's alpha states from its checkpoint
+        float aB[KU][R], aL[KU][R];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            if (k < nrows) {
+                const float* rowp = cur + k * K;
+                const float eb = rowp[A.blank];
+                float el[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float v = rowp[a_lab[r]];
+                    el[r] = a_ok[r] ? v : SA_NEG;
+                }
+                wave_step<R, 0>(aBs, aLs, el, eb, skip);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { aB[k][r] = aBs[r]; aL[k][r] = aLs[r]; }
+        }
+        // (2) beta steps, backwards in time, with the occupancies and the gradient row of each step
+#pragma unroll
+        for (int k = KU - 1; k >= 0; --k) {
+            if (k < nrows) {
+                const int t = tlo + k;
+                const float* rowp = cur + k * K;
+                const float eb = rowp[A.blank];
+                float el[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float v = rowp[b_lab[r]];
+                    el[r] = b_ok[r] ? v : SA_NEG;
+                }
+                wave_step<R, 1>(Bst, Lst, el, eb, skip);
+                // occupancy = exp2(alpha + beta - one emission - log2 p); alpha's label state of pair j-1
+                const float aedge = sa_wave_shr1(aL[k][R - 1], SA_NEG);
+                float gb = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    gb += blank_ok[r] ? sa_exp2((aB[k][r] + Bst[r] - eb - lp) + io) : 0.f;
+                    const float al = r == 0 ? aedge : aL[k][r - 1];
+                    if (b_ok[r]) atomicAdd(&occ[b_lab[r]], sa_exp2((al + Lst[r] - el[r] - lp) + io));
+                }
+                gb = sa_wave_sum_dpp(gb);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                float* g = A.grads + (long)b * A.sb + (long)t * A.st;
+                if (SMALLK) {  // K <= 64: lanes past K repeat lane K-1's store (same address, same value)
+                    const int c = min(lane, K - 1);
+                    const float o = c == A.blank ? gb : occ[c];
+                    g[c] = sa_exp2(rowp[c]) - o;
+                    occ[c] = 0.f;
+                } else {
+                    for (int c = lane; c < K; c += 64) {
+                        const float o = c == A.blank ? gb : occ[c];
+                        g[c] = sa_exp2(rowp[c]) - o;
+                        occ[c] = 0.f;
+                    }
+                }
+            }
+        }
+        if (q > 0) stage.commit(tlo - KU, KU, nxt);
+    }
+}
+
+template <int R, bool WITH_GRAD, bool SMALLK>
+__global__ __launch_bounds__(256) void ctc_wave_kernel(WaveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= A.B) return;  // waves are independent: no workgroup barrier anywhere in this kernel
+    constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
+    float* base = reinterpret_cast<float*>(smem_raw) + (long)wave * A.wave_lds_floats;
+    float* ring = base;                                       // [2][KU][K]  (SMALLK: [2][64 * NU])
+    float* occ = ring + 2 * (SMALLK ? 64 * NU : KU * A.K);    // [K]
+    float* aoff = occ + A.K;                                  // [nren]
+    const int L = A.label_lens[b];
+    const int T = A.in_lens[b];
+    int loff = 0;
+    for (int i = lane; i < b; i += 64) loff += A.label_lens[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loff += __shfl_xor(loff, o, 64);
+    const int* lab = A.labels + loff;
+    if (WITH_GRAD)
+        for (int c = lane; c < A.K; c += 64) occ[c] = 0.f;
+
+    float lp = SA_NEG, lpo = 0.f;
+    ctc_wave_alpha<R, WITH_GRAD, SMALLK>(A, b, lane, L, T, lab, ring, aoff, &lp, &lpo);
+    const bool dead = lp < SA_NEG_TEST;
+    if (lane == 0) A.costs[b] = dead ? __builtin_inff() : (float)(-((double)lp + (double)lpo) * 0.6931471805599453);
+    if (!WITH_GRAD) return;
+    const int T_live = (dead || T <= 0) ? 0 : T;
+    // each lane reads back only the checkpoint slots it wrote itself: program order suffices, no fence
+    if (T_live > 0) ctc_wave_beta<R, SMALLK>(A, b, lane, L, T, lab, ring, occ, aoff, lp, lpo);
+    for (int t = T_live; t < A.T_max; ++t) {  // padding rows / infeasible alignment: zero gradient
+        float* g = A.grads + (long)b * A.sb + (long)t * A.st;
+        for (int c = lane; c < A.K; c += 64) g[c] = 0.f;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------ host side
@@ -470,7 +844,13 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.costs = d_costs;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
-    {  // K_A
+    if (K <= 64 && (long)B * ((max_T + 255) / 256) >= 1024) {  // K_A, one lane per row out of an LDS tile: the
+        // throughput form; with fewer than ~4 workgroups per CU its serial 3 * K-step row loop is the slower one
+        dim3 grid((max_T + 255) / 256, B);
+        hipLaunchKernelGGL(ctc_logsoftmax2_rows_kernel, grid, dim3(256), (size_t)256 * (K | 1) * sizeof(float), stream,
+                           acts, stride_t, stride_b, d_input_lengths, K, A.ly_sb, (float*)(ws + o_ly2));
+        SA_CHECK_LAUNCH();
+    } else {  // K_A, a lane group per row
         const int G = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
         const int rows_per_block = 4 * (64 / G);
         dim3 grid((max_T + rows_per_block - 1) / rows_per_block, B);
@@ -485,6 +865,45 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
             hipLaunchKernelGGL(ctc_logsoftmax2_kernel<64>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
                                d_input_lengths, K, A.ly_sb, ly2);
         SA_CHECK_LAUNCH();
+    }
+    // K_W: the throughput-regime kernel (one wave per utterance) once every CU holds several utterances
+    {
+        int R = 1;
+        while (R * 64 < max_L + 1) R *= 2;
+        const int KU = R <= 4 ? 8 : 4;
+        const int nren = max_T / 32 + 2;
+        const bool smallk = KU * K <= 512 && K <= 64;  // a batch of emission rows fits the 8 staging registers
+        const size_t wave_floats = sa_align_up((size_t)2 * (smallk ? 512 : KU * K) + K + nren, 4);
+        const size_t wave_bytes = wave_floats * sizeof(float);
+        const char* env = getenv("SA_CTC_WIDE");
+        const bool want = env ? (env[0] == '1') : (B >= kWideMinBatch);
+        if (want && wave_bytes <= 150 * 1024) {
+            const int waves = 4 * wave_bytes <= 64 * 1024 ? 4 : 1;
+            WaveArgs W;
+            W.ly2 = A.ly2; W.labels = d_flat_labels; W.label_lens = d_label_lengths; W.in_lens = d_input_lengths;
+            W.K = K; W.T_max = max_T; W.blank = blank_label; W.B = B; W.nren = nren; W.nq = (max_T + KU - 1) / KU;
+            W.wave_lds_floats = (int)wave_floats;
+            W.ly_sb = A.ly_sb; W.stash = A.stash; W.costs = d_costs; W.grads = grads;
+            W.st = stride_t; W.sb = stride_b;
+            const size_t smem = waves * wave_bytes;
+            const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+#define SA_WIDE_LAUNCH(R_)                                                                                        \
+    do {                                                                                                          \
+        void (*fn)(WaveArgs) = grads ? (smallk ? ctc_wave_kernel<R_, true, true> : ctc_wave_kernel<R_, true, false>)    \
+                                     : (smallk ? ctc_wave_kernel<R_, false, true> : ctc_wave_kernel<R_, false, false>); \
+        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                    (int)smem) != hipSuccess)                                     \
+            return CTC_STATUS_EXECUTION_FAILED;                                                                   \
+        hipLaunchKernelGGL(fn, grid, block, smem, stream, W);                                                     \
+    } while (0)
+            if (R == 1) SA_WIDE_LAUNCH(1);
+            else if (R == 2) SA_WIDE_LAUNCH(2);
+            else if (R == 4) SA_WIDE_LAUNCH(4);
+            else SA_WIDE_LAUNCH(8);
+#undef SA_WIDE_LAUNCH
+            SA_CHECK_LAUNCH();
+            return CTC_STATUS_SUCCESS;
+        }
     }
     {  // K_B
         const size_t fixed = kAbSharedBytes + (size_t)2 * nch * (A.hand_stride + A.nbatch) * sizeof(float);

@@ -166,3 +166,65 @@ def test_warpctc_shaped_entry_point():
     bad[0] = 28  # label == blank
     assert L.compute_ctc_loss(d_acts.data_ptr(), None, bad.ctypes.data, ll.ctypes.data, al.ctypes.data, 29, 5,
                               costs.ctypes.data, ws.data_ptr(), opts) == 2
+
+
+# ---- K_W, the one-wave-per-utterance kernel of the throughput regime (default from B >= 512; forced here) ----------
+@pytest.fixture
+def wide(monkeypatch):
+    monkeypatch.setenv("SA_CTC_WIDE", "1")
+
+
+@pytest.mark.parametrize("B,T,K,Lmin,Lmax", [
+    (4, 100, 11, 20, 20), (3, 48, 11, 0, 20), (8, 144, 49, 10, 70),
+    (5, 300, 29, 60, 130),     # R = 2 and R = 4 pairs per lane
+    (2, 50, 29, 63, 64),       # R boundary
+    (2, 700, 29, 300, 400),    # R = 8
+    (3, 90, 80, 5, 30),        # K > 64: emission staging takes the looped path
+    (1, 1, 5, 0, 0), (1, 1, 5, 1, 1), (2, 7, 3, 1, 3), (9, 33, 29, 1, 12),
+])
+def test_wide_matches_oracle(wide, B, T, K, Lmin, Lmax):
+    compare(*make(B * 1000 + T + 1, B, T, K, Lmin, Lmax))
+
+
+def test_wide_ragged_time_major_blank_zero_peaky(wide):
+    acts, labs, al, ll = make(7, 6, 120, 29, 5, 40, ragged_T=True)
+    compare(acts, labs, al, ll)
+    compare(np.ascontiguousarray(acts.transpose(1, 0, 2)), labs, al, ll, batch_first=False)
+    rng = np.random.RandomState(3)
+    a0 = rng.randn(3, 40, 9).astype(np.float32)
+    l0 = np.array([5, 9, 1], dtype=np.int32)
+    compare(a0, rng.randint(1, 9, int(l0.sum())).astype(np.int32), np.full(3, 40, np.int32), l0, blank=0)
+    compare(*make(11, 4, 200, 29, 20, 60, scale=8.0))
+
+
+def test_wide_infeasible_and_score_only(wide):
+    rng = np.random.RandomState(5)
+    acts = rng.randn(3, 6, 4).astype(np.float32)
+    labs = np.array([0, 0, 0, 0, 0, 0, 1, 2, 1, 1, 1, 2], dtype=np.int32)
+    ll = np.array([6, 3, 3], dtype=np.int32)
+    al = np.full(3, 6, np.int32)
+    c, g = run_hip(acts, labs, al, ll)
+    co, go = ctc_ref.ctc_loss(acts, labs, al, ll)
+    assert np.isinf(c[0]) and c[0] > 0 and np.all(g[0] == 0)
+    np.testing.assert_allclose(c[1:], co[1:], rtol=COST_RTOL)
+    assert np.abs(g - go).max() < grad_atol(co[1:])
+    c2, g2 = run_hip(acts, labs, al, ll, want_grad=False)
+    assert g2 is None and np.array_equal(c, c2)
+
+
+def test_wide_full_size_rows_and_default_switch(monkeypatch):
+    # M-CTC rows (T=1000, V+1=29, L=100) through K_W against the fp64 oracle, then a batch past the switch-over
+    # (B >= 512 selects K_W by default) against the latency kernel K_B on the same inputs: same costs to fp32
+    # rounding, same gradients to the stated tolerance, and every gradient row sums to zero (softmax - occupancy).
+    monkeypatch.setenv("SA_CTC_WIDE", "1")
+    compare(*make(2017, 8, 1000, 29, 100, 100))
+    monkeypatch.delenv("SA_CTC_WIDE")
+    acts, labs, al, ll = make(23, 640, 120, 29, 5, 60, ragged_T=True)
+    cw, gw = run_hip(acts, labs, al, ll)
+    monkeypatch.setenv("SA_CTC_WIDE", "0")
+    cn, gn = run_hip(acts, labs, al, ll)
+    np.testing.assert_allclose(cw, cn, rtol=COST_RTOL)
+    assert np.abs(gw - gn).max() < grad_atol(cn)
+    assert np.abs(gw.sum(axis=2)).max() < 1e-4
+    for b in range(0, 640, 97):
+        assert np.all(gw[b, al[b]:] == 0)
