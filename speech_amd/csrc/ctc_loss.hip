@@ -531,8 +531,10 @@ __device__ __forceinline__ void wave_step(float (&Bst)[R], float (&Lst)[R], cons
         const float xn = sa_exp2(n - m);
         const float sB = xB + xn;
         const float sL = xL + xB + (skip[r] ? xn : 0.f);
-        nB[r] = eb + (sB > 0.f ? m + sa_log2(sB) : mBn);
-        nL[r] = el[r] + (sL > 0.f ? m + sa_log2(sL) : mLB);
+        // a sum that flushed to 0 gives log2 = -inf and the max picks the larger operand (K_B's fallback, one
+        // v_max instead of compare + select); otherwise lse >= max holds up to one rounding
+        nB[r] = eb + fmaxf(m + sa_log2(sB), mBn);
+        nL[r] = el[r] + fmaxf(m + sa_log2(sL), mLB);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) { Bst[r] = nB[r]; Lst[r] = nL[r]; }
@@ -548,6 +550,18 @@ __device__ __forceinline__ float wave_renorm(float (&Bst)[R], float (&Lst)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) { Bst[r] -= d; Lst[r] -= d; }
     return d;
+}
+
+// Inclusive prefix sum over the 64 lanes on the DPP network (the same six steps as sa_wave_sum_dpp, whose lane 63
+// holds the total): row_shr 1/2/4/8 scan each 16-lane row, row_bcast15 / row_bcast31 carry the row totals forward.
+__device__ __forceinline__ float wave_scan_dpp(float v) {
+    v += SA_DPP_F(0.f, v, 0x111, 0xf);
+    v += SA_DPP_F(0.f, v, 0x112, 0xf);
+    v += SA_DPP_F(0.f, v, 0x114, 0xf);
+    v += SA_DPP_F(0.f, v, 0x118, 0xf);
+    v += SA_DPP_F(0.f, v, 0x142, 0xa);
+    v += SA_DPP_F(0.f, v, 0x143, 0xc);
+    return v;
 }
 
 template <int R, bool WITH_GRAD, bool SMALLK>
@@ -627,7 +641,7 @@ __device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane
     constexpr int KU = WaveCfg<R>::KU, P = 64 * R;
     const int K = A.K;
     int a_lab[R], b_lab[R];
-    bool a_ok[R], b_ok[R], skip[R], blank_ok[R];
+    bool a_ok[R], b_ok[R], skip[R];
     float Bst[R], Lst[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -637,9 +651,41 @@ __device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane
         b_ok[r] = j >= 1 && j - 1 < L;
         b_lab[r] = b_ok[r] ? lab[j - 1] : A.blank;
         skip[r] = (j >= 1 && j <= L - 1) ? (lab[j] != lab[j - 1]) : false;
-        blank_ok[r] = j <= L;
         Bst[r] = j == L ? 0.0f : SA_NEG;
         Lst[r] = SA_NEG;
+    }
+    // Label occupancies of a row, occ[c] = sum over the label states i with lab[i] = c.  LDS float atomics cost
+    // ~4 cycles per lane on the CU's one LDS pipe and were THE bottleneck of this pass (adding 27 % more atomic
+    // lanes cost 28 % more kernel time).  For K <= 64 the scatter-add is a fixed sparse matrix per utterance, so it
+    // is done as a sorted segment sum instead: once, label states are counting-sorted by class (pos[] is a
+    // permutation of the P slots, deterministic: rank = number of earlier equal labels); per step each lane drops
+    // its R occupancies at pos[] (plain conflict-free LDS writes), the wave takes an inclusive prefix sum over the
+    // sorted array (DPP scan), and class lane c reads two prefix sums: S[last of c] - S[before first of c].
+    int pos[R], seg_hi = P, seg_lo = P;  // occ[] doubles as the sorted array [P + 1]; slot P stays 0
+    if (SMALLK) {
+        int cnt = 0, rank[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rank[r] = 0;
+        for (int i = 0; i < L; ++i) {
+            const int li = lab[i];
+            cnt += li == lane ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rank[r] += (i < lane * R + r - 1 && li == b_lab[r]) ? 1 : 0;
+        }
+        const int incl = (int)wave_scan_dpp((float)cnt);  // counts <= 511: exact in fp32
+        const int start = incl - cnt;
+        occ[lane] = (float)start;
+        if (lane == 0) occ[P] = 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = lane * R + r;
+            // label state j-1 -> its sorted slot; the P - L pairs without one (j = 0, j > L) fill slots [L, P)
+            pos[r] = b_ok[r] ? (int)occ[b_lab[r]] + rank[r] : (j == 0 ? P - 1 : j - 1);
+        }
+        seg_lo = start > 0 ? start - 1 : P;
+        seg_hi = cnt > 0 ? start + cnt - 1 : seg_lo;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     float off = 0.f;
     RowStager<R, SMALLK> stage;
@@ -710,21 +756,39 @@ __device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane
                 // occupancy = exp2(alpha + beta - one emission - log2 p); alpha's label state of pair j-1
                 const float aedge = sa_wave_shr1(aL[k][R - 1], SA_NEG);
                 float gb = 0.f;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    gb += blank_ok[r] ? sa_exp2((aB[k][r] + Bst[r] - eb - lp) + io) : 0.f;
-                    const float al = r == 0 ? aedge : aL[k][r - 1];
-                    if (b_ok[r]) atomicAdd(&occ[b_lab[r]], sa_exp2((al + Lst[r] - el[r] - lp) + io));
-                }
-                gb = sa_wave_sum_dpp(gb);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 float* g = A.grads + (long)b * A.sb + (long)t * A.st;
-                if (SMALLK) {  // K <= 64: lanes past K repeat lane K-1's store (same address, same value)
+                if (SMALLK) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        // states that do not exist hold SA_NEG in alpha and in beta: their exp2 is exactly 0
+                        gb += sa_exp2((aB[k][r] + Bst[r] - eb - lp) + io);
+                        const float al = r == 0 ? aedge : aL[k][r - 1];
+                        occ[pos[r]] = sa_exp2((al + Lst[r] - (b_ok[r] ? el[r] : 0.f) - lp) + io);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    float sv[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) sv[r] = occ[lane * R + r];
+#pragma unroll
+                    for (int r = 1; r < R; ++r) sv[r] += sv[r - 1];
+                    const float excl = wave_scan_dpp(sv[R - 1]) - sv[R - 1];
+                    gb = sa_wave_sum_dpp(gb);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) occ[lane * R + r] = sv[r] + excl;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    // K <= 64: lanes past K repeat lane K-1's store (same address, same value)
                     const int c = min(lane, K - 1);
-                    const float o = c == A.blank ? gb : occ[c];
+                    const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
                     g[c] = sa_exp2(rowp[c]) - o;
-                    occ[c] = 0.f;
                 } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        gb += sa_exp2((aB[k][r] + Bst[r] - eb - lp) + io);
+                        const float al = r == 0 ? aedge : aL[k][r - 1];
+                        if (b_ok[r]) atomicAdd(&occ[b_lab[r]], sa_exp2((al + Lst[r] - el[r] - lp) + io));
+                    }
+                    gb = sa_wave_sum_dpp(gb);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     for (int c = lane; c < K; c += 64) {
                         const float o = c == A.blank ? gb : occ[c];
                         g[c] = sa_exp2(rowp[c]) - o;
@@ -747,8 +811,8 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(WaveArgs A) {
     constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
     float* base = reinterpret_cast<float*>(smem_raw) + (long)wave * A.wave_lds_floats;
     float* ring = base;                                       // [2][KU][K]  (SMALLK: [2][64 * NU])
-    float* occ = ring + 2 * (SMALLK ? 64 * NU : KU * A.K);    // [K]
-    float* aoff = occ + A.K;                                  // [nren]
+    float* occ = ring + 2 * (SMALLK ? 64 * NU : KU * A.K);    // SMALLK: sorted occupancies [64 R + 1]; else row [K]
+    float* aoff = occ + (SMALLK ? 64 * R + 1 : A.K);          // [nren]
     const int L = A.label_lens[b];
     const int T = A.in_lens[b];
     int loff = 0;
@@ -756,7 +820,7 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(WaveArgs A) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) loff += __shfl_xor(loff, o, 64);
     const int* lab = A.labels + loff;
-    if (WITH_GRAD)
+    if (WITH_GRAD && !SMALLK)
         for (int c = lane; c < A.K; c += 64) occ[c] = 0.f;
 
     float lp = SA_NEG, lpo = 0.f;
@@ -873,7 +937,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         const int KU = R <= 4 ? 8 : 4;
         const int nren = max_T / 32 + 2;
         const bool smallk = KU * K <= 512 && K <= 64;  // a batch of emission rows fits the 8 staging registers
-        const size_t wave_floats = sa_align_up((size_t)2 * (smallk ? 512 : KU * K) + K + nren, 4);
+        const size_t wave_floats = sa_align_up((size_t)2 * (smallk ? 512 : KU * K) + (smallk ? 64 * R + 1 : K) + nren, 4);
         const size_t wave_bytes = wave_floats * sizeof(float);
         const char* env = getenv("SA_CTC_WIDE");
         const bool want = env ? (env[0] == '1') : (B >= kWideMinBatch);
