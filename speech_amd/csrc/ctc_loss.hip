@@ -68,27 +68,29 @@ __global__ __launch_bounds__(256) void ctc_logsoftmax2_kernel(const float* __res
     }
 }
 
-// K_A for small alphabets (K <= 64, i.e. every character-level model of the reference): a workgroup stages 256 rows
+// K_A for small alphabets (K <= 64, i.e. every character-level model of the reference): a workgroup stages kRowTile rows
 // in LDS with coalesced loads, then ONE LANE normalises ONE ROW out of LDS (row stride odd -> conflict-free) and the
 // tile is written back coalesced.  ~8 wave instructions per row instead of ~50 for the lane-group kernel above
 // (whose two butterfly reductions per row dominate at K = 29), which makes K_A HBM-bound at large B.
-__global__ __launch_bounds__(256) void ctc_logsoftmax2_rows_kernel(const float* __restrict__ acts, long st, long sb,
+constexpr int kRowTile = 64;  // rows (= lanes) per workgroup: one wave, so its phases need no cross-wave barrier and
+                              // a CU interleaves ~20 independent tiles
+__global__ __launch_bounds__(kRowTile) void ctc_logsoftmax2_rows_kernel(const float* __restrict__ acts, long st, long sb,
                                                                    const int* __restrict__ in_lens, int K, long ly_sb,
                                                                    float* __restrict__ ly2) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* tile = reinterpret_cast<float*>(smem_raw);  // [256][KS]
+    float* tile = reinterpret_cast<float*>(smem_raw);  // [kRowTile][KS]
     const int KS = K | 1;
     const int b = blockIdx.y;
     const int T = in_lens[b];
-    const int t0 = blockIdx.x * 256;
-    const int nrows = min(256, T - t0);
+    const int t0 = blockIdx.x * kRowTile;
+    const int nrows = min(kRowTile, T - t0);
     if (nrows <= 0) return;
     const int n = nrows * K;
-    const int dr = 256 / K, dk = 256 - dr * K;  // idx += 256  ->  (row, k) += (dr, dk) with one carry
+    const int dr = kRowTile / K, dk = kRowTile - dr * K;  // idx += kRowTile -> (row, k) += (dr, dk), one carry
     const float* src = acts + (long)b * sb + (long)t0 * st;
     {
         int r = threadIdx.x / K, k = threadIdx.x - r * K;
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += kRowTile) {
             tile[r * KS + k] = src[(long)r * st + k];
             r += dr; k += dk;
             if (k >= K) { k -= K; ++r; }
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void ctc_logsoftmax2_rows_kernel(const float* 
     {
         float* dst = ly2 + (long)b * ly_sb + (long)t0 * K;
         int r = threadIdx.x / K, k = threadIdx.x - r * K;
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += kRowTile) {
             dst[i] = tile[r * KS + k];
             r += dr; k += dk;
             if (k >= K) { k -= K; ++r; }
@@ -908,10 +910,10 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.costs = d_costs;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
-    if (K <= 64 && (long)B * ((max_T + 255) / 256) >= 1024) {  // K_A, one lane per row out of an LDS tile: the
+    if (K <= 64 && (long)B * max_T >= 256 * 1024) {  // K_A, one lane per row out of an LDS tile: the
         // throughput form; with fewer than ~4 workgroups per CU its serial 3 * K-step row loop is the slower one
-        dim3 grid((max_T + 255) / 256, B);
-        hipLaunchKernelGGL(ctc_logsoftmax2_rows_kernel, grid, dim3(256), (size_t)256 * (K | 1) * sizeof(float), stream,
+        dim3 grid((max_T + kRowTile - 1) / kRowTile, B);
+        hipLaunchKernelGGL(ctc_logsoftmax2_rows_kernel, grid, dim3(kRowTile), (size_t)kRowTile * (K | 1) * sizeof(float), stream,
                            acts, stride_t, stride_b, d_input_lengths, K, A.ly_sb, (float*)(ws + o_ly2));
         SA_CHECK_LAUNCH();
     } else {  // K_A, a lane group per row
