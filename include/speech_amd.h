@@ -211,6 +211,39 @@ ctcStatus_t sa_log_specgram(const short* d_audio, int n, int sample_rate, int np
                             const float* d_mean, const float* d_std, float eps, float* out, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * 7. RNN-Transducer.  The reference takes the loss and the decoder from the un-vendored,
+ *    un-pinned package github.com/awni/transducer (Makefile:11): transducer.functions.transducer.TransducerLoss
+ *    (speech/models/transducer_model.py:10-11,50-51) and transducer.decoders.decode_static (:98).  Its C interface
+ *    is not on disk, so the binding contract is the Python one; these are the entry points speech_amd.transducer
+ *    (and the `transducer` import shim) call.
+ *
+ *    sa_transducer_loss: log_probs = the LOG-softmax lattice (B, max_T, max_U1, K) contiguous, as the model builds it
+ *    (transducer_model.py:76-77); labels flat int32, U_b = label_lengths[b] <= max_U1 - 1, T_b = input_lengths[b];
+ *    blank_label = K - 1 at the reference's call site (:32).  d_costs[b] = -log p(y_b | lattice_b); grads (same shape
+ *    as log_probs, may be NULL) = d costs[b] / d log_probs (zero outside the utterance's (T_b, U_b + 1) window and for
+ *    every class other than blank and the cell's label).  All pointers DEVICE; stream-ordered; no host sync.
+ * ----------------------------------------------------------------------------------------------------------------*/
+size_t sa_transducer_workspace_bytes(int max_T, int max_U1, int minibatch);
+ctcStatus_t sa_transducer_loss(const float* log_probs, float* grads /* or NULL */, const int* d_flat_labels,
+                               const int* d_label_lengths, const int* d_input_lengths, int alphabet_size, int minibatch,
+                               int max_T, int max_U1, int blank_label, float* d_costs, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/* Prediction / joint network pieces of Transducer.decode (transducer_model.py:54-78); the products around them are
+ * sa_gemm_f32, the prediction GRU is sa_gru_stack_*.
+ *   embedding: out[i,:] = table[idx[i],:] (idx int64, as torch.LongTensor);  bwd: dtable[v,:] = sum_{idx[i]=v} dout[i,:]
+ *   joint:     z[b,t,u,:] = relu(xa[b,t,:] + ya[b,u,:])  with xa = fc1(x) (B,T,H), ya = fc1(y) (B,U1,H)  (:72-74)
+ *              bwd: dxa[b,t,:] = sum_u dz * [xa+ya>0],  dya[b,u,:] = sum_t dz * [xa+ya>0]
+ *   log_softmax over the last axis of (rows, K)  (:76) and its gradient dx = dy - exp(y) * sum(dy). */
+ctcStatus_t sa_embedding_fwd(const float* table, const long long* idx, float* out, int n, int E, void* stream);
+ctcStatus_t sa_embedding_bwd(const float* dout, const long long* idx, float* dtable, int n, int E, int V, void* stream);
+ctcStatus_t sa_joint_relu_fwd(const float* xa, const float* ya, float* z, int B, int T, int U1, int H, void* stream);
+ctcStatus_t sa_joint_relu_bwd(const float* dz, const float* xa, const float* ya, float* dxa, float* dya, int B, int T,
+                              int U1, int H, void* stream);
+ctcStatus_t sa_log_softmax_fwd(const float* x, float* y, long rows, int K, void* stream);
+ctcStatus_t sa_log_softmax_bwd(const float* dy, const float* y, float* dx, long rows, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

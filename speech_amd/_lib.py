@@ -70,6 +70,16 @@ SIGNATURES = {
     "sa_log_specgram_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sa_log_specgram": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
+    "sa_transducer_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sa_transducer_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "sa_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sa_joint_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_joint_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
+    "sa_log_softmax_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "sa_log_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),
     "sa_clip_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
