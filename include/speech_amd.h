@@ -230,6 +230,18 @@ ctcStatus_t sa_transducer_loss(const float* log_probs, float* grads /* or NULL *
                                int max_T, int max_U1, int blank_label, float* d_costs, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Static beam search of transducer.decoders.decode_static (transducer_model.py:98) for every utterance of a batch:
+ * utterance b searches frames [0, d_T[b]) and lattice rows [0, d_U1[b]) of log_probs (B, max_T, max_U1, K); the search
+ * never re-runs the prediction network, looks for hypotheses of exactly d_U1[b] - 1 labels' worth of rows, merges equal
+ * hypotheses by log-sum-exp and keeps `beam_size` (<= 16) per step by a stable descending sort; K <= 64.
+ * d_out_labels (B, max_U1) / d_out_lens (B): the best hypothesis; d_out_scores (B, double): its log-probability
+ * including the final blank.  All pointers DEVICE. */
+size_t sa_transducer_decode_workspace_bytes(int max_T, int max_U1, int minibatch, int beam_size);
+ctcStatus_t sa_transducer_decode_static(const float* log_probs, const int* d_T, const int* d_U1, int alphabet_size,
+                                        int minibatch, int max_T, int max_U1, int beam_size, int blank_label,
+                                        int* d_out_labels, int* d_out_lens, double* d_out_scores, void* workspace,
+                                        size_t workspace_bytes, void* stream);
+
 /* Prediction / joint network pieces of Transducer.decode (transducer_model.py:54-78); the products around them are
  * sa_gemm_f32, the prediction GRU is sa_gru_stack_*.
  *   embedding: out[i,:] = table[idx[i],:] (idx int64, as torch.LongTensor);  bwd: dtable[v,:] = sum_{idx[i]=v} dout[i,:]

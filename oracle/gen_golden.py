@@ -124,9 +124,36 @@ def specgram_case():
     print("specgram", feats.shape, feats.dtype)
 
 
+def transducer_case(models):
+    """The reference's own Transducer (transducer_model.py) under a fixed seed: parameters, a seeded fake batch
+    (tests/shared.py:18-26 shapes) and the LOG-softmax lattice Transducer.forward returns.  The loss and the decoder
+    live in the un-vendored `transducer` package and are NOT exercised (parity unpinned there)."""
+    from speech.models import transducer_model
+    torch.manual_seed(2017)
+    np.random.seed(2017)
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}},
+           "decoder": {"embedding_dim": 12, "layers": 2}}
+    freq_dim, vocab, B, T = 40, 10, 3, 61
+    model = transducer_model.Transducer(freq_dim, vocab, cfg)
+    model.eval()
+    inputs = tuple(np.random.randn(T - 7 * i, freq_dim) for i in range(B))
+    labels = tuple(np.random.randint(0, vocab, 6 + 2 * i) for i in range(B))
+    with torch.no_grad():
+        out = model((inputs, labels))
+    res = {"param." + k: v.numpy() for k, v in model.state_dict().items()}
+    res["x"] = models.model.zero_pad_concat(inputs)
+    res["y_mat"] = model.label_collate(labels).numpy()
+    res["labels_flat"] = np.array([l for lab in labels for l in lab], dtype=np.int32)
+    res["label_lens"] = np.array([len(l) for l in labels], dtype=np.int32)
+    res["out"] = out.numpy()
+    np.savez_compressed(os.path.join(OUT, "transducer_tiny.npz"), **res)
+    print("transducer_tiny out", out.shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     models, ctc_decoder = import_reference()
+    transducer_case(models)
     specgram_case()
     sys.path.insert(0, os.path.join(REF, "tests"))
     import shared  # the reference's own test config (tests/shared.py:4-16)

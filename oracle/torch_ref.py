@@ -76,3 +76,54 @@ def train_step(model, opt, x, labels, label_lens, threads=0):
     gn = nn.utils.clip_grad_norm_(model.parameters(), 200)
     opt.step()
     return float(loss.item()), float(gn)
+
+
+# ---- Transducer (speech/models/transducer_model.py) -------------------------------------------------------------------
+from . import transducer_ref  # noqa: E402
+
+
+class TorchRefTransducer(TorchRefCTC):
+    """The reference's Transducer restated with the same torch.nn CPU modules (transducer_model.py:14-78): encoder of
+    model.py, nn.Embedding, nn.GRU prediction network over [0, y], fc1(x)[:, :, None] + fc1(y)[:, None], relu, fc2,
+    log_softmax.  Pinned to the live reference by tests/golden/transducer_tiny.npz."""
+
+    def __init__(self, freq_dim, vocab_size, config):
+        super().__init__(freq_dim, vocab_size, config)
+        del self.fc
+        dec = config["decoder"]
+        H = config["encoder"]["rnn"]["dim"]
+        self.embedding = nn.Embedding(vocab_size, dec["embedding_dim"])
+        self.dec_rnn = nn.GRU(input_size=dec["embedding_dim"], hidden_size=H, num_layers=dec["layers"],
+                              batch_first=True, dropout=config["dropout"])
+        self.blank = vocab_size
+        self.fc1, self.fc2 = nn.Module(), nn.Module()
+        self.fc1.fc = nn.Linear(H, H)
+        self.fc2.fc = nn.Linear(H, vocab_size + 1)
+
+    def forward(self, x, y_mat):
+        x = self.encode(x)
+        y = self.embedding(y_mat)
+        b, t, h = y.shape
+        y = torch.cat([torch.zeros((b, 1, h), dtype=y.dtype), y], dim=1)
+        y, _ = self.dec_rnn(y)
+        out = self.fc1.fc(x.unsqueeze(2)) + self.fc1.fc(y.unsqueeze(1))
+        out = self.fc2.fc(torch.relu(out))
+        return torch.log_softmax(out, dim=3)
+
+
+class _TransducerRef(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_probs, labels, act_lens, label_lens, blank):
+        costs, grads = transducer_ref.transducer_loss(log_probs.detach().numpy(), labels, act_lens, label_lens,
+                                                      blank=blank)
+        ctx.g = torch.from_numpy(grads / log_probs.shape[0]).to(log_probs.dtype)
+        return torch.tensor([costs.sum() / log_probs.shape[0]], dtype=log_probs.dtype)
+
+    @staticmethod
+    def backward(ctx, go):
+        return ctx.g * go, None, None, None, None
+
+
+def transducer_loss(model, x, y_mat, labels, act_lens, label_lens):
+    """mean-over-batch Transducer loss of the restated model (the reduction speech_amd.transducer defaults to)."""
+    return _TransducerRef.apply(model(x, y_mat), labels, act_lens, label_lens, model.blank)

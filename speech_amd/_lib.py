@@ -73,6 +73,9 @@ SIGNATURES = {
     "sa_transducer_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sa_transducer_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_transducer_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sa_transducer_decode_static": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sa_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sa_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sa_joint_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -262,6 +262,154 @@ __global__ __launch_bounds__(64) void tr_grad_kernel(TrArgs A, float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- T_D
+// Static beam search over one utterance's lattice (the call at transducer_model.py:98; the callee is in the un-vendored
+// package, restated in the header's section 7): the search never re-runs the prediction network, so a hypothesis with u
+// labels reads row u of the lattice.  Step i of T+U-2 extends every beam entry (hyp, score), u = len(hyp), t = i - u,
+// by a blank (t < T-1: same hyp) or by any label (u < U-1); equal hypotheses merge by log-sum-exp; the best `beam`
+// survive a stable descending sort.  Scores are double precision with double exp / log, as the Python original's.
+// One wave per utterance, lane = class (K <= 64), candidates c[entry][class] in LDS.  Hypotheses are nodes of a
+// prefix tree (parent, symbol); a hypothesis can be reached twice in one step only as "stay on A" + "extend A's parent
+// by A's last symbol", which is found by looking A's parent up in the beam -- no hash table.  The dict's insertion
+// order (beam order, then class order) is the candidate's sequence number e * K + v; a merged key keeps the smaller.
+constexpr int kDecMaxBeam = 16;
+
+struct DecArgs {
+    const float* lp;        // (B, T_max, U1_max, K)
+    const int* T_arr;       // [B] frames to search
+    const int* U_arr;       // [B] lattice rows to search (label length + 1)
+    int K, T_max, U1_max, beam, blank, max_nodes;
+    int* node_parent;       // [B][max_nodes]
+    int* node_sym;          // [B][max_nodes]
+    int* out_labels;        // [B][U1_max]
+    int* out_lens;          // [B]
+    double* out_scores;     // [B]
+};
+
+// the prefix tree lives in global memory and is written by lane 0, read by every lane: device-scope accesses
+// (they bypass the per-CU L1, which a plain load after another lane's store could hit stale)
+__device__ __forceinline__ int dec_ld(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dec_st(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double dec_lse(double a, double b) {
+    const double m = a > b ? a : b;
+    return m + log(exp(a - m) + exp(b - m));
+}
+
+__global__ __launch_bounds__(64) void tr_decode_static_kernel(DecArgs A) {
+    __shared__ double c[kDecMaxBeam][64];      // candidate scores of this step (-inf: none)
+    __shared__ int exist[kDecMaxBeam][64];     // candidate is an existing node (its id) or -1
+    __shared__ int b_node[2][kDecMaxBeam], b_len[2][kDecMaxBeam];
+    __shared__ double b_score[2][kDecMaxBeam];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int T = A.T_arr[b], U = A.U_arr[b], K = A.K;
+    const float* lp = A.lp + (long)b * A.T_max * A.U1_max * K;
+    int* parent = A.node_parent + (long)b * A.max_nodes;
+    int* sym = A.node_sym + (long)b * A.max_nodes;
+    const double NINF = -__builtin_inf();
+    int nbeam = 1, nnodes = 1, cur = 0;
+    if (lane == 0) { b_node[0][0] = 0; b_len[0][0] = 0; b_score[0][0] = 0.0; dec_st(parent, -1); dec_st(sym, -1); }
+    __syncthreads();
+
+    for (int i = 0; i < T + U - 2; ++i) {
+        // (1) candidates: lane = class v
+        for (int e = 0; e < nbeam; ++e) {
+            const int u = b_len[cur][e], t = i - u;
+            double v = NINF;
+            if (t >= 0 && t <= T - 1 && lane < K) {
+                const bool ok = lane == A.blank ? (t < T - 1) : (u < U - 1);
+                if (ok) v = b_score[cur][e] + (double)lp[((long)t * A.U1_max + u) * K + lane];
+            }
+            c[e][lane] = v;
+            exist[e][lane] = -1;
+        }
+        __syncthreads();
+        // (2) merges: "stay on A" with "extend parent(A) by sym(A)"   (uniform control flow, lane 0 writes)
+        for (int a = 0; a < nbeam; ++a) {
+            const int na = b_node[cur][a];
+            const int pa = dec_ld(parent + na), sa = dec_ld(sym + na);
+            if (pa < 0) continue;
+            int bidx = -1;
+            for (int e = 0; e < nbeam; ++e)
+                if (b_node[cur][e] == pa) bidx = e;
+            if (bidx < 0) continue;
+            if (lane == 0) {
+                const double ext = c[bidx][sa], stay = c[a][A.blank];
+                if (ext != NINF) {
+                    if (stay == NINF) {
+                        exist[bidx][sa] = na;  // the extension re-creates the existing hypothesis A
+                    } else {
+                        const double m = dec_lse(stay, ext);  // two contributions at most: order-independent
+                        const bool ext_first = bidx * K + sa < a * K + A.blank;
+                        if (ext_first) { c[bidx][sa] = m; exist[bidx][sa] = na; c[a][A.blank] = NINF; }
+                        else { c[a][A.blank] = m; c[bidx][sa] = NINF; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        // (3) stable top-`beam`: repeated wave arg-max over (score desc, sequence number asc)
+        const int nxt = cur ^ 1;
+        int nnew = 0;
+        for (int w = 0; w < A.beam; ++w) {
+            double best = NINF;
+            int bseq = 0x7fffffff;
+            for (int e = 0; e < nbeam; ++e) {
+                const double v = c[e][lane];
+                if (v > best) { best = v; bseq = e * K + lane; }  // e ascending: the first maximum has the smaller seq
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int os = __shfl_xor(bseq, o, 64);
+                if (ob > best || (ob == best && os < bseq)) { best = ob; bseq = os; }
+            }
+            if (best == NINF) break;  // uniform: every lane holds the same winner
+            const int e = bseq / K, v = bseq - e * K;
+            if (lane == 0) {
+                int node, len;
+                if (v == A.blank) { node = b_node[cur][e]; len = b_len[cur][e]; }
+                else {
+                    len = b_len[cur][e] + 1;
+                    node = exist[e][v];
+                    if (node < 0) {
+                        node = nnodes;
+                        dec_st(parent + node, b_node[cur][e]);
+                        dec_st(sym + node, v);
+                    }
+                }
+                b_node[nxt][nnew] = node; b_len[nxt][nnew] = len; b_score[nxt][nnew] = best;
+                c[e][v] = NINF;
+            }
+            if (v != A.blank && exist[e][v] < 0) ++nnodes;  // uniform (LDS value read by all lanes before lane 0 moves on)
+            ++nnew;
+            __syncthreads();
+        }
+        nbeam = nnew;
+        cur = nxt;
+        __syncthreads();
+        if (nbeam == 0) break;
+    }
+    if (lane == 0) {
+        int n = 0;
+        double score = NINF;
+        if (nbeam > 0) {
+            int node = b_node[cur][0];
+            n = b_len[cur][0];
+            score = b_score[cur][0] + (double)lp[((long)(T - 1) * A.U1_max + (U - 1)) * K + A.blank];
+            int* out = A.out_labels + (long)b * A.U1_max;
+            for (int k = n - 1; k >= 0; --k) { out[k] = dec_ld(sym + node); node = dec_ld(parent + node); }
+        }
+        A.out_lens[b] = n;
+        A.out_scores[b] = score;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------ host side
@@ -338,5 +486,35 @@ extern "C" ctcStatus_t sa_transducer_loss(const float* log_probs, float* grads, 
         hipLaunchKernelGGL(tr_grad_kernel, cells, dim3(64), 0, stream, A, grads);
         SA_CHECK_LAUNCH();
     }
+    return CTC_STATUS_SUCCESS;
+}
+
+extern "C" size_t sa_transducer_decode_workspace_bytes(int max_T, int max_U1, int minibatch, int beam_size) {
+    if (max_T <= 0 || max_U1 <= 0 || minibatch <= 0 || beam_size <= 0 || beam_size > kDecMaxBeam) return 0;
+    const size_t max_nodes = (size_t)(max_T + max_U1) * beam_size + 2;
+    return 2 * sa_align_up((size_t)minibatch * max_nodes * sizeof(int), 256);
+}
+
+extern "C" ctcStatus_t sa_transducer_decode_static(const float* log_probs, const int* d_T, const int* d_U1,
+                                                   int alphabet_size, int minibatch, int max_T, int max_U1,
+                                                   int beam_size, int blank_label, int* d_out_labels, int* d_out_lens,
+                                                   double* d_out_scores, void* workspace, size_t workspace_bytes,
+                                                   void* stream) {
+    SA_CLEAR_ERR();
+    if (!log_probs || !d_T || !d_U1 || !d_out_labels || !d_out_lens || !d_out_scores || !workspace)
+        return CTC_STATUS_INVALID_VALUE;
+    if (alphabet_size <= 0 || alphabet_size > 64 || minibatch <= 0 || max_T <= 0 || max_U1 <= 0 || beam_size <= 0 ||
+        beam_size > kDecMaxBeam || blank_label < 0 || blank_label >= alphabet_size)
+        return CTC_STATUS_INVALID_VALUE;
+    const size_t need = sa_transducer_decode_workspace_bytes(max_T, max_U1, minibatch, beam_size);
+    if (workspace_bytes < need) return CTC_STATUS_INVALID_VALUE;
+    DecArgs A;
+    A.lp = log_probs; A.T_arr = d_T; A.U_arr = d_U1; A.K = alphabet_size; A.T_max = max_T; A.U1_max = max_U1;
+    A.beam = beam_size; A.blank = blank_label; A.max_nodes = (max_T + max_U1) * beam_size + 2;
+    A.node_parent = (int*)workspace;
+    A.node_sym = (int*)((char*)workspace + need / 2);
+    A.out_labels = d_out_labels; A.out_lens = d_out_lens; A.out_scores = d_out_scores;
+    hipLaunchKernelGGL(tr_decode_static_kernel, dim3(minibatch), dim3(64), 0, (hipStream_t)stream, A);
+    SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }

@@ -5,6 +5,9 @@ Mirrors (names, arguments, return types, state-dict keys):
                                               is_cuda, encoder_dim; LinearND; zero_pad_concat
   /root/reference/speech/models/ctc_model.py  CTC(freq_dim, output_dim, config): forward, forward_impl, loss, collate,
                                               infer, max_decode, blank, fc
+  /root/reference/speech/models/transducer_model.py  Transducer(freq_dim, vocab_size, config): forward, forward_impl,
+                                              loss, decode, collate, label_collate, infer, blank, embedding, dec_rnn,
+                                              fc1, fc2
 
 Parameters live in torch.nn containers (nn.Conv2d / nn.GRU / nn.Linear are used ONLY as parameter holders: they give
 the reference's state-dict names -- conv.0.weight, rnn.weight_ih_l0, fc.fc.weight ... -- and, under the same
@@ -21,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, ctc, decoder
+from . import _lib, ctc, decoder, transducer as _tr
 from .encoder import EncoderFunction, EncoderPlan
 
 
@@ -151,6 +154,9 @@ class _LinearFunction(torch.autograd.Function):
         from . import ops
         _lib.require_cuda(x, "x")
         ctx.save_for_backward(x, w)
+        # parameters re-homed by Model.flatten_parameters_() carry a slot of the flat gradient buffer (one use of the
+        # layer per step: the slot is written, not accumulated)
+        ctx.slots = (getattr(w, "_grad_slot", None), getattr(b, "_grad_slot", None))
         return ops.gemm(x, w, trans_b=True, bias=b)
 
     @staticmethod
@@ -158,7 +164,8 @@ class _LinearFunction(torch.autograd.Function):
         from . import ops
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        return ops.gemm(dy, w), ops.gemm(dy, x, trans_a=True), ops.colsum(dy)
+        dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, ops.gemm(dy, x, trans_a=True, out=ctx.slots[0]), ops.colsum(dy, out=ctx.slots[1])
 
 
 def zero_pad_concat(inputs):
@@ -229,3 +236,101 @@ class CTC(Model):
                 seq.append(p)
             prev = p
         return seq
+
+
+class Transducer(Model):
+    """transducer_model.py:14-113 on the HIP ops.  The joint lattice (B, T', U+1, H) is materialised (3.3 GB at
+    B=32, T'=498, U=100, H=512: sized for 288 GB of HBM); every product is sa_gemm_f32, the prediction network runs on
+    the GRU recurrence kernels, the loss is sa_transducer_loss."""
+
+    def __init__(self, freq_dim, vocab_size, config):
+        super().__init__(freq_dim, config)
+        self._ctor_args = (freq_dim, vocab_size, config)
+        decoder_cfg = config["decoder"]
+        rnn_dim = self.encoder_dim
+        embed_dim = decoder_cfg["embedding_dim"]
+        self.embedding = nn.Embedding(vocab_size, embed_dim)
+        self.dec_rnn = nn.GRU(input_size=embed_dim, hidden_size=rnn_dim, num_layers=decoder_cfg["layers"],
+                              batch_first=True, dropout=config["dropout"])
+        self._dec_dropout = float(config["dropout"])
+        # include the blank token (transducer_model.py:31-32): blank is the LAST class
+        self.blank = vocab_size
+        self.fc1 = LinearND(rnn_dim, rnn_dim)
+        self.fc2 = LinearND(rnn_dim, vocab_size + 1)
+        self.loss_denominator = None  # data-parallel training sets the GLOBAL batch size here (speech_amd.dist)
+
+    def forward(self, batch):
+        x, y, x_lens, y_lens = self.collate(*batch)
+        y_mat = self.label_collate(batch[1])
+        return self.forward_impl(x, y_mat)
+
+    def forward_impl(self, x, y):
+        if self.is_cuda:
+            x = x.cuda(non_blocking=True)
+            y = y.cuda(non_blocking=True)
+        x = self.encode(x)
+        return self.decode(x, y)
+
+    def loss(self, batch):
+        x, y, x_lens, y_lens = self.collate(*batch)
+        y_mat = self.label_collate(batch[1])
+        with torch.set_grad_enabled(not self.volatile):
+            out = self.forward_impl(x, y_mat)
+            loss_fn = _tr.TransducerLoss(denom=self.loss_denominator)
+            return loss_fn(out, y, x_lens, y_lens)
+
+    def _dec_params(self, l):
+        return [getattr(self.dec_rnn, "%s_l%d" % (n, l)) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+
+    def decode(self, x, y):
+        """transducer_model.py:54-78.  x (B, T', H) encoder states, y (B, U) int64 labels -> (B, T', U+1, V+1)
+        log-probabilities."""
+        _lib.require_cuda(x, "x (move the model to the GPU: model.cuda())")
+        H, L = self.encoder_dim, self.dec_rnn.num_layers
+        emb = _tr.EmbeddingFunction.apply(y, self.embedding.weight)
+        b, u, e = emb.shape
+        # prepend zeros (:61-66)
+        inp = torch.cat([torch.zeros((b, 1, e), dtype=torch.float32, device=emb.device), emb], dim=1)
+        p_drop = self._dec_dropout if self.training else 0.0
+        if p_drop and L > 1:  # nn.GRU's inter-layer dropout: one layer per call, a Bernoulli mask in between
+            for l in range(L):
+                inp = _tr.GRUStackFunction.apply(inp, H, *self._dec_params(l))
+                if l + 1 < L:
+                    inp = inp * ((torch.rand_like(inp) >= p_drop).to(inp.dtype) / (1.0 - p_drop))
+            yd = inp
+        else:
+            yd = _tr.GRUStackFunction.apply(inp, H, *[p for l in range(L) for p in self._dec_params(l)])
+        # fc1 on the encoder states and on the prediction states (:72): ONE product over the stacked rows
+        B, T = x.shape[0], x.shape[1]
+        U1 = yd.shape[1]
+        rows = torch.cat([x.reshape(B * T, H), yd.reshape(B * U1, H)], dim=0)
+        a = self.fc1(rows)
+        z = _tr.JointFunction.apply(a[:B * T].view(B, T, H), a[B * T:].view(B, U1, H))  # (:73)
+        out = self.fc2(z)
+        return _tr.LogSoftmaxFunction.apply(out)
+
+    def collate(self, inputs, labels):
+        max_t = max(i.shape[0] for i in inputs)
+        max_t = self.conv_out_size(max_t, 0)
+        x_lens = torch.IntTensor([max_t] * len(inputs))
+        x = torch.from_numpy(zero_pad_concat(inputs))
+        y_lens = torch.IntTensor([len(l) for l in labels])
+        y = torch.IntTensor([int(l) for label in labels for l in label])
+        return [x, y, x_lens, y_lens]
+
+    def label_collate(self, labels):
+        """transducer_model.py:101-113: pad with the first utterance's last label (ignored by the loss)."""
+        batch_size = len(labels)
+        end_tok = labels[0][-1]
+        max_len = max(len(l) for l in labels)
+        cat_labels = np.full((batch_size, max_len), fill_value=end_tok, dtype=np.int64)
+        for e, l in enumerate(labels):
+            cat_labels[e, :len(l)] = l
+        return torch.LongTensor(cat_labels)
+
+    def infer(self, batch, beam_size=4):
+        """transducer_model.py:91-100: static beam search over each utterance's lattice out[e, :T, :len(l)+1]."""
+        with torch.no_grad():
+            out = self(batch)
+        u1 = [len(l) + 1 for l in batch[1]]
+        return _tr.decode_static_batch(out, u1, beam_size=beam_size, blank=self.blank)[0]

@@ -207,3 +207,42 @@ class LogSoftmaxFunction(torch.autograd.Function):
         _lib.check(_lib.lib().sa_log_softmax_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dx), y.numel() // K, K,
                                                  _lib.cur_stream()), "sa_log_softmax_bwd")
         return dx
+
+
+# ---- static beam search (transducer.decoders.decode_static) ----------------------------------------------------------
+def decode_static_batch(log_probs, u1=None, t=None, beam_size=1, blank=None):
+    """log_probs (B, T, U1, K) lattice on the GPU; utterance b searches rows [0, u1[b]) and frames [0, t[b])
+    (defaults: all).  Returns (list of label tuples, scores tensor (B,) float64 on the GPU)."""
+    _lib.require_cuda(log_probs, "log_probs")
+    lp = log_probs.detach().float().contiguous()
+    B, T, U1, K = lp.shape
+    if blank is None:
+        blank = K - 1
+    u1_h = np.full(B, U1, np.int32) if u1 is None else np.asarray(u1, np.int32)
+    t_h = np.full(B, T, np.int32) if t is None else np.minimum(np.asarray(t, np.int32), T)
+    if u1_h.min() < 1 or u1_h.max() > U1 or t_h.min() < 1:
+        raise _lib.SpeechAmdError("decode_static: rows / frames out of range")
+    ints = torch.from_numpy(np.concatenate([t_h, u1_h])).to(lp.device)
+    L = _lib.lib()
+    nbytes = L.sa_transducer_decode_workspace_bytes(T, U1, B, beam_size)
+    if nbytes == 0 or K > 64:
+        raise _lib.SpeechAmdError("decode_static: beam_size <= 16 and at most 64 classes are supported")
+    ws = _lib.WORKSPACE.get(nbytes, lp.device, "transducer_decode")
+    labels = torch.zeros(B, U1, dtype=torch.int32, device=lp.device)
+    lens = torch.zeros(B, dtype=torch.int32, device=lp.device)
+    scores = torch.zeros(B, dtype=torch.float64, device=lp.device)
+    _lib.check(L.sa_transducer_decode_static(_lib.ptr(lp), _lib.ptr(ints[:B]), _lib.ptr(ints[B:]), K, B, T, U1,
+                                             beam_size, blank, _lib.ptr(labels), _lib.ptr(lens), _lib.ptr(scores),
+                                             _lib.ptr(ws), ws.numel(), _lib.cur_stream()),
+               "sa_transducer_decode_static")
+    lab_h, len_h = labels.cpu().numpy(), lens.cpu().numpy()
+    return [tuple(int(v) for v in lab_h[b, :len_h[b]]) for b in range(B)], scores
+
+
+def decode_static(log_probs, beam_size=1, blank=0):
+    """Single-utterance face with the package's signature: log_probs (T, U, V) -> (labels tuple, score float)."""
+    p = log_probs if torch.is_tensor(log_probs) else torch.from_numpy(np.ascontiguousarray(log_probs, np.float32))
+    if not p.is_cuda:
+        p = p.cuda()
+    hyps, scores = decode_static_batch(p.float().unsqueeze(0), beam_size=beam_size, blank=blank)
+    return hyps[0], float(scores[0])

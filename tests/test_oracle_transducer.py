@@ -67,3 +67,21 @@ def test_decode_static_greedy_cases():
     assert hyp == (1, 2)
     assert abs(score - (-0.06)) < 1e-6
     assert R.decode_static(lp, beam_size=1, blank=3)[0] == (1, 2)
+
+
+def test_torch_restatement_matches_live_reference_fixture():
+    """oracle/torch_ref.TorchRefTransducer (the model part, everything but the loss) against the lattice the reference's
+    own Transducer.forward produced (tests/golden/transducer_tiny.npz, made by oracle/gen_golden.py)."""
+    import os
+    import torch
+    from oracle import torch_ref
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "transducer_tiny.npz"))
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}},
+           "decoder": {"embedding_dim": 12, "layers": 2}}
+    m = torch_ref.TorchRefTransducer(40, 10, cfg)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")})
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]), torch.from_numpy(g["y_mat"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-5, atol=1e-6)
+    assert np.abs(np.exp(out.numpy()).sum(axis=3) - 1).max() < 1e-5
