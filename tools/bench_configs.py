@@ -78,6 +78,43 @@ def m_step(name, F, V, cfg, B, T, L, iters):
             "forward_ms": fwd * 1e3, "loss": float(out["loss"].item())}
 
 
+def m_transducer(iters):
+    """BASELINE config 5: RNN-Transducer on the S-LIBRI encoder (4 x GRU-512 uni), 1-layer prediction network,
+    B=32, T=1000 -> T'=498, U=100: the loss alone on a (32, 498, 101, 29) lattice, and the full train step."""
+    from speech_amd.models import Transducer
+    from speech_amd.transducer import TransducerLabels, transducer_loss_raw
+    B, T, F, V, L = 32, 1000, 80, 28, 100
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 512, "layers": 4, "bidirectional": False}},
+           "decoder": {"embedding_dim": 256, "layers": 1}}
+    torch.manual_seed(2017)
+    model = Transducer(F, V, cfg).cuda()
+    model.set_train()
+    flat_p, flat_g = model.flatten_parameters_()
+    rng = np.random.RandomState(2017)
+    inputs = tuple(rng.randn(T, F).astype(np.float32) for _ in range(B))
+    labels = tuple(rng.randint(0, V, L) for _ in range(B))
+    Tp = model.conv_out_size(T, 0)
+    lat = torch.log_softmax(torch.from_numpy(rng.randn(B, Tp, L + 1, V + 1).astype(np.float32)).to(DEV), dim=3)
+    lab = TransducerLabels(np.concatenate(labels).astype(np.int32), np.full(B, Tp, np.int32), np.full(B, L, np.int32), DEV)
+    loss_ms = timed(lambda: transducer_loss_raw(lat, lab), 20) * 1e3
+    norm = torch.zeros(1, device=DEV)
+    out = {}
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss = model.loss((inputs, labels))
+        loss.backward()
+        ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
+        out["loss"] = loss
+
+    sec = timed(step, iters, warmup=2)
+    alg = 2 * lat.numel() * 4
+    return {"workload": "RNN-T S-LIBRI (config 5)", "B": B, "T_out": Tp, "U": L, "classes": V + 1,
+            "params": int(flat_p.numel()), "loss_fwd_bwd_ms": loss_ms, "loss_algorithmic_GBps": alg / loss_ms / 1e6,
+            "train_step_ms": sec * 1e3, "train_utt_per_s": B / sec, "loss": float(out["loss"].item()),
+            "note": "train step includes the host-side collate of the reference's loss(batch) API"}
+
+
 def m_dec(beam, iters):
     rng = np.random.RandomState(2017)
     z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
@@ -105,7 +142,7 @@ def main():
                      m_step("S-LIBRI bidirectional", 80, 28, bi, 32, 1000, 100, 3)]
     res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
                       m_step("2xGRU-256 F=40 |V|=61", 40, 61, small, 32, 1000, 100, 5)]
-    t0 = time.perf_counter()
+    res["M-RNNT"] = [m_transducer(3)]
     rng = np.random.RandomState(2017)
     z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
     greedy = timed(lambda: decoder.greedy_decode(z, blank=28), 20)
