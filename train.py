@@ -36,7 +36,7 @@ def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank):
     for batch in tq:
         start_t = time.time()
         batch, global_b = dist.shard_batch(batch, world, rank)
-        model.ctc_denominator = global_b
+        model.ctc_denominator = model.loss_denominator = global_b  # CTC / Transducer: mean over the GLOBAL batch
         model.zero_grad(set_to_none=True)
         loss = model.loss(batch)
         loss.backward()
@@ -60,7 +60,7 @@ def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank):
 def eval_dev(model, ldr, preproc):
     losses, all_preds, all_labels = [], [], []
     model.set_eval()
-    model.ctc_denominator = None
+    model.ctc_denominator = model.loss_denominator = None
     for batch in tqdm.tqdm(ldr):
         preds = model.infer(batch)
         losses.append(float(model.loss(batch).item()))
