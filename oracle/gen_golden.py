@@ -150,10 +150,43 @@ def transducer_case(models):
     print("transducer_tiny out", out.shape)
 
 
+def seq2seq_case(models):
+    """The reference's own Seq2Seq (speech/models/seq2seq.py) under the seeds of its test (tests/seq2seq_test.py:15-16):
+    parameters, a seeded fake batch with start / end tokens, the teacher-forced logits of Seq2Seq.forward, the loss of
+    Seq2Seq.loss, every parameter gradient from the reference's own autograd, the alignments, and the greedy decode of
+    Seq2Seq.infer.  Everything on this path is in the reference tree, so these vectors PIN it."""
+    from speech.models import seq2seq
+    torch.manual_seed(1337)
+    np.random.seed(1337)
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}},
+           "decoder": {"embedding_dim": 16, "layers": 1, "log_t": True}}
+    freq_dim, vocab, B, T = 40, 10, 3, 61
+    model = seq2seq.Seq2Seq(freq_dim, vocab + 1, cfg)
+    model.train()
+    inputs = tuple(np.random.randn(T - 7 * i, freq_dim).astype(np.float32) for i in range(B))
+    # start token = vocab (never predicted, seq2seq.py:33-35), end token = vocab - 1 (last item of every label)
+    labels = tuple([vocab] + list(np.random.randint(0, vocab - 1, 5 + 2 * i)) + [vocab - 1] for i in range(B))
+    x, y = model.collate(inputs, labels)
+    out, alis = model.forward_impl(x, y)
+    loss = model.loss((inputs, labels))
+    loss.backward()
+    res = {"param." + k: v.numpy() for k, v in model.state_dict().items()}
+    for n, p in model.named_parameters():
+        res["grad." + n] = p.grad.numpy()
+    res["x"], res["y"] = x.numpy(), y.numpy()
+    res["out"], res["aligns"], res["loss"] = out.detach().numpy(), alis.detach().numpy(), np.array(float(loss))
+    model.set_eval()
+    with torch.no_grad():
+        res["infer"] = np.array(model.infer((inputs, labels), max_len=12), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "seq2seq_tiny.npz"), **res)
+    print("seq2seq_tiny out", out.shape, "loss", float(loss), "infer", res["infer"].shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     models, ctc_decoder = import_reference()
     transducer_case(models)
+    seq2seq_case(models)
     specgram_case()
     sys.path.insert(0, os.path.join(REF, "tests"))
     import shared  # the reference's own test config (tests/shared.py:4-16)

@@ -127,3 +127,83 @@ class _TransducerRef(torch.autograd.Function):
 def transducer_loss(model, x, y_mat, labels, act_lens, label_lens):
     """mean-over-batch Transducer loss of the restated model (the reduction speech_amd.transducer defaults to)."""
     return _TransducerRef.apply(model(x, y_mat), labels, act_lens, label_lens, model.blank)
+
+
+# ---- Seq2Seq (speech/models/seq2seq.py) -------------------------------------------------------------------------------
+class _RefNNAttention(nn.Module):
+    """seq2seq.py:331-360 (NNAttention)."""
+
+    def __init__(self, n_channels, kernel_size=15, log_t=False):
+        super().__init__()
+        self.conv = nn.Conv1d(1, n_channels, kernel_size, padding=(kernel_size - 1) // 2)
+        lin = nn.Module()
+        lin.fc = nn.Linear(n_channels, 1)
+        self.nn = nn.Sequential(nn.ReLU(), lin)
+        self.log_t = log_t
+
+    def forward(self, eh, dhx, ax=None):
+        pax = eh + dhx
+        if ax is not None:
+            pax = pax + self.conv(ax.unsqueeze(1)).transpose(1, 2)
+        pax = self.nn[1].fc(torch.relu(pax)).squeeze(2)
+        if self.log_t:
+            pax = math.log(pax.size()[1]) * pax
+        ax = torch.softmax(pax, dim=1)
+        sx = torch.sum(eh * ax.unsqueeze(2), dim=1, keepdim=True)
+        return sx, ax
+
+
+class TorchRefSeq2Seq(TorchRefCTC):
+    """The reference's Seq2Seq restated with the same torch.nn CPU modules (seq2seq.py:14-127): encoder of model.py,
+    nn.Embedding, nn.GRUCell, NNAttention, fc to vocab_size - 1 classes, teacher forcing (scheduled sampling off).
+    Pinned to the live reference by tests/golden/seq2seq_tiny.npz (logits, loss, every parameter gradient)."""
+
+    def __init__(self, freq_dim, vocab_size, config):
+        super().__init__(freq_dim, vocab_size, config)
+        dec = config["decoder"]
+        H = config["encoder"]["rnn"]["dim"]
+        self.embedding = nn.Embedding(vocab_size, dec["embedding_dim"])
+        self.dec_rnn = nn.GRUCell(input_size=dec["embedding_dim"], hidden_size=H)
+        self.attend = _RefNNAttention(H, log_t=dec.get("log_t", False))
+        self.fc = nn.Module()
+        self.fc.fc = nn.Linear(H, vocab_size - 1)
+
+    def decode_step(self, x, y, state=None):
+        if state is None:
+            hx, ax, sx = torch.zeros((x.shape[0], x.shape[2]), dtype=x.dtype), None, None
+        else:
+            hx, ax, sx = state
+        ix = self.embedding(y)
+        if sx is not None:
+            ix = ix + sx
+        hx = self.dec_rnn(ix.squeeze(1), hx)
+        ox = hx.unsqueeze(1)
+        sx, ax = self.attend(x, ox, ax)
+        return self.fc.fc((ox + sx).squeeze(1)), (hx, ax, sx)
+
+    def forward(self, x, y):
+        """x (B, T, F) float, y (B, U) int64 with start / end tokens -> (logits (B, U-1, V-1), aligns (B, U-1, T'))."""
+        x = self.encode(x)
+        out, aligns, state = [], [], None
+        for t in range(y.size()[1] - 1):
+            o, state = self.decode_step(x, y[:, t:t + 1], state)
+            out.append(o)
+            aligns.append(state[1])
+        return torch.stack(out, dim=1), torch.stack(aligns, dim=1)
+
+    def loss(self, x, y):
+        out, _ = self(x, y)
+        b, _, k = out.size()
+        return nn.functional.cross_entropy(out.reshape(-1, k), y[:, 1:].reshape(-1), reduction="sum") / b
+
+    def infer(self, x, y0, end_tok, max_len):
+        """seq2seq.py:150-185: greedy decode from the start tokens y0 (B, 1)."""
+        x = self.encode(x)
+        y, state, seq = y0, None, [y0]
+        for _ in range(max_len):
+            o, state = self.decode_step(x, y, state)
+            y = torch.max(o, dim=1)[1].unsqueeze(1)
+            seq.append(y)
+            if int(torch.sum(y == end_tok)) == y.numel():
+                break
+        return torch.cat(seq, dim=1)
