@@ -256,6 +256,40 @@ ctcStatus_t sa_joint_relu_bwd(const float* dz, const float* xa, const float* ya,
 ctcStatus_t sa_log_softmax_fwd(const float* x, float* y, long rows, int K, void* stream);
 ctcStatus_t sa_log_softmax_bwd(const float* dy, const float* y, float* dx, long rows, int K, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * 8. Seq2Seq attention decoder (speech/models/seq2seq.py).  Per output token the decoder runs an
+ *    nn.GRUCell (:20-21,97), NNAttention (:331-360) and, over all tokens, a linear layer and a summed cross-entropy
+ *    (:59-63).  The projections are sa_gemm_f32; these are the pieces in between.
+ *
+ *    grucell gates: gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh (both (B, 3H), gate order r|z|n as torch);
+ *        h' = (1-z) n + z h,  r = sig(gi_r+gh_r), z = sig(gi_z+gh_z), n = tanh(gi_n + r gh_n).
+ *        stash (B, 4H) = r|z|n|gh_n (may be NULL forward-only).  bwd: dgi, dgh (B, 3H), dh_prev = dh * z.
+ *    attention: eh (B,T,H) encoder states, ox (B,H) decoder state, ax_prev (B,T) previous alignment or NULL (then the
+ *        location term is absent, :343), conv_w (H,KS) / conv_b (H) = Conv1d(1,H,KS,padding=(KS-1)/2) (KS odd, <= 15),
+ *        nn_w (H) / nn_b (1) = Linear(H,1), scale = log(T) if log_t else 1.
+ *        score_t = scale * (nn_b + sum_h nn_w[h] relu(eh[t,h] + ox[h] + conv_b[h] + sum_k conv_w[h,k] ax_prev[t+k-(KS-1)/2]))
+ *        ax = softmax_t(score), sx = sum_t ax[t] eh[t,:].
+ *        bwd: given d_sx (B,H) and d_ax_next (B,T) or NULL: d_eh += , d_ox =, d_ax_prev =, and per-utterance
+ *        parameter-gradient partials g_* (+=; the caller sums them over B once per batch).
+ *    softmax_xent: loss_rows[i] = lse(logits_i) - logits_i[target_i]; dlogits = (softmax - onehot) * scale (or NULL).
+ *    argmax_rows: first index of each row's maximum (int64 out).
+ * ----------------------------------------------------------------------------------------------------------------*/
+ctcStatus_t sa_grucell_gates_fwd(const float* gi, const float* gh, const float* h_prev, float* h_out, float* stash,
+                                 int B, int H, void* stream);
+ctcStatus_t sa_grucell_gates_bwd(const float* dh, const float* stash, const float* h_prev, float* dgi, float* dgh,
+                                 float* dh_prev, int B, int H, void* stream);
+ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const float* ax_prev, const float* conv_w,
+                             const float* conv_b, const float* nn_w, const float* nn_b, float scale, float* ax,
+                             float* sx, int B, int T, int H, int KS, void* stream);
+ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const float* ax_prev, const float* conv_w,
+                             const float* conv_b, const float* nn_w, const float* nn_b, float scale, const float* ax,
+                             const float* d_sx, const float* d_ax_next, float* d_eh, float* d_ox, float* d_ax_prev,
+                             float* g_conv_w, float* g_conv_b, float* g_nn_w, float* g_nn_b, int B, int T, int H,
+                             int KS, void* stream);
+ctcStatus_t sa_softmax_xent(const float* logits, const long long* targets, float scale, float* loss_rows,
+                            float* dlogits, long rows, int K, void* stream);
+ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

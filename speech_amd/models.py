@@ -8,6 +8,9 @@ Mirrors (names, arguments, return types, state-dict keys):
   /root/reference/speech/models/transducer_model.py  Transducer(freq_dim, vocab_size, config): forward, forward_impl,
                                               loss, decode, collate, label_collate, infer, blank, embedding, dec_rnn,
                                               fc1, fc2
+  /root/reference/speech/models/seq2seq.py    Seq2Seq(freq_dim, vocab_size, config): forward, forward_impl, loss, decode,
+                                              decode_step, predict, infer, infer_decode, beam_search, collate,
+                                              set_eval / set_train (scheduled sampling), NNAttention, end_pad_concat
 
 Parameters live in torch.nn containers (nn.Conv2d / nn.GRU / nn.Linear are used ONLY as parameter holders: they give
 the reference's state-dict names -- conv.0.weight, rnn.weight_ih_l0, fc.fc.weight ... -- and, under the same
@@ -24,7 +27,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, ctc, decoder, transducer as _tr
+from . import _lib, ctc, decoder, seq2seq as _s2s, transducer as _tr
 from .encoder import EncoderFunction, EncoderPlan
 
 
@@ -334,3 +337,181 @@ class Transducer(Model):
             out = self(batch)
         u1 = [len(l) + 1 for l in batch[1]]
         return _tr.decode_static_batch(out, u1, beam_size=beam_size, blank=self.blank)[0]
+
+
+def end_pad_concat(labels):
+    """seq2seq.py:239-248: pad with the first utterance's last item (assumed to be the end token)."""
+    batch_size = len(labels)
+    end_tok = labels[0][-1]
+    max_len = max(len(l) for l in labels)
+    cat_labels = np.full((batch_size, max_len), fill_value=end_tok, dtype=np.int64)
+    for e, l in enumerate(labels):
+        cat_labels[e, :len(l)] = l
+    return cat_labels
+
+
+class NNAttention(nn.Module):
+    """seq2seq.py:331-360 as a parameter holder (conv.{weight,bias}, nn.1.fc.{weight,bias}); the arithmetic is
+    sa_attention_fwd / sa_attention_bwd."""
+
+    def __init__(self, n_channels, kernel_size=15, log_t=False):
+        super().__init__()
+        assert kernel_size % 2 == 1, "Kernel size should be odd for 'same' conv."
+        padding = (kernel_size - 1) // 2
+        self.conv = nn.Conv1d(1, n_channels, kernel_size, padding=padding)
+        self.nn = nn.Sequential(nn.ReLU(), LinearND(n_channels, 1))
+        self.log_t = log_t
+
+    def forward(self, eh, dhx, ax=None):
+        """eh (B, T, H), dhx (B, 1, H) or (B, H), ax (B, T) or None -> (sx (B, 1, H), ax (B, T))."""
+        sx, ax = _s2s.attention(eh.contiguous(), dhx.reshape(eh.shape[0], -1).contiguous(), ax,
+                                self.conv.weight.detach().reshape(eh.shape[2], -1).contiguous(),
+                                self.conv.bias.detach(), self.nn[1].fc.weight.detach().reshape(-1).contiguous(),
+                                self.nn[1].fc.bias.detach(), self.log_t)
+        return sx.unsqueeze(1), ax
+
+
+class Seq2Seq(Model):
+    """seq2seq.py:14-237 on the HIP ops: the shared encoder, then ONE autograd node for the attention decoder
+    (speech_amd.seq2seq.DecoderFunction) and the summed cross-entropy (XentFunction)."""
+
+    def __init__(self, freq_dim, vocab_size, config):
+        super().__init__(freq_dim, config)
+        self._ctor_args = (freq_dim, vocab_size, config)
+        decoder_cfg = config["decoder"]
+        rnn_dim = self.encoder_dim
+        embed_dim = decoder_cfg["embedding_dim"]
+        assert embed_dim == rnn_dim, "the context vector is added to the embedding (seq2seq.py:95): dims must match"
+        self.embedding = nn.Embedding(vocab_size, embed_dim)
+        self.dec_rnn = nn.GRUCell(input_size=embed_dim, hidden_size=rnn_dim)
+        self.attend = NNAttention(rnn_dim, log_t=decoder_cfg.get("log_t", False))
+        self.sample_prob = decoder_cfg.get("sample_prob", 0)
+        self.scheduled_sampling = (self.sample_prob != 0)
+        # *NB* vocab_size - 1 classes: the start-of-sequence token is never predicted (seq2seq.py:33-35)
+        self.fc = LinearND(rnn_dim, vocab_size - 1)
+
+    def set_eval(self):
+        self.eval()
+        self.volatile = True
+        self.scheduled_sampling = False
+
+    def set_train(self):
+        self.train()
+        self.volatile = False
+        self.scheduled_sampling = (self.sample_prob != 0)
+
+    def _dec_params(self):
+        return [self.embedding.weight, self.dec_rnn.weight_ih, self.dec_rnn.weight_hh, self.dec_rnn.bias_ih,
+                self.dec_rnn.bias_hh, self.attend.conv.weight, self.attend.conv.bias, self.attend.nn[1].fc.weight,
+                self.attend.nn[1].fc.bias, self.fc.fc.weight, self.fc.fc.bias]
+
+    def _param_dict(self):
+        H = self.encoder_dim
+        P = dict(zip(_s2s._NAMES, [p.detach() for p in self._dec_params()]))
+        P["conv_w"] = P["conv_w"].reshape(H, -1).contiguous()
+        P["nn_w"] = P["nn_w"].reshape(H).contiguous()
+        return P
+
+    def loss(self, batch):
+        x, y = self.collate(*batch)
+        if self.is_cuda:
+            x = x.cuda(non_blocking=True)
+            y = y.cuda(non_blocking=True)
+        with torch.set_grad_enabled(not self.volatile):
+            out, alis = self.forward_impl(x, y)
+            batch_size, _, out_dim = out.size()
+            out = out.reshape(-1, out_dim)
+            tgt = y[:, 1:].contiguous().view(-1)
+            return _s2s.XentFunction.apply(out, tgt, 1.0 / batch_size)  # sum / batch_size (:61-63)
+
+    def forward_impl(self, x, y):
+        x = self.encode(x)
+        return self.decode(x, y)
+
+    def forward(self, batch):
+        x, y = self.collate(*batch)
+        if self.is_cuda:
+            x = x.cuda(non_blocking=True)
+            y = y.cuda(non_blocking=True)
+        return self.forward_impl(x, y)[0]
+
+    def decode(self, x, y):
+        """seq2seq.py:77-112.  x (B, T', H) encoder states, y (B, U) labels -> (logits (B, U-1, V-1), aligns)."""
+        sp = self.sample_prob if self.scheduled_sampling else 0
+        return _s2s.DecoderFunction.apply(x, y, self.attend.log_t, sp, *self._dec_params())
+
+    def decode_step(self, x, y, state=None, softmax=False):
+        """seq2seq.py:114-138.  y (B, 1) labels; state None or (hx, ax, sx) as returned by the previous call."""
+        with torch.no_grad():
+            st = None if state is None else (state[0], state[1], state[2].reshape(x.shape[0], -1))
+            out, (hx, ax, sx) = _s2s.step(x.contiguous(), y.reshape(-1).to(x.device), st, self._param_dict(),
+                                          self.attend.log_t)
+            if softmax:
+                out = _tr.LogSoftmaxFunction.apply(out)
+        return out, (hx, ax, sx.unsqueeze(1))
+
+    def predict(self, batch):
+        probs = self(batch)
+        B, U1, K = probs.shape
+        return _s2s.argmax_rows(probs.reshape(B * U1, K).contiguous()).view(B, U1).cpu().numpy().tolist()
+
+    def infer_decode(self, x, y, end_tok, max_len):
+        probs = []
+        argmaxs = [y]
+        state = None
+        for e in range(max_len):
+            out, state = self.decode_step(x, y, state=state)
+            probs.append(out)
+            y = _s2s.argmax_rows(out).unsqueeze(1)
+            argmaxs.append(y)
+            if int(torch.sum(y == end_tok)) == y.numel():
+                break
+        return torch.cat(probs), torch.cat(argmaxs, dim=1)
+
+    def infer(self, batch, max_len=200):
+        """seq2seq.py:160-178: greedy decode from the start tokens (no beam search)."""
+        x, y = self.collate(*batch)
+        end_tok = int(y[0, -1])
+        with torch.no_grad():
+            x = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
+            y0 = y[:, 0:1].to(x.device)
+            _, argmaxs = self.infer_decode(x, y0, end_tok, max_len)
+        return [seq.tolist() for seq in argmaxs.cpu().numpy()]
+
+    def beam_search(self, batch, beam_size=10, max_len=200):
+        """seq2seq.py:180-229 for a batch of ONE utterance, with the reference's py2 `filter(...)[:n]` (:211-212)
+        read as the list it was written for.  The per-hypothesis decoder steps run on the GPU; the beam bookkeeping is
+        host-side Python exactly as in the reference."""
+        x, y = self.collate(*batch)
+        start_tok, end_tok = int(y[0, 0]), int(y[0, -1])
+        with torch.no_grad():
+            x = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
+        beam = [((start_tok,), 0, None)]
+        complete = []
+        for _ in range(max_len):
+            new_beam = []
+            for hyp, score, state in beam:
+                tok = torch.full((1, 1), hyp[-1], dtype=torch.int64, device=x.device)
+                out, state = self.decode_step(x, tok, state=state, softmax=True)
+                out = out.cpu().numpy().squeeze(axis=0).tolist()
+                for i, p in enumerate(out):
+                    new_beam.append((hyp + (i,), score + p, state))
+            new_beam = sorted(new_beam, key=lambda c: c[1], reverse=True)
+            for cand in new_beam[:beam_size]:
+                if cand[0][-1] == end_tok:
+                    complete.append(cand)
+            beam = [c for c in new_beam if c[0][-1] != end_tok][:beam_size]
+            if len(beam) == 0:
+                break
+            if sum(c[1] > beam[0][1] for c in complete) >= beam_size:
+                break
+        complete = sorted(complete, key=lambda c: c[1], reverse=True)
+        if len(complete) == 0:
+            complete = beam
+        hyp, score, _ = complete[0]
+        return [hyp]
+
+    def collate(self, inputs, labels):
+        inputs = zero_pad_concat(inputs)
+        labels = end_pad_concat(labels)
+        return torch.from_numpy(inputs), torch.from_numpy(labels)

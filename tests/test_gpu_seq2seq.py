@@ -1,0 +1,130 @@
+"""speech_amd.models.Seq2Seq (the reference's seq2seq.py on the HIP ops).  Nothing on this path is un-vendored, so the
+LIVE reference pins it (tests/golden/seq2seq_tiny.npz, made by oracle/gen_golden.py): teacher-forced logits,
+alignments, the loss, EVERY parameter gradient from the reference's own autograd, and the greedy decode.  Other shapes /
+options go against oracle/torch_ref.TorchRefSeq2Seq (itself pinned to the same fixture, tests/test_oracle_seq2seq.py).
+Tolerances: logits / alignments rtol 2e-4; loss rtol 1e-4; gradients within 1e-3 of the tensor's max magnitude."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}},
+       "decoder": {"embedding_dim": 16, "layers": 1, "log_t": True}}
+
+
+def fixture():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "seq2seq_tiny.npz"))
+
+
+def build(g, cfg=CFG, flatten=False):
+    from speech_amd.models import Seq2Seq
+    m = Seq2Seq(40, 11, cfg)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")})
+    m = m.cuda()
+    if flatten:
+        m.flatten_parameters_()
+    return m
+
+
+def batch_of(g):
+    x, y = g["x"], g["y"]
+    B = x.shape[0]
+    # the fixture's padded tensors re-enter through the reference's batch format (inputs, labels)
+    return tuple(x[b] for b in range(B)), tuple(list(y[b]) for b in range(B))
+
+
+def test_logits_alignments_loss_gradients_match_live_reference():
+    g = fixture()
+    for flatten in (False, True):
+        m = build(g, flatten=flatten)
+        m.set_train()
+        out, alis = m.forward_impl(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda())
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(alis.cpu().numpy(), g["aligns"], rtol=2e-4, atol=1e-6)
+        m.zero_grad(set_to_none=True)
+        loss = m.loss(batch_of(g))
+        assert abs(float(loss.item()) - float(g["loss"])) < 1e-4 * float(g["loss"])
+        loss.backward()
+        for name, p in m.named_parameters():
+            w = g["grad." + name]
+            got = (p._grad_slot if flatten else p.grad).cpu().numpy()
+            assert np.abs(got - w).max() < 1e-3 * max(np.abs(w).max(), 1e-3), (name, np.abs(got - w).max())
+
+
+def test_decode_step_and_greedy_infer_match_live_reference():
+    g = fixture()
+    m = build(g)
+    m.set_eval()
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    with torch.no_grad():
+        enc = m.encode(x)
+        out, _ = m.forward_impl(x, y)
+    # the reference's own test (tests/seq2seq_test.py:32-45): token-by-token decode_step reproduces forward
+    state, outs = None, []
+    for t in range(y.shape[1] - 1):
+        o, state = m.decode_step(enc, y[:, t:t + 1], state=state)
+        outs.append(o)
+    np.testing.assert_allclose(torch.stack(outs, dim=1).cpu().numpy(), out.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    seqs = m.infer(batch_of(g), max_len=12)
+    assert np.array_equal(np.array(seqs), g["infer"])
+    assert len(m.predict(batch_of(g))) == 3
+
+
+def test_other_shapes_against_restatement_and_beam_search():
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[4, 5, 9, 2]], "rnn": {"dim": 24, "bidirectional": False, "layers": 1}},
+           "decoder": {"embedding_dim": 24, "layers": 1, "log_t": False}}
+    torch.manual_seed(5)
+    ref = torch_ref.TorchRefSeq2Seq(20, 9, cfg)
+    from speech_amd.models import Seq2Seq
+    m = Seq2Seq(20, 9, cfg)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda()
+    rng = np.random.RandomState(7)
+    B, T = 5, 90   # T' = 43 > 15-tap window; 5 utterances of ragged label length
+    inputs = tuple(rng.randn(T - 3 * i, 20).astype(np.float32) for i in range(B))
+    labels = tuple([8] + list(rng.randint(0, 7, 3 + i)) + [7] for i in range(B))
+    x, y = m.collate(inputs, labels)
+    ref.train()
+    loss_ref = ref.loss(x, y)
+    loss_ref.backward()
+    m.set_train()
+    loss = m.loss((inputs, labels))
+    loss.backward()
+    assert abs(float(loss.item()) - float(loss_ref)) < 1e-4 * float(loss_ref)
+    want = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        w = want[name].grad.numpy()
+        assert np.abs(p.grad.cpu().numpy() - w).max() < 1e-3 * max(np.abs(w).max(), 1e-3), name
+    # beam search (batch of one): with beam 1 it follows the greedy path until the end token
+    m.set_eval()
+    one = (inputs[:1], labels[:1])
+    hyp = m.beam_search(one, beam_size=1, max_len=10)[0]
+    greedy = m.infer(one, max_len=10)[0]
+    n = min(len(hyp), len(greedy))
+    assert list(hyp[:n]) == list(greedy[:n]) and hyp[0] == 8
+    assert len(m.beam_search(one, beam_size=4, max_len=10)[0]) >= 2
+
+
+def test_scheduled_sampling_consumes_the_rng_like_the_reference_and_trains():
+    g = fixture()
+    cfg = dict(CFG, decoder=dict(CFG["decoder"], sample_prob=0.5))
+    m = build(g, cfg)
+    m.set_train()
+    assert m.scheduled_sampling
+    random.seed(3)
+    loss = m.loss(batch_of(g))
+    drawn = random.random()
+    random.seed(3)
+    for _ in range(g["y"].shape[1] - 2):   # one draw per token after the first (seq2seq.py:91-92)
+        random.random()
+    assert drawn == random.random()
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.set_eval()
+    assert not m.scheduled_sampling
