@@ -278,14 +278,16 @@ ctcStatus_t sa_grucell_gates_fwd(const float* gi, const float* gh, const float* 
                                  int B, int H, void* stream);
 ctcStatus_t sa_grucell_gates_bwd(const float* dh, const float* stash, const float* h_prev, float* dgi, float* dgh,
                                  float* dh_prev, int B, int H, void* stream);
+size_t sa_attention_workspace_bytes(int B, int T, int H, int KS);
 ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const float* ax_prev, const float* conv_w,
                              const float* conv_b, const float* nn_w, const float* nn_b, float scale, float* ax,
-                             float* sx, int B, int T, int H, int KS, void* stream);
+                             float* sx, int B, int T, int H, int KS, void* workspace, size_t workspace_bytes,
+                             void* stream);
 ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const float* ax_prev, const float* conv_w,
                              const float* conv_b, const float* nn_w, const float* nn_b, float scale, const float* ax,
                              const float* d_sx, const float* d_ax_next, float* d_eh, float* d_ox, float* d_ax_prev,
                              float* g_conv_w, float* g_conv_b, float* g_nn_w, float* g_nn_b, int B, int T, int H,
-                             int KS, void* stream);
+                             int KS, void* workspace, size_t workspace_bytes, void* stream);
 ctcStatus_t sa_softmax_xent(const float* logits, const long long* targets, float scale, float* loss_rows,
                             float* dlogits, long rows, int K, void* stream);
 ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows, int K, void* stream);

@@ -85,8 +85,11 @@ SIGNATURES = {
     "sa_log_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_grucell_gates_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "sa_grucell_gates_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
-    "sa_attention_fwd": (c_int, [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "sa_attention_bwd": (c_int, [c_void_p] * 7 + [c_float] + [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sa_attention_fwd": (c_int, [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                                  c_size_t, c_void_p]),
+    "sa_attention_bwd": (c_int, [c_void_p] * 7 + [c_float] + [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_void_p,
+                                                                                 c_size_t, c_void_p]),
     "sa_softmax_xent": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_argmax_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),

@@ -1,7 +1,8 @@
 // seq2seq.hip -- the per-token pieces of the attention decoder of /root/reference/speech/models/seq2seq.py:
 //   GRUCell gate math (:20-21, :97; the two projections around it are sa_gemm_f32),
 //   NNAttention (:331-360): score_t = w . relu(eh_t + ox + conv1d(ax_prev)_t) + b, optional log(T) temperature (:351-353),
-//   softmax over time, context sx = sum_t ax_t eh_t -- one kernel forward, one backward, a workgroup per utterance,
+//   softmax over time, context sx = sum_t ax_t eh_t -- the score network is parallel over (utterance, 16-step time
+//   chunk) in both directions; only the softmax / context and the final fold run one workgroup per utterance,
 //   softmax cross-entropy over the output classes (:59-63) with the gradient produced in the same pass, row argmax
 //   (scheduled sampling :93 and greedy decode :157).
 // All tensors fp32, contiguous, DEVICE.
@@ -63,6 +64,9 @@ struct AttArgs {
     int B, T, H, KS;
 };
 
+constexpr int kAttTB = 16;  // time steps per workgroup: grid (ceil(T / 16), B) fills the chip where one workgroup per
+                            // utterance (B = 16) would use 16 of 256 CUs
+
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {  // 256 threads, red[4]
     v = is_max ? sa_wave_max_dpp(v) : sa_wave_sum_dpp(v);
     __syncthreads();
@@ -72,70 +76,87 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
     return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
 }
 
-// LDS layout shared by both kernels: axp[T + KS - 1] (ax_prev zero-padded by (KS-1)/2 on both sides), cw[H * KS]
-__device__ __forceinline__ void att_stage(const AttArgs& A, int b, float* axp, float* cw) {
+// LDS staging of a time chunk [t0, t0 + kAttTB): axp[kAttTB + KS - 1] = ax_prev[t0 - pad ..] zero-padded, cw[H * KS]
+__device__ __forceinline__ void att_stage(const AttArgs& A, int b, int t0, float* axp, float* cw) {
     const int pad = (A.KS - 1) / 2;
-    for (int i = threadIdx.x; i < A.T + A.KS - 1; i += blockDim.x) {
-        const int t = i - pad;
+    for (int i = threadIdx.x; i < kAttTB + A.KS - 1; i += blockDim.x) {
+        const int t = t0 + i - pad;
         axp[i] = (A.ax_prev && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
     }
     for (int i = threadIdx.x; i < A.H * A.KS; i += blockDim.x) cw[i] = A.conv_w[i];
 }
 
-// pre-activation of the score network at (t, h)
+// pre-activation of the score network at (t0 + tl, h)
 __device__ __forceinline__ float att_pre(const AttArgs& A, const float* ehb, const float* oxb, const float* axp,
-                                         const float* cw, int t, int h) {
-    float v = ehb[(long)t * A.H + h] + oxb[h];
+                                         const float* cw, int t0, int tl, int h) {
+    float v = ehb[(long)(t0 + tl) * A.H + h] + oxb[h];
     if (A.ax_prev) {
         float c = A.conv_b[h];
-        for (int k = 0; k < A.KS; ++k) c += cw[h * A.KS + k] * axp[t + k];
+        for (int k = 0; k < A.KS; ++k) c += cw[h * A.KS + k] * axp[tl + k];
         v += c;
     }
     return v;
 }
 
-// grid B, 256 threads.  dynamic LDS: axp | cw | score[T] | red[4]
-__global__ __launch_bounds__(256) void attention_fwd_kernel(AttArgs A, float* __restrict__ ax, float* __restrict__ sx) {
+// ---- forward, stage 1: scores.  grid (ceil(T / 16), B), 256 threads: a wave per time step (4 per wave).
+// dynamic LDS: axp[kAttTB + KS - 1] | cw[H * KS]
+__global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* __restrict__ score) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* axp = reinterpret_cast<float*>(smem_raw);
-    float* cw = axp + A.T + A.KS - 1;
-    float* score = cw + A.H * A.KS;
-    float* red = score + A.T;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* cw = axp + kAttTB + A.KS - 1;
+    const int b = blockIdx.y, t0 = blockIdx.x * kAttTB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* ehb = A.eh + (long)b * A.T * A.H;
     const float* oxb = A.ox + (long)b * A.H;
-    att_stage(A, b, axp, cw);
+    att_stage(A, b, t0, axp, cw);
     __syncthreads();
     const float nb = A.nn_b[0];
-    for (int t = wave; t < A.T; t += 4) {
+    for (int tl = wave; tl < kAttTB && t0 + tl < A.T; tl += 4) {
         float v = 0.f;
-        for (int h = lane; h < A.H; h += 64) v += fmaxf(att_pre(A, ehb, oxb, axp, cw, t, h), 0.f) * A.nn_w[h];
+        for (int h = lane; h < A.H; h += 64) v += fmaxf(att_pre(A, ehb, oxb, axp, cw, t0, tl, h), 0.f) * A.nn_w[h];
         v = sa_wave_sum_dpp(v);
-        if (lane == 0) score[t] = (v + nb) * A.scale;
+        if (lane == 0) score[(long)b * A.T + t0 + tl] = (v + nb) * A.scale;
     }
-    __syncthreads();
+}
+
+// ---- forward, stage 2: softmax over time and the context.  grid B, 256 threads.  dynamic LDS: a[T] | red[4] | part[4][H]
+__global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const float* __restrict__ score,
+                                                                float* __restrict__ ax, float* __restrict__ sx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* a = reinterpret_cast<float*>(smem_raw);
+    float* red = a + A.T;
+    float* part = red + 4;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* ehb = A.eh + (long)b * A.T * A.H;
     float m = -3.0e38f;
-    for (int t = threadIdx.x; t < A.T; t += 256) m = fmaxf(m, score[t]);
+    for (int t = threadIdx.x; t < A.T; t += 256) {
+        a[t] = score[(long)b * A.T + t];
+        m = fmaxf(m, a[t]);
+    }
     m = block_reduce(m, red, true);
     float s = 0.f;
     for (int t = threadIdx.x; t < A.T; t += 256) {
-        const float e = __expf(score[t] - m);
-        score[t] = e;
+        const float e = __expf(a[t] - m);
+        a[t] = e;
         s += e;
     }
     s = block_reduce(s, red, false);
     const float inv = 1.0f / s;
     for (int t = threadIdx.x; t < A.T; t += 256) {
-        const float a = score[t] * inv;
-        score[t] = a;
-        ax[(long)b * A.T + t] = a;
+        const float v = a[t] * inv;
+        a[t] = v;
+        ax[(long)b * A.T + t] = v;
     }
     __syncthreads();
-    for (int h = threadIdx.x; h < A.H; h += 256) {
+    // context: each wave sums a quarter of the time axis for every hidden unit, then the quarters are combined
+    const int tq = (A.T + 3) / 4, tb = wave * tq, te = min(A.T, tb + tq);
+    for (int h = lane; h < A.H; h += 64) {
         float acc = 0.f;
-        for (int t = 0; t < A.T; ++t) acc += score[t] * ehb[(long)t * A.H + h];
-        sx[(long)b * A.H + h] = acc;
+        for (int t = tb; t < te; ++t) acc += a[t] * ehb[(long)t * A.H + h];
+        part[wave * A.H + h] = acc;
     }
+    __syncthreads();
+    for (int h = threadIdx.x; h < A.H; h += 256)
+        sx[(long)b * A.H + h] = (part[h] + part[A.H + h]) + (part[2 * A.H + h] + part[3 * A.H + h]);
 }
 
 struct AttBwd {
@@ -149,100 +170,132 @@ struct AttBwd {
     float* g_conv_b;         // (B, H)     +=
     float* g_nn_w;           // (B, H)     +=
     float* g_nn_b;           // (B)        +=
+    float* dpax;             // workspace (B, T): d ax, then d score
+    float* part;             // workspace (B, nchunk, H, 2 + KS): per-chunk sums of d_pre, d_pre-weighted terms
+    float* q;                // workspace (B, T, KS): sum_h d_pre[t,h] conv_w[h,k]
+    int nchunk;
 };
 
-// grid B, 256 threads.  dynamic LDS: axp | cw | axs[T] | dpax[T] | q[T * KS] | red[4]
-__global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs A, AttBwd G) {
+// ---- backward, stage 1: d ax[t] = (from the next token) + d_sx . eh[t].  grid (ceil(T / 16), B), a wave per time step
+__global__ __launch_bounds__(256) void attention_bwd_dax_kernel(AttArgs A, AttBwd G) {
+    const int b = blockIdx.y, t0 = blockIdx.x * kAttTB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* ehb = A.eh + (long)b * A.T * A.H;
+    const float* dsx = G.d_sx + (long)b * A.H;
+    for (int tl = wave; tl < kAttTB && t0 + tl < A.T; tl += 4) {
+        const int t = t0 + tl;
+        float v = 0.f;
+        for (int h = lane; h < A.H; h += 64) v += dsx[h] * ehb[(long)t * A.H + h];
+        v = sa_wave_sum_dpp(v);
+        if (lane == 0) G.dpax[(long)b * A.T + t] = v + (G.d_ax_next ? G.d_ax_next[(long)b * A.T + t] : 0.f);
+    }
+}
+
+// ---- backward, stage 2: through the softmax and the temperature (in place: dpax becomes d score).  grid B
+__global__ __launch_bounds__(256) void attention_bwd_softmax_kernel(AttArgs A, AttBwd G) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* ax = G.ax + (long)b * A.T;
+    float* d = G.dpax + (long)b * A.T;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < A.T; t += 256) s += ax[t] * d[t];
+    s = block_reduce(s, red, false);
+    float sb = 0.f;
+    for (int t = threadIdx.x; t < A.T; t += 256) {
+        const float v = ax[t] * (d[t] - s) * A.scale;
+        d[t] = v;
+        sb += v;
+    }
+    sb = block_reduce(sb, red, false);
+    if (threadIdx.x == 0) G.g_nn_b[b] += sb;
+}
+
+// ---- backward, stage 3: the score network over one time chunk.  grid (nchunk, B), 256 threads.
+// phase 1, a thread per hidden unit, serial over the chunk's 16 steps: d_pre, d_eh, the chunk's per-unit partial sums;
+// phase 2, a thread per (step, tap): q[t][k] = sum_h d_pre[t,h] cw[h,k] out of an LDS tile of d_pre.
+// dynamic LDS: axp | cw | dps[kAttTB] | axs[kAttTB] | dp_tile[kAttTB][H]
+__global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttBwd G) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* axp = reinterpret_cast<float*>(smem_raw);
-    float* cw = axp + A.T + A.KS - 1;
-    float* axs = cw + A.H * A.KS;
-    float* dpax = axs + A.T;
-    float* q = dpax + A.T;
-    float* red = q + A.T * A.KS;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* cw = axp + kAttTB + A.KS - 1;
+    float* dps = cw + A.H * A.KS;
+    float* axs = dps + kAttTB;
+    float* dp_tile = axs + kAttTB;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * kAttTB;
+    const int nt = min(kAttTB, A.T - t0);
     const float* ehb = A.eh + (long)b * A.T * A.H;
     const float* oxb = A.ox + (long)b * A.H;
     const float* dsx = G.d_sx + (long)b * A.H;
     float* dehb = G.d_eh + (long)b * A.T * A.H;
-    att_stage(A, b, axp, cw);
-    for (int t = threadIdx.x; t < A.T; t += 256) axs[t] = G.ax[(long)b * A.T + t];
-    __syncthreads();
-    // (i) d ax[t] = (from the next token) + d_sx . eh[t]
-    for (int t = wave; t < A.T; t += 4) {
-        float v = 0.f;
-        for (int h = lane; h < A.H; h += 64) v += dsx[h] * ehb[(long)t * A.H + h];
-        v = sa_wave_sum_dpp(v);
-        if (lane == 0) dpax[t] = v + (G.d_ax_next ? G.d_ax_next[(long)b * A.T + t] : 0.f);
+    att_stage(A, b, t0, axp, cw);
+    if ((int)threadIdx.x < kAttTB) {
+        const bool ok = (int)threadIdx.x < nt;
+        dps[threadIdx.x] = ok ? G.dpax[(long)b * A.T + t0 + threadIdx.x] : 0.f;
+        axs[threadIdx.x] = ok ? G.ax[(long)b * A.T + t0 + threadIdx.x] : 0.f;
     }
     __syncthreads();
-    // (ii) through the softmax and the temperature
-    float s = 0.f;
-    for (int t = threadIdx.x; t < A.T; t += 256) s += axs[t] * dpax[t];
-    s = block_reduce(s, red, false);
-    float sb = 0.f;
-    for (int t = threadIdx.x; t < A.T; t += 256) {
-        const float d = axs[t] * (dpax[t] - s) * A.scale;
-        dpax[t] = d;
-        sb += d;
-    }
-    sb = block_reduce(sb, red, false);
-    if (threadIdx.x == 0) G.g_nn_b[b] += sb;
-    __syncthreads();
-    // (iii-a) one thread per hidden unit, serial over time: d_eh, d_ox and this utterance's parameter-gradient partials
+    const int W = 2 + A.KS;
     for (int h = threadIdx.x; h < A.H; h += 256) {
         const float w = A.nn_w[h], dsxh = dsx[h];
         float a_ox = 0.f, a_nw = 0.f;
         float a_cw[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) a_cw[k] = 0.f;
-        for (int t = 0; t < A.T; ++t) {
-            const float pre = att_pre(A, ehb, oxb, axp, cw, t, h);
-            const float dp = pre > 0.f ? dpax[t] * w : 0.f;
+        for (int tl = 0; tl < nt; ++tl) {
+            const float pre = att_pre(A, ehb, oxb, axp, cw, t0, tl, h);
+            const float dp = pre > 0.f ? dps[tl] * w : 0.f;
             a_ox += dp;
-            a_nw += dpax[t] * fmaxf(pre, 0.f);
+            a_nw += dps[tl] * fmaxf(pre, 0.f);
             if (A.ax_prev) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    if (k < A.KS) a_cw[k] += dp * axp[t + k];
+                    if (k < A.KS) a_cw[k] += dp * axp[tl + k];
             }
-            dehb[(long)t * A.H + h] += axs[t] * dsxh + dp;
+            dehb[(long)(t0 + tl) * A.H + h] += axs[tl] * dsxh + dp;
+            dp_tile[tl * A.H + h] = dp;
         }
-        G.d_ox[(long)b * A.H + h] = a_ox;
-        G.g_nn_w[(long)b * A.H + h] += a_nw;
+        float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + h) * W;
+        p[0] = a_ox;
+        p[1] = a_nw;
+        for (int k = 0; k < A.KS; ++k) p[2 + k] = a_cw[k];
+    }
+    if (!A.ax_prev) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * A.KS; i += 256) {
+        const int tl = i / A.KS, k = i - tl * A.KS;
+        float acc = 0.f;
+        for (int h = 0; h < A.H; ++h) acc += dp_tile[tl * A.H + h] * cw[h * A.KS + k];
+        G.q[((long)b * A.T + t0 + tl) * A.KS + k] = acc;
+    }
+}
+
+// ---- backward, stage 4: fold the chunks.  grid B, 256 threads
+__global__ __launch_bounds__(256) void attention_bwd_fold_kernel(AttArgs A, AttBwd G) {
+    const int b = blockIdx.x;
+    const int W = 2 + A.KS;
+    for (int h = threadIdx.x; h < A.H; h += 256) {
+        float acc[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) acc[k] = 0.f;
+        for (int c = 0; c < G.nchunk; ++c) {
+            const float* p = G.part + (((long)b * G.nchunk + c) * A.H + h) * W;
+#pragma unroll
+            for (int k = 0; k < 18; ++k)
+                if (k < W) acc[k] += p[k];
+        }
+        G.d_ox[(long)b * A.H + h] = acc[0];
+        G.g_nn_w[(long)b * A.H + h] += acc[1];
         if (A.ax_prev) {
-            G.g_conv_b[(long)b * A.H + h] += a_ox;
-            for (int k = 0; k < A.KS; ++k) G.g_conv_w[((long)b * A.H + h) * A.KS + k] += a_cw[k];
+            G.g_conv_b[(long)b * A.H + h] += acc[0];
+            for (int k = 0; k < A.KS; ++k) G.g_conv_w[((long)b * A.H + h) * A.KS + k] += acc[2 + k];
         }
     }
     if (!A.ax_prev) return;
-    // (iii-b) q[t][k] = sum_h d_pre[t,h] cw[h,k]   (a wave per time step)
-    for (int t = wave; t < A.T; t += 4) {
-        float part[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) part[k] = 0.f;
-        for (int h = lane; h < A.H; h += 64) {
-            const float pre = att_pre(A, ehb, oxb, axp, cw, t, h);
-            const float dp = pre > 0.f ? dpax[t] * A.nn_w[h] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < A.KS) part[k] += dp * cw[h * A.KS + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k < A.KS) {
-                const float v = sa_wave_sum_dpp(part[k]);
-                if (lane == 0) q[t * A.KS + k] = v;
-            }
-    }
-    __syncthreads();
-    // (iii-c) d ax_prev[t'] = sum_k q[t' + pad - k][k]
     const int pad = (A.KS - 1) / 2;
     for (int tp = threadIdx.x; tp < A.T; tp += 256) {
         float acc = 0.f;
         for (int k = 0; k < A.KS; ++k) {
             const int t = tp + pad - k;
-            if (t >= 0 && t < A.T) acc += q[t * A.KS + k];
+            if (t >= 0 && t < A.T) acc += G.q[((long)b * A.T + t) * A.KS + k];
         }
         G.d_ax_prev[(long)b * A.T + tp] = acc;
     }
@@ -312,21 +365,48 @@ extern "C" ctcStatus_t sa_grucell_gates_bwd(const float* dh, const float* stash,
     return CTC_STATUS_SUCCESS;
 }
 
-static bool att_ok(int B, int T, int H, int KS) { return B > 0 && T > 0 && H > 0 && KS >= 1 && KS <= 16 && (KS & 1); }
+static bool att_ok(int B, int T, int H, int KS) {
+    return B > 0 && B <= 65535 && T > 0 && H > 0 && KS >= 1 && KS <= 15 && (KS & 1);
+}
+
+static size_t att_layout(int B, int T, int H, int KS, size_t o[4]) {
+    const size_t nchunk = (T + kAttTB - 1) / kAttTB;
+    size_t p = 0;
+    o[0] = p; p += sa_align_up((size_t)B * T * sizeof(float), 256);                          // scores / dpax
+    o[1] = p; p += sa_align_up((size_t)B * nchunk * H * (2 + KS) * sizeof(float), 256);      // part
+    o[2] = p; p += sa_align_up((size_t)B * T * KS * sizeof(float), 256);                     // q
+    return p;
+}
+
+extern "C" size_t sa_attention_workspace_bytes(int B, int T, int H, int KS) {
+    if (!att_ok(B, T, H, KS)) return 0;
+    size_t o[4];
+    return att_layout(B, T, H, KS, o);
+}
+
+static bool att_smem(const void* fn, size_t smem) {
+    if (smem > 150 * 1024) return false;
+    return smem <= 48 * 1024 ||
+           hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+}
 
 extern "C" ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const float* ax_prev, const float* conv_w,
                                         const float* conv_b, const float* nn_w, const float* nn_b, float scale,
-                                        float* ax, float* sx, int B, int T, int H, int KS, void* stream) {
+                                        float* ax, float* sx, int B, int T, int H, int KS, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
     SA_CLEAR_ERR();
-    if (!eh || !ox || !conv_w || !conv_b || !nn_w || !nn_b || !ax || !sx || !att_ok(B, T, H, KS))
+    if (!eh || !ox || !conv_w || !conv_b || !nn_w || !nn_b || !ax || !sx || !workspace || !att_ok(B, T, H, KS))
         return CTC_STATUS_INVALID_VALUE;
+    if (workspace_bytes < sa_attention_workspace_bytes(B, T, H, KS)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
     AttArgs A{eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, scale, B, T, H, KS};
-    const size_t smem = ((size_t)(T + KS - 1) + (size_t)H * KS + T + 4) * sizeof(float);
-    if (smem > 150 * 1024) return CTC_STATUS_INVALID_VALUE;
-    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)attention_fwd_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return CTC_STATUS_EXECUTION_FAILED;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, A, ax, sx);
+    float* score = (float*)workspace;
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 4 + 4 * (size_t)H) * sizeof(float);
+    if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
+        return CTC_STATUS_INVALID_VALUE;
+    hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+    hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
@@ -335,19 +415,27 @@ extern "C" ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const 
                                         const float* conv_b, const float* nn_w, const float* nn_b, float scale,
                                         const float* ax, const float* d_sx, const float* d_ax_next, float* d_eh,
                                         float* d_ox, float* d_ax_prev, float* g_conv_w, float* g_conv_b, float* g_nn_w,
-                                        float* g_nn_b, int B, int T, int H, int KS, void* stream) {
+                                        float* g_nn_b, int B, int T, int H, int KS, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
     SA_CLEAR_ERR();
     if (!eh || !ox || !conv_w || !conv_b || !nn_w || !nn_b || !ax || !d_sx || !d_eh || !d_ox || !g_conv_w ||
-        !g_conv_b || !g_nn_w || !g_nn_b || !att_ok(B, T, H, KS) || (ax_prev && !d_ax_prev))
+        !g_conv_b || !g_nn_w || !g_nn_b || !workspace || !att_ok(B, T, H, KS) || (ax_prev && !d_ax_prev))
         return CTC_STATUS_INVALID_VALUE;
+    if (workspace_bytes < sa_attention_workspace_bytes(B, T, H, KS)) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t o[4];
+    att_layout(B, T, H, KS, o);
+    char* ws = (char*)workspace;
+    const int nchunk = (T + kAttTB - 1) / kAttTB;
     AttArgs A{eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, scale, B, T, H, KS};
-    AttBwd G{ax, d_sx, d_ax_next, d_eh, d_ox, d_ax_prev, g_conv_w, g_conv_b, g_nn_w, g_nn_b};
-    const size_t smem = ((size_t)(T + KS - 1) + (size_t)H * KS + 2 * (size_t)T + (size_t)T * KS + 4) * sizeof(float);
-    if (smem > 150 * 1024) return CTC_STATUS_INVALID_VALUE;
-    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)attention_bwd_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return CTC_STATUS_EXECUTION_FAILED;
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, A, G);
+    AttBwd G{ax, d_sx, d_ax_next, d_eh, d_ox, d_ax_prev, g_conv_w, g_conv_b, g_nn_w, g_nn_b,
+             (float*)(ws + o[0]), (float*)(ws + o[1]), (float*)(ws + o[2]), nchunk};
+    const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * H) * sizeof(float);
+    if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
+    hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
+    hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
+    hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
+    hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(B), dim3(256), 0, stream, A, G);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }

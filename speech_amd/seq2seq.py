@@ -45,6 +45,13 @@ def gru_cell(ix, hprev, w_ih, w_hh, b_ih, b_hh, stash=None):
     return hx
 
 
+def _att_ws(B, T, H, KS, device):
+    n = _L().sa_attention_workspace_bytes(B, T, H, KS)
+    if n == 0:
+        raise _lib.SpeechAmdError("attention: unsupported shape (odd location kernel <= 15 taps)")
+    return _lib.WORKSPACE.get(n, device, "attention")
+
+
 def attention(eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, log_t):
     """NNAttention.forward (seq2seq.py:341-360): returns (sx (B, H), ax (B, T))."""
     B, T, H = eh.shape
@@ -52,9 +59,10 @@ def attention(eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, log_t):
     ax = torch.empty(B, T, dtype=torch.float32, device=eh.device)
     sx = torch.empty(B, H, dtype=torch.float32, device=eh.device)
     scale = math.log(T) if log_t else 1.0
+    ws = _att_ws(B, T, H, KS, eh.device)
     _lib.check(_L().sa_attention_fwd(_lib.ptr(eh), _lib.ptr(ox), _lib.ptr(ax_prev), _lib.ptr(conv_w), _lib.ptr(conv_b),
                                      _lib.ptr(nn_w), _lib.ptr(nn_b), scale, _lib.ptr(ax), _lib.ptr(sx), B, T, H, KS,
-                                     _lib.cur_stream()), "sa_attention_fwd")
+                                     _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_attention_fwd")
     return sx, ax
 
 
@@ -105,6 +113,7 @@ class DecoderFunction(torch.autograd.Function):
         L = _L()
         hprev = torch.zeros(B, H, **f)
         sx = torch.empty(B, H, **f)
+        ws = _att_ws(B, T, H, conv_w.shape[1], dev)
         for t in range(U1):
             idx = y[:, t]
             # scheduled sampling (:91-96): feed back the argmax of the previous token's logits
@@ -122,7 +131,7 @@ class DecoderFunction(torch.autograd.Function):
             _lib.check(L.sa_attention_fwd(_lib.ptr(eh), _lib.ptr(HX[t]), _lib.ptr(AX[t - 1]) if t > 0 else None,
                                           _lib.ptr(conv_w), _lib.ptr(P["conv_b"]), _lib.ptr(nn_w), _lib.ptr(P["nn_b"]),
                                           scale, _lib.ptr(AX[t]), _lib.ptr(sx), B, T, H, conv_w.shape[1],
-                                          _lib.cur_stream()), "sa_attention_fwd")
+                                          _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_attention_fwd")
             ops.add_rows(HX[t], sx, out=OIN[t])
             hprev = HX[t]
         out = ops.gemm(OIN.view(U1 * B, H), P["fc_w"], trans_b=True, bias=P["fc_b"]).view(U1, B, K)
@@ -158,6 +167,7 @@ class DecoderFunction(torch.autograd.Function):
         d_sx = torch.empty(B, H, **f)
         d_ax = [torch.empty(B, T, **f), torch.empty(B, T, **f)]
         have_next = False
+        ws = _att_ws(B, T, H, KS, dev)
         for t in range(U1 - 1, -1, -1):
             # the context of token t feeds the fc (dOIN[t]) and the next token's GRU input (DIX[t + 1])
             if have_next:
@@ -170,7 +180,7 @@ class DecoderFunction(torch.autograd.Function):
                                           scale, _lib.ptr(AX[t]), _lib.ptr(d_sx), _lib.ptr(d_ax_next), _lib.ptr(d_eh),
                                           _lib.ptr(d_ox), _lib.ptr(d_ax[t & 1]) if t > 0 else None, _lib.ptr(g_cw),
                                           _lib.ptr(g_cb), _lib.ptr(g_nw), _lib.ptr(g_nb), B, T, H, KS,
-                                          _lib.cur_stream()), "sa_attention_bwd")
+                                          _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_attention_bwd")
             # the decoder state of token t feeds the fc, the attention and the next token's GRU
             ops.add_rows(dOIN[t], d_ox, out=d_hx)
             ops.add_rows(d_hx, d_hprev, out=d_hx)

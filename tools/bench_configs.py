@@ -115,6 +115,43 @@ def m_transducer(iters):
             "note": "train step includes the host-side collate of the reference's loss(batch) API"}
 
 
+def m_seq2seq(iters):
+    """BASELINE config 4: examples/wsj/seq2seq_config.json shapes (conv [[32,5,8,2],[32,5,8,2]], 4 x biGRU-256, F=161,
+    batch 16, log_t, sample_prob 0.2), T=800 frames -> T'=197, 100 output tokens; train step, greedy infer, beam 8."""
+    import random
+    from speech_amd.models import Seq2Seq
+    B, T, F, V, U = 16, 800, 161, 30, 100
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 8, 2], [32, 5, 8, 2]],
+                                       "rnn": {"dim": 256, "layers": 4, "bidirectional": True}},
+           "decoder": {"sample_prob": 0.2, "embedding_dim": 256, "log_t": True, "layers": 1}}
+    torch.manual_seed(2017)
+    random.seed(2017)
+    model = Seq2Seq(F, V + 2, cfg).cuda()     # + start and end tokens
+    model.set_train()
+    flat_p, flat_g = model.flatten_parameters_()
+    rng = np.random.RandomState(2017)
+    inputs = tuple(rng.randn(T, F).astype(np.float32) for _ in range(B))
+    labels = tuple([V + 1] + list(rng.randint(0, V, U - 2)) + [V] for _ in range(B))
+    norm = torch.zeros(1, device=DEV)
+    out = {}
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss = model.loss((inputs, labels))
+        loss.backward()
+        ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
+        out["loss"] = loss
+
+    sec = timed(step, iters, warmup=2)
+    model.set_eval()
+    one = (inputs[:1], labels[:1])
+    greedy = timed(lambda: model.infer((inputs, labels), max_len=U), 2, warmup=1)
+    beam = timed(lambda: model.beam_search(one, beam_size=8, max_len=U), 1, warmup=1)
+    return {"workload": "Seq2Seq WSJ config shapes (config 4)", "B": B, "T": T, "T_out": model.conv_out_size(T, 0),
+            "tokens": U, "params": int(flat_p.numel()), "train_step_ms": sec * 1e3, "train_utt_per_s": B / sec,
+            "greedy_infer_batch_ms": greedy * 1e3, "beam8_one_utt_ms": beam * 1e3, "loss": float(out["loss"].item())}
+
+
 def m_dec(beam, iters):
     rng = np.random.RandomState(2017)
     z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
@@ -143,6 +180,7 @@ def main():
     res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
                       m_step("2xGRU-256 F=40 |V|=61", 40, 61, small, 32, 1000, 100, 5)]
     res["M-RNNT"] = [m_transducer(3)]
+    res["M-S2S"] = [m_seq2seq(3)]
     rng = np.random.RandomState(2017)
     z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
     greedy = timed(lambda: decoder.greedy_decode(z, blank=28), 20)
