@@ -288,6 +288,24 @@ ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const float* ax_p
                              const float* d_sx, const float* d_ax_next, float* d_eh, float* d_ox, float* d_ax_prev,
                              float* g_conv_w, float* g_conv_b, float* g_nn_w, float* g_nn_b, int B, int T, int H,
                              int KS, void* workspace, size_t workspace_bytes, void* stream);
+/* The whole decoder loop (seq2seq.py:77-112) and its backward through the tokens, enqueued by ONE call each.
+ *   params / grads: HOST arrays of 11 DEVICE pointers in the order embedding.weight (V,E), dec_rnn.weight_ih (3H,E),
+ *   weight_hh (3H,H), bias_ih, bias_hh, attend.conv.weight (H,KS), attend.conv.bias, attend.nn.1.fc.weight (H),
+ *   attend.nn.1.fc.bias (1), fc.fc.weight (K,H), fc.fc.bias (K).  E == H (the context is added to the embedding, :95).
+ *   y (B,U) int64 labels with start / end tokens; token t consumes y[:, t] -- or, where the HOST flag sample[t] is set
+ *   (t >= 1; NULL = teacher forcing), the argmax of token t-1's logits (scheduled sampling, :91-96).
+ *   Time-major outputs / stashes for the backward: out (U-1,B,K) logits, IDX (U-1,B) int64 inputs actually used,
+ *   IX (U-1,B,E), ST (U-1,B,4H), HX (U-1,B,H), AX (U-1,B,T) alignments, OIN (U-1,B,H) = state + context.
+ *   bwd: d_out (U-1,B,K) -> d_eh (B,T,H) and every parameter gradient (grads[i] written, not accumulated). */
+size_t sa_s2s_decoder_workspace_bytes(int B, int T, int U1, int H, int E, int KS, int K);
+ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, const unsigned char* sample,
+                               const float* const* params, int B, int T, int U, int H, int E, int KS, int K, float scale,
+                               float* out, long long* IDX, float* IX, float* ST, float* HX, float* AX, float* OIN,
+                               void* workspace, size_t workspace_bytes, void* stream);
+ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* params, const float* d_out, const long long* IDX,
+                               const float* IX, const float* ST, const float* HX, const float* AX, const float* OIN,
+                               int B, int T, int U, int H, int E, int KS, int K, int V, float scale, float* d_eh,
+                               float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
 ctcStatus_t sa_softmax_xent(const float* logits, const long long* targets, float scale, float* loss_rows,
                             float* dlogits, long rows, int K, void* stream);
 ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows, int K, void* stream);

@@ -32,18 +32,21 @@ __global__ __launch_bounds__(256) void grucell_gates_fwd_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void grucell_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ stash,
-                                                                const float* __restrict__ h_prev, float* __restrict__ dgi,
-                                                                float* __restrict__ dgh, float* __restrict__ dh_prev,
-                                                                int B, int H) {
+// dh = dh + dh2 + dh3 (the two extra addends may be NULL; dh3 may alias dh_prev: it is read before the write);
+// h_prev NULL = zeros (first token)
+__global__ __launch_bounds__(256) void grucell_gates_bwd_kernel(const float* __restrict__ dh, const float* dh2,
+                                                                const float* dh3, const float* __restrict__ stash,
+                                                                const float* h_prev, float* __restrict__ dgi,
+                                                                float* __restrict__ dgh, float* dh_prev, int B, int H) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, j = i - b * H;
     const float* s = stash + (long)b * 4 * H;
     const float r = s[j], z = s[H + j], n = s[2 * H + j], ghn = s[3 * H + j];
-    const float g = dh[i];
+    const float g = dh[i] + (dh2 ? dh2[i] : 0.f) + (dh3 ? dh3[i] : 0.f);
+    const float hp = h_prev ? h_prev[i] : 0.f;
     const float dn = g * (1.0f - z) * (1.0f - n * n);       // through tanh
-    const float dz = g * (h_prev[i] - n) * z * (1.0f - z);  // through sigmoid
+    const float dz = g * (hp - n) * z * (1.0f - z);  // through sigmoid
     const float dr = dn * ghn * r * (1.0f - r);
     float* a = dgi + (long)b * 3 * H;
     float* c = dgh + (long)b * 3 * H;
@@ -120,7 +123,8 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
 
 // ---- forward, stage 2: softmax over time and the context.  grid B, 256 threads.  dynamic LDS: a[T] | red[4] | part[4][H]
 __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const float* __restrict__ score,
-                                                                float* __restrict__ ax, float* __restrict__ sx) {
+                                                                float* __restrict__ ax, float* __restrict__ sx,
+                                                                float* __restrict__ oin /* ox + sx, or NULL */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* a = reinterpret_cast<float*>(smem_raw);
     float* red = a + A.T;
@@ -155,13 +159,17 @@ __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const
         part[wave * A.H + h] = acc;
     }
     __syncthreads();
-    for (int h = threadIdx.x; h < A.H; h += 256)
-        sx[(long)b * A.H + h] = (part[h] + part[A.H + h]) + (part[2 * A.H + h] + part[3 * A.H + h]);
+    for (int h = threadIdx.x; h < A.H; h += 256) {
+        const float v = (part[h] + part[A.H + h]) + (part[2 * A.H + h] + part[3 * A.H + h]);
+        sx[(long)b * A.H + h] = v;
+        if (oin) oin[(long)b * A.H + h] = A.ox[(long)b * A.H + h] + v;
+    }
 }
 
 struct AttBwd {
     const float* ax;         // (B, T) this step's alignment
     const float* d_sx;       // (B, H)
+    const float* d_sx2;      // (B, H) or NULL: added to d_sx (the next token's input gradient)
     const float* d_ax_next;  // (B, T) or NULL: gradient arriving through the next token's location term
     float* d_eh;             // (B, T, H)  +=
     float* d_ox;             // (B, H)     =
@@ -181,10 +189,11 @@ __global__ __launch_bounds__(256) void attention_bwd_dax_kernel(AttArgs A, AttBw
     const int b = blockIdx.y, t0 = blockIdx.x * kAttTB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* ehb = A.eh + (long)b * A.T * A.H;
     const float* dsx = G.d_sx + (long)b * A.H;
+    const float* dsx2 = G.d_sx2 ? G.d_sx2 + (long)b * A.H : nullptr;
     for (int tl = wave; tl < kAttTB && t0 + tl < A.T; tl += 4) {
         const int t = t0 + tl;
         float v = 0.f;
-        for (int h = lane; h < A.H; h += 64) v += dsx[h] * ehb[(long)t * A.H + h];
+        for (int h = lane; h < A.H; h += 64) v += (dsx[h] + (dsx2 ? dsx2[h] : 0.f)) * ehb[(long)t * A.H + h];
         v = sa_wave_sum_dpp(v);
         if (lane == 0) G.dpax[(long)b * A.T + t] = v + (G.d_ax_next ? G.d_ax_next[(long)b * A.T + t] : 0.f);
     }
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
     __syncthreads();
     const int W = 2 + A.KS;
     for (int h = threadIdx.x; h < A.H; h += 256) {
-        const float w = A.nn_w[h], dsxh = dsx[h];
+        const float w = A.nn_w[h], dsxh = dsx[h] + (G.d_sx2 ? G.d_sx2[(long)b * A.H + h] : 0.f);
         float a_ox = 0.f, a_nw = 0.f;
         float a_cw[16];
 #pragma unroll
@@ -360,7 +369,7 @@ extern "C" ctcStatus_t sa_grucell_gates_bwd(const float* dh, const float* stash,
     SA_CLEAR_ERR();
     if (!dh || !stash || !h_prev || !dgi || !dgh || !dh_prev || B <= 0 || H <= 0) return CTC_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(grucell_gates_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, dh,
-                       stash, h_prev, dgi, dgh, dh_prev, B, H);
+                       nullptr, nullptr, stash, h_prev, dgi, dgh, dh_prev, B, H);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
@@ -406,7 +415,7 @@ extern "C" ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const 
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
-    hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx);
+    hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, (float*)nullptr);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
@@ -428,7 +437,7 @@ extern "C" ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const 
     char* ws = (char*)workspace;
     const int nchunk = (T + kAttTB - 1) / kAttTB;
     AttArgs A{eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, scale, B, T, H, KS};
-    AttBwd G{ax, d_sx, d_ax_next, d_eh, d_ox, d_ax_prev, g_conv_w, g_conv_b, g_nn_w, g_nn_b,
+    AttBwd G{ax, d_sx, nullptr, d_ax_next, d_eh, d_ox, d_ax_prev, g_conv_w, g_conv_b, g_nn_w, g_nn_b,
              (float*)(ws + o[0]), (float*)(ws + o[1]), (float*)(ws + o[2]), nchunk};
     const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * H) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
@@ -456,5 +465,324 @@ extern "C" ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows,
     hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out,
                        rows, K);
     SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+// =====================================================================================================================
+// The decoder loop itself (seq2seq.py:77-112 and its BPTT), host side in C++: one library call enqueues every token's
+// kernels back to back (13 launches per token forward + backward), so the Python interpreter is off the launch path
+// -- the same move as sa_gru_stack_* for the encoder.  Tokens are strictly sequential (token t's input contains token
+// t-1's context), batch rows are few (B = 16 in the shipped config), so the projections are "skinny" products.
+// =====================================================================================================================
+#include "internal.h"
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// C[m, n] = sum_k A[m, k] B[n, k] (+ bias[n]) (+ C[m, n])  for few rows m: a workgroup owns a 16 x 16 output tile,
+// its four waves split K (v_mfma_f32_16x16x4_f32, 16-byte k-contiguous operand loads on both sides, LDS reduce).
+// Up to two problems per launch (blockIdx.z).  K % 4 == 0, lda / ldb % 4 == 0.
+struct SkinnyProb {
+    const float* A;
+    const float* B;
+    const float* bias;   // or NULL
+    float* C;
+    int N, K, accumulate;
+    long lda, ldb, ldc;
+};
+struct SkinnyArgs {
+    SkinnyProb p[2];
+    int M;
+};
+
+__global__ __launch_bounds__(256) void skinny_gemm_nt_kernel(SkinnyArgs S) {
+    __shared__ float red[4][256];
+    const SkinnyProb& P = S.p[blockIdx.z];
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    if (n0 >= P.N) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int kq = ((P.K / 4 + 3) / 4) * 4;  // per-wave K range, a multiple of 4
+    const int kbeg = wave * kq, kend = min(P.K, kbeg + kq);
+    const int row = min(m0 + i, S.M - 1), col = min(n0 + i, P.N - 1);
+    const float* a_row = P.A + (long)row * P.lda;
+    const float* b_row = P.B + (long)col * P.ldb;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {  // 4 x 16 k per trip: four independent 16-byte loads per side in flight
+        float4 a[4], b[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int k = k0 + 16 * it + 4 * g;
+            const bool ok = k < kend;
+            a[it] = ok ? *reinterpret_cast<const float4*>(a_row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[it] = ok ? *reinterpret_cast<const float4*>(b_row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, b[it].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, b[it].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, b[it].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, b[it].w, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(g * 4 + r) * 16 + i] = acc[r];
+    __syncthreads();
+    const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    const int m = m0 + rr, n = n0 + cc;
+    if (m < S.M && n < P.N) {
+        float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (P.bias) v += P.bias[n];
+        float* c = P.C + (long)m * P.ldc + n;
+        if (P.accumulate) v += *c;
+        *c = v;
+    }
+}
+
+void skinny_launch(const SkinnyProb* probs, int nprob, int M, hipStream_t stream) {
+    SkinnyArgs S;
+    int maxN = 0;
+    for (int i = 0; i < nprob; ++i) { S.p[i] = probs[i]; maxN = probs[i].N > maxN ? probs[i].N : maxN; }
+    if (nprob == 1) S.p[1] = S.p[0];
+    S.M = M;
+    hipLaunchKernelGGL(skinny_gemm_nt_kernel, dim3((maxN + 15) / 16, (M + 15) / 16, nprob), dim3(256), 0, stream, S);
+}
+
+// IDX[b] = y[b * U + t]
+__global__ void s2s_idx_kernel(const long long* __restrict__ y, long long* __restrict__ idx, int B, int U, int t) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) idx[b] = y[(long)b * U + t];
+}
+
+// ix[b, :] = emb[idx[b], :] (+ sx[b, :])
+__global__ __launch_bounds__(256) void s2s_embed_add_kernel(const float* __restrict__ emb, const long long* __restrict__ idx,
+                                                            const float* sx, float* __restrict__ ix, int E) {
+    const int b = blockIdx.x;
+    const float* src = emb + (long)idx[b] * E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x)
+        ix[(long)b * E + e] = src[e] + (sx ? sx[(long)b * E + e] : 0.f);
+}
+
+// out (C, R) = in (R, C)^T
+__global__ void s2s_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[(long)c * R + r] = tile[threadIdx.x][j];
+    }
+}
+
+struct S2SDims { int B, T, U1, H, E, KS, K; };
+
+struct S2SLayout {
+    size_t gi, gh, sx, logits, att, gemm, colsum;                                 // forward (+ shared)
+    size_t dOIN, DGI, DGH, DIX, d_ox, d_hprev, d_ax0, d_ax1, g_cw, g_cb, g_nw, g_nb, wihT, whhT;  // backward
+    size_t total;
+};
+
+S2SLayout s2s_layout(const S2SDims& d) {
+    S2SLayout L;
+    size_t p = 0;
+    auto take = [&](size_t nfloat) { size_t o = p; p += sa_align_up(nfloat * sizeof(float), 256); return o; };
+    const size_t BH = (size_t)d.B * d.H, UB = (size_t)d.U1 * d.B;
+    L.gi = take(3 * BH); L.gh = take(3 * BH); L.sx = take(BH); L.logits = take((size_t)d.B * d.K);
+    L.att = p; p += sa_align_up(sa_attention_workspace_bytes(d.B, d.T, d.H, d.KS), 256);
+    size_t gw = sa_gemm_workspace_bytes((int)UB, d.K, d.H);
+    const size_t c1 = sa_gemm_workspace_bytes(d.K, d.H, (int)UB), c2 = sa_gemm_workspace_bytes((int)UB, d.H, d.K);
+    const size_t c3 = sa_gemm_workspace_bytes(3 * d.H, d.E, (int)UB), c4 = sa_gemm_workspace_bytes(3 * d.H, d.H, (int)UB);
+    gw = gw > c1 ? gw : c1; gw = gw > c2 ? gw : c2; gw = gw > c3 ? gw : c3; gw = gw > c4 ? gw : c4;
+    L.gemm = p; p += sa_align_up(gw, 256);
+    size_t cs = sa_colsum_workspace_bytes((int)UB, 3 * d.H);
+    const size_t cs2 = sa_colsum_workspace_bytes((int)UB, d.K), cs3 = sa_colsum_workspace_bytes(d.B, d.H * d.KS);
+    cs = cs > cs2 ? cs : cs2; cs = cs > cs3 ? cs : cs3;
+    L.colsum = p; p += sa_align_up(cs, 256);
+    L.dOIN = take(UB * d.H); L.DGI = take(UB * 3 * d.H); L.DGH = take(UB * 3 * d.H); L.DIX = take(UB * d.E);
+    L.d_ox = take(BH); L.d_hprev = take(BH); L.d_ax0 = take((size_t)d.B * d.T); L.d_ax1 = take((size_t)d.B * d.T);
+    L.g_cw = take(BH * d.KS); L.g_cb = take(BH); L.g_nw = take(BH); L.g_nb = take(d.B);
+    L.wihT = take((size_t)3 * d.H * d.E); L.whhT = take((size_t)3 * d.H * d.H);
+    L.total = p;
+    return L;
+}
+
+bool s2s_ok(const S2SDims& d) {
+    return att_ok(d.B, d.T, d.H, d.KS) && d.U1 > 0 && d.E > 0 && d.K > 0 && (d.H & 3) == 0 && (d.E & 3) == 0 && d.E == d.H;
+}
+
+enum { P_EMB, P_WIH, P_WHH, P_BIH, P_BHH, P_CW, P_CB, P_NW, P_NB, P_FCW, P_FCB, P_COUNT };
+
+}  // namespace
+
+extern "C" size_t sa_s2s_decoder_workspace_bytes(int B, int T, int U1, int H, int E, int KS, int K) {
+    S2SDims d{B, T, U1, H, E, KS, K};
+    if (!s2s_ok(d)) return 0;
+    return s2s_layout(d).total;
+}
+
+#define S2S_CHECK(call)                                          \
+    do {                                                         \
+        ctcStatus_t st__ = (call);                               \
+        if (st__ != CTC_STATUS_SUCCESS) return st__;             \
+    } while (0)
+
+extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, const unsigned char* sample,
+                                          const float* const* params, int B, int T, int U, int H, int E, int KS, int K,
+                                          float scale, float* out, long long* IDX, float* IX, float* ST, float* HX,
+                                          float* AX, float* OIN, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
+    SA_CLEAR_ERR();
+    S2SDims d{B, T, U - 1, H, E, KS, K};
+    if (!eh || !y || !params || !out || !IDX || !IX || !ST || !HX || !AX || !OIN || !workspace || !s2s_ok(d))
+        return CTC_STATUS_INVALID_VALUE;
+    const S2SLayout L = s2s_layout(d);
+    if (workspace_bytes < L.total) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* gi = (float*)(ws + L.gi);
+    float* gh = (float*)(ws + L.gh);
+    float* sx = (float*)(ws + L.sx);
+    float* logits = (float*)(ws + L.logits);
+    float* hzero = (float*)(ws + L.d_hprev);  // a zero state for the first token (the backward region is free here)
+    if (hipMemsetAsync(hzero, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+    const float* const* P = params;
+    const size_t att_bytes = sa_attention_workspace_bytes(B, T, H, KS);
+    const int U1 = U - 1;
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 4 + 4 * (size_t)H) * sizeof(float);
+    if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
+        return CTC_STATUS_INVALID_VALUE;
+    (void)att_bytes;
+    for (int t = 0; t < U1; ++t) {
+        long long* idx = IDX + (long)t * B;
+        float* ix = IX + (long)t * B * E;
+        float* hx = HX + (long)t * B * H;
+        const float* hprev = t > 0 ? HX + (long)(t - 1) * B * H : hzero;
+        if (t > 0 && sample && sample[t]) {  // scheduled sampling: feed back the argmax of the previous token's logits
+            SkinnyProb q{OIN + (long)(t - 1) * B * H, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
+            skinny_launch(&q, 1, B, stream);
+            hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, logits, idx, (long)B, K);
+        } else {
+            hipLaunchKernelGGL(s2s_idx_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, y, idx, B, U, t);
+        }
+        hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], idx,
+                           t > 0 ? (const float*)sx : (const float*)nullptr, ix, E);
+        SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
+                            {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
+        skinny_launch(pr, 2, B, stream);
+        hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
+                           ST + (long)t * B * 4 * H, B, H);
+        AttArgs A{eh, hx, t > 0 ? AX + (long)(t - 1) * B * T : nullptr, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale,
+                  B, T, H, KS};
+        float* score = (float*)(ws + L.att);
+        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+        hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, AX + (long)t * B * T,
+                           sx, OIN + (long)t * B * H);
+    }
+    SA_CHECK_LAUNCH();
+    return sa_gemm_f32_impl(0, 1, U1 * B, K, H, 1.0f, OIN, H, P[P_FCW], H, 0.0f, out, K, P[P_FCB], nullptr,
+                            ws + L.gemm, L.colsum - L.gemm, stream);
+}
+
+extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* params, const float* d_out,
+                                          const long long* IDX, const float* IX, const float* ST, const float* HX,
+                                          const float* AX, const float* OIN, int B, int T, int U, int H, int E, int KS,
+                                          int K, int V, float scale, float* d_eh, float* const* grads, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
+    S2SDims d{B, T, U - 1, H, E, KS, K};
+    if (!eh || !params || !d_out || !IDX || !IX || !ST || !HX || !AX || !OIN || !d_eh || !grads || !workspace ||
+        !s2s_ok(d) || V <= 0)
+        return CTC_STATUS_INVALID_VALUE;
+    const S2SLayout L = s2s_layout(d);
+    if (workspace_bytes < L.total) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const float* const* P = params;
+    const int U1 = U - 1, UB = U1 * B;
+    float* dOIN = (float*)(ws + L.dOIN);
+    float* DGI = (float*)(ws + L.DGI);
+    float* DGH = (float*)(ws + L.DGH);
+    float* DIX = (float*)(ws + L.DIX);
+    float* d_ox = (float*)(ws + L.d_ox);
+    float* d_hprev = (float*)(ws + L.d_hprev);
+    float* d_ax[2] = {(float*)(ws + L.d_ax0), (float*)(ws + L.d_ax1)};
+    float* g_cw = (float*)(ws + L.g_cw);
+    float* wihT = (float*)(ws + L.wihT);
+    float* whhT = (float*)(ws + L.whhT);
+    void* gws = ws + L.gemm;
+    const size_t gbytes = L.colsum - L.gemm;
+    void* cws = ws + L.colsum;
+    const size_t cbytes = L.dOIN - L.colsum;
+
+    // everything that does not depend on the token loop: fc gradients and the gradient entering every token
+    S2S_CHECK(sa_gemm_f32_impl(1, 0, K, H, UB, 1.0f, d_out, K, OIN, H, 0.0f, grads[P_FCW], H, nullptr, nullptr, gws,
+                               gbytes, stream));
+    S2S_CHECK(sa_colsum_f32(d_out, K, UB, K, grads[P_FCB], 0, cws, cbytes, stream));
+    S2S_CHECK(sa_gemm_f32_impl(0, 0, UB, H, K, 1.0f, d_out, K, P[P_FCW], H, 0.0f, dOIN, H, nullptr, nullptr, gws, gbytes,
+                               stream));
+    // zero: d_eh, the running state gradient, the per-utterance attention-parameter partials (g_cw .. g_nb contiguous)
+    if (hipMemsetAsync(d_eh, 0, (size_t)B * T * H * sizeof(float), stream) != hipSuccess ||
+        hipMemsetAsync(d_hprev, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess ||
+        hipMemsetAsync(g_cw, 0, L.wihT - L.g_cw, stream) != hipSuccess)
+        return CTC_STATUS_MEMOPS_FAILED;
+    // W^T once, so that the per-token input gradients are k-contiguous "NT" products too
+    hipLaunchKernelGGL(s2s_transpose_kernel, dim3((E + 31) / 32, (3 * H + 31) / 32), dim3(32, 8), 0, stream, P[P_WIH],
+                       wihT, 3 * H, E);
+    hipLaunchKernelGGL(s2s_transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(32, 8), 0, stream, P[P_WHH],
+                       whhT, 3 * H, H);
+    const int nchunk = (T + kAttTB - 1) / kAttTB;
+    size_t ao[4];
+    att_layout(B, T, H, KS, ao);
+    char* aws = ws + L.att;
+    const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * H) * sizeof(float);
+    if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
+    for (int t = U1 - 1; t >= 0; --t) {
+        const bool has_next = t + 1 < U1;
+        const float* hx = HX + (long)t * B * H;
+        AttArgs A{eh, hx, t > 0 ? AX + (long)(t - 1) * B * T : nullptr, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale,
+                  B, T, H, KS};
+        // the context of token t fed the fc (dOIN[t]) and the next token's GRU input (DIX[t + 1])
+        AttBwd G{AX + (long)t * B * T, dOIN + (long)t * B * H, has_next ? DIX + (long)(t + 1) * B * E : nullptr,
+                 has_next ? d_ax[(t + 1) & 1] : nullptr, d_eh, d_ox, t > 0 ? d_ax[t & 1] : nullptr, g_cw,
+                 (float*)(ws + L.g_cb), (float*)(ws + L.g_nw), (float*)(ws + L.g_nb), (float*)(aws + ao[0]),
+                 (float*)(aws + ao[1]), (float*)(aws + ao[2]), nchunk};
+        hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
+        hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
+        hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
+        hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(B), dim3(256), 0, stream, A, G);
+        // the state of token t fed the fc, the attention and the next token's GRU
+        float* dgi = DGI + (long)t * B * 3 * H;
+        float* dgh = DGH + (long)t * B * 3 * H;
+        hipLaunchKernelGGL(grucell_gates_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream,
+                           dOIN + (long)t * B * H, (const float*)d_ox, (const float*)d_hprev, ST + (long)t * B * 4 * H,
+                           t > 0 ? HX + (long)(t - 1) * B * H : (const float*)nullptr, dgi, dgh, d_hprev, B, H);
+        SkinnyProb pr[2] = {{dgh, whhT, nullptr, d_hprev, H, 3 * H, 1, 3 * H, 3 * H, H},
+                            {dgi, wihT, nullptr, DIX + (long)t * B * E, E, 3 * H, 0, 3 * H, 3 * H, E}};
+        skinny_launch(pr, 2, B, stream);
+    }
+    SA_CHECK_LAUNCH();
+    // batched over all tokens: weight / bias / embedding gradients, attention parameters summed over utterances
+    S2S_CHECK(sa_gemm_f32_impl(1, 0, 3 * H, E, UB, 1.0f, DGI, 3 * H, IX, E, 0.0f, grads[P_WIH], E, nullptr, nullptr, gws,
+                               gbytes, stream));
+    if (U1 > 1) {
+        S2S_CHECK(sa_gemm_f32_impl(1, 0, 3 * H, H, UB - B, 1.0f, DGH + (long)B * 3 * H, 3 * H, HX, H, 0.0f, grads[P_WHH],
+                                   H, nullptr, nullptr, gws, gbytes, stream));
+    } else if (hipMemsetAsync(grads[P_WHH], 0, (size_t)3 * H * H * sizeof(float), stream) != hipSuccess) {
+        return CTC_STATUS_MEMOPS_FAILED;
+    }
+    S2S_CHECK(sa_colsum_f32(DGI, 3 * H, UB, 3 * H, grads[P_BIH], 0, cws, cbytes, stream));
+    S2S_CHECK(sa_colsum_f32(DGH, 3 * H, UB, 3 * H, grads[P_BHH], 0, cws, cbytes, stream));
+    S2S_CHECK(sa_embedding_bwd(DIX, IDX, grads[P_EMB], UB, E, V, stream));
+    S2S_CHECK(sa_colsum_f32(g_cw, (long)H * KS, B, H * KS, grads[P_CW], 0, cws, cbytes, stream));
+    S2S_CHECK(sa_colsum_f32((float*)(ws + L.g_cb), H, B, H, grads[P_CB], 0, cws, cbytes, stream));
+    S2S_CHECK(sa_colsum_f32((float*)(ws + L.g_nw), H, B, H, grads[P_NW], 0, cws, cbytes, stream));
+    S2S_CHECK(sa_colsum_f32((float*)(ws + L.g_nb), 1, B, 1, grads[P_NB], 0, cws, cbytes, stream));
     return CTC_STATUS_SUCCESS;
 }

@@ -2,12 +2,14 @@
 
 DecoderFunction is ONE autograd node for Seq2Seq.decode (:77-112): the teacher-forced (or scheduled-sampled) loop over
 output tokens -- embedding lookup (+ previous context), nn.GRUCell, NNAttention, fc -- with an explicit backward
-through the tokens (BPTT) that writes every parameter gradient straight into its slot.  Per token the forward issues
-an embedding gather, two small projections (sa_gemm_f32), the gate kernel, the attention kernel and an add; everything
-that does not depend on the loop (the fc over all tokens, every weight gradient, the embedding gradient) is one batched
-call after the loop.  `step` is the same arithmetic for one token without autograd (Seq2Seq.decode_step, :114-138).
+through the tokens (BPTT) that writes every parameter gradient straight into its slot.  The loop lives in the library
+(sa_s2s_decoder_fwd / _bwd): per token an index pick, an embedding gather (+ context), ONE launch for both GRU
+projections (MFMA "skinny" product), the gate kernel and two attention kernels; everything that does not depend on the
+loop (the fc over all tokens, every weight gradient, the embedding gradient) is one batched product after it.
+`step` is the same arithmetic for one token without autograd (Seq2Seq.decode_step, :114-138).
 All compute is the HIP library; a CPU tensor raises.
 """
+import ctypes
 import math
 import random
 
@@ -86,128 +88,73 @@ def step(eh, idx, state, P, log_t):
 _NAMES = ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "conv_w", "conv_b", "nn_w", "nn_b", "fc_w", "fc_b")
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class DecoderFunction(torch.autograd.Function):
     """(logits (B, U-1, V-1), aligns (B, U-1, T)) = decode(eh, y)  -- seq2seq.py:77-112.
     params (in _NAMES order): embedding.weight, dec_rnn.{weight_ih,weight_hh,bias_ih,bias_hh}, attend.conv.{weight,bias},
-    attend.nn.1.fc.{weight,bias}, fc.fc.{weight,bias}."""
+    attend.nn.1.fc.{weight,bias}, fc.fc.{weight,bias}.  The token loop and its backward are ONE library call each
+    (sa_s2s_decoder_fwd / _bwd)."""
 
     @staticmethod
     def forward(ctx, eh, y, log_t, sample_prob, *params):
         _lib.require_cuda(eh, "encoder states (move the model to the GPU: model.cuda())")
-        P = dict(zip(_NAMES, [p.detach() for p in params]))
         eh = eh.detach().contiguous()
-        y = y.to(device=eh.device, dtype=torch.int64)
+        y = y.to(device=eh.device, dtype=torch.int64).contiguous()
         B, T, H = eh.shape
-        U1 = y.shape[1] - 1
-        E = P["emb"].shape[1]
-        K = P["fc_w"].shape[0]
+        U = y.shape[1]
+        U1 = U - 1
+        V, E = params[0].shape
+        K = params[9].shape[0]
+        KS = params[5].shape[-1]
         dev = eh.device
-        conv_w = P["conv_w"].reshape(H, -1).contiguous()
-        nn_w = P["nn_w"].reshape(H).contiguous()
+        plist = [p.detach().contiguous() for p in params]
+        # scheduled sampling (:91-96): one draw of Python's RNG per token after the first, in the reference's order
+        flags = None
+        if sample_prob:
+            flags = (ctypes.c_ubyte * U1)(*([0] + [1 if random.random() < sample_prob else 0 for _ in range(U1 - 1)]))
         f = dict(dtype=torch.float32, device=dev)
+        out = torch.empty(U1, B, K, **f)
         IDX = torch.empty(U1, B, dtype=torch.int64, device=dev)
-        IX, HPREV = torch.empty(U1, B, E, **f), torch.empty(U1, B, H, **f)
-        ST, HX = torch.empty(U1, B, 4 * H, **f), torch.empty(U1, B, H, **f)
+        IX, ST, HX = torch.empty(U1, B, E, **f), torch.empty(U1, B, 4 * H, **f), torch.empty(U1, B, H, **f)
         AX, OIN = torch.empty(U1, B, T, **f), torch.empty(U1, B, H, **f)
         scale = math.log(T) if log_t else 1.0
         L = _L()
-        hprev = torch.zeros(B, H, **f)
-        sx = torch.empty(B, H, **f)
-        ws = _att_ws(B, T, H, conv_w.shape[1], dev)
-        for t in range(U1):
-            idx = y[:, t]
-            # scheduled sampling (:91-96): feed back the argmax of the previous token's logits
-            if t > 0 and sample_prob and random.random() < sample_prob:
-                idx = argmax_rows(ops.gemm(OIN[t - 1], P["fc_w"], trans_b=True, bias=P["fc_b"]))
-            IDX[t].copy_(idx)
-            embedding_rows(P["emb"], IDX[t], IX[t])
-            if t > 0:
-                ops.add_rows(IX[t], sx, out=IX[t])
-            HPREV[t].copy_(hprev)
-            gi = ops.gemm(IX[t], P["w_ih"], trans_b=True, bias=P["b_ih"])
-            gh = ops.gemm(hprev, P["w_hh"], trans_b=True, bias=P["b_hh"])
-            _lib.check(L.sa_grucell_gates_fwd(_lib.ptr(gi), _lib.ptr(gh), _lib.ptr(hprev), _lib.ptr(HX[t]),
-                                              _lib.ptr(ST[t]), B, H, _lib.cur_stream()), "sa_grucell_gates_fwd")
-            _lib.check(L.sa_attention_fwd(_lib.ptr(eh), _lib.ptr(HX[t]), _lib.ptr(AX[t - 1]) if t > 0 else None,
-                                          _lib.ptr(conv_w), _lib.ptr(P["conv_b"]), _lib.ptr(nn_w), _lib.ptr(P["nn_b"]),
-                                          scale, _lib.ptr(AX[t]), _lib.ptr(sx), B, T, H, conv_w.shape[1],
-                                          _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_attention_fwd")
-            ops.add_rows(HX[t], sx, out=OIN[t])
-            hprev = HX[t]
-        out = ops.gemm(OIN.view(U1 * B, H), P["fc_w"], trans_b=True, bias=P["fc_b"]).view(U1, B, K)
+        nbytes = L.sa_s2s_decoder_workspace_bytes(B, T, U1, H, E, KS, K)
+        if nbytes == 0:
+            raise _lib.SpeechAmdError("Seq2Seq decoder: unsupported shape (embedding_dim == rnn dim, dims % 4 == 0, "
+                                      "odd location kernel <= 15 taps)")
+        ws = _lib.WORKSPACE.get(nbytes, dev, "s2s_decoder")
+        _lib.check(L.sa_s2s_decoder_fwd(_lib.ptr(eh), _lib.ptr(y), flags, _ptr_array(plist), B, T, U, H, E, KS, K, scale,
+                                        _lib.ptr(out), _lib.ptr(IDX), _lib.ptr(IX), _lib.ptr(ST), _lib.ptr(HX),
+                                        _lib.ptr(AX), _lib.ptr(OIN), _lib.ptr(ws), ws.numel(), _lib.cur_stream()),
+                   "sa_s2s_decoder_fwd")
         if any(ctx.needs_input_grad):
-            ctx.saved = (eh, P, conv_w, nn_w, IDX, IX, HPREV, ST, HX, AX, OIN, scale)
+            ctx.saved = (eh, plist, IDX, IX, ST, HX, AX, OIN, scale, (B, T, U, H, E, KS, K, V))
             ctx.slots = [getattr(p, "_grad_slot", None) for p in params]
+            ctx.shapes = [tuple(p.shape) for p in params]
         aligns = AX.transpose(0, 1)
         ctx.mark_non_differentiable(aligns)
         return out.transpose(0, 1), aligns
 
     @staticmethod
     def backward(ctx, d_out, _d_aligns):
-        eh, P, conv_w, nn_w, IDX, IX, HPREV, ST, HX, AX, OIN, scale = ctx.saved
-        S = dict(zip(_NAMES, ctx.slots))
-        B, T, H = eh.shape
-        U1, E = IX.shape[0], IX.shape[2]
-        K = P["fc_w"].shape[0]
-        KS = conv_w.shape[1]
+        eh, plist, IDX, IX, ST, HX, AX, OIN, scale, (B, T, U, H, E, KS, K, V) = ctx.saved
         dev = eh.device
-        f = dict(dtype=torch.float32, device=dev)
+        dO = d_out.transpose(0, 1).contiguous()
+        d_eh = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+        # every gradient goes straight into its slot of the flat buffer when the parameter has one
+        grads = [s if s is not None else torch.empty(shape, dtype=torch.float32, device=dev)
+                 for s, shape in zip(ctx.slots, ctx.shapes)]
         L = _L()
-        dO = d_out.transpose(0, 1).contiguous().view(U1 * B, K)
-        g = {}
-        g["fc_w"] = ops.gemm(dO, OIN.view(U1 * B, H), trans_a=True, out=S["fc_w"])
-        g["fc_b"] = ops.colsum(dO, out=S["fc_b"])
-        dOIN = ops.gemm(dO, P["fc_w"]).view(U1, B, H)
-        d_eh = torch.zeros(B, T, H, **f)
-        g_cw, g_cb = torch.zeros(B, H * KS, **f), torch.zeros(B, H, **f)
-        g_nw, g_nb = torch.zeros(B, H, **f), torch.zeros(B, 1, **f)
-        DGI, DGH = torch.empty(U1, B, 3 * H, **f), torch.empty(U1, B, 3 * H, **f)
-        DIX = torch.empty(U1, B, E, **f)
-        d_ox, d_hx, d_hprev = torch.empty(B, H, **f), torch.empty(B, H, **f), torch.zeros(B, H, **f)
-        d_sx = torch.empty(B, H, **f)
-        d_ax = [torch.empty(B, T, **f), torch.empty(B, T, **f)]
-        have_next = False
-        ws = _att_ws(B, T, H, KS, dev)
-        for t in range(U1 - 1, -1, -1):
-            # the context of token t feeds the fc (dOIN[t]) and the next token's GRU input (DIX[t + 1])
-            if have_next:
-                ops.add_rows(dOIN[t], DIX[t + 1], out=d_sx)
-            else:
-                d_sx.copy_(dOIN[t])
-            d_ax_next = d_ax[(t + 1) & 1] if have_next else None
-            _lib.check(L.sa_attention_bwd(_lib.ptr(eh), _lib.ptr(HX[t]), _lib.ptr(AX[t - 1]) if t > 0 else None,
-                                          _lib.ptr(conv_w), _lib.ptr(P["conv_b"]), _lib.ptr(nn_w), _lib.ptr(P["nn_b"]),
-                                          scale, _lib.ptr(AX[t]), _lib.ptr(d_sx), _lib.ptr(d_ax_next), _lib.ptr(d_eh),
-                                          _lib.ptr(d_ox), _lib.ptr(d_ax[t & 1]) if t > 0 else None, _lib.ptr(g_cw),
-                                          _lib.ptr(g_cb), _lib.ptr(g_nw), _lib.ptr(g_nb), B, T, H, KS,
-                                          _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_attention_bwd")
-            # the decoder state of token t feeds the fc, the attention and the next token's GRU
-            ops.add_rows(dOIN[t], d_ox, out=d_hx)
-            ops.add_rows(d_hx, d_hprev, out=d_hx)
-            _lib.check(L.sa_grucell_gates_bwd(_lib.ptr(d_hx), _lib.ptr(ST[t]), _lib.ptr(HPREV[t]), _lib.ptr(DGI[t]),
-                                              _lib.ptr(DGH[t]), _lib.ptr(d_hprev), B, H, _lib.cur_stream()),
-                       "sa_grucell_gates_bwd")
-            ops.gemm(DGH[t], P["w_hh"], out=d_hprev, beta=1.0)
-            ops.gemm(DGI[t], P["w_ih"], out=DIX[t])
-            have_next = True
-        g["w_ih"] = ops.gemm(DGI.view(U1 * B, 3 * H), IX.view(U1 * B, E), trans_a=True, out=S["w_ih"])
-        g["w_hh"] = ops.gemm(DGH.view(U1 * B, 3 * H), HPREV.view(U1 * B, H), trans_a=True, out=S["w_hh"])
-        g["b_ih"] = ops.colsum(DGI.view(U1 * B, 3 * H), out=S["b_ih"])
-        g["b_hh"] = ops.colsum(DGH.view(U1 * B, 3 * H), out=S["b_hh"])
-        V = P["emb"].shape[0]
-        g["emb"] = S["emb"] if S["emb"] is not None else torch.empty(V, E, **f)
-        _lib.check(L.sa_embedding_bwd(_lib.ptr(DIX), _lib.ptr(IDX), _lib.ptr(g["emb"]), U1 * B, E, V,
-                                      _lib.cur_stream()), "sa_embedding_bwd")
-
-        def reduce_b(part, name, shape):  # per-utterance partials -> the parameter's gradient (slot if it has one)
-            out = S[name].view(-1) if S[name] is not None else None
-            return ops.colsum(part, out=out).view(shape)
-
-        g["conv_w"] = reduce_b(g_cw, "conv_w", (H, 1, KS))
-        g["conv_b"] = reduce_b(g_cb, "conv_b", (H,))
-        g["nn_w"] = reduce_b(g_nw, "nn_w", (1, H))
-        g["nn_b"] = reduce_b(g_nb, "nn_b", (1,))
-        return (d_eh, None, None, None) + tuple(g[n] for n in _NAMES)
+        ws = _lib.WORKSPACE.get(L.sa_s2s_decoder_workspace_bytes(B, T, U - 1, H, E, KS, K), dev, "s2s_decoder")
+        _lib.check(L.sa_s2s_decoder_bwd(_lib.ptr(eh), _ptr_array(plist), _lib.ptr(dO), _lib.ptr(IDX), _lib.ptr(IX),
+                                        _lib.ptr(ST), _lib.ptr(HX), _lib.ptr(AX), _lib.ptr(OIN), B, T, U, H, E, KS, K, V,
+                                        scale, _lib.ptr(d_eh), _ptr_array(grads), _lib.ptr(ws), ws.numel(),
+                                        _lib.cur_stream()), "sa_s2s_decoder_bwd")
+        return (d_eh, None, None, None) + tuple(grads)
 
 
 class XentFunction(torch.autograd.Function):
