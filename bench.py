@@ -87,7 +87,8 @@ def gpu_leg(args, world, rank, local):
         for kind, name in ((0, "gru_fwd_step_kernel"), (1, "gru_bwd_step_kernel")):
             vi, vk = ctypes.c_float(0.0), ctypes.c_float(0.0)
             n = _lib.lib().sa_gru_profile_read(kind, ctypes.byref(vi), ctypes.byref(vk))
-            step_us[name] = (float(vi.value), float(vk.value), int(n))
+            step_us[name] = (float(vi.value), float(vk.value), int(n),
+                             int(_lib.lib().sa_gru_profile_steps_per_launch(kind)))
         _lib.lib().sa_gru_profile_configure(0)
     # per-op HIP-event spans (two event records per op on the host) are taken in a separate, untimed pass right after:
     # on a slow host they would otherwise sit on the launch path of the timed steps
@@ -163,15 +164,22 @@ def roofline(prof, step_us, steps):
     except Exception:
         traffic = {}
     for name, per_job in (("gru_bwd_step_kernel", 17), ("gru_fwd_step_kernel", 10)):
-        us, kern_us, n = step_us.get(name, (0.0, 0.0, 0))
-        if n == 0 or us <= 0:
+        us, kern_us, n, nsteps = step_us.get(name, (0.0, 0.0, 0, 1))
+        if n == 0:
             continue
-        nbytes = 4.0 * B * 512 * per_job * 4  # 4 layer-jobs per launch, B x H fp32 elements each
+        if nsteps > 1:
+            # the recurrence ran as persistent chunk kernels (one launch = `nsteps` time steps x 4 layer-jobs, launches
+            # separated by the chunk's GEMMs): duration = the kernel's own entry-to-exit clock
+            name, us = name.replace("_step_", "_persist_"), kern_us
+        if us <= 0:
+            continue
+        nbytes = 4.0 * B * 512 * per_job * 4 * nsteps  # 4 layer-jobs x nsteps steps per launch, B x H fp32 each
         ach = nbytes / (us * 1e-6) / 1e9
-        out[name] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name, {}).get("bytes_per_launch"),
-                     "avg_launch_us": us, "block0_kernel_us": kern_us,
-                     "samples": n, "bytes_per_launch": nbytes}
+        tr = traffic.get(name, {}).get("bytes_per_launch")
+        key = name.replace("_persist_", "_step_")
+        out[key] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": tr, "avg_launch_us": us, "block0_kernel_us": kern_us,
+                    "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps}
     g = prof.get("gemm")
     gemm = None
     if g and g["ms"] > 0:
@@ -180,8 +188,8 @@ def roofline(prof, step_us, steps):
                 "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFS, "traffic": None}
     main_entry = out.get("gru_bwd_step_kernel") or out.get("gru_fwd_step_kernel") or gemm
     if main_entry is not None and main_entry.get("bound") == "hbm":
-        main_entry = dict(main_entry, note="latency-bound recurrence: every launch starts with a cold L2 (per-XCD L2s "
-                          "are invalidated at kernel boundaries) and W_hh is re-streamed; see DESIGN.md 3.3")
+        main_entry = dict(main_entry, note="latency-bound recurrence (a cross-CU hand-off of the state every time step); "
+                          "see DESIGN.md 3.3")
     return main_entry, {"gru_fwd_step_kernel": out.get("gru_fwd_step_kernel"), "gemm_f32_kernel": gemm}
 
 

@@ -177,6 +177,18 @@ ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, con
  * configure(0) switches it off (the default).  The library's only process-global state. */
 void sa_gru_profile_configure(int enable);
 int sa_gru_profile_read(int kind, float* avg_interval_us, float* avg_kernel_us);
+/* time steps covered by each launch averaged by the last sa_gru_profile_read(kind): 1 for the step kernels, the chunk
+ * length for the persistent chunk kernels (whose launches are separated by GEMMs: their avg_interval_us is 0). */
+int sa_gru_profile_steps_per_launch(int kind);
+
+/* Unidirectional stacks with H = 512 (32 unit tiles), layers x ceil(B/16) <= 8, on a 256-CU device run the recurrence
+ * as PERSISTENT chunk kernels whose sync groups are XCD-local (one (layer, batch tile) group per XCD, hand-off through
+ * that XCD's L2; bit-identical to the step kernels; SA_GRU_PERSIST=0 switches them off).  A workgroup derives its
+ * group from the XCC id it actually runs on, so a dispatcher that does not spread 32 workgroups per XCD -- or a
+ * hand-off that times out -- cannot hang or silently corrupt: it raises the kernels' error word, which is copied to
+ * the host asynchronously and makes the NEXT sa_gru_stack_* call return CTC_STATUS_EXECUTION_FAILED (and the path
+ * switch itself off).  sa_gru_persist_status() waits for the latest word and returns it (0 = fine). */
+int sa_gru_persist_status(void);
 
 /* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients; two deterministic stages through `workspace`. */
 size_t sa_colsum_workspace_bytes(int M, int N);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "sa_gru_stack_bwd": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "sa_gru_profile_configure": (None, [c_int]),
     "sa_gru_profile_read": (c_int, [c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
+    "sa_gru_profile_steps_per_launch": (c_int, [c_int]),
+    "sa_gru_persist_status": (c_int, []),
     "sa_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),

@@ -193,22 +193,54 @@ struct PFwdJob {
 struct PFwdJobs {
     int n, B, H;
     long rb, rt;
+    // XCD-local mode (SA_GRU_PERSIST=2): the launch is always 8 groups x 32 workgroups; a workgroup takes its group
+    // from the XCC id it actually runs on and its unit tile from an arrival counter, so a sync group never spans
+    // XCDs whatever the dispatcher did (a group short of members times out into `err`, it cannot hang or corrupt).
+    int xcd_mode, nbt, ntile_u;
+    unsigned* reg;       // [8] arrival counters, monotonic over the stack call
+    unsigned reg_base;   // arrivals per counter before this launch
+    unsigned long long* stamp;  // profiling: the (0, 0, 0) workgroup writes wall_clock64() at entry / exit (null: off)
     unsigned* err;
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
     PFwdJob j[kMaxJobs];
 };
 
+__device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;
+}
+
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
-    const PFwdJob& J = P.j[blockIdx.z];
+    int role_x = blockIdx.x, role_y = blockIdx.y, role_z = blockIdx.z;
+    if (P.xcd_mode) {
+        __shared__ int s_role[2];
+        if (threadIdx.x == 0) {
+            const int x = xcc_id();
+            s_role[0] = x;
+            s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                              P.reg_base);
+        }
+        __syncthreads();
+        role_z = s_role[0] / P.nbt;
+        role_y = s_role[0] - role_z * P.nbt;
+        role_x = s_role[1];
+        if (role_x < 0 || role_x >= P.ntile_u) {  // more than 32 workgroups landed on this XCD
+            if (threadIdx.x == 0) atomicExch(P.err, 2u);
+            return;
+        }
+        if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront
+    }
+    const PFwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B;
+    const bool stamper = P.xcd_mode && P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
     const int LDW = H + 4;                       // padded row pitch: 16-byte aligned, spreads the fragment reads
     float* Wl = psm;                             // [48][LDW]: rows u0.., H+u0.., 2H+u0.. of W_hh
     float* red = psm + 48 * LDW;                 // [4][3][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int ntile_u = gridDim.x;
-    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int ntile_u = P.xcd_mode ? P.ntile_u : (int)gridDim.x;
+    const int u0 = role_x * 16, b0 = role_y * 16;
 
     // W_hh slice -> LDS, once per launch
     for (int idx = tid; idx < 48 * (H / 4); idx += 256) {
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     const float e_br = J.b_hh[u], e_bz = J.b_hh[H + u], e_bn = J.b_hh[2 * H + u];
     float hp = 0.f;
     if (live && J.t0 > 0) hp = J.h_out[(long)b * J.hs_b + (long)(J.t0 - 1) * J.hs_t + u];
-    unsigned* counter = J.counters + blockIdx.y;
+    unsigned* counter = J.counters + role_y;
     const int kslice = H / 4, kbeg = wave * kslice;  // H % 64 == 0 (checked by the host)
     const int brow = min(b0 + i, B - 1);
     __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)J.h_out, 0, 0x7fffffff, 0x00020000);
@@ -316,14 +348,41 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         SA_TICK(2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the flag
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            // XCD-local groups: the RMW executes in the XCD's own L2 (workgroup scope = no sc1) and the pollers' sc1
+            // loads are served by that same L2 -- 1.3 us per barrier instead of a memory round trip
+            // (tools/ubench/xcd_exchange.hip).  NB a workgroup-scope LOAD would keep hitting a stale L1 line.
+            if (P.xcd_mode) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         SA_TICK(3)
     }
     if (timed) {
-        unsigned long long* o = P.timing + 4 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        unsigned long long* o = P.timing + 4 * ((role_z * (P.xcd_mode ? P.nbt : (int)gridDim.y) + role_y) * ntile_u + role_x);
         for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
     }
+    if (stamper) P.stamp[1] = wall_clock64();
 #undef SA_TICK
+}
+
+// Gate-gradient arithmetic shared by the step kernel and the persistent kernel.  Contraction is switched off inside:
+// the two kernels inline this into different surroundings and hipcc would otherwise pick different mul+add -> fma
+// fusions (observed: 1-ulp differences between the two paths); the explicit fmaf calls pin the fused ones.
+__device__ __forceinline__ float gru_bwd_total_dh(float dh_out, float r0, float r1, float r2, float r3, float dh_next,
+                                                  float z_next) {
+#pragma clang fp contract(off)
+    const float acc = ((r0 + r1) + r2) + r3;
+    return __builtin_fmaf(dh_next, z_next, dh_out + acc);
+}
+__device__ __forceinline__ void gru_bwd_gates(float dh, float r, float z, float n, float q, float hp, float& dpr,
+                                              float& dpz, float& dpn, float& dqn) {
+#pragma clang fp contract(off)
+    const float dn = dh * (1.0f - z);
+    const float dz = dh * (hp - n);
+    dpn = dn * (1.0f - n * n);
+    dpr = dpn * q * r * (1.0f - r);
+    dpz = dz * z * (1.0f - z);
+    dqn = dpn * r;
 }
 
 // ----------------------------------------------------------------------------------------------------- backward step
@@ -388,20 +447,159 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
     }
     __syncthreads();
     if (!live) { if (stamper) P.stamp[1] = wall_clock64(); return; }
-    if (have_next) {
-        dh += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        dh += dh_prev * z_next;
-    }
+    if (have_next)
+        dh = gru_bwd_total_dh(dh, red[0][threadIdx.x], red[1][threadIdx.x], red[2][threadIdx.x], red[3][threadIdx.x],
+                              dh_prev, z_next);
     J.dh_ping[(long)b * H + u] = dh;
-    const float dn = dh * (1.0f - z);
-    const float dz = dh * (hp - n);
-    const float dpn = dn * (1.0f - n * n);
-    const float dpr = dpn * q * r * (1.0f - r);
-    const float dpz = dz * z * (1.0f - z);
+    float dpr, dpz, dpn, dqn;
+    gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
     float* di = J.dai + row * H3;
     float* dhh = J.dah + row * H3;
     di[u] = dpr; di[H + u] = dpz; di[2 * H + u] = dpn;
-    dhh[u] = dpr; dhh[H + u] = dpz; dhh[2 * H + u] = dpn * r;
+    dhh[u] = dpr; dhh[H + u] = dpz; dhh[2 * H + u] = dqn;
+    if (stamper) P.stamp[1] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------- persistent backward chunk
+// The backward counterpart of gru_fwd_persist_kernel, XCD-local groups only (see PFwdJobs): one launch unwinds
+// `nsteps` consecutive time steps (descending) of up to 8 layer-jobs.  A block keeps its 16 rows of W_hh^T (16 x 3H)
+// in LDS and carries dh / z of the step it just produced in registers; what crosses CUs every step is the (B, 3H)
+// gate-gradient row block dah[t+1], published with write-through stores and read back with sc1 loads out of the
+// XCD's own L2.
+struct PBwdJob {
+    const float* dh_out;   // gradient wrt h_out, [b * ds_b + t * ds_t + j]
+    const float* stash;    // rows x 5H
+    const float* w_hh_t;   // (H, 3H)
+    float* dai;            // rows x 3H
+    float* dah;            // rows x 3H
+    float* dh_state;       // (B, H): running dh carried across launches
+    unsigned* counters;    // one per batch tile; monotonic over the whole stack call
+    long ds_b, ds_t;
+    int t_hi, nsteps, T;
+    unsigned base;
+};
+struct PBwdJobs {
+    int n, B, H, nbt, ntile_u;
+    long rb, rt;
+    unsigned* reg;
+    unsigned reg_base;
+    unsigned long long* stamp;
+    unsigned* err;
+    PBwdJob j[kMaxJobs];
+};
+
+__global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    const int role_z = s_role[0] / P.nbt, role_y = s_role[0] - role_z * P.nbt, role_x = s_role[1];
+    if (role_x < 0 || role_x >= P.ntile_u) {
+        if (threadIdx.x == 0) atomicExch(P.err, 2u);
+        return;
+    }
+    if (role_z >= P.n) return;
+    const PBwdJob& J = P.j[role_z];
+    const int H = P.H, B = P.B, H3 = 3 * P.H;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    const int LDW = H3 + 4;
+    float* Wl = psm;              // [16][LDW]: rows u0 .. u0+15 of W_hh^T
+    float* red = psm + 16 * LDW;  // [4][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    for (int idx = tid; idx < 16 * (H3 / 4); idx += 256) {
+        const int r = idx / (H3 / 4), c4 = idx - r * (H3 / 4);
+        *reinterpret_cast<float4*>(&Wl[r * LDW + 4 * c4]) =
+            *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + r) * H3 + 4 * c4);
+    }
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    float dh_run = 0.f, z_next = 0.f;
+    if (live && J.t_hi < J.T - 1) {
+        dh_run = J.dh_state[(long)b * H + u];
+        z_next = J.stash[((long)b * P.rb + (long)(J.t_hi + 1) * P.rt) * 5 * H + H + u];
+    }
+    unsigned* counter = J.counters + role_y;
+    const int kslice = H3 / 4, kbeg = wave * kslice;  // 3H % 64 == 0 (checked by the host)
+    const int brow = min(b0 + i, B - 1);
+    __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.dah, 0, 0x7fffffff, 0x00020000);
+    bool dead = false;
+    __syncthreads();
+
+    for (int s = 0; s < J.nsteps; ++s) {
+        const int t = J.t_hi - s;
+        const bool have_next = t < J.T - 1;
+        const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
+        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
+        if (live) {
+            dh = J.dh_out[(long)b * J.ds_b + (long)t * J.ds_t + u];
+            const float* st = J.stash + row * 5 * H;
+            r = st[u]; z = st[H + u]; n = st[2 * H + u]; q = st[3 * H + u]; hp = st[4 * H + u];
+        }
+        if (s > 0) {  // every unit tile of this (job, batch tile) must have published dah[t + 1]
+            if (tid == 0 && !dead) {
+                const unsigned need = J.base + (unsigned)P.ntile_u * (unsigned)s;
+                int spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    if (++spins > (1 << 22)) { dead = true; atomicExch(P.err, 1u); break; }
+                }
+            }
+            __syncthreads();
+        }
+        if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int abase = (int)((((long)brow * P.rb + (long)(t + 1) * P.rt) * H3) * 4);  // byte offset of the row
+            for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 192) {
+                f32x4v a[12];
+#pragma unroll
+                for (int it = 0; it < 12; ++it) {
+                    const int k = kk0 + 16 * it + 4 * g;
+                    a[it] = kk0 + 16 * it < kbeg + kslice
+                                ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
+                                : f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int it = 0; it < 12; ++it) {
+                    if (kk0 + 16 * it < kbeg + kslice) {
+                        const int k = kk0 + 16 * it + 4 * g;
+                        const float4 w = *reinterpret_cast<const float4*>(&Wl[i * LDW + k]);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, acc, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr];
+        }
+        __syncthreads();
+        if (live) {
+            if (have_next)
+                dh = gru_bwd_total_dh(dh, red[tid], red[256 + tid], red[512 + tid], red[768 + tid], dh_run, z_next);
+            float dpr, dpz, dpn, dqn;
+            gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
+            float* di = J.dai + row * H3;
+            float* dhh = J.dah + row * H3;
+            di[u] = dpr; di[H + u] = dpz; di[2 * H + u] = dpn;
+            __hip_atomic_store(dhh + u, dpr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through
+            __hip_atomic_store(dhh + H + u, dpz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dhh + 2 * H + u, dqn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dh_run = dh;
+            z_next = z;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (live) J.dh_state[(long)b * H + u] = dh_run;
     if (stamper) P.stamp[1] = wall_clock64();
 }
 
@@ -600,13 +798,47 @@ struct StepProfiler {
     unsigned long long* ring[2] = {nullptr, nullptr};   // device: [kRing][2] per kind
     unsigned char* full[2] = {nullptr, nullptr};        // host: launch was full width (L jobs)
     long count[2] = {0, 0};
+    int steps[2] = {1, 1};      // time steps covered by each launch recorded since the last read (1: step kernels)
     // flags: bit 0 = full width (L jobs), bit 1 = directly follows another step launch (no GEMM in between)
-    unsigned long long* slot(int kind, bool full_width, bool follows_step) {
+    unsigned long long* slot(int kind, bool full_width, bool follows_step, int nsteps = 1) {
         if (!on || count[kind] >= kRing) return nullptr;
         full[kind][count[kind]] = (full_width ? 1 : 0) | (follows_step ? 2 : 0);
+        if (full_width) steps[kind] = nsteps;
         return ring[kind] + 2 * (count[kind]++);
     }
 };
+
+// Outcome of the XCD-local persistent kernels (the library's other piece of process-global state): their error word is
+// copied to pinned host memory at the end of every stack call and looked at when the NEXT call starts (or on demand by
+// sa_gru_persist_status), so a placement / hand-off failure is reported one call late instead of costing a sync.
+struct PersistHealth {
+    unsigned* host = nullptr;
+    hipEvent_t ev = nullptr;
+    bool pending = false, broken = false;
+    bool init() {
+        if (host) return true;
+        if (hipHostMalloc((void**)&host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { host = nullptr; return false; }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+        *host = 0;
+        return true;
+    }
+    void submit(const unsigned* dev_err, hipStream_t stream) {
+        if (!init()) return;
+        if (hipMemcpyAsync(host, dev_err, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipEventRecord(ev, stream) == hipSuccess)
+            pending = true;
+    }
+    // 0 = fine (or nothing to report yet)
+    unsigned poll(bool wait) {
+        if (!pending) return 0;
+        if (wait) { if (hipEventSynchronize(ev) != hipSuccess) return 0; }
+        else if (hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        pending = false;
+        if (*host) broken = true;
+        return *host;
+    }
+};
+PersistHealth g_health;
 StepProfiler g_prof;
 }  // namespace
 
@@ -641,10 +873,15 @@ extern "C" int sa_gru_profile_read(int kind, float* avg_interval_us, float* avg_
         if (i + 1 < n && g_prof.full[kind][i + 1] == 3) { ti += (double)(h[2 * i + 2] - h[2 * i]); ++ni; }
     }
     free(h);
+    g_prof.steps[kind] = g_prof.steps[kind] > 0 ? g_prof.steps[kind] : 1;
     *avg_kernel_us = nk ? (float)(tk / nk * 0.01) : 0.f;      // 100 MHz ticks -> us
     *avg_interval_us = ni ? (float)(ti / ni * 0.01) : 0.f;
     return (int)nk;
 }
+
+extern "C" int sa_gru_profile_steps_per_launch(int kind) { return kind == 0 || kind == 1 ? g_prof.steps[kind] : 0; }
+
+extern "C" int sa_gru_persist_status(void) { return (int)g_health.poll(true); }
 
 constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
 
@@ -664,9 +901,10 @@ static int device_cus() {
 // tools/gru_persist_timing.py): bit-identical to the step kernels but 8.1 ms vs 7.0 ms per stack forward -- an
 // in-kernel step costs ~10 us (4.9 us waiting for the group's publish, 2.7 us reading the fresh 32 KB h rows with
 // sc1 loads, 1.3 us MFMA, 1 us epilogue + drain), i.e. the all-to-all seam is as expensive as the kernel boundary.
-static bool persist_enabled() {
+static int persist_mode() {  // 2 XCD-local groups (default where eligible), 1 chip-wide groups, 0 off
     const char* e = getenv("SA_GRU_PERSIST");
-    return e && e[0] == '1';
+    const int m = e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0)) : 2;
+    return (m == 2 && g_health.broken) ? 0 : m;
 }
 
 static int clamp_chunk(int chunk, int T) {
@@ -699,6 +937,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
@@ -750,9 +989,13 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
     const size_t plds = ((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float);
-    const bool persist = persist_enabled() && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
-                         (long)L * ntile_u * nbt <= device_cus() && (size_t)(L * nbt + 1) * 4 <= kSyncBytes &&
-                         (long)T * B * H * 4 < 0x7fffffffL;
+    bool persist = persist_mode() != 0 && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
+                   (long)L * ntile_u * nbt <= device_cus() && (size_t)(L * nbt + 1 + 8) * 4 <= 1024 &&
+                   (long)T * B * H * 4 < 0x7fffffffL;
+    // XCD-local groups: 8 XCDs x 32 CUs, one (layer, batch tile) group per XCD, 32 unit tiles per group
+    const bool xcd = persist && persist_mode() == 2 && ntile_u == 32 && L * nbt <= 8 && device_cus() == 256;
+    if (persist_mode() == 2 && !xcd) persist = false;
+    unsigned persist_launches = 0;
     if (persist) {
         if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -788,6 +1031,10 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         if (persist) {  // ONE launch runs the whole chunk of every active layer
             PFwdJobs Q;
             Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + L * nbt;
+            Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + L * nbt + 1;
+            Q.reg_base = persist_launches * 32u;
+            ++persist_launches;
+            Q.stamp = nullptr;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;  // 3 KB of the sync page
             int n = 0;
             for (int l = 0; l < L; ++l) {
@@ -800,7 +1047,9 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 J.base = (unsigned)ntile_u * (unsigned)J.t0;
             }
             Q.n = n;
-            hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
+            if (xcd) Q.stamp = g_prof.slot(0, n == L, false, chunk);
+            if (xcd) hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(256), dim3(256), plds, stream, Q);
+            else hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
             continue;
         }
         ch.fork();
@@ -824,6 +1073,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         ch.join();
     }
     SA_CHECK_LAUNCH();
+    if (xcd) g_health.submit(sync + L * nbt, stream);
     return CTC_STATUS_SUCCESS;
 }
 
@@ -834,7 +1084,7 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
-    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw;
+    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw + kSyncBytes;
 }
 
 // dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d] (T, B, 3H) for every layer and
@@ -849,6 +1099,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
@@ -856,7 +1107,8 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     char* ws = (char*)workspace;
     const size_t fixed_bytes = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
     char* gws = ws + fixed_bytes;
-    const size_t gws_bytes = workspace_bytes - fixed_bytes;
+    const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes;
+    unsigned* sync = (unsigned*)(ws + workspace_bytes - kSyncBytes);
     auto dh_buf = [&](int l, int d, int which) {
         return (float*)(ws + (size_t)(l * D + d) * per_dir) + (size_t)which * B * H;
     };
@@ -911,6 +1163,18 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     if (!ch.ok) return CTC_STATUS_EXECUTION_FAILED;
     P.tile_rows = ch.tile_rows;
     const int nch = (T + chunk - 1) / chunk;
+    // persistent XCD-local chunk kernel (SA_GRU_PERSIST=2; see gru_bwd_persist_kernel)
+    const int nbt = (B + 15) / 16, ntile_u = H / 16;
+    const size_t plds = ((size_t)16 * (3 * H + 4) + 4 * 256) * sizeof(float);
+    const bool xcd = persist_mode() == 2 && ch.n == 1 && (H % 64) == 0 && ntile_u == 32 && L * nbt <= 8 &&
+                     device_cus() == 256 && plds <= 160 * 1024 && (long)T * B * 3 * H * 4 < 0x7fffffffL;
+    unsigned persist_launches = 0;
+    if (xcd) {
+        if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+        if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)plds) != hipSuccess)
+            return CTC_STATUS_EXECUTION_FAILED;
+    }
     for (int w = 0; w < nch + L - 1; ++w) {
         // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
         {
@@ -937,6 +1201,28 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                 if (st != CTC_STATUS_SUCCESS) return st;
             }
         }
+        if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
+            PBwdJobs Q;
+            Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
+            Q.err = sync + L * nbt; Q.reg = sync + L * nbt + 1; Q.reg_base = persist_launches * 32u;
+            ++persist_launches;
+            int n = 0;
+            for (int l = L - 1; l >= 0; --l) {
+                const int cc = w - (L - 1 - l);
+                if (cc < 0 || cc >= nch) continue;
+                const int c = nch - 1 - cc;
+                PBwdJob& J = Q.j[n++];
+                J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
+                J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
+                J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
+                J.t_hi = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t_hi - c * chunk + 1; J.T = T;
+                J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t_hi);
+            }
+            Q.n = n;
+            Q.stamp = g_prof.slot(1, n == L, false, chunk);
+            hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(256), dim3(256), plds, stream, Q);
+            continue;
+        }
         ch.fork();
         for (int s = 0; s < chunk; ++s) {
             int n = 0;
@@ -959,6 +1245,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         ch.join();
     }
     SA_CHECK_LAUNCH();
+    if (xcd) g_health.submit(sync + L * nbt, stream);
     if (dx) {
         st = sa_gemm_f32_impl(0, 0, T * B, I0, 3 * H, 1.f, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, nullptr,
                               nullptr, 0, stream);

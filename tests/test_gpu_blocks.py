@@ -289,3 +289,40 @@ def test_persistent_chunk_kernel_is_bit_identical():
         subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=120)
         res.append(torch.load(out))
     assert len(res[0]) == len(res[1]) and all(torch.equal(a, b) for a, b in zip(*res))
+
+
+def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
+    """The default recurrence path at 512-wide unidirectional stacks (XCD-local persistent chunk kernels, forward and
+    backward) against the one-launch-per-step kernels (SA_GRU_PERSIST=0): every output bit-identical,
+    ragged last chunk included, and the kernels' error word clean."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_blocks import _stack_case\nfrom speech_amd import ops, _lib\n"
+            "L, B, T, I0, H = 4, 32, 70, 48, 512\n"
+            "x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)\n"
+            "dtop = torch.randn(T, B, H, device='cuda')\n"
+            "for _ in range(2):\n"
+            "    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True)\n"
+            "    dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0)\n"
+            "torch.cuda.synchronize()\n"
+            "assert _lib.lib().sa_gru_persist_status() == 0\n"
+            "torch.save([t.cpu() for t in h + st + dai + dah + [dx]], sys.argv[1])\n") % (root, root)
+    res = []
+    for mode in ("0", "2"):
+        out = "/tmp/sa_xcd_%s.pt" % mode
+        env = dict(os.environ, SA_GRU_PERSIST=mode)
+        subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=180)
+        res.append(torch.load(out))
+    assert len(res[0]) == len(res[1]) and all(torch.equal(a, b) for a, b in zip(*res))
+    # two batch tiles x 2 layers and a narrower batch also take the path (groups <= 8)
+    code2 = code.replace("L, B, T, I0, H = 4, 32, 70, 48, 512", "L, B, T, I0, H = 2, 20, 33, 48, 512")
+    res = []
+    for mode in ("0", "2"):
+        out = "/tmp/sa_xcd2_%s.pt" % mode
+        subprocess.run([sys.executable, "-c", code2, out], env=dict(os.environ, SA_GRU_PERSIST=mode), check=True,
+                       timeout=180)
+        res.append(torch.load(out))
+    assert all(torch.equal(a, b) for a, b in zip(*res))
