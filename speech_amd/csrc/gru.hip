@@ -907,8 +907,16 @@ static int persist_mode() {  // 2 XCD-local groups (default where eligible), 1 c
     return (m == 2 && g_health.broken) ? 0 : m;
 }
 
-static int clamp_chunk(int chunk, int T) {
-    if (chunk <= 0) chunk = 16;  // measured on MI355X at S-LIBRI: 16 -> 19.6 ms/step, 32 -> 19.9, 8 -> 20.5
+// shapes the XCD-local persistent kernels take: 8 XCDs x 32 CUs, one (layer, batch tile) group per XCD, 32 unit tiles
+static bool xcd_shape_ok(int L, int D, int B, int H) {
+    return persist_mode() == 2 && D == 1 && H == 512 && L * ((B + 15) / 16) <= 8 && device_cus() == 256;
+}
+
+static int clamp_chunk(int chunk, int T, bool persistent = false) {
+    // measured on MI355X at S-LIBRI, whole train step: step kernels 16 -> 19.6 ms, 32 -> 19.9, 8 -> 20.5;
+    // persistent chunk kernels (a wave of the layer wavefront costs one launch + one grouped GEMM whatever its
+    // length) 8 -> 18.3, 16 -> 16.4, 24 -> 16.0, 28 -> 15.7, 32 -> 15.8, 40 -> 15.7, 48 -> 15.8, 64 -> 16.5
+    if (chunk <= 0) chunk = persistent ? 32 : 16;
     return chunk > T ? T : chunk;
 }
 static size_t stack_gemm_ws(int L, int B, int T, int H, int chunk, bool fwd) {
@@ -938,7 +946,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
-    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && xcd_shape_ok(L, D, B, H));
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
     const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kSyncBytes;
@@ -1100,7 +1108,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
-    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && xcd_shape_ok(L, D, B, H));
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
     const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
