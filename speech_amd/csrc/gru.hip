@@ -187,7 +187,8 @@ struct PFwdJob {
     float* stash;
     unsigned* counters;  // one per batch tile; monotonic over the whole stack call
     long hs_b, hs_t;
-    int t0, nsteps;
+    int t0, nsteps;      // first time index of this launch, number of steps
+    int dt, t_first;     // +1 / -1 (reverse direction of a bidirectional layer); the sequence's very first time index
     unsigned base;       // arrivals per counter before this launch
 };
 struct PFwdJobs {
@@ -221,14 +222,16 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                               P.reg_base);
         }
         __syncthreads();
-        role_z = s_role[0] / P.nbt;
-        role_y = s_role[0] - role_z * P.nbt;
-        role_x = s_role[1];
-        if (role_x < 0 || role_x >= P.ntile_u) {  // more than 32 workgroups landed on this XCD
+        if (s_role[1] < 0 || s_role[1] >= 32) {  // more than 32 workgroups landed on this XCD
             if (threadIdx.x == 0) atomicExch(P.err, 2u);
             return;
         }
-        if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront
+        // an XCD hosts 32 / ntile_u groups (narrower layers: 16 or 8 unit tiles per group)
+        const int sub = s_role[1] / P.ntile_u, g = s_role[0] * (32 / P.ntile_u) + sub;
+        role_x = s_role[1] - sub * P.ntile_u;
+        role_z = g / P.nbt;
+        role_y = g - role_z * P.nbt;
+        if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront, or fewer groups than slots
     }
     const PFwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     const bool live = b < B;
     const float e_br = J.b_hh[u], e_bz = J.b_hh[H + u], e_bn = J.b_hh[2 * H + u];
     float hp = 0.f;
-    if (live && J.t0 > 0) hp = J.h_out[(long)b * J.hs_b + (long)(J.t0 - 1) * J.hs_t + u];
+    if (live && J.t0 != J.t_first) hp = J.h_out[(long)b * J.hs_b + (long)(J.t0 - J.dt) * J.hs_t + u];
     unsigned* counter = J.counters + role_y;
     const int kslice = H / 4, kbeg = wave * kslice;  // H % 64 == 0 (checked by the host)
     const int brow = min(b0 + i, B - 1);
@@ -267,7 +270,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
 
     for (int s = 0; s < J.nsteps; ++s) {
-        const int t = J.t0 + s;
+        const int t = J.t0 + s * J.dt;
+        const bool has_prev = t != J.t_first;
         const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
         float e_ai_r = 0.f, e_ai_z = 0.f, e_ai_n = 0.f;
         if (live) {
@@ -286,11 +290,11 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
             __syncthreads();
         }
         SA_TICK(0)
-        if (t > 0) {
+        if (has_prev) {
             f32x4 acc[3];
 #pragma unroll
             for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int abase = (int)(((long)brow * J.hs_b + (long)(t - 1) * J.hs_t) * 4);  // byte offset of the h row
+            const int abase = (int)(((long)brow * J.hs_b + (long)(t - J.dt) * J.hs_t) * 4);  // byte offset of the h row
             for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 128) {
                 f32x4v a[8];
 #pragma unroll
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         __syncthreads();
         SA_TICK(1)
         float sr = 0.f, sz = 0.f, sn = 0.f;
-        if (t > 0) {
+        if (has_prev) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 sr += red[(w * 3 + 0) * 256 + tid];
@@ -475,7 +479,8 @@ struct PBwdJob {
     float* dh_state;       // (B, H): running dh carried across launches
     unsigned* counters;    // one per batch tile; monotonic over the whole stack call
     long ds_b, ds_t;
-    int t_hi, nsteps, T;
+    int t0, nsteps;        // first time index this launch unwinds, number of steps
+    int dt, t_first;       // -1 for a forward-in-time chain (unwinds from T-1), +1 for a reverse chain; the very first index
     unsigned base;
 };
 struct PBwdJobs {
@@ -497,11 +502,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
     }
     __syncthreads();
-    const int role_z = s_role[0] / P.nbt, role_y = s_role[0] - role_z * P.nbt, role_x = s_role[1];
-    if (role_x < 0 || role_x >= P.ntile_u) {
+    if (s_role[1] < 0 || s_role[1] >= 32) {
         if (threadIdx.x == 0) atomicExch(P.err, 2u);
         return;
     }
+    const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt;
     if (role_z >= P.n) return;
     const PBwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B, H3 = 3 * P.H;
@@ -522,9 +528,9 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     const int b = b0 + bi, u = u0 + uj;
     const bool live = b < B;
     float dh_run = 0.f, z_next = 0.f;
-    if (live && J.t_hi < J.T - 1) {
+    if (live && J.t0 != J.t_first) {
         dh_run = J.dh_state[(long)b * H + u];
-        z_next = J.stash[((long)b * P.rb + (long)(J.t_hi + 1) * P.rt) * 5 * H + H + u];
+        z_next = J.stash[((long)b * P.rb + (long)(J.t0 - J.dt) * P.rt) * 5 * H + H + u];
     }
     unsigned* counter = J.counters + role_y;
     const int kslice = H3 / 4, kbeg = wave * kslice;  // 3H % 64 == 0 (checked by the host)
@@ -534,8 +540,8 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     __syncthreads();
 
     for (int s = 0; s < J.nsteps; ++s) {
-        const int t = J.t_hi - s;
-        const bool have_next = t < J.T - 1;
+        const int t = J.t0 + s * J.dt;
+        const bool have_next = t != J.t_first;
         const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
         float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
         if (live) {
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         }
         if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int abase = (int)((((long)brow * P.rb + (long)(t + 1) * P.rt) * H3) * 4);  // byte offset of the row
+            const int abase = (int)((((long)brow * P.rb + (long)(t - J.dt) * P.rt) * H3) * 4);  // byte offset of the row
             for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 192) {
                 f32x4v a[12];
 #pragma unroll
@@ -907,10 +913,16 @@ static int persist_mode() {  // 2 XCD-local groups (default where eligible), 1 c
     return (m == 2 && g_health.broken) ? 0 : m;
 }
 
-// shapes the XCD-local persistent kernels take: 8 XCDs x 32 CUs, one (layer, batch tile) group per XCD, 32 unit tiles
-static bool xcd_shape_ok(int L, int D, int B, int H) {
-    return persist_mode() == 2 && D == 1 && H == 512 && L * ((B + 15) / 16) <= 8 && device_cus() == 256;
+// shapes the XCD-local persistent kernels take: 8 XCDs x 32 CUs; a sync group = one (concurrent job, batch tile) with
+// H / 16 = 32, 16 or 8 unit tiles, so an XCD hosts 1, 2 or 4 groups.  jobs = layers in flight (unidirectional layer
+// wavefront) or the 2 directions of one bidirectional layer.
+constexpr int kSyncErr = 200, kSyncReg = 201;  // word offsets in the sync page (counters occupy [0, 200))
+static bool xcd_shape_ok(int jobs, int B, int H) {
+    const int ntile_u = H / 16;
+    if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256) return false;
+    return jobs * ((B + 15) / 16) <= 8 * (32 / ntile_u);
 }
+static size_t xcd_lds(size_t need) { return need < 84 * 1024 ? 84 * 1024 : need; }  // > half a CU's LDS: one per CU
 
 static int clamp_chunk(int chunk, int T, bool persistent = false) {
     // measured on MI355X at S-LIBRI, whole train step: step kernels 16 -> 19.6 ms, 32 -> 19.9, 8 -> 20.5;
@@ -946,7 +958,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
-    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && xcd_shape_ok(L, D, B, H));
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H));
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
     const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kSyncBytes;
@@ -967,6 +979,16 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
 
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
                    // the two directions of a layer share every launch
+        const int bi_nbt = (B + 15) / 16;
+        const size_t bi_lds = xcd_lds(((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float));
+        const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
+                            (long)T * B * DH * 4 < 0x7fffffffL;
+        if (bi_xcd) {
+            if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bi_lds) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+        }
         for (int l = 0; l < L; ++l) {
             const float* in = l == 0 ? x : h_out[l - 1];
             const int I = l == 0 ? I0 : 2 * H;
@@ -974,6 +996,22 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I, 1.f, in, I, w_ih[l * 2 + d], I, 0.f, ai_of(l, d), 3 * H,
                                       b_ih[l * 2 + d], nullptr, nullptr, 0, stream);
                 if (st != CTC_STATUS_SUCCESS) return st;
+            }
+            if (bi_xcd) {  // ONE persistent launch runs both directions of the layer over all T steps
+                PFwdJobs Q;
+                Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + kSyncErr; Q.timing = nullptr;
+                Q.xcd_mode = 1; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
+                Q.reg_base = (unsigned)l * 32u; Q.stamp = nullptr; Q.n = 2;
+                for (int d = 0; d < 2; ++d) {
+                    PFwdJob& J = Q.j[d];
+                    J.ai = ai_of(l, d); J.w_hh = w_hh[l * 2 + d]; J.b_hh = b_hh[l * 2 + d];
+                    J.h_out = h_out[l] + (long)d * H; J.stash = stash ? stash[l * 2 + d] : nullptr;
+                    J.counters = sync + (l * 2 + d) * bi_nbt;
+                    J.hs_b = DH; J.hs_t = (long)B * DH; J.nsteps = T; J.base = 0;
+                    J.dt = d ? -1 : 1; J.t0 = J.t_first = d ? T - 1 : 0;
+                }
+                hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(256), dim3(256), bi_lds, stream, Q);
+                continue;
             }
             P.n = 2; grid.z = 2;
             for (int s = 0; s < T; ++s) {
@@ -983,6 +1021,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
         }
         SA_CHECK_LAUNCH();
+        if (bi_xcd) g_health.submit(sync + kSyncErr, stream);
         return CTC_STATUS_SUCCESS;
     }
 
@@ -996,13 +1035,14 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     const int nch = (T + chunk - 1) / chunk;
     // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
-    const size_t plds = ((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float);
+    size_t plds = ((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float);
     bool persist = persist_mode() != 0 && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
-                   (long)L * ntile_u * nbt <= device_cus() && (size_t)(L * nbt + 1 + 8) * 4 <= 1024 &&
+                   (long)L * ntile_u * nbt <= device_cus() && L * nbt <= kSyncErr &&
                    (long)T * B * H * 4 < 0x7fffffffL;
-    // XCD-local groups: 8 XCDs x 32 CUs, one (layer, batch tile) group per XCD, 32 unit tiles per group
-    const bool xcd = persist && persist_mode() == 2 && ntile_u == 32 && L * nbt <= 8 && device_cus() == 256;
+    // XCD-local groups: 8 XCDs x 32 CUs, 32 / ntile_u (layer, batch tile) groups per XCD
+    const bool xcd = persist && xcd_shape_ok(L, B, H);
     if (persist_mode() == 2 && !xcd) persist = false;
+    if (xcd) plds = xcd_lds(plds);
     unsigned persist_launches = 0;
     if (persist) {
         if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
@@ -1038,8 +1078,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         }
         if (persist) {  // ONE launch runs the whole chunk of every active layer
             PFwdJobs Q;
-            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + L * nbt;
-            Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + L * nbt + 1;
+            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + kSyncErr;
+            Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
             Q.reg_base = persist_launches * 32u;
             ++persist_launches;
             Q.stamp = nullptr;
@@ -1052,6 +1092,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 J.ai = ai_of(l, 0); J.w_hh = w_hh[l]; J.b_hh = b_hh[l]; J.h_out = h_out[l];
                 J.stash = stash ? stash[l] : nullptr; J.counters = sync + l * nbt;
                 J.hs_b = H; J.hs_t = (long)B * H; J.t0 = c * chunk; J.nsteps = min(chunk, T - J.t0);
+                J.dt = 1; J.t_first = 0;
                 J.base = (unsigned)ntile_u * (unsigned)J.t0;
             }
             Q.n = n;
@@ -1081,7 +1122,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         ch.join();
     }
     SA_CHECK_LAUNCH();
-    if (xcd) g_health.submit(sync + L * nbt, stream);
+    if (xcd) g_health.submit(sync + kSyncErr, stream);
     return CTC_STATUS_SUCCESS;
 }
 
@@ -1108,7 +1149,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
-    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && xcd_shape_ok(L, D, B, H));
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H));
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
     const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
@@ -1145,12 +1186,39 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     };
 
     if (D == 2) {
+        const int bi_nbt = (B + 15) / 16;
+        const size_t bi_lds = xcd_lds(((size_t)16 * (3 * H + 4) + 4 * 256) * sizeof(float));
+        const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
+                            (long)T * B * 3 * H * 4 < 0x7fffffffL;
+        if (bi_xcd) {
+            if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bi_lds) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+        }
         for (int l = L - 1; l >= 0; --l) {
+            if (bi_xcd) {  // ONE persistent launch unwinds both directions of the layer over all T steps
+                PBwdJobs Q;
+                Q.B = B; Q.H = H; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.rb = 1; Q.rt = B;
+                Q.err = sync + kSyncErr; Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
+                Q.stamp = nullptr; Q.n = 2;
+                for (int d = 0; d < 2; ++d) {
+                    PBwdJob& J = Q.j[d];
+                    const float* dho = (l == L - 1) ? dh_top : mid_of(l);
+                    J.dh_out = dho + (long)d * H; J.ds_b = DH; J.ds_t = (long)B * DH;
+                    J.stash = stash[l * 2 + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * 2 + d]; J.dah = dah[l * 2 + d];
+                    J.dh_state = dh_buf(l, d, 0); J.counters = sync + (l * 2 + d) * bi_nbt;
+                    J.nsteps = T; J.base = 0;
+                    J.dt = d ? 1 : -1; J.t0 = J.t_first = d ? 0 : T - 1;   // the reverse chain unwinds forward in time
+                }
+                hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(256), dim3(256), bi_lds, stream, Q);
+            } else {
             P.n = 2; grid.z = 2;
             for (int s = 0; s < T; ++s) {
                 P.j[0] = make_job(l, 0, T - 1 - s, s == 0 ? -1 : T - s, s);      // forward-in-time direction unwinds
                 P.j[1] = make_job(l, 1, s, s == 0 ? -1 : s - 1, s);              // reverse direction unwinds forward
                 hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, stream, P);
+            }
             }
             // gradient wrt this layer's input = sum over directions of dai W_ih
             float* din = l > 0 ? mid_of(l - 1) : dx;
@@ -1163,6 +1231,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                 }
         }
         SA_CHECK_LAUNCH();
+        if (bi_xcd) g_health.submit(sync + kSyncErr, stream);
         return CTC_STATUS_SUCCESS;
     }
 
@@ -1173,9 +1242,9 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     const int nch = (T + chunk - 1) / chunk;
     // persistent XCD-local chunk kernel (SA_GRU_PERSIST=2; see gru_bwd_persist_kernel)
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
-    const size_t plds = ((size_t)16 * (3 * H + 4) + 4 * 256) * sizeof(float);
-    const bool xcd = persist_mode() == 2 && ch.n == 1 && (H % 64) == 0 && ntile_u == 32 && L * nbt <= 8 &&
-                     device_cus() == 256 && plds <= 160 * 1024 && (long)T * B * 3 * H * 4 < 0x7fffffffL;
+    const size_t plds = xcd_lds(((size_t)16 * (3 * H + 4) + 4 * 256) * sizeof(float));
+    const bool xcd = ch.n == 1 && xcd_shape_ok(L, B, H) && L * nbt <= kSyncErr && plds <= 160 * 1024 &&
+                     (long)T * B * 3 * H * 4 < 0x7fffffffL;
     unsigned persist_launches = 0;
     if (xcd) {
         if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
@@ -1212,7 +1281,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
-            Q.err = sync + L * nbt; Q.reg = sync + L * nbt + 1; Q.reg_base = persist_launches * 32u;
+            Q.err = sync + kSyncErr; Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
             ++persist_launches;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
@@ -1223,8 +1292,8 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                 J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
                 J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
-                J.t_hi = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t_hi - c * chunk + 1; J.T = T;
-                J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t_hi);
+                J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
+                J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);
             }
             Q.n = n;
             Q.stamp = g_prof.slot(1, n == L, false, chunk);
@@ -1253,7 +1322,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         ch.join();
     }
     SA_CHECK_LAUNCH();
-    if (xcd) g_health.submit(sync + L * nbt, stream);
+    if (xcd) g_health.submit(sync + kSyncErr, stream);
     if (dx) {
         st = sa_gemm_f32_impl(0, 0, T * B, I0, 3 * H, 1.f, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, nullptr,
                               nullptr, 0, stream);

@@ -294,7 +294,8 @@ def test_persistent_chunk_kernel_is_bit_identical():
 def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     """The default recurrence path at 512-wide unidirectional stacks (XCD-local persistent chunk kernels, forward and
     backward) against the one-launch-per-step kernels (SA_GRU_PERSIST=0): every output bit-identical,
-    ragged last chunk included, and the kernels' error word clean."""
+    ragged last chunk included, and the kernels' error word clean.  (Same chunk length on both sides: the library's
+    default differs per path, and the chunk sets the shape -- hence the split-K order -- of the projection GEMMs.)"""
     import os
     import subprocess
     import sys
@@ -305,8 +306,8 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
             "x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)\n"
             "dtop = torch.randn(T, B, H, device='cuda')\n"
             "for _ in range(2):\n"
-            "    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True)\n"
-            "    dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0)\n"
+            "    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True, chunk=16)\n"
+            "    dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0, chunk=16)\n"
             "torch.cuda.synchronize()\n"
             "assert _lib.lib().sa_gru_persist_status() == 0\n"
             "torch.save([t.cpu() for t in h + st + dai + dah + [dx]], sys.argv[1])\n") % (root, root)
@@ -317,12 +318,46 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
         subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=180)
         res.append(torch.load(out))
     assert len(res[0]) == len(res[1]) and all(torch.equal(a, b) for a, b in zip(*res))
-    # two batch tiles x 2 layers and a narrower batch also take the path (groups <= 8)
-    code2 = code.replace("L, B, T, I0, H = 4, 32, 70, 48, 512", "L, B, T, I0, H = 2, 20, 33, 48, 512")
-    res = []
-    for mode in ("0", "2"):
-        out = "/tmp/sa_xcd2_%s.pt" % mode
-        subprocess.run([sys.executable, "-c", code2, out], env=dict(os.environ, SA_GRU_PERSIST=mode), check=True,
-                       timeout=180)
-        res.append(torch.load(out))
-    assert all(torch.equal(a, b) for a, b in zip(*res))
+    # narrower layers share an XCD (H = 256: two groups per XCD, H = 128: four), fewer groups than slots idle
+    for shape in ("2, 20, 33, 48, 512", "2, 32, 45, 40, 256", "3, 16, 37, 24, 128", "4, 64, 21, 24, 256"):
+        code2 = code.replace("L, B, T, I0, H = 4, 32, 70, 48, 512", "L, B, T, I0, H = " + shape)
+        res = []
+        for mode in ("0", "2"):
+            out = "/tmp/sa_xcd2_%s.pt" % mode
+            subprocess.run([sys.executable, "-c", code2, out], env=dict(os.environ, SA_GRU_PERSIST=mode), check=True,
+                           timeout=180)
+            res.append(torch.load(out))
+        assert all(torch.equal(a, b) for a, b in zip(*res)), shape
+
+
+def test_xcd_local_persistent_kernels_bidirectional():
+    """Bidirectional layers (the shipped TIMIT / WSJ configs: 4 x biGRU-256) run one persistent launch per layer with
+    the two directions as the two sync groups; bit-identical to the step kernels, forward and backward."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\nfrom speech_amd import ops, _lib\n"
+            "L, B, T, I0, H = [int(v) for v in sys.argv[2:7]]\n"
+            "torch.manual_seed(0)\nk = 1.0 / H ** 0.5\n"
+            "x = torch.randn(T, B, I0, device='cuda')\n"
+            "mk = lambda *s: torch.empty(*s, device='cuda').uniform_(-k, k)\n"
+            "w_ih = [mk(3 * H, I0 if l == 0 else 2 * H) for l in range(L) for d in range(2)]\n"
+            "w_hh = [mk(3 * H, H) for l in range(L) for d in range(2)]\n"
+            "b_ih = [mk(3 * H) for l in range(L) for d in range(2)]\n"
+            "b_hh = [mk(3 * H) for l in range(L) for d in range(2)]\n"
+            "dtop = torch.randn(T, B, 2 * H, device='cuda')\n"
+            "for _ in range(2):\n"
+            "    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 2, H, want_stash=True)\n"
+            "    dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 2, H, I0)\n"
+            "torch.cuda.synchronize()\n"
+            "assert _lib.lib().sa_gru_persist_status() == 0\n"
+            "torch.save([t.cpu() for t in h + st + dai + dah + [dx]], sys.argv[1])\n") % (root,)
+    for shape in ((2, 8, 40, 24, 256), (2, 20, 31, 24, 512), (3, 48, 17, 16, 128), (1, 1, 5, 8, 256)):
+        res = []
+        for mode in ("0", "2"):
+            out = "/tmp/sa_xcd_bi_%s.pt" % mode
+            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
+                           env=dict(os.environ, SA_GRU_PERSIST=mode), check=True, timeout=180)
+            res.append(torch.load(out))
+        assert len(res[0]) == len(res[1]) and all(torch.equal(a, b) for a, b in zip(*res)), shape
