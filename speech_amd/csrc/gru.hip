@@ -924,12 +924,29 @@ static bool xcd_shape_ok(int jobs, int B, int H) {
 }
 static size_t xcd_lds(size_t need) { return need < 84 * 1024 ? 84 * 1024 : need; }  // > half a CU's LDS: one per CU
 
-static int clamp_chunk(int chunk, int T, bool persistent = false) {
+static int clamp_chunk(int chunk, int T) {
     // measured on MI355X at S-LIBRI, whole train step: step kernels 16 -> 19.6 ms, 32 -> 19.9, 8 -> 20.5;
     // persistent chunk kernels (a wave of the layer wavefront costs one launch + one grouped GEMM whatever its
     // length) 8 -> 18.3, 16 -> 16.4, 24 -> 16.0, 28 -> 15.7, 32 -> 15.8, 40 -> 15.7, 48 -> 15.8, 64 -> 16.5
-    if (chunk <= 0) chunk = persistent ? 32 : 16;
+    if (chunk <= 0) chunk = 16;
     return chunk > T ? T : chunk;
+}
+
+// Default chunk of the persistent path: among 24 .. 40 steps, the length whose grouped projection GEMM
+// ((L-1) problems of (chunk * B) x 3H, 128 x 128 tiles) fills whole rounds of the device's CUs best -- at S-LIBRI
+// 28 steps = 252 tiles on 256 CUs (15.7 ms / step) against 32 steps = 288 tiles (15.8 ms).  Ties go to the longer chunk.
+static int persistent_chunk(int L, int B, int T, int H) {
+    if (L < 2) return T < 32 ? T : 32;
+    const int cus = device_cus();
+    int best = 32;
+    double best_eff = -1.0;
+    for (int c = 24; c <= 40; ++c) {
+        const long tiles = (long)((c * B + 127) / 128) * ((3 * H + 127) / 128) * (L - 1);
+        const long rounds = (tiles + cus - 1) / cus;
+        const double eff = (double)tiles / (double)(rounds * cus);
+        if (eff >= best_eff) { best_eff = eff; best = c; }
+    }
+    return best > T ? T : best;
 }
 static size_t stack_gemm_ws(int L, int B, int T, int H, int chunk, bool fwd) {
     // split-K workspace of the grouped per-chunk projections (up to L-1 problems per launch)
@@ -958,7 +975,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
-    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H));
+    if (chunk <= 0 && n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H)) chunk = persistent_chunk(L, B, T, H);
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
     const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kSyncBytes;
@@ -1149,7 +1167,8 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
-    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T, n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H));
+    if (chunk <= 0 && n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H)) chunk = persistent_chunk(L, B, T, H);
+    chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
     const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
