@@ -198,6 +198,11 @@ struct PFwdJobs {
     // from the XCC id it actually runs on and its unit tile from an arrival counter, so a sync group never spans
     // XCDs whatever the dispatcher did (a group short of members times out into `err`, it cannot hang or corrupt).
     int xcd_mode, nbt, ntile_u;
+    // flag-less hand-off (XCD-local mode only): h_out is pre-filled with a NaN sentinel by the host; a consumer wave
+    // simply re-reads the rows it needs (sc1 loads, served by the XCD's L2) until no element is the sentinel any more.
+    // No arrival counter, no store acknowledgement wait, no workgroup barrier before the MFMAs: a wave starts as soon
+    // as ITS k-slice's producers have published.
+    int flagless;
     unsigned* reg;       // [8] arrival counters, monotonic over the stack call
     unsigned reg_base;   // arrivals per counter before this launch
     unsigned long long* stamp;  // profiling: the (0, 0, 0) workgroup writes wall_clock64() at entry / exit (null: off)
@@ -205,6 +210,12 @@ struct PFwdJobs {
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
     PFwdJob j[kMaxJobs];
 };
+
+constexpr unsigned kSentinel = 0x7fc0deadu;  // a quiet NaN no finite state or gradient can equal
+__device__ __forceinline__ bool has_sentinel(f32x4v v) {
+    return __builtin_bit_cast(unsigned, v.x) == kSentinel || __builtin_bit_cast(unsigned, v.y) == kSentinel ||
+           __builtin_bit_cast(unsigned, v.z) == kSentinel || __builtin_bit_cast(unsigned, v.w) == kSentinel;
+}
 
 __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
     return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
             const float* ai = J.ai + row * 3 * H;
             e_ai_r = ai[u]; e_ai_z = ai[H + u]; e_ai_n = ai[2 * H + u];
         }
-        if (s > 0) {  // every unit tile of this (job, batch tile) must have published h_{t-1}
+        if (s > 0 && !P.flagless) {  // every unit tile of this (job, batch tile) must have published h_{t-1}
             if (tid == 0 && !dead) {
                 const unsigned need = J.base + (unsigned)ntile_u * (unsigned)s;
                 int spins = 0;
@@ -297,12 +308,20 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
             const int abase = (int)(((long)brow * J.hs_b + (long)(t - J.dt) * J.hs_t) * 4);  // byte offset of the h row
             for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 128) {
                 f32x4v a[8];
+                for (int spins = 0;; ++spins) {
+                    bool stale = false;
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int k = kk0 + 16 * it + 4 * g;
-                    a[it] = kk0 + 16 * it < kbeg + kslice
-                                ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
-                                : f32x4v{0.f, 0.f, 0.f, 0.f};
+                    for (int it = 0; it < 8; ++it) {
+                        const int k = kk0 + 16 * it + 4 * g;
+                        a[it] = kk0 + 16 * it < kbeg + kslice
+                                    ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
+                                    : f32x4v{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (!P.flagless) break;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
+                    if (__builtin_amdgcn_ballot_w64(stale) == 0) break;  // wave-uniform: the MFMAs below stay convergent
+                    if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
                 }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -319,20 +338,22 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                     }
                 }
             }
+            float* rd = red + (P.flagless ? (s & 1) * 3072 : 0);  // flag-less: double-buffered, one barrier per step
 #pragma unroll
             for (int n = 0; n < 3; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[(wave * 3 + n) * 256 + (g * 4 + r) * 16 + i] = acc[n][r];
+                for (int r = 0; r < 4; ++r) rd[(wave * 3 + n) * 256 + (g * 4 + r) * 16 + i] = acc[n][r];
         }
         __syncthreads();
         SA_TICK(1)
         float sr = 0.f, sz = 0.f, sn = 0.f;
         if (has_prev) {
+            const float* rd = red + (P.flagless ? (s & 1) * 3072 : 0);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                sr += red[(w * 3 + 0) * 256 + tid];
-                sz += red[(w * 3 + 1) * 256 + tid];
-                sn += red[(w * 3 + 2) * 256 + tid];
+                sr += rd[(w * 3 + 0) * 256 + tid];
+                sz += rd[(w * 3 + 1) * 256 + tid];
+                sn += rd[(w * 3 + 2) * 256 + tid];
             }
         }
         if (live) {
@@ -350,6 +371,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
             hp = h;
         }
         SA_TICK(2)
+        if (P.flagless) continue;  // the data is its own flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the flag
         __syncthreads();
         if (tid == 0) {
@@ -484,7 +506,7 @@ struct PBwdJob {
     unsigned base;
 };
 struct PBwdJobs {
-    int n, B, H, nbt, ntile_u;
+    int n, B, H, nbt, ntile_u, flagless;
     long rb, rt;
     unsigned* reg;
     unsigned reg_base;
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
             const float* st = J.stash + row * 5 * H;
             r = st[u]; z = st[H + u]; n = st[2 * H + u]; q = st[3 * H + u]; hp = st[4 * H + u];
         }
-        if (s > 0) {  // every unit tile of this (job, batch tile) must have published dah[t + 1]
+        if (s > 0 && !P.flagless) {  // every unit tile of this (job, batch tile) must have published dah[t + 1]
             if (tid == 0 && !dead) {
                 const unsigned need = J.base + (unsigned)P.ntile_u * (unsigned)s;
                 int spins = 0;
@@ -564,12 +586,20 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
             const int abase = (int)((((long)brow * P.rb + (long)(t - J.dt) * P.rt) * H3) * 4);  // byte offset of the row
             for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 192) {
                 f32x4v a[12];
+                for (int spins = 0;; ++spins) {
+                    bool stale = false;
 #pragma unroll
-                for (int it = 0; it < 12; ++it) {
-                    const int k = kk0 + 16 * it + 4 * g;
-                    a[it] = kk0 + 16 * it < kbeg + kslice
-                                ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
-                                : f32x4v{0.f, 0.f, 0.f, 0.f};
+                    for (int it = 0; it < 12; ++it) {
+                        const int k = kk0 + 16 * it + 4 * g;
+                        a[it] = kk0 + 16 * it < kbeg + kslice
+                                    ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
+                                    : f32x4v{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (!P.flagless) break;
+#pragma unroll
+                    for (int it = 0; it < 12; ++it) stale |= has_sentinel(a[it]);
+                    if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+                    if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
                 }
 #pragma unroll
                 for (int it = 0; it < 12; ++it) {
@@ -583,13 +613,15 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                     }
                 }
             }
+            float* rd = red + (P.flagless ? (s & 1) * 1024 : 0);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) red[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr];
+            for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr];
         }
         __syncthreads();
         if (live) {
+            const float* rd = red + (P.flagless ? (s & 1) * 1024 : 0);
             if (have_next)
-                dh = gru_bwd_total_dh(dh, red[tid], red[256 + tid], red[512 + tid], red[768 + tid], dh_run, z_next);
+                dh = gru_bwd_total_dh(dh, rd[tid], rd[256 + tid], rd[512 + tid], rd[768 + tid], dh_run, z_next);
             float dpr, dpz, dpn, dqn;
             gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
             float* di = J.dai + row * H3;
@@ -601,6 +633,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
             dh_run = dh;
             z_next = z;
         }
+        if (P.flagless) continue;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -909,8 +942,15 @@ static int device_cus() {
 // sc1 loads, 1.3 us MFMA, 1 us epilogue + drain), i.e. the all-to-all seam is as expensive as the kernel boundary.
 static int persist_mode() {  // 2 XCD-local groups (default where eligible), 1 chip-wide groups, 0 off
     const char* e = getenv("SA_GRU_PERSIST");
-    const int m = e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0)) : 2;
+    const int m = e ? (e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == '3') ? 2 : 0)) : 2;
     return (m == 2 && g_health.broken) ? 0 : m;
+}
+static bool flagless_mode() {  // the flag-less (sentinel) hand-off is the default; SA_GRU_PERSIST=2 keeps the counters
+    const char* e = getenv("SA_GRU_PERSIST");
+    return !e || e[0] == '3';
+}
+static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
+    return hipMemsetD32Async((hipDeviceptr_t)p, (int)kSentinel, n, stream) == hipSuccess;
 }
 
 // shapes the XCD-local persistent kernels take: 8 XCDs x 32 CUs; a sync group = one (concurrent job, batch tile) with
@@ -998,7 +1038,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
                    // the two directions of a layer share every launch
         const int bi_nbt = (B + 15) / 16;
-        const size_t bi_lds = xcd_lds(((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float));
+        const size_t bi_lds = xcd_lds(((size_t)48 * (H + 4) + 2 * 4 * 3 * 256) * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * DH * 4 < 0x7fffffffL;
         if (bi_xcd) {
@@ -1019,6 +1059,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 PFwdJobs Q;
                 Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + kSyncErr; Q.timing = nullptr;
                 Q.xcd_mode = 1; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
+                Q.flagless = flagless_mode() ? 1 : 0;
+                if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
                 Q.reg_base = (unsigned)l * 32u; Q.stamp = nullptr; Q.n = 2;
                 for (int d = 0; d < 2; ++d) {
                     PFwdJob& J = Q.j[d];
@@ -1053,7 +1095,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     const int nch = (T + chunk - 1) / chunk;
     // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
-    size_t plds = ((size_t)48 * (H + 4) + 4 * 3 * 256) * sizeof(float);
+    size_t plds = ((size_t)48 * (H + 4) + 2 * 4 * 3 * 256) * sizeof(float);
     bool persist = persist_mode() != 0 && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
                    (long)L * ntile_u * nbt <= device_cus() && L * nbt <= kSyncErr &&
                    (long)T * B * H * 4 < 0x7fffffffL;
@@ -1062,6 +1104,10 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (persist_mode() == 2 && !xcd) persist = false;
     if (xcd) plds = xcd_lds(plds);
     unsigned persist_launches = 0;
+    const bool flagless = xcd && flagless_mode();
+    if (flagless)
+        for (int l = 0; l < L; ++l)
+            if (!sentinel_fill(h_out[l], (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
     if (persist) {
         if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1098,6 +1144,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             PFwdJobs Q;
             Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + kSyncErr;
             Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
+            Q.flagless = flagless ? 1 : 0;
             Q.reg_base = persist_launches * 32u;
             ++persist_launches;
             Q.stamp = nullptr;
@@ -1206,7 +1253,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
 
     if (D == 2) {
         const int bi_nbt = (B + 15) / 16;
-        const size_t bi_lds = xcd_lds(((size_t)16 * (3 * H + 4) + 4 * 256) * sizeof(float));
+        const size_t bi_lds = xcd_lds(((size_t)16 * (3 * H + 4) + 2 * 4 * 256) * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
         if (bi_xcd) {
@@ -1219,6 +1266,10 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
             if (bi_xcd) {  // ONE persistent launch unwinds both directions of the layer over all T steps
                 PBwdJobs Q;
                 Q.B = B; Q.H = H; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.rb = 1; Q.rt = B;
+                Q.flagless = flagless_mode() ? 1 : 0;
+                if (Q.flagless)
+                    for (int d = 0; d < 2; ++d)
+                        if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
                 Q.err = sync + kSyncErr; Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
                 Q.stamp = nullptr; Q.n = 2;
                 for (int d = 0; d < 2; ++d) {
@@ -1261,10 +1312,14 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     const int nch = (T + chunk - 1) / chunk;
     // persistent XCD-local chunk kernel (SA_GRU_PERSIST=2; see gru_bwd_persist_kernel)
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
-    const size_t plds = xcd_lds(((size_t)16 * (3 * H + 4) + 4 * 256) * sizeof(float));
+    const size_t plds = xcd_lds(((size_t)16 * (3 * H + 4) + 2 * 4 * 256) * sizeof(float));
     const bool xcd = ch.n == 1 && xcd_shape_ok(L, B, H) && L * nbt <= kSyncErr && plds <= 160 * 1024 &&
                      (long)T * B * 3 * H * 4 < 0x7fffffffL;
     unsigned persist_launches = 0;
+    const bool flagless = xcd && flagless_mode();
+    if (flagless)
+        for (int l = 0; l < L; ++l)
+            if (!sentinel_fill(dah[l], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
     if (xcd) {
         if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1299,7 +1354,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         }
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
-            Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
+            Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.err = sync + kSyncErr; Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
             ++persist_launches;
             int n = 0;

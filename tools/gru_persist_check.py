@@ -13,34 +13,34 @@ if len(sys.argv) > 1:
     b_ih = [torch.empty(3 * H, device="cuda").uniform_(-k, k) for l in range(L)]
     b_hh = [torch.empty(3 * H, device="cuda").uniform_(-k, k) for l in range(L)]
     for _ in range(2):
-        h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=True)
+        h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=True, chunk=28)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
-        h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=True)
+        h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=True, chunk=28)
     e1.record(); torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1) / 3
     dtop = torch.randn(T, B, H, device="cuda")
     for _ in range(2):
-        dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, D, H, I0, want_dx=True)
+        dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=28)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(3):
-        dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, D, H, I0, want_dx=True)
+        dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=28)
     e1.record(); torch.cuda.synchronize()
     torch.save({"h": [t.cpu() for t in h], "st": [t.cpu() for t in st] + [t.cpu() for t in dai] + [t.cpu() for t in dah] +
                 [dx.cpu()], "ms": fwd_ms, "bwd_ms": e0.elapsed_time(e1) / 3}, sys.argv[1])
 else:
     for shape in [(4, 1, 32, 498, 512, 800)]:
         outs = []
-        for mode in ("0", "1", "2"):   # step kernels, chip-wide persistent groups, XCD-local persistent groups
+        for mode in ("0", "2", "3"):   # step kernels, XCD-local persistent groups, + flag-less hand-off
             f = "/tmp/persist_%s.pt" % mode
             env = dict(os.environ, SA_GRU_PERSIST=mode)
             r = subprocess.run([sys.executable, __file__, f] + [str(v) for v in shape], env=env, timeout=120)
             outs.append(torch.load(f) if r.returncode == 0 else None)
         a = outs[0]
-        for name, b in (("persistent", outs[1]), ("xcd-local", outs[2])):
+        for name, b in (("xcd-local", outs[1]), ("xcd-flagless", outs[2])):
             if a is None or b is None:
                 print(shape, name, "FAILED to run"); continue
             same = all(torch.equal(x, y) for x, y in zip(a["h"], b["h"])) and all(torch.equal(x, y) for x, y in zip(a["st"], b["st"]))
