@@ -584,12 +584,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             const int abase = (int)((((long)brow * P.rb + (long)(t - J.dt) * P.rt) * H3) * 4);  // byte offset of the row
-            for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 192) {
-                f32x4v a[12];
+            for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 384) {  // H = 512: the whole k-slice in ONE round trip
+                f32x4v a[24];
                 for (int spins = 0;; ++spins) {
                     bool stale = false;
 #pragma unroll
-                    for (int it = 0; it < 12; ++it) {
+                    for (int it = 0; it < 24; ++it) {
                         const int k = kk0 + 16 * it + 4 * g;
                         a[it] = kk0 + 16 * it < kbeg + kslice
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
@@ -597,12 +597,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                     }
                     if (!P.flagless) break;
 #pragma unroll
-                    for (int it = 0; it < 12; ++it) stale |= has_sentinel(a[it]);
+                    for (int it = 0; it < 24; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
                     if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
                 }
 #pragma unroll
-                for (int it = 0; it < 12; ++it) {
+                for (int it = 0; it < 24; ++it) {
                     if (kk0 + 16 * it < kbeg + kslice) {
                         const int k = kk0 + 16 * it + 4 * g;
                         const float4 w = *reinterpret_cast<const float4*>(&Wl[i * LDW + k]);
