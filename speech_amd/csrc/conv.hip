@@ -17,18 +17,38 @@ struct ConvGeom {
 
 __host__ __device__ inline int conv_out(int n, int k, int s) { return (n - k + 1 + s - 1) / s; }
 
-// cols[pos][k], pos = (b, t', f'), k = (c, i, j)
+// cols[pos][k], pos = (b, t', f'), k = (c, i, j).  grid (npos / 16) blocks of 256 threads; a block copies 16 output
+// positions: the (c, i) rows of a position's window are kw contiguous floats in x and in cols, so the block walks the
+// K / kw rows of its 16 positions with kw-wide coalesced segments (4 floats per lane when kw % 4 == 0).  The index
+// decomposition (the divisions) is done once per (position, row), not per element.
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols,
                                                      ConvGeom g) {
-    const long total = (long)g.B * g.To * g.Fo * g.K;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int k = (int)(idx % g.K);
-        const long pos = idx / g.K;
+    const long npos = (long)g.B * g.To * g.Fo;
+    const int rows = g.C * g.kh;                      // (c, i) rows per position
+    const int vec = (g.kw & 3) == 0 ? 4 : 1;
+    const int lanes_per_row = g.kw / vec;             // threads covering one kw-wide row
+    const int rows_per_pass = 256 / lanes_per_row;    // (position, row) pairs handled per pass of the block
+    if (rows_per_pass == 0) return;                   // kw > 1024: not a shape this library builds
+    const int lr = threadIdx.x / lanes_per_row, lj = (threadIdx.x - lr * lanes_per_row) * vec;
+    if (lr >= rows_per_pass) return;
+    const long pos0 = (long)blockIdx.x * 16;
+    const int work = 16 * rows;
+    for (int wi = lr; wi < work; wi += rows_per_pass) {
+        const int p = wi / rows, r = wi - p * rows;   // position within the block's 16, row (c, i)
+        const long pos = pos0 + p;
+        if (pos >= npos) break;
+        const int c = r / g.kh, i = r - c * g.kh;
         const int fo = (int)(pos % g.Fo);
-        const int to = (int)((pos / g.Fo) % g.To);
-        const int b = (int)(pos / ((long)g.Fo * g.To));
-        const int j = k % g.kw, i = (k / g.kw) % g.kh, c = k / (g.kw * g.kh);
-        cols[idx] = x[(((long)b * g.C + c) * g.T + (g.s * to + i)) * g.F + g.s * fo + j];
+        const long bt = pos / g.Fo;
+        const int to = (int)(bt % g.To), b = (int)(bt / g.To);
+        const float* src = x + (((long)b * g.C + c) * g.T + (g.s * to + i)) * g.F + g.s * fo + lj;
+        float* dst = cols + pos * g.K + (long)r * g.kw + lj;
+        if (vec == 4) {
+            const float4 v = make_float4(src[0], src[1], src[2], src[3]);  // x rows are not 16-byte aligned in general
+            *reinterpret_cast<float4*>(dst) = v;                            // cols rows are (K % 4 == 0)
+        } else {
+            *dst = *src;
+        }
     }
 }
 
@@ -50,27 +70,44 @@ __global__ __launch_bounds__(256) void relu_mask_pack_kernel(const float* __rest
     }
 }
 
-// dx[b, c, t, f] = sum over windows covering (t, f) of dcols[(b, t', f')][(c, i, j)]   (gather: deterministic)
+// dx[b, c, t, f] = sum over windows covering (t, f) of dcols[(b, t', f')][(c, i, j)]   (deterministic).
+// One WAVE per output row (b, c, t); lane = tap j (kw <= 64).  For each kernel row i with t' = (t - i) / s valid, the
+// wave walks f' = 0 .. Fo-1 reading the kw contiguous taps of dcols[(b, t', f')][(c, i, :)] (one coalesced segment)
+// into a per-lane accumulator that holds the partial sum of output column f = s * f' + lane; after each position the
+// s leftmost columns are complete (no later window reaches them): they are emitted and the accumulators slide left by
+// s lanes (DPP wave shifts) -- an anti-diagonal sum without any scattered access.  The row's F sums are collected in
+// LDS over the kh kernel rows and written once.
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx,
                                                      ConvGeom g) {
-    const long total = (long)g.B * g.C * g.T * g.F;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int f = (int)(idx % g.F);
-        const int t = (int)((idx / g.F) % g.T);
-        const int c = (int)((idx / ((long)g.F * g.T)) % g.C);
-        const int b = (int)(idx / ((long)g.F * g.T * g.C));
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* row = reinterpret_cast<float*>(smem_raw) + wave * g.F;  // [F] sums of this wave's output row
+    const long nrows = (long)g.B * g.C * g.T;
+    const long rid = (long)blockIdx.x * 4 + wave;
+    if (rid >= nrows) return;
+    const int t = (int)(rid % g.T);
+    const int c = (int)((rid / g.T) % g.C);
+    const int b = (int)(rid / ((long)g.T * g.C));
+    for (int f = lane; f < g.F; f += 64) row[f] = 0.f;
+    for (int i = t % g.s; i < g.kh; i += g.s) {
+        const int to = (t - i) / g.s;
+        if (t - i < 0 || to >= g.To) continue;
+        const float* src = dcols + (((long)b * g.To + to) * g.Fo) * g.K + (long)(c * g.kh + i) * g.kw + lane;
         float acc = 0.f;
-        for (int i = t % g.s; i < g.kh; i += g.s) {
-            const int to = (t - i) / g.s;
-            if (t - i < 0 || to >= g.To) continue;
-            for (int j = f % g.s; j < g.kw; j += g.s) {
-                const int fo = (f - j) / g.s;
-                if (f - j < 0 || fo >= g.Fo) continue;
-                acc += dcols[(((long)b * g.To + to) * g.Fo + fo) * g.K + (c * g.kh + i) * g.kw + j];
+        for (int fo = 0; fo < g.Fo; ++fo) {
+            acc += lane < g.kw ? src[(long)fo * g.K] : 0.f;
+            for (int k = 0; k < g.s; ++k) {  // columns s*fo .. s*fo + s-1 are final: emit lane 0, slide left
+                if (lane == 0) row[g.s * fo + k] += acc;
+                acc = sa_wave_shl1(acc, 0.f);
             }
         }
-        dx[idx] = acc;
+        // the kw - s columns still in flight: f = s*Fo + lane, lane < kw - s
+        const int f = g.s * g.Fo + lane;
+        if (lane < g.kw - g.s && f < g.F) row[f] += acc;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float* out = dx + rid * g.F;
+    for (int f = lane; f < g.F; f += 64) out[f] = row[f];
 }
 
 // dW[o][k] = sum_pos dyp[pos][o] * cols[pos][k] for small O*K (the first conv: 32 x 160): an outer-product reduction
@@ -189,7 +226,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
     const long npos = (long)g.B * g.To * g.Fo;
     float* cols = keep_cols ? keep_cols : (float*)workspace;  // keep_cols: caller-owned (npos x K) buffer reused by bwd
     char* gws = (char*)workspace + sa_align_up((size_t)npos * g.K * sizeof(float), 256);
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((npos + 15) / 16)), dim3(256), 0, stream, x, cols, g);
     SA_CHECK_LAUNCH();
     SaGemmEpilogue ep;
     ep.m_inner = g.Fo; ep.m_mid = g.To; ep.s_outer = ys_b; ep.s_mid = ys_t; ep.col_stride = ys_c; ep.relu = 1;
@@ -231,7 +268,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
     if (fwd_cols && !dx) {
         cols = const_cast<float*>(fwd_cols);  // the forward pass's im2col matrix, kept by the caller (read only here)
     } else {
-        hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(npos * g.K)), dim3(256), 0, stream, x, cols, g);
+        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((npos + 15) / 16)), dim3(256), 0, stream, x, cols, g);
     }
     hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, dyp, g, ys_b,
                        ys_c, ys_t);
@@ -261,8 +298,9 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
         st = sa_gemm_f32_impl(0, 0, (int)npos, g.K, g.O, 1.0f, dyp, g.O, w, g.K, 0.f, cols, g.K, nullptr, nullptr,
                               gws, gws_bytes, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
-        hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)g.B * g.C * g.T * g.F)), dim3(256), 0, stream, cols,
-                           dx, g);
+        if (g.kw > 64) return CTC_STATUS_INVALID_VALUE;  // one lane per tap
+        hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)(((long)g.B * g.C * g.T + 3) / 4)), dim3(256),
+                           (size_t)4 * g.F * sizeof(float), stream, cols, dx, g);
         SA_CHECK_LAUNCH();
     }
     return CTC_STATUS_SUCCESS;
