@@ -170,13 +170,13 @@ def roofline(prof, step_us, steps):
         if nsteps > 1:
             # the recurrence ran as persistent chunk kernels (one launch = `nsteps` time steps x 4 layer-jobs, launches
             # separated by the chunk's GEMMs): duration = the kernel's own entry-to-exit clock
-            name, us = name.replace("_step_", "_persist_"), kern_us
+            name, us = name.replace("_step_", "_fused_" if (nsteps > 64 and "fwd" in name) else "_persist_"), kern_us
         if us <= 0:
             continue
         nbytes = 4.0 * B * 512 * per_job * 4 * nsteps  # 4 layer-jobs x nsteps steps per launch, B x H fp32 each
         ach = nbytes / (us * 1e-6) / 1e9
         tr = traffic.get(name, {}).get("bytes_per_launch")
-        key = name.replace("_persist_", "_step_")
+        key = name.replace("_persist_", "_step_").replace("_fused_", "_step_")
         out[key] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": tr, "avg_launch_us": us, "block0_kernel_us": kern_us,
                     "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps}

@@ -391,6 +391,285 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
 #undef SA_TICK
 }
 
+// ------------------------------------------------------------------------------------- fused forward layer wavefront
+// ONE launch runs the whole unidirectional stack over all T steps: the (layer, batch tile) groups sit on their own XCDs
+// as in the persistent chunk kernel, but a layer's input projection W_ih h_{l-1}[t] is computed inside the kernel too,
+// so the layers pipeline at STEP granularity (no chunks, no per-chunk GEMM launches, no fill / drain of whole chunks).
+//   per step and block:  (a) input phase   (l >= 1) wait until layer l-1 has published step t, read its h rows ONCE
+//                            (sc1 loads: the rows were written through to memory by another XCD and are not in this
+//                            XCD's L2 before this first read), MFMA against the W_ih rows streamed from L2;
+//                        (b) recurrent phase: flag-less poll of h_l[t-1] inside the XCD, MFMA against W_hh in LDS;
+//                        (c) reduce, gates, publish h_l[t] with write-through stores.
+//   (a) of step t needs nothing of the block's own recurrence, so it fills the store -> L2 -> load hop of (b).
+// Cross-XCD readiness is an arrival counter per (layer, batch tile) in memory (agent-scope RMW, fire and forget): a
+// block reports step t-1 at step t, after its own stores of step t-1 have been acknowledged (a wait that is already
+// satisfied) and its step-t barrier -- the consumer layer therefore trails by one step more than it strictly must.
+struct PFusedFwd {
+    int L, B, H, T, nbt, ntile_u;
+    long rb, rt;
+    const float* ai0;            // (T*B, 3H): layer 0's input projection incl. bias (one GEMM before the launch)
+    const float* w_ih[kMaxJobs]; // l >= 1: (3H, H)
+    const float* b_ih[kMaxJobs];
+    const float* w_hh[kMaxJobs];
+    const float* b_hh[kMaxJobs];
+    float* h_out[kMaxJobs];      // (T, B, H), pre-filled with the sentinel
+    float* stash[kMaxJobs];      // rows x 5H or null
+    unsigned* prog;              // [L][nbt] arrival counters, zeroed by the host
+    unsigned* reg;
+    unsigned reg_base;
+    unsigned* err;
+    unsigned long long* stamp;
+    unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
+};
+
+__global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {
+        if (threadIdx.x == 0) atomicExch(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt;
+    if (l >= P.L) return;
+    const int H = P.H, B = P.B, T = P.T;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    float* red = psm;             // [2][4 waves][4 sums][256]  (the weights live in registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const float* w_hh = P.w_hh[l];
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    const float e_br = P.b_hh[l][u], e_bz = P.b_hh[l][H + u], e_bn = P.b_hh[l][2 * H + u];
+    float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;
+    if (l > 0) { bi_r = P.b_ih[l][u]; bi_z = P.b_ih[l][H + u]; bi_n = P.b_ih[l][2 * H + u]; }
+    float* h_out = P.h_out[l];
+    float* stash = P.stash[l];
+    const long hs_t = (long)B * H;
+    const int kslice = H / 4, kbeg = wave * kslice;
+    const int brow = min(b0 + i, B - 1);
+    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)h_out, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)(l > 0 ? P.h_out[l - 1] : h_out), 0, 0x7fffffff,
+                                                                    0x00020000);
+    unsigned* my_prog = P.prog + l * P.nbt + role_y;
+    const unsigned* lower_prog = P.prog + (l > 0 ? l - 1 : 0) * P.nbt + role_y;
+    const float* w_ih = l > 0 ? P.w_ih[l] : nullptr;
+    unsigned avail = 0;  // steps of the lower layer known to be published
+    float hp = 0.f;
+    __syncthreads();
+
+    // (a) is software-pipelined one step ahead: the loads of step t+1's input (the lower layer's rows out of memory,
+    // the W_ih rows out of L2) are issued BEFORE the recurrent phase of step t and their MFMAs run AFTER step t's h has
+    // been published, i.e. inside the store -> L2 -> load hop every block waits out anyway.
+    f32x4 accg[3];  // input projection of the step about to be processed
+    f32x4v an[8];
+    float4 wn[8][3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) accg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto wait_lower = [&](int tt) {  // the lower layer has published step tt (every wave polls for itself)
+        if (avail >= (unsigned)(tt + 1)) return;
+        int spins = 0;
+        unsigned c;
+        while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
+               (unsigned)P.ntile_u * (unsigned)(tt + 1)) {
+            if (++spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
+        }
+        avail = c / (unsigned)P.ntile_u;
+    };
+    // H <= 512: the wave's k-slice is at most 8 iterations of 16
+    auto issue_rows = [&](int tt) {  // the lower layer's rows of step tt: from memory (another XCD wrote them), slow
+        const int abase = (int)((((long)tt * B + brow) * H) * 4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int k = kbeg + 16 * it + 4 * g;
+            an[it] = 16 * it < kslice
+                         ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(lres, abase + 4 * k, 0, 16 | 2))  // sc1 + nt: read once
+                         : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto issue_weights = [&]() {  // this block's W_ih rows: read-only, resident in the XCD's L2
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int k = kbeg + 16 * it + 4 * g;
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                wn[it][n] = 16 * it < kslice ? *reinterpret_cast<const float4*>(w_ih + (long)(n * H + u0 + i) * H + k)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto mfma_input = [&]() {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) accg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (16 * it < kslice) {
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].x, wn[it][n].x, accg[n], 0, 0, 0);
+                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].y, wn[it][n].y, accg[n], 0, 0, 0);
+                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].z, wn[it][n].z, accg[n], 0, 0, 0);
+                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].w, wn[it][n].w, accg[n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // Order of the VMEM operations matters: vmcnt is one in-order queue, so a slow load (the lower layer's rows, the
+    // arrival counter: both come from memory) issued BEFORE the polling loads of phase (b) would put its latency on
+    // the critical path.  Per step: [W_ih loads, input MFMAs of step t on rows fetched a step ago] -> [(b) poll]
+    // -> [consume the counter value requested a step ago, issue the rows of step t+1, request the counter again]
+    // -> [(b) MFMAs, reduce, gates, publish].
+    unsigned cnt_pending = 0;
+    // The W_ih fragments a lane feeds to its MFMAs are the same every step (3 gates x 8 k-groups x 4 floats = 96
+    // registers): they are loaded ONCE and stay in the register file -- streaming the block's 96 KB slice from L2 every
+    // step measured 3 us per step (32 blocks x 96 KB = 3 MB per step saturate the XCD's L2 read path).
+    if (l > 0) issue_weights();
+    // ... and so are the W_hh fragments (another 96 registers; the file holds 512 per lane at one wave per SIMD), which
+    // takes the 24 LDS reads per step out of the recurrent phase.  LDS keeps only the reduction scratch.
+    float4 wh[8][3];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int k = kbeg + 16 * it + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            wh[it][n] = 16 * it < kslice ? *reinterpret_cast<const float4*>(w_hh + (long)(n * H + u0 + i) * H + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (l > 0 && T > 0) { wait_lower(0); issue_rows(0); }
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;  // debug (SA_GRU_TIMING): input / poll / recurrent MFMA / rest
+    const bool timed = P.timing != nullptr && tid == 0;
+    if (timed) tprev = wall_clock64();
+#define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
+
+    for (int t = 0; t < T; ++t) {
+        const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
+        float e_ai_r = bi_r, e_ai_z = bi_z, e_ai_n = bi_n;
+        f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (l == 0) {
+            if (live) {
+                const float* ai = P.ai0 + row * 3 * H;
+                e_ai_r = ai[u]; e_ai_z = ai[H + u]; e_ai_n = ai[2 * H + u];
+            }
+        }
+        if (l > 0) {  // (a) input projection of THIS step: fills the wait for the neighbours' h[t-1]
+            mfma_input();
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = accg[n];
+        }
+        SA_TICK(0)
+        const bool prefetch = l > 0 && t + 1 < T;
+        if (t == 0 && prefetch) {  // no recurrent phase at t = 0: do the prefetch bookkeeping here
+            wait_lower(1);
+            issue_rows(1);
+            cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t > 0) {
+            // (b) own layer's h[t-1]: flag-less poll inside the XCD, W_hh out of LDS; r and z share accumulators with (a)
+            const int abase = (int)((((long)(t - 1) * B + brow) * H) * 4);
+            for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 128) {
+                f32x4v a[8];
+                for (int spins = 0;; ++spins) {
+                    bool stale = false;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int k = kk0 + 16 * it + 4 * g;
+                        a[it] = kk0 + 16 * it < kbeg + kslice
+                                    ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
+                                    : f32x4v{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
+                    if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+                    if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
+                }
+                SA_TICK(1)
+                if (prefetch) {  // the slow loads go out only now, behind the poll (H <= 512: this loop runs once)
+                    const unsigned got = cnt_pending / (unsigned)P.ntile_u;
+                    if (got > avail) avail = got;
+                    wait_lower(t + 1);  // almost always satisfied by the value requested a step ago
+                    issue_rows(t + 1);
+                    cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    if (kk0 + 16 * it < kbeg + kslice) {
+#pragma unroll
+                        for (int n = 0; n < 3; ++n) {
+                            const float4 w = wh[it][n];
+                            f32x4& dst = n == 2 ? acc_hn : acc[n];
+                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, dst, 0, 0, 0);
+                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, dst, 0, 0, 0);
+                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, dst, 0, 0, 0);
+                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, dst, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        SA_TICK(2)
+        float* rd = red + (t & 1) * 4096;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (g * 4 + r) * 16 + i;
+            rd[(wave * 4 + 0) * 256 + o] = acc[0][r];
+            rd[(wave * 4 + 1) * 256 + o] = acc[1][r];
+            rd[(wave * 4 + 2) * 256 + o] = acc[2][r];
+            rd[(wave * 4 + 3) * 256 + o] = acc_hn[r];
+        }
+        // vmcnt is one in-order queue for loads and stores on gfx9: every thread has just consumed loads it issued
+        // AFTER its stores of step t-1 (the poll of phase (b)), so those stores are acknowledged; after the barrier
+        // that holds for the whole block, which can report step t-1 to the layer above without waiting for anything.
+        __syncthreads();
+        if (t > 0 && tid == 0)
+            __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float sr = 0.f, sz = 0.f, sin_ = 0.f, shn = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sr += rd[(w * 4 + 0) * 256 + tid];
+            sz += rd[(w * 4 + 1) * 256 + tid];
+            sin_ += rd[(w * 4 + 2) * 256 + tid];
+            shn += rd[(w * 4 + 3) * 256 + tid];
+        }
+        if (live) {
+            const float r = sigmoidf_(e_ai_r + sr + e_br);
+            const float z = sigmoidf_(e_ai_z + sz + e_bz);
+            const float q = shn + e_bn;
+            const float n = tanhf(e_ai_n + sin_ + r * q);
+            const float h = (1.0f - z) * n + z * hp;
+            __hip_atomic_store(h_out + (long)t * hs_t + (long)b * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stash) {  // streaming stores: the stash must not push the W_ih rows out of the XCD's L2
+                float* st = stash + row * 5 * H;
+                __builtin_nontemporal_store(r, st + u);
+                __builtin_nontemporal_store(z, st + H + u);
+                __builtin_nontemporal_store(n, st + 2 * H + u);
+                __builtin_nontemporal_store(q, st + 3 * H + u);
+                __builtin_nontemporal_store(hp, st + 4 * H + u);
+            }
+            hp = h;
+        }
+        SA_TICK(3)
+    }
+    if (timed) {
+        unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y) * P.ntile_u + role_x);
+        for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
+    }
+#undef SA_TICK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamper) P.stamp[1] = wall_clock64();
+}
+
 // Gate-gradient arithmetic shared by the step kernel and the persistent kernel.  Contraction is switched off inside:
 // the two kernels inline this into different surroundings and hipcc would otherwise pick different mul+add -> fma
 // fusions (observed: 1-ulp differences between the two paths); the explicit fmaf calls pin the fused ones.
@@ -1108,6 +1387,30 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (flagless)
         for (int l = 0; l < L; ++l)
             if (!sentinel_fill(h_out[l], (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+    {   // the whole stack as ONE launch with in-kernel input projections (gru_fwd_fused_kernel); SA_GRU_FUSED=0: off
+        const char* fe = getenv("SA_GRU_FUSED");
+        const size_t flds = xcd_lds((size_t)2 * 4 * 4 * 256 * sizeof(float));
+        if (!(fe && fe[0] == '0') && flagless && flds <= 160 * 1024 && L * nbt <= kSyncErr) {
+            if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            if (hipFuncSetAttribute((const void*)gru_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)flds) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+            PFusedFwd Q;
+            Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
+            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.reg_base = 0; Q.err = sync + kSyncErr;
+            Q.stamp = g_prof.slot(0, true, false, T);
+            Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;
+            if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            for (int l = 0; l < L; ++l) {
+                Q.w_ih[l] = w_ih[l]; Q.b_ih[l] = b_ih[l]; Q.w_hh[l] = w_hh[l]; Q.b_hh[l] = b_hh[l];
+                Q.h_out[l] = h_out[l]; Q.stash[l] = stash ? stash[l] : nullptr;
+            }
+            hipLaunchKernelGGL(gru_fwd_fused_kernel, dim3(256), dim3(256), flds, stream, Q);
+            SA_CHECK_LAUNCH();
+            g_health.submit(sync + kSyncErr, stream);
+            return CTC_STATUS_SUCCESS;
+        }
+    }
     if (persist) {
         if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

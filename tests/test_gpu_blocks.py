@@ -314,7 +314,7 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     res = []
     for mode in ("0", "2", "3"):   # step kernels; XCD-local groups with arrival counters; flag-less hand-off (default)
         out = "/tmp/sa_xcd_%s.pt" % mode
-        env = dict(os.environ, SA_GRU_PERSIST=mode)
+        env = dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0")  # the fused forward sums in another order
         subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=180)
         res.append(torch.load(out))
     for other in res[1:]:
@@ -325,8 +325,8 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
         res = []
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd2_%s.pt" % mode
-            subprocess.run([sys.executable, "-c", code2, out], env=dict(os.environ, SA_GRU_PERSIST=mode), check=True,
-                           timeout=180)
+            subprocess.run([sys.executable, "-c", code2, out],
+                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0"), check=True, timeout=180)
             res.append(torch.load(out))
         for other in res[1:]:
             assert all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
@@ -364,3 +364,41 @@ def test_xcd_local_persistent_kernels_bidirectional():
             res.append(torch.load(out))
         for other in res[1:]:
             assert len(res[0]) == len(other) and all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
+
+
+def test_fused_forward_wavefront_matches_oracle_and_default():
+    """gru_fwd_fused_kernel (the default forward of eligible unidirectional stacks: one launch, in-kernel input
+    projections, weights resident in registers) against the NumPy oracle and against the chunked path; its stash feeds
+    the backward pass.  The projection is summed in another order than the chunk GEMM: rtol 1e-4 on h."""
+    import os
+    import subprocess
+    import sys
+    from oracle import encoder_np as E
+    from speech_amd import ops, _lib
+    L, B, T, I0, H = 3, 20, 25, 24, 128
+    x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)
+    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True)
+    torch.cuda.synchronize()
+    assert _lib.lib().sa_gru_persist_status() == 0
+    inp = x.cpu().numpy().transpose(1, 0, 2).astype(np.float64)
+    for l in range(L):
+        inp, _ = E.gru_dir_fwd(inp, w_ih[l].cpu().numpy().astype(np.float64), w_hh[l].cpu().numpy().astype(np.float64),
+                               b_ih[l].cpu().numpy().astype(np.float64), b_hh[l].cpu().numpy().astype(np.float64), False)
+        np.testing.assert_allclose(h[l].cpu().numpy().transpose(1, 0, 2), inp, rtol=1e-4, atol=1e-5)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_blocks import _stack_case\nfrom speech_amd import ops, _lib\n"
+            "L, B, T, I0, H = 4, 32, 90, 48, 512\n"
+            "x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)\n"
+            "dtop = torch.randn(T, B, H, device='cuda')\n"
+            "h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True)\n"
+            "dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0)\n"
+            "torch.cuda.synchronize()\nassert _lib.lib().sa_gru_persist_status() == 0\n"
+            "torch.save([t.cpu() for t in h + [dx]], sys.argv[1])\n") % (root, root)
+    res = []
+    for fused in ("0", "1"):
+        out = "/tmp/sa_fused_%s.pt" % fused
+        subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, SA_GRU_FUSED=fused), check=True, timeout=180)
+        res.append(torch.load(out))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max()))
