@@ -814,17 +814,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     const int H = P.H, B = P.B, H3 = 3 * P.H;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
     if (stamper) P.stamp[0] = wall_clock64();
-    const int LDW = H3 + 4;
-    float* Wl = psm;              // [16][LDW]: rows u0 .. u0+15 of W_hh^T
-    float* red = psm + 16 * LDW;  // [4][256]
+    float* red = psm;  // [2][4][256]; the block's 16 rows of W_hh^T live in registers (see below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int u0 = role_x * 16, b0 = role_y * 16;
-    for (int idx = tid; idx < 16 * (H3 / 4); idx += 256) {
-        const int r = idx / (H3 / 4), c4 = idx - r * (H3 / 4);
-        *reinterpret_cast<float4*>(&Wl[r * LDW + 4 * c4]) =
-            *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + r) * H3 + 4 * c4);
-    }
     const int bi = tid >> 4, uj = tid & 15;
     const int b = b0 + bi, u = u0 + uj;
     const bool live = b < B;
@@ -838,6 +831,15 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     const int brow = min(b0 + i, B - 1);
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.dah, 0, 0x7fffffff, 0x00020000);
     bool dead = false;
+    // The W_hh^T fragments a lane feeds to its MFMAs are the same every step (row u0 + i, the wave's k-slice, the
+    // lane's k-group: at most 24 x 4 floats at H = 512): loaded once, resident in the register file.
+    float4 wr[24];
+#pragma unroll
+    for (int it = 0; it < 24; ++it) {
+        const int k = kbeg + 16 * it + 4 * g;
+        wr[it] = 16 * it < kslice ? *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + i) * H3 + k)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
 
     for (int s = 0; s < J.nsteps; ++s) {
@@ -883,8 +885,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 #pragma unroll
                 for (int it = 0; it < 24; ++it) {
                     if (kk0 + 16 * it < kbeg + kslice) {
-                        const int k = kk0 + 16 * it + 4 * g;
-                        const float4 w = *reinterpret_cast<const float4*>(&Wl[i * LDW + k]);
+                        const float4 w = wr[it];  // H <= 512: the k loop runs once, `it` indexes the resident fragments
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, acc, 0, 0, 0);
@@ -1556,7 +1557,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
 
     if (D == 2) {
         const int bi_nbt = (B + 15) / 16;
-        const size_t bi_lds = xcd_lds(((size_t)16 * (3 * H + 4) + 2 * 4 * 256) * sizeof(float));
+        const size_t bi_lds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
         if (bi_xcd) {
@@ -1615,7 +1616,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     const int nch = (T + chunk - 1) / chunk;
     // persistent XCD-local chunk kernel (SA_GRU_PERSIST=2; see gru_bwd_persist_kernel)
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
-    const size_t plds = xcd_lds(((size_t)16 * (3 * H + 4) + 2 * 4 * 256) * sizeof(float));
+    const size_t plds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
     const bool xcd = ch.n == 1 && xcd_shape_ok(L, B, H) && L * nbt <= kSyncErr && plds <= 160 * 1024 &&
                      (long)T * B * 3 * H * 4 < 0x7fffffffL;
     unsigned persist_launches = 0;
