@@ -221,6 +221,7 @@ __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID =
     return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;
 }
 
+template <bool WREG>  // W_hh fragments resident in registers (XCD-local mode, H <= 512) instead of LDS
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     int role_x = blockIdx.x, role_y = blockIdx.y, role_z = blockIdx.z;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     const int u0 = role_x * 16, b0 = role_y * 16;
 
     // W_hh slice -> LDS, once per launch
-    for (int idx = tid; idx < 48 * (H / 4); idx += 256) {
+    for (int idx = tid; !WREG && idx < 48 * (H / 4); idx += 256) {
         const int r = idx / (H / 4), c4 = idx - r * (H / 4);
         const int grow = (r >> 4) * H + u0 + (r & 15);
         *reinterpret_cast<float4*>(&Wl[r * LDW + 4 * c4]) =
@@ -274,6 +275,19 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     const int brow = min(b0 + i, B - 1);
     __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)J.h_out, 0, 0x7fffffff, 0x00020000);
     bool dead = false;
+    // XCD-local mode, H <= 512: the W_hh fragments this lane feeds to its MFMAs (3 gates x up to 8 k-groups x 4 floats)
+    // are the same every step -- resident in registers instead of re-read from LDS
+    float4 wr[8][3];
+    if (WREG) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int k = kbeg + 16 * it + 4 * g;
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                wr[it][n] = 16 * it < kslice ? *reinterpret_cast<const float4*>(J.w_hh + (long)(n * H + u0 + i) * H + k)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __syncthreads();
     unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
     const bool timed = P.timing != nullptr && tid == 0;
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                         const int k = kk0 + 16 * it + 4 * g;
 #pragma unroll
                         for (int n = 0; n < 3; ++n) {
-                            const float4 w = *reinterpret_cast<const float4*>(&Wl[(n * 16 + i) * LDW + k]);
+                            const float4 w = WREG ? wr[it][n] : *reinterpret_cast<const float4*>(&Wl[(n * 16 + i) * LDW + k]);
                             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, acc[n], 0, 0, 0);
                             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, acc[n], 0, 0, 0);
                             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, acc[n], 0, 0, 0);
@@ -1323,7 +1337,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                             (long)T * B * DH * 4 < 0x7fffffffL;
         if (bi_xcd) {
             if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
-            if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)bi_lds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
         }
@@ -1350,7 +1364,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                     J.hs_b = DH; J.hs_t = (long)B * DH; J.nsteps = T; J.base = 0;
                     J.dt = d ? -1 : 1; J.t0 = J.t_first = d ? T - 1 : 0;
                 }
-                hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(256), dim3(256), bi_lds, stream, Q);
+                hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
                 continue;
             }
             P.n = 2; grid.z = 2;
@@ -1414,8 +1428,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     }
     if (persist) {
         if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
-        if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)plds) != hipSuccess)
+        if (hipFuncSetAttribute(xcd ? (const void*)gru_fwd_persist_kernel<true> : (const void*)gru_fwd_persist_kernel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
     }
     for (int w = 0; w < nch + L - 1; ++w) {
@@ -1466,8 +1480,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
             Q.n = n;
             if (xcd) Q.stamp = g_prof.slot(0, n == L, false, chunk);
-            if (xcd) hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(256), dim3(256), plds, stream, Q);
-            else hipLaunchKernelGGL(gru_fwd_persist_kernel, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
+            if (xcd) hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), plds, stream, Q);
+            else hipLaunchKernelGGL(gru_fwd_persist_kernel<false>, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
             continue;
         }
         ch.fork();
