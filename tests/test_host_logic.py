@@ -96,3 +96,50 @@ def test_import_shims_match_reference_paths():
     assert ctc.CTCLoss is CTCLoss and hasattr(models, "CTC") and hasattr(models, "Model")
     assert callable(speech.save) and callable(speech.load) and callable(speech.compute_cer)
     assert ctc.CTCLoss().blank is None  # no-arg constructor, as ctc_model.py:38 uses it
+
+
+def test_transducer_and_seq2seq_host_methods_and_cpu_refusal():
+    """The other two model classes of the reference: constructor surface and state-dict keys
+    (transducer_model.py:14-34, seq2seq.py:14-36), collate / label_collate / end_pad_concat, scheduled-sampling
+    switches, the `transducer` import shim, and that a CPU model refuses to compute."""
+    from speech.models import Seq2Seq, Transducer
+    from speech_amd.models import end_pad_concat
+    from speech_amd._lib import SpeechAmdError
+    import transducer.decoders as td
+    import transducer.functions.transducer as tf
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 32, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}},
+           "decoder": {"embedding_dim": 16, "layers": 1, "sample_prob": 0.3, "log_t": True}}
+    rng = np.random.RandomState(0)
+    inputs = tuple(rng.randn(60 - 5 * i, 40).astype(np.float32) for i in range(3))
+
+    t = Transducer(40, 10, cfg)
+    keys = set(t.state_dict().keys())
+    assert {"embedding.weight", "dec_rnn.weight_ih_l0", "fc1.fc.weight", "fc2.fc.bias", "rnn.weight_hh_l1_reverse"} <= keys
+    assert t.blank == 10 and t.fc2.fc.out_features == 11
+    labels = ([1, 2, 3], [4, 5], [6, 7, 8, 9])
+    x, y, x_lens, y_lens = t.collate(inputs, labels)
+    assert x.shape == (3, 60, 40) and y.tolist() == [1, 2, 3, 4, 5, 6, 7, 8, 9]
+    assert x_lens.tolist() == [28, 28, 28] and y_lens.tolist() == [3, 2, 4]      # ceil((60 - 5 + 1) / 2) = 28
+    ym = t.label_collate(labels)
+    assert ym.dtype == torch.int64 and ym.tolist() == [[1, 2, 3, 3], [4, 5, 3, 3], [6, 7, 8, 9]]  # pad = labels[0][-1]
+    with pytest.raises(SpeechAmdError):
+        t.loss((inputs, labels))
+    assert tf.TransducerLoss.__name__ == "TransducerLoss" and callable(td.decode_static)
+
+    s = Seq2Seq(40, 11, cfg)
+    keys = set(s.state_dict().keys())
+    assert {"embedding.weight", "dec_rnn.weight_ih", "attend.conv.weight", "attend.nn.1.fc.weight", "fc.fc.bias"} <= keys
+    assert s.fc.fc.out_features == 10 and tuple(s.attend.conv.weight.shape) == (16, 1, 15)
+    assert s.scheduled_sampling and s.sample_prob == 0.3
+    s.set_eval()
+    assert not s.scheduled_sampling and s.volatile
+    s.set_train()
+    assert s.scheduled_sampling and not s.volatile
+    seqs = ([10, 1, 2, 9], [10, 3, 9], [10, 4, 5, 6, 9])
+    assert end_pad_concat(seqs).tolist() == [[10, 1, 2, 9, 9], [10, 3, 9, 9, 9], [10, 4, 5, 6, 9]]
+    xs, ys = s.collate(inputs, seqs)
+    assert xs.shape == (3, 60, 40) and ys.dtype == torch.int64 and ys.shape == (3, 5)
+    with pytest.raises(SpeechAmdError):
+        s.loss((inputs, seqs))
+    with pytest.raises(AssertionError):   # the context vector is added to the embedding: the two widths must match
+        Seq2Seq(40, 11, dict(cfg, decoder={"embedding_dim": 8, "layers": 1}))
