@@ -480,29 +480,41 @@ class Seq2Seq(Model):
 
     def beam_search(self, batch, beam_size=10, max_len=200):
         """seq2seq.py:180-229 for a batch of ONE utterance, with the reference's py2 `filter(...)[:n]` (:211-212)
-        read as the list it was written for.  The per-hypothesis decoder steps run on the GPU; the beam bookkeeping is
-        host-side Python exactly as in the reference."""
+        read as the list it was written for.  The reference runs one decoder step per live hypothesis (a batch of 1
+        each); here the live hypotheses of a search step are ONE batched decoder step (their states stacked on the
+        batch axis, the encoder states repeated), and only the beam bookkeeping is host-side Python as in the
+        reference.  Hypotheses are independent rows of that step, so the search is the same search."""
         x, y = self.collate(*batch)
         start_tok, end_tok = int(y[0, 0]), int(y[0, -1])
         with torch.no_grad():
             x = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
-        beam = [((start_tok,), 0, None)]
+        dev = x.device
+        x_rep = x.expand(beam_size, x.shape[1], x.shape[2]).contiguous()
+        beam = [((start_tok,), 0, None)]  # (hypothesis, score, row state (hx, ax, sx) or None)
         complete = []
         for _ in range(max_len):
+            n = len(beam)
+            toks = torch.tensor([[h[-1]] for h, _, _ in beam], dtype=torch.int64, device=dev)
+            if beam[0][2] is None:
+                state = None
+            else:
+                state = tuple(torch.stack([st[k] for _, _, st in beam], dim=0) for k in range(3))
+            out, (hx, ax, sx) = self.decode_step(x_rep[:n], toks, state=state, softmax=True)
+            out = out.cpu().numpy()
             new_beam = []
-            for hyp, score, state in beam:
-                tok = torch.full((1, 1), hyp[-1], dtype=torch.int64, device=x.device)
-                out, state = self.decode_step(x, tok, state=state, softmax=True)
-                out = out.cpu().numpy().squeeze(axis=0).tolist()
-                for i, p in enumerate(out):
-                    new_beam.append((hyp + (i,), score + p, state))
+            for e, (hyp, score, _) in enumerate(beam):
+                st = (hx[e], ax[e], sx[e])
+                for i, p in enumerate(out[e].tolist()):
+                    new_beam.append((hyp + (i,), score + p, st))
             new_beam = sorted(new_beam, key=lambda c: c[1], reverse=True)
+            # Remove complete hypotheses
             for cand in new_beam[:beam_size]:
                 if cand[0][-1] == end_tok:
                     complete.append(cand)
             beam = [c for c in new_beam if c[0][-1] != end_tok][:beam_size]
             if len(beam) == 0:
                 break
+            # Stopping criteria: complete contains beam_size more probable candidates than anything left in the beam
             if sum(c[1] > beam[0][1] for c in complete) >= beam_size:
                 break
         complete = sorted(complete, key=lambda c: c[1], reverse=True)
