@@ -268,6 +268,20 @@ ctcStatus_t sa_joint_relu_bwd(const float* dz, const float* xa, const float* ya,
 ctcStatus_t sa_log_softmax_fwd(const float* x, float* y, long rows, int K, void* stream);
 ctcStatus_t sa_log_softmax_bwd(const float* dy, const float* y, float* dx, long rows, int K, void* stream);
 
+/* The joint of Transducer.decode as ONE operator (transducer_model.py:72-76: relu(xa + ya) -> fc2 -> log_softmax) that
+ * never materialises the (B, T, U1, H) joint tensor: the MFMA operand is built from xa / ya rows on the fly.
+ *   fwd: logp[b,t,u,:] = log_softmax(W2 relu(xa[b,t,:] + ya[b,u,:]) + b2)          W2 (K, H), b2 (K), logp (B,T,U1,K)
+ *   bwd: given glp = dLoss/dlogp (B,T,U1,K) and the saved logp: dxa (B,T,H), dya (B,U1,H), dW2 (K,H), db2 (K), all
+ *        WRITTEN (not accumulated); partial sums are folded in a fixed order (deterministic).
+ * Supported shapes: H % 64 == 0, H <= 512, K <= 32; sa_joint_fused_workspace_bytes returns 0 for any other shape (use
+ * sa_joint_relu_* + sa_gemm_f32 + sa_log_softmax_*), otherwise the backward workspace size in bytes. */
+size_t sa_joint_fused_workspace_bytes(int B, int T, int U1, int H, int K);
+ctcStatus_t sa_joint_fused_fwd(const float* xa, const float* ya, const float* w2, const float* b2, float* logp, int B,
+                               int T, int U1, int H, int K, void* stream);
+ctcStatus_t sa_joint_fused_bwd(const float* glp, const float* logp, const float* xa, const float* ya, const float* w2,
+                               float* dxa, float* dya, float* dw2, float* db2, int B, int T, int U1, int H, int K,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * 8. Seq2Seq attention decoder (speech/models/seq2seq.py).  Per output token the decoder runs an
  *    nn.GRUCell (:20-21,97), NNAttention (:331-360) and, over all tokens, a linear layer and a summed cross-entropy

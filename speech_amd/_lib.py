@@ -85,6 +85,9 @@ SIGNATURES = {
                                   c_void_p]),
     "sa_log_softmax_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_log_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "sa_joint_fused_workspace_bytes": (c_size_t, [c_int] * 5),
+    "sa_joint_fused_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "sa_joint_fused_bwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "sa_grucell_gates_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "sa_grucell_gates_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "sa_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -167,6 +167,25 @@ class _LinearFunction(torch.autograd.Function):
         from . import ops
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
+        n_out = dy.shape[1]
+        if n_out % 4 and dy.shape[0] >= 4096:
+            # A narrow, odd-width gradient (the Transducer's 29-class lattice: 1.6 M rows) defeats the GEMM's 16-byte
+            # operand loads on both products: its rows are not 16-byte aligned (dx = dy w) and its columns are the
+            # contiguous axis of a transposed operand (dw = dy^T x).  Two data movements fix that: zero-pad the class
+            # axis to a multiple of 4 for dx, and hand dw a materialised dy^T whose rows are the long, aligned axis.
+            pad = 4 - n_out % 4
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dy_p = torch.nn.functional.pad(dy, (0, pad))
+                w_p = torch.nn.functional.pad(w.detach(), (0, 0, 0, pad))
+                dx = ops.gemm(dy_p, w_p)
+            rows = dy.shape[0]
+            rows_p = (rows + 3) // 4 * 4  # dy^T (n_out, rows): pad the row count so that every row of dy^T is aligned
+            dy_t = torch.zeros(n_out, rows_p, dtype=dy.dtype, device=dy.device)
+            dy_t[:, :rows].copy_(dy.t())
+            x_p = x if rows_p == rows else torch.nn.functional.pad(x, (0, 0, 0, rows_p - rows))
+            dw = ops.gemm(dy_t, x_p, out=ctx.slots[0])
+            return dx, dw, ops.colsum(dy, out=ctx.slots[1])
         dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
         return dx, ops.gemm(dy, x, trans_a=True, out=ctx.slots[0]), ops.colsum(dy, out=ctx.slots[1])
 
@@ -308,7 +327,12 @@ class Transducer(Model):
         U1 = yd.shape[1]
         rows = torch.cat([x.reshape(B * T, H), yd.reshape(B * U1, H)], dim=0)
         a = self.fc1(rows)
-        z = _tr.JointFunction.apply(a[:B * T].view(B, T, H), a[B * T:].view(B, U1, H))  # (:73)
+        xa, ya = a[:B * T].view(B, T, H), a[B * T:].view(B, U1, H)
+        K = self.fc2.fc.weight.shape[0]
+        if _tr.joint_fused_supported(B, T, U1, H, K):
+            # (:73-76) as one operator: the (B, T, U1, H) joint tensor exists only inside the MFMA operands
+            return _tr.FusedJointFunction.apply(xa, ya, self.fc2.fc.weight, self.fc2.fc.bias)
+        z = _tr.JointFunction.apply(xa, ya)  # (:73)
         out = self.fc2(z)
         return _tr.LogSoftmaxFunction.apply(out)
 

@@ -184,6 +184,47 @@ class JointFunction(torch.autograd.Function):
         return dxa, dya
 
 
+def joint_fused_supported(B, T, U1, H, K):
+    """True when the one-operator joint (sa_joint_fused_*) takes this shape."""
+    return _lib.lib().sa_joint_fused_workspace_bytes(B, T, U1, H, K) != 0
+
+
+class FusedJointFunction(torch.autograd.Function):
+    """log_softmax(fc2(relu(xa[:, :, None, :] + ya[:, None, :, :])))  (transducer_model.py:72-76) as one operator:
+    (B,T,H), (B,U1,H), fc2.weight (K,H), fc2.bias (K) -> (B,T,U1,K) log-probabilities.  The (B,T,U1,H) joint tensor is
+    never written; the backward rebuilds it inside the matrix products and writes the fc2 gradients into their slots."""
+
+    @staticmethod
+    def forward(ctx, xa, ya, w2, b2):
+        _lib.require_cuda(xa, "xa")
+        xa, ya = xa.detach().contiguous(), ya.detach().contiguous()
+        w, b = w2.detach().contiguous(), b2.detach().contiguous()
+        B, T, H = xa.shape
+        U1, K = ya.shape[1], w.shape[0]
+        logp = torch.empty(B, T, U1, K, dtype=torch.float32, device=xa.device)
+        _lib.check(_lib.lib().sa_joint_fused_fwd(_lib.ptr(xa), _lib.ptr(ya), _lib.ptr(w), _lib.ptr(b), _lib.ptr(logp),
+                                                 B, T, U1, H, K, _lib.cur_stream()), "sa_joint_fused_fwd")
+        ctx.save_for_backward(xa, ya, w, logp)
+        ctx.slots = (getattr(w2, "_grad_slot", None), getattr(b2, "_grad_slot", None))
+        return logp
+
+    @staticmethod
+    def backward(ctx, glp):
+        xa, ya, w, logp = ctx.saved_tensors
+        B, T, H = xa.shape
+        U1, K = ya.shape[1], w.shape[0]
+        glp = glp.contiguous()
+        L = _lib.lib()
+        ws = _lib.WORKSPACE.get(L.sa_joint_fused_workspace_bytes(B, T, U1, H, K), xa.device, "joint_fused")
+        dxa, dya = torch.empty_like(xa), torch.empty_like(ya)
+        dw = ctx.slots[0] if ctx.slots[0] is not None else torch.empty_like(w)
+        db = ctx.slots[1] if ctx.slots[1] is not None else torch.empty(K, dtype=torch.float32, device=xa.device)
+        _lib.check(L.sa_joint_fused_bwd(_lib.ptr(glp), _lib.ptr(logp), _lib.ptr(xa), _lib.ptr(ya), _lib.ptr(w),
+                                        _lib.ptr(dxa), _lib.ptr(dya), _lib.ptr(dw), _lib.ptr(db), B, T, U1, H, K,
+                                        _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_joint_fused_bwd")
+        return dxa, dya, dw, db
+
+
 class LogSoftmaxFunction(torch.autograd.Function):
     """log_softmax over the last axis (transducer_model.py:76)."""
 
