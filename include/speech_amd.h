@@ -332,6 +332,14 @@ ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* params, cons
                                const float* IX, const float* ST, const float* HX, const float* AX, const float* OIN,
                                int B, int T, int U, int H, int E, int KS, int K, int V, float scale, float* d_eh,
                                float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+/* One decoder token without the training stashes (Seq2Seq.decode_step, seq2seq.py:114-138) -- the greedy / beam-search
+ * step.  idx (B) int64 tokens; hprev (B,H), ax_prev (B,T), sx_prev (B,H) the previous state, all three NULL for the
+ * first token.  Writes the new state hx, ax, sx and the logits out (B,K).  Same arithmetic as one iteration of
+ * sa_s2s_decoder_fwd; workspace: sa_s2s_decoder_workspace_bytes(B, T, 1, H, E, KS, K). */
+ctcStatus_t sa_s2s_decoder_step(const float* eh, const long long* idx, const float* hprev, const float* ax_prev,
+                                const float* sx_prev, const float* const* params, int B, int T, int H, int E, int KS,
+                                int K, float scale, float* hx, float* ax, float* sx, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream);
 ctcStatus_t sa_softmax_xent(const float* logits, const long long* targets, float scale, float* loss_rows,
                             float* dlogits, long rows, int K, void* stream);
 ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows, int K, void* stream);

@@ -690,6 +690,55 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
                             ws + L.gemm, L.colsum - L.gemm, stream);
 }
 
+// One decoder token without the training stashes (Seq2Seq.decode_step, seq2seq.py:114-138): the inference / beam-search
+// step.  Same kernels and the same arithmetic as one iteration of sa_s2s_decoder_fwd: embedding (+ previous context),
+// both GRU projections in ONE skinny launch, the gate kernel, attention score + context, fc as a skinny product.
+//   idx (B) int64 tokens; hprev / ax_prev / sx_prev null for the first token (zero state, no location features).
+//   out (B,K) logits; hx (B,H), ax (B,T), sx (B,H) the new state.  workspace: sa_s2s_decoder_workspace_bytes(.., U1=1, ..).
+extern "C" ctcStatus_t sa_s2s_decoder_step(const float* eh, const long long* idx, const float* hprev,
+                                           const float* ax_prev, const float* sx_prev, const float* const* params,
+                                           int B, int T, int H, int E, int KS, int K, float scale, float* hx, float* ax,
+                                           float* sx, float* out, void* workspace, size_t workspace_bytes,
+                                           void* stream_) {
+    SA_CLEAR_ERR();
+    S2SDims d{B, T, 1, H, E, KS, K};
+    if (!eh || !idx || !params || !hx || !ax || !sx || !out || !workspace || !s2s_ok(d)) return CTC_STATUS_INVALID_VALUE;
+    if ((hprev == nullptr) != (ax_prev == nullptr) || (hprev == nullptr) != (sx_prev == nullptr))
+        return CTC_STATUS_INVALID_VALUE;
+    const S2SLayout L = s2s_layout(d);
+    if (workspace_bytes < L.total) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* gi = (float*)(ws + L.gi);
+    float* gh = (float*)(ws + L.gh);
+    float* ix = (float*)(ws + L.DIX);    // the backward regions are free in a forward-only step
+    float* oin = (float*)(ws + L.dOIN);
+    float* score = (float*)(ws + L.att);
+    const float* const* P = params;
+    if (!hprev) {
+        float* hzero = (float*)(ws + L.d_hprev);
+        if (hipMemsetAsync(hzero, 0, (size_t)B * H * sizeof(float), stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+        hprev = hzero;
+    }
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 4 + 4 * (size_t)H) * sizeof(float);
+    if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
+        return CTC_STATUS_INVALID_VALUE;
+    hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], idx, sx_prev, ix, E);
+    SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
+                        {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
+    skinny_launch(pr, 2, B, stream);
+    hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
+                       (float*)nullptr, B, H);
+    AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
+    hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+    hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
+    SkinnyProb q{oin, P[P_FCW], P[P_FCB], out, K, H, 0, H, H, K};
+    skinny_launch(&q, 1, B, stream);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
 extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* params, const float* d_out,
                                           const long long* IDX, const float* IX, const float* ST, const float* HX,
                                           const float* AX, const float* OIN, int B, int T, int U, int H, int E, int KS,

@@ -71,8 +71,25 @@ def attention(eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, log_t):
 def step(eh, idx, state, P, log_t):
     """One decoder token without autograd.  idx (B,) int64; state None or (hx, ax, sx).  P: parameter dict.
     Returns (logits (B, V-1), (hx, ax, sx))."""
-    B, H = eh.shape[0], eh.shape[2]
-    ix = torch.empty(B, P["emb"].shape[1], dtype=torch.float32, device=eh.device)
+    B, T, H = eh.shape
+    E, K, KS = P["emb"].shape[1], P["fc_w"].shape[0], P["conv_w"].shape[-1]
+    L = _L()
+    nbytes = L.sa_s2s_decoder_workspace_bytes(B, T, 1, H, E, KS, K)
+    if nbytes:
+        # the whole token in the library: 7 launches, both GRU projections and the fc on the small-M MFMA kernel
+        f = dict(dtype=torch.float32, device=eh.device)
+        hx, ax, sx = torch.empty(B, H, **f), torch.empty(B, T, **f), torch.empty(B, H, **f)
+        out = torch.empty(B, K, **f)
+        ws = _lib.WORKSPACE.get(nbytes, eh.device, "s2s_decoder")
+        hp, ap, sp = state if state is not None else (None, None, None)
+        plist = [P[n].contiguous() for n in _NAMES]
+        _lib.check(L.sa_s2s_decoder_step(_lib.ptr(eh.contiguous()), _lib.ptr(idx.contiguous()), _lib.ptr(hp),
+                                         _lib.ptr(ap), _lib.ptr(sp), _ptr_array(plist), B, T, H, E, KS, K,
+                                         math.log(T) if log_t else 1.0, _lib.ptr(hx), _lib.ptr(ax), _lib.ptr(sx),
+                                         _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.cur_stream()),
+                   "sa_s2s_decoder_step")
+        return out, (hx, ax, sx)
+    ix = torch.empty(B, E, dtype=torch.float32, device=eh.device)
     embedding_rows(P["emb"], idx, ix)
     if state is None:
         hprev, ax_prev = torch.zeros(B, H, dtype=torch.float32, device=eh.device), None
