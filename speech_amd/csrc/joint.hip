@@ -18,16 +18,47 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restr
     for (int e = threadIdx.x; e < E; e += blockDim.x) dst[e] = src[e];
 }
 
-// dtable[v, :] = sum over i with idx[i] == v of dout[i, :]   (fixed order: deterministic)
+// dtable[v, :] = sum over i with idx[i] == v of dout[i, :]   (ascending i: deterministic)
+// One block per table row.  The n indices are scanned 256 at a time: a wave ballot + a 4-entry prefix compacts the
+// matching positions, in order, into LDS, and only those rows are read (n / V of them on average, not n).
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dout,
                                                             const long long* __restrict__ idx,
                                                             float* __restrict__ dtable, int n, int E) {
-    const int v = blockIdx.x;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        float acc = 0.f;
-        for (int i = 0; i < n; ++i)
-            if (idx[i] == v) acc += dout[(long)i * E + e];
-        dtable[(long)v * E + e] = acc;
+    __shared__ int list[256];
+    __shared__ int wcount[4];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kMaxE = 4;  // columns per thread held in registers (E <= 1024); wider tables loop below
+    float acc[kMaxE];
+#pragma unroll
+    for (int c = 0; c < kMaxE; ++c) acc[c] = 0.f;
+    for (int e0 = 0; e0 < E; e0 += 256 * kMaxE) {
+        for (int base = 0; base < n; base += 256) {
+            const int i = base + tid;
+            const bool hit = i < n && idx[i] == v;
+            const unsigned long long mask = __ballot(hit);
+            if (lane == 0) wcount[wave] = __popcll(mask);
+            __syncthreads();
+            int off = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) off += wcount[w];
+                total += wcount[w];
+            }
+            if (hit) list[off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+            __syncthreads();
+            for (int k = 0; k < total; ++k) {
+                const float* row = dout + (long)list[k] * E + e0 + tid;
+#pragma unroll
+                for (int c = 0; c < kMaxE; ++c)
+                    if (e0 + tid + 256 * c < E) acc[c] += row[256 * c];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxE; ++c) {
+            if (e0 + tid + 256 * c < E) dtable[(long)v * E + e0 + tid + 256 * c] = acc[c];
+            acc[c] = 0.f;
+        }
     }
 }
 

@@ -143,6 +143,17 @@ def test_joint_pieces_match_torch():
     (e * we.float().cuda()).sum().backward()
     np.testing.assert_allclose(e.detach().cpu().numpy(), table[idx].numpy(), rtol=1e-6)
     np.testing.assert_allclose(tg.grad.cpu().numpy(), tr_.grad.numpy(), rtol=1e-5, atol=1e-5)
+    # embedding gradient over several 256-index scan chunks, a table wider than one pass of the block, unused rows
+    for (Vb, Eb, nb) in ((28, 512, 3200), (7, 1100, 700), (300, 36, 257)):
+        table = torch.randn(Vb, Eb, dtype=torch.float64)
+        idx = torch.randint(0, Vb - 1, (nb // 10, 10))   # the last row never occurs: its gradient must be zero
+        we = torch.randn(nb // 10, 10, Eb, dtype=torch.float64)
+        tr_ = table.clone().requires_grad_(True)
+        (torch.nn.functional.embedding(idx, tr_) * we).sum().backward()
+        tg = table.float().cuda().requires_grad_(True)
+        (tr.EmbeddingFunction.apply(idx, tg) * we.float().cuda()).sum().backward()
+        np.testing.assert_allclose(tg.grad.cpu().numpy(), tr_.grad.numpy(), rtol=1e-4, atol=1e-4)
+        assert float(tg.grad[Vb - 1].abs().max()) == 0.0
     # prediction GRU against nn.GRU
     gru = torch.nn.GRU(E, H, num_layers=2, batch_first=True).double()
     xin = torch.randn(B, U1, E, dtype=torch.float64)

@@ -107,7 +107,7 @@ def m_transducer(iters):
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         out["loss"] = loss
 
-    sec = timed(step, iters, warmup=2)
+    sec = timed(step, iters, warmup=4)
     alg = 2 * lat.numel() * 4
     return {"workload": "RNN-T S-LIBRI (config 5)", "B": B, "T_out": Tp, "U": L, "classes": V + 1,
             "params": int(flat_p.numel()), "loss_fwd_bwd_ms": loss_ms, "loss_algorithmic_GBps": alg / loss_ms / 1e6,
@@ -179,7 +179,7 @@ def main():
                      m_step("S-LIBRI bidirectional", 80, 28, bi, 32, 1000, 100, 3)]
     res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
                       m_step("2xGRU-256 F=40 |V|=61", 40, 61, small, 32, 1000, 100, 5)]
-    res["M-RNNT"] = [m_transducer(3)]
+    res["M-RNNT"] = [m_transducer(8)]
     res["M-S2S"] = [m_seq2seq(3)]
     rng = np.random.RandomState(2017)
     z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
