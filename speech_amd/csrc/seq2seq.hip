@@ -121,14 +121,14 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
     }
 }
 
-// ---- forward, stage 2: softmax over time and the context.  grid B, 256 threads.  dynamic LDS: a[T] | red[4] | part[4][H]
+// ---- forward, stage 2: softmax over time and the context.  grid B, 256 threads.  dynamic LDS: a[T] | red[4] | pad | part[4][H]
 __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const float* __restrict__ score,
                                                                 float* __restrict__ ax, float* __restrict__ sx,
                                                                 float* __restrict__ oin /* ox + sx, or NULL */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* a = reinterpret_cast<float*>(smem_raw);
     float* red = a + A.T;
-    float* part = red + 4;
+    float* part = a + ((A.T + 4 + 3) & ~3);  // 16-byte aligned: the context partials are written as float4
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* ehb = A.eh + (long)b * A.T * A.H;
     float m = -3.0e38f;
@@ -153,10 +153,36 @@ __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const
     __syncthreads();
     // context: each wave sums a quarter of the time axis for every hidden unit, then the quarters are combined
     const int tq = (A.T + 3) / 4, tb = wave * tq, te = min(A.T, tb + tq);
-    for (int h = lane; h < A.H; h += 64) {
-        float acc = 0.f;
-        for (int t = tb; t < te; ++t) acc += a[t] * ehb[(long)t * A.H + h];
-        part[wave * A.H + h] = acc;
+    if ((A.H & 3) == 0) {
+        // a lane owns 4 consecutive hidden units (one 16-byte load per row), 4 rows in flight; the sum over t keeps its
+        // ascending order, so the result is the same as the scalar loop's
+        const int H4 = A.H >> 2;
+        const float4* e4 = reinterpret_cast<const float4*>(ehb);
+        for (int c = lane; c < H4; c += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int t = tb;
+            for (; t + 4 <= te; t += 4) {
+                const float4 v0 = e4[(long)t * H4 + c], v1 = e4[(long)(t + 1) * H4 + c];
+                const float4 v2 = e4[(long)(t + 2) * H4 + c], v3 = e4[(long)(t + 3) * H4 + c];
+                const float a0 = a[t], a1 = a[t + 1], a2 = a[t + 2], a3 = a[t + 3];
+                acc.x += a0 * v0.x; acc.y += a0 * v0.y; acc.z += a0 * v0.z; acc.w += a0 * v0.w;
+                acc.x += a1 * v1.x; acc.y += a1 * v1.y; acc.z += a1 * v1.z; acc.w += a1 * v1.w;
+                acc.x += a2 * v2.x; acc.y += a2 * v2.y; acc.z += a2 * v2.z; acc.w += a2 * v2.w;
+                acc.x += a3 * v3.x; acc.y += a3 * v3.y; acc.z += a3 * v3.z; acc.w += a3 * v3.w;
+            }
+            for (; t < te; ++t) {
+                const float4 v = e4[(long)t * H4 + c];
+                const float at = a[t];
+                acc.x += at * v.x; acc.y += at * v.y; acc.z += at * v.z; acc.w += at * v.w;
+            }
+            *reinterpret_cast<float4*>(part + wave * A.H + 4 * c) = acc;
+        }
+    } else {
+        for (int h = lane; h < A.H; h += 64) {
+            float acc = 0.f;
+            for (int t = tb; t < te; ++t) acc += a[t] * ehb[(long)t * A.H + h];
+            part[wave * A.H + h] = acc;
+        }
     }
     __syncthreads();
     for (int h = threadIdx.x; h < A.H; h += 256) {
@@ -411,7 +437,7 @@ extern "C" ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const 
     AttArgs A{eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, scale, B, T, H, KS};
     float* score = (float*)workspace;
     const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
-    const size_t smem2 = ((size_t)T + 4 + 4 * (size_t)H) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
@@ -655,7 +681,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
     const size_t att_bytes = sa_attention_workspace_bytes(B, T, H, KS);
     const int U1 = U - 1;
     const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
-    const size_t smem2 = ((size_t)T + 4 + 4 * (size_t)H) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
     (void)att_bytes;
@@ -721,7 +747,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_step(const float* eh, const long long* idx
         hprev = hzero;
     }
     const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
-    const size_t smem2 = ((size_t)T + 4 + 4 * (size_t)H) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], idx, sx_prev, ix, E);

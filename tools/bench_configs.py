@@ -142,7 +142,7 @@ def m_seq2seq(iters):
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         out["loss"] = loss
 
-    sec = timed(step, iters, warmup=2)
+    sec = timed(step, iters, warmup=4)
     model.set_eval()
     one = (inputs[:1], labels[:1])
     greedy = timed(lambda: model.infer((inputs, labels), max_len=U), 2, warmup=1)
@@ -180,7 +180,7 @@ def main():
     res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
                       m_step("2xGRU-256 F=40 |V|=61", 40, 61, small, 32, 1000, 100, 5)]
     res["M-RNNT"] = [m_transducer(8)]
-    res["M-S2S"] = [m_seq2seq(3)]
+    res["M-S2S"] = [m_seq2seq(8)]
     rng = np.random.RandomState(2017)
     z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
     greedy = timed(lambda: decoder.greedy_decode(z, blank=28), 20)

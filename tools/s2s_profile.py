@@ -6,4 +6,4 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_configs as bc  # noqa: E402
 
-print(json.dumps(bc.m_seq2seq(3)))
+print(json.dumps(bc.m_seq2seq(10)))
