@@ -86,20 +86,27 @@ __device__ __forceinline__ void att_stage(const AttArgs& A, int b, int t0, float
         const int t = t0 + i - pad;
         axp[i] = (A.ax_prev && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
     }
-    for (int i = threadIdx.x; i < A.H * A.KS; i += blockDim.x) cw[i] = A.conv_w[i];
+    // eight loads in flight per thread: one load -> LDS store per trip is a serial chain of L2 round trips
+    // (H * KS / 256 = 15 of them at the shipped shapes, and it was most of the score / backward kernels' time)
+    const int n = A.H * A.KS, stride = blockDim.x;
+    for (int base = 0; base < n; base += stride * 8) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + j * stride + (int)threadIdx.x;
+            r[j] = i < n ? A.conv_w[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + j * stride + (int)threadIdx.x;
+            if (i < n) cw[i] = r[j];
+        }
+    }
 }
 
-// pre-activation of the score network at (t0 + tl, h)
-__device__ __forceinline__ float att_pre(const AttArgs& A, const float* ehb, const float* oxb, const float* axp,
-                                         const float* cw, int t0, int tl, int h) {
-    float v = ehb[(long)(t0 + tl) * A.H + h] + oxb[h];
-    if (A.ax_prev) {
-        float c = A.conv_b[h];
-        for (int k = 0; k < A.KS; ++k) c += cw[h * A.KS + k] * axp[tl + k];
-        v += c;
-    }
-    return v;
-}
+// The score network's pre-activation at (t, h) is, in this order in every kernel that forms it (forward and backward
+// must agree on the ReLU mask):  v = eh[t,h] + ox[h];  c = conv_b[h];  c += conv_w[h,k] * ax_prev[t + k - pad] (k
+// ascending);  v += c   -- the location term only when ax_prev is given.
 
 // ---- forward, stage 1: scores.  grid (ceil(T / 16), B), 256 threads: a wave per time step (4 per wave).
 // dynamic LDS: axp[kAttTB + KS - 1] | cw[H * KS]
@@ -113,11 +120,42 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
     att_stage(A, b, t0, axp, cw);
     __syncthreads();
     const float nb = A.nn_b[0];
-    for (int tl = wave; tl < kAttTB && t0 + tl < A.T; tl += 4) {
-        float v = 0.f;
-        for (int h = lane; h < A.H; h += 64) v += fmaxf(att_pre(A, ehb, oxb, axp, cw, t0, tl, h), 0.f) * A.nn_w[h];
-        v = sa_wave_sum_dpp(v);
-        if (lane == 0) score[(long)b * A.T + t0 + tl] = (v + nb) * A.scale;
+    // hidden unit outer, the wave's four time steps inner: the unit's conv taps are read from LDS once, the four eh
+    // loads are independent.  Each step still sums its units in ascending order (same result as a step-outer loop).
+    float vs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int h = lane; h < A.H; h += 64) {
+        const float oxh = oxb[h], nw = A.nn_w[h];
+        float cwr[16], cb = 0.f;
+        if (A.ax_prev) {
+            cb = A.conv_b[h];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cwr[k] = k < A.KS ? cw[h * A.KS + k] : 0.f;
+        }
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tl = wave + 4 * q;
+            e[q] = ehb[(long)min(t0 + tl, A.T - 1) * A.H + h];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tl = wave + 4 * q;
+            float v = e[q] + oxh;
+            if (A.ax_prev) {
+                float c = cb;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < A.KS) c += cwr[k] * axp[tl + k];
+                v += c;
+            }
+            vs[q] += fmaxf(v, 0.f) * nw;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tl = wave + 4 * q;
+        const float v = sa_wave_sum_dpp(vs[q]);
+        if (lane == 0 && t0 + tl < A.T) score[(long)b * A.T + t0 + tl] = (v + nb) * A.scale;
     }
 }
 
@@ -275,18 +313,44 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
         float a_cw[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) a_cw[k] = 0.f;
-        for (int tl = 0; tl < nt; ++tl) {
-            const float pre = att_pre(A, ehb, oxb, axp, cw, t0, tl, h);
-            const float dp = pre > 0.f ? dps[tl] * w : 0.f;
-            a_ox += dp;
-            a_nw += dps[tl] * fmaxf(pre, 0.f);
-            if (A.ax_prev) {
+        // the unit's conv taps from LDS once; the chunk's 16 eh / d_eh values are fetched up front (16 serial
+        // load -> compute -> store round trips were the whole cost of this kernel)
+        const float oxh = oxb[h];
+        float cwr[16], cb = 0.f;
+        if (A.ax_prev) {
+            cb = A.conv_b[h];
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < A.KS) a_cw[k] += dp * axp[tl + k];
+            for (int k = 0; k < 16; ++k) cwr[k] = k < A.KS ? cw[h * A.KS + k] : 0.f;
+        }
+        float ev[kAttTB], dv[kAttTB];
+#pragma unroll
+        for (int tl = 0; tl < kAttTB; ++tl) {
+            const long o = (long)(t0 + (tl < nt ? tl : 0)) * A.H + h;
+            ev[tl] = ehb[o];
+            dv[tl] = dehb[o];
+        }
+#pragma unroll
+        for (int tl = 0; tl < kAttTB; ++tl) {
+            if (tl < nt) {
+                float pre = ev[tl] + oxh;
+                if (A.ax_prev) {
+                    float c = cb;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < A.KS) c += cwr[k] * axp[tl + k];
+                    pre += c;
+                }
+                const float dp = pre > 0.f ? dps[tl] * w : 0.f;
+                a_ox += dp;
+                a_nw += dps[tl] * fmaxf(pre, 0.f);
+                if (A.ax_prev) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < A.KS) a_cw[k] += dp * axp[tl + k];
+                }
+                dehb[(long)(t0 + tl) * A.H + h] = dv[tl] + (axs[tl] * dsxh + dp);
+                dp_tile[tl * A.H + h] = dp;
             }
-            dehb[(long)(t0 + tl) * A.H + h] += axs[tl] * dsxh + dp;
-            dp_tile[tl * A.H + h] = dp;
         }
         float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + h) * W;
         p[0] = a_ox;
