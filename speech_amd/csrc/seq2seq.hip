@@ -108,7 +108,7 @@ __device__ __forceinline__ void att_stage(const AttArgs& A, int b, int t0, float
 // must agree on the ReLU mask):  v = eh[t,h] + ox[h];  c = conv_b[h];  c += conv_w[h,k] * ax_prev[t + k - pad] (k
 // ascending);  v += c   -- the location term only when ax_prev is given.
 
-// ---- forward, stage 1: scores.  grid (ceil(T / 16), B), 256 threads: a wave per time step (4 per wave).
+// ---- forward, stage 1: scores.  grid (ceil(T / 16), B), 256 threads: four consecutive time steps per wave.
 // dynamic LDS: axp[kAttTB + KS - 1] | cw[H * KS]
 __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* __restrict__ score) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
     // hidden unit outer, the wave's four time steps inner: the unit's conv taps are read from LDS once, the four eh
     // loads are independent.  Each step still sums its units in ascending order (same result as a step-outer loop).
     float vs[4] = {0.f, 0.f, 0.f, 0.f};
+    // the alignment window is the same for every lane: keep its 16 + KS - 1 values in registers instead of issuing a
+    // broadcast LDS read per multiply (the reads, not the arithmetic, were most of this kernel)
+    // (a wave takes four consecutive steps, so its window is 4 + KS - 1 values at compile-time offsets)
+    float axr[4 + 15];
+#pragma unroll
+    for (int i = 0; i < 4 + 15; ++i) axr[i] = i < 4 + A.KS - 1 ? axp[4 * wave + i] : 0.f;
     for (int h = lane; h < A.H; h += 64) {
         const float oxh = oxb[h], nw = A.nn_w[h];
         float cwr[16], cb = 0.f;
@@ -134,18 +140,17 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
         float e[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int tl = wave + 4 * q;
+            const int tl = 4 * wave + q;
             e[q] = ehb[(long)min(t0 + tl, A.T - 1) * A.H + h];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int tl = wave + 4 * q;
             float v = e[q] + oxh;
             if (A.ax_prev) {
                 float c = cb;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    if (k < A.KS) c += cwr[k] * axp[tl + k];
+                    if (k < A.KS) c += cwr[k] * axr[q + k];
                 v += c;
             }
             vs[q] += fmaxf(v, 0.f) * nw;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int tl = wave + 4 * q;
+        const int tl = 4 * wave + q;
         const float v = sa_wave_sum_dpp(vs[q]);
         if (lane == 0 && t0 + tl < A.T) score[(long)b * A.T + t0 + tl] = (v + nb) * A.scale;
     }
@@ -322,6 +327,12 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
 #pragma unroll
             for (int k = 0; k < 16; ++k) cwr[k] = k < A.KS ? cw[h * A.KS + k] : 0.f;
         }
+        // the alignment window and the per-step scalars are the same for every lane: registers, not an LDS read per use
+        float axr[kAttTB + 15], dpr[kAttTB], axsr[kAttTB];
+#pragma unroll
+        for (int i = 0; i < kAttTB + 15; ++i) axr[i] = i < kAttTB + A.KS - 1 ? axp[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < kAttTB; ++i) { dpr[i] = dps[i]; axsr[i] = axs[i]; }
         float ev[kAttTB], dv[kAttTB];
 #pragma unroll
         for (int tl = 0; tl < kAttTB; ++tl) {
@@ -337,18 +348,18 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
                     float c = cb;
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
-                        if (k < A.KS) c += cwr[k] * axp[tl + k];
+                        if (k < A.KS) c += cwr[k] * axr[tl + k];
                     pre += c;
                 }
-                const float dp = pre > 0.f ? dps[tl] * w : 0.f;
+                const float dp = pre > 0.f ? dpr[tl] * w : 0.f;
                 a_ox += dp;
-                a_nw += dps[tl] * fmaxf(pre, 0.f);
+                a_nw += dpr[tl] * fmaxf(pre, 0.f);
                 if (A.ax_prev) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
-                        if (k < A.KS) a_cw[k] += dp * axp[tl + k];
+                        if (k < A.KS) a_cw[k] += dp * axr[tl + k];
                 }
-                dehb[(long)(t0 + tl) * A.H + h] = dv[tl] + (axs[tl] * dsxh + dp);
+                dehb[(long)(t0 + tl) * A.H + h] = dv[tl] + (axsr[tl] * dsxh + dp);
                 dp_tile[tl * A.H + h] = dp;
             }
         }
@@ -367,26 +378,35 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
     }
 }
 
-// ---- backward, stage 4: fold the chunks.  grid B, 256 threads
+// ---- backward, stage 4: fold the chunks.  grid (2 + KS + 1, B), 256 threads: block (j, b) folds quantity j of the
+// per-chunk partials for every hidden unit (j = 0: d_pre sums -> d_ox and conv bias, 1: nn weight, 2 + k: conv tap k);
+// the last block row gathers d ax_prev from q.  (One block per utterance doing all 17 quantities serially was 25 us of
+// dependent L2 round trips on 16 CUs.)  Sums stay in chunk order.
 __global__ __launch_bounds__(256) void attention_bwd_fold_kernel(AttArgs A, AttBwd G) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, j = blockIdx.x;
     const int W = 2 + A.KS;
-    for (int h = threadIdx.x; h < A.H; h += 256) {
-        float acc[18];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) acc[k] = 0.f;
-        for (int c = 0; c < G.nchunk; ++c) {
-            const float* p = G.part + (((long)b * G.nchunk + c) * A.H + h) * W;
-#pragma unroll
-            for (int k = 0; k < 18; ++k)
-                if (k < W) acc[k] += p[k];
+    if (j < W) {
+        if (j >= 2 && !A.ax_prev) return;
+        for (int h = threadIdx.x; h < A.H; h += 256) {
+            const float* p = G.part + ((long)b * G.nchunk * A.H + h) * W + j;
+            const long cs = (long)A.H * W;
+            float acc = 0.f;
+            int c = 0;
+            for (; c + 4 <= G.nchunk; c += 4) {
+                const float v0 = p[c * cs], v1 = p[(c + 1) * cs], v2 = p[(c + 2) * cs], v3 = p[(c + 3) * cs];
+                acc += v0; acc += v1; acc += v2; acc += v3;
+            }
+            for (; c < G.nchunk; ++c) acc += p[c * cs];
+            if (j == 0) {
+                G.d_ox[(long)b * A.H + h] = acc;
+                if (A.ax_prev) G.g_conv_b[(long)b * A.H + h] += acc;
+            } else if (j == 1) {
+                G.g_nn_w[(long)b * A.H + h] += acc;
+            } else {
+                G.g_conv_w[((long)b * A.H + h) * A.KS + j - 2] += acc;
+            }
         }
-        G.d_ox[(long)b * A.H + h] = acc[0];
-        G.g_nn_w[(long)b * A.H + h] += acc[1];
-        if (A.ax_prev) {
-            G.g_conv_b[(long)b * A.H + h] += acc[0];
-            for (int k = 0; k < A.KS; ++k) G.g_conv_w[((long)b * A.H + h) * A.KS + k] += acc[2 + k];
-        }
+        return;
     }
     if (!A.ax_prev) return;
     const int pad = (A.KS - 1) / 2;
@@ -534,7 +554,7 @@ extern "C" ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const 
     hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
     hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
     hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
-    hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(B), dim3(256), 0, stream, A, G);
+    hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(2 + KS + 1, B), dim3(256), 0, stream, A, G);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
@@ -895,7 +915,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
         hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
         hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
         hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
-        hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(B), dim3(256), 0, stream, A, G);
+        hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(2 + KS + 1, B), dim3(256), 0, stream, A, G);
         // the state of token t fed the fc, the attention and the next token's GRU
         float* dgi = DGI + (long)t * B * 3 * H;
         float* dgh = DGH + (long)t * B * 3 * H;
