@@ -110,6 +110,56 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
     for (int f = lane; f < g.F; f += 64) out[f] = row[f];
 }
 
+// The same gather for narrow kernels (kw <= 32: the stacked 32-channel convs of the shipped TIMIT / WSJ configs, kw = 8),
+// where one lane per tap leaves most of a wave idle and every load a 32-byte sliver.  One BLOCK per output frame (b, t);
+// a wave owns 64 / kw channels and a lane is (channel, tap): for each kernel row i with a valid t' and each f' the wave
+// loads its channels' taps of dcols[(b, t', f')] and adds them into the channels' LDS rows at column s f' + tap (within
+// one step the columns of a channel are distinct, steps are sequential in the wave: no atomics, a fixed order).
+// Loads are issued four positions ahead.  dynamic LDS: 4 waves x (64 / kw) channels x F floats.
+__global__ __launch_bounds__(256) void col2im_narrow_kernel(const float* __restrict__ dcols, float* __restrict__ dx,
+                                                            ConvGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpw = 64 / g.kw, cpb = 4 * cpw;
+    const int cl = lane / g.kw, j = lane - cl * g.kw;
+    const bool live = cl < cpw;
+    float* rows = reinterpret_cast<float*>(smem_raw) + (long)wave * cpw * g.F;  // this wave's [cpw][F]
+    const int t = blockIdx.x % g.T, b = blockIdx.x / g.T;
+    for (int c0 = 0; c0 < g.C; c0 += cpb) {
+        const int c = c0 + wave * cpw + cl;
+        const bool on = live && c < g.C;
+        for (int idx = lane; idx < cpw * g.F; idx += 64) rows[idx] = 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float* myrow = rows + cl * g.F + j;
+        for (int i = t % g.s; i < g.kh; i += g.s) {
+            const int to = (t - i) / g.s;
+            if (t - i < 0 || to >= g.To) continue;
+            const float* src = dcols + (((long)b * g.To + to) * g.Fo) * g.K + (long)((on ? c : 0) * g.kh + i) * g.kw + j;
+            int fo = 0;
+            for (; fo + 4 <= g.Fo; fo += 4) {
+                const float v0 = src[(long)fo * g.K], v1 = src[(long)(fo + 1) * g.K];
+                const float v2 = src[(long)(fo + 2) * g.K], v3 = src[(long)(fo + 3) * g.K];
+                if (on) {
+                    myrow[g.s * fo] += v0;
+                    myrow[g.s * (fo + 1)] += v1;
+                    myrow[g.s * (fo + 2)] += v2;
+                    myrow[g.s * (fo + 3)] += v3;
+                }
+            }
+            for (; fo < g.Fo; ++fo) {
+                const float v = src[(long)fo * g.K];
+                if (on) myrow[g.s * fo] += v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int idx = lane; idx < cpw * g.F; idx += 64) {
+            const int cc = c0 + wave * cpw + idx / g.F;
+            if (cc < g.C) dx[(((long)b * g.C + cc) * g.T + t) * g.F + idx % g.F] = rows[idx];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // dW[o][k] = sum_pos dyp[pos][o] * cols[pos][k] for small O*K (the first conv: 32 x 160): an outer-product reduction
 // over ~4e5 positions.  As a GEMM it has M = O = 32 of a 128-row tile (75 % of the MFMAs wasted) and needs a 128-way
 // split-K; here each block reduces a slab of positions with the O*K accumulators register-tiled over its threads
@@ -299,8 +349,13 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
                               gws, gws_bytes, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
         if (g.kw > 64) return CTC_STATUS_INVALID_VALUE;  // one lane per tap
-        hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)(((long)g.B * g.C * g.T + 3) / 4)), dim3(256),
-                           (size_t)4 * g.F * sizeof(float), stream, cols, dx, g);
+        if (g.kw <= 32 && (size_t)4 * (64 / g.kw) * g.F * sizeof(float) <= 64 * 1024 && (long)g.B * g.T < 0x7fffffffL) {
+            hipLaunchKernelGGL(col2im_narrow_kernel, dim3((unsigned)(g.B * g.T)), dim3(256),
+                               (size_t)4 * (64 / g.kw) * g.F * sizeof(float), stream, cols, dx, g);
+        } else {
+            hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)(((long)g.B * g.C * g.T + 3) / 4)), dim3(256),
+                               (size_t)4 * g.F * sizeof(float), stream, cols, dx, g);
+        }
         SA_CHECK_LAUNCH();
     }
     return CTC_STATUS_SUCCESS;

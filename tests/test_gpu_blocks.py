@@ -72,7 +72,12 @@ def test_gemm_split_k_alpha_beta_and_strided():
 
 # ------------------------------------------------------------------------------------------------------------- conv
 @pytest.mark.parametrize("B,C,T,F,O,kh,kw,s", [(2, 1, 40, 40, 8, 5, 32, 2), (3, 4, 21, 17, 6, 5, 7, 1),
-                                               (1, 1, 9, 33, 32, 5, 32, 2), (2, 3, 30, 30, 5, 3, 4, 3)])
+                                               (1, 1, 9, 33, 32, 5, 32, 2), (2, 3, 30, 30, 5, 3, 4, 3),
+                                               # the stacked 32-channel conv of the shipped configs (narrow-kernel
+                                               # col2im: 8 channels per wave, several channel passes when C > 32)
+                                               (2, 32, 30, 37, 32, 5, 8, 2), (1, 40, 13, 21, 8, 5, 8, 2),
+                                               # kw > 32: the one-lane-per-tap col2im
+                                               (1, 2, 12, 40, 4, 3, 33, 2)])
 @pytest.mark.parametrize("feature_layout", [False, True])
 def test_conv_relu_fwd_bwd(B, C, T, F, O, kh, kw, s, feature_layout):
     from speech_amd import ops
