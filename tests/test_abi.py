@@ -43,6 +43,34 @@ def test_host_side_argument_checks_need_no_gpu():
                                 ctypes.byref(n)) == 3
 
 
+def test_shape_gates_of_the_fused_operators_need_no_gpu():
+    """The host-side shape gates that choose between the fused and the general operators."""
+    L = _lib.lib()
+    # one-operator Transducer joint: H % 64 == 0, H <= 512, K <= 32
+    assert L.sa_joint_fused_workspace_bytes(32, 498, 101, 512, 29) > 0
+    assert L.sa_joint_fused_workspace_bytes(2, 9, 17, 64, 7) > 0
+    for bad in ((2, 40, 18, 100, 29), (2, 40, 18, 1024, 29), (2, 40, 18, 128, 40), (0, 40, 18, 128, 29),
+                (2, 0, 18, 128, 29), (2, 40, 0, 128, 29)):
+        assert L.sa_joint_fused_workspace_bytes(*bad) == 0
+    # the partial-sum workspace grows with every dimension it is indexed by
+    w0 = L.sa_joint_fused_workspace_bytes(4, 100, 20, 256, 29)
+    assert L.sa_joint_fused_workspace_bytes(8, 100, 20, 256, 29) > w0
+    assert L.sa_joint_fused_workspace_bytes(4, 200, 20, 256, 29) > w0
+    assert L.sa_joint_fused_workspace_bytes(4, 100, 40, 256, 29) > w0
+    # null pointers are rejected before any launch
+    assert L.sa_joint_fused_fwd(None, None, None, None, None, 2, 9, 17, 64, 7, None) == 2
+    assert L.sa_joint_fused_bwd(None, None, None, None, None, None, None, None, None, 2, 9, 17, 64, 7, None, 0, None) == 2
+    # Seq2Seq decoder (loop and single step): embedding dim == rnn dim, dims % 4 == 0, odd location kernel <= 15 taps
+    assert L.sa_s2s_decoder_workspace_bytes(16, 197, 1, 256, 256, 15, 31) > 0
+    assert L.sa_s2s_decoder_workspace_bytes(16, 197, 99, 256, 256, 15, 31) > L.sa_s2s_decoder_workspace_bytes(
+        16, 197, 1, 256, 256, 15, 31)
+    assert L.sa_s2s_decoder_workspace_bytes(16, 197, 1, 256, 128, 15, 31) == 0   # E != H
+    assert L.sa_s2s_decoder_workspace_bytes(16, 197, 1, 256, 256, 14, 31) == 0   # even kernel
+    assert L.sa_s2s_decoder_workspace_bytes(16, 197, 1, 256, 256, 17, 31) == 0   # > 15 taps
+    assert L.sa_s2s_decoder_step(None, None, None, None, None, None, 16, 197, 256, 256, 15, 31, 1.0, None, None, None,
+                                 None, None, 0, None) == 2
+
+
 def test_cpu_tensor_fails_loudly():
     import torch
     from speech_amd.ctc import CTCLoss
