@@ -29,9 +29,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKP = 32;        // classes padded to two 16-wide MFMA tiles
 constexpr int kFwdTc = 64;     // frames per forward block (8 waves x 4 pairs)
-constexpr int kDataTc = 64;    // frames per backward-data block (4 waves x 16)
+constexpr int kDataTc = 64;    // frames per backward-data block (4 frame lanes x 16, each lane two half-width waves)
 constexpr int kWeightTc = 16;  // frames per backward-weight work item
-constexpr int kWeightGrid = 768;
+constexpr int kWeightGrid = 768;  // persistent backward-weight blocks: 3 per CU (161 registers per lane)
 constexpr int kLdT = 36;       // row stride of the transposed W2 tile in LDS (conflict-free 16-byte reads)
 
 struct JArgs {
