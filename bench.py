@@ -5,10 +5,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): weak scaling, every rank
-trains B=32 utterances per step and the flat gradient buffer is SUM all-reduced once per step.
+trains B=32 utterances per step and the flat gradient buffer is SUM all-reduced once per step.  Run by hand without
+a torchrun environment, `python bench.py --gpus N` launches those N ranks itself (it re-executes under
+torch.distributed.run on 127.0.0.1).
 
-One step = zero_grad + forward + CTC loss + backward + (all-reduce) + clip_grad_norm(200) + SGD, nothing skipped;
-inputs and labels are resident in HBM before the timed region (synthetic, seed 2017).  Rank 0 prints ONE JSON line.
+One step = zero_grad + forward + CTC loss + backward + health stamp + (all-reduce) + clip_grad_norm(200) + SGD +
+the loss read-back of the shipped loop (train.py: asynchronous, ops.ScalarPipe), nothing skipped; inputs and labels are
+resident in HBM before the timed region (synthetic, seed 2017).  Rank 0 prints ONE JSON line.
+
+Matched loss (north_star: "at matched CTC loss (rtol 1e-4)"): before any update the GPU model's loss on the batch is
+recorded as `loss_step0`; the CPU baseline copies the SAME initial weights into oracle/torch_ref.py and its first
+step's loss is `cpu_baseline.loss_step0`; `loss_rel_err` is their relative difference.
 """
 import argparse
 import json
@@ -43,7 +50,9 @@ def gpu_leg(args, world, rank, local):
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(2017)
-    model = CTC(F, V, S_LIBRI).cuda()
+    model = CTC(F, V, S_LIBRI)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None  # for the CPU leg
+    model = model.cuda()
     model.set_train()
     flat_p, flat_g = model.flatten_parameters_()
     x_h, lab_h = synthetic(rank)
@@ -54,6 +63,9 @@ def gpu_leg(args, world, rank, local):
     lr = 1e-3
     norm = torch.zeros(1, device=dev)
     last = {}
+    pipe = ops.ScalarPipe()
+    with torch.no_grad():  # the loss of the initial weights on this batch, before any update
+        loss_step0 = float(loss_fn(model.forward_impl(x), labels, None, None).item())
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -61,8 +73,11 @@ def gpu_leg(args, world, rank, local):
         with ops._span("ctc_loss", 3, 0.0):
             loss = loss_fn(logits, labels, None, None)
         loss.backward()
+        ops.stamp_health(flat_g)
         dist.allreduce_gradients(flat_g)
         ops.clip_sgd_step(flat_p, flat_g, None, lr, 0.0, 200.0, norm_out=norm)
+        for _, v in pipe.push(loss):  # train.py's read-back of the loss: asynchronous, one or two steps late
+            last["loss_host"] = v
         last["loss"] = loss
 
     for _ in range(args.warmup):
@@ -102,7 +117,9 @@ def gpu_leg(args, world, rank, local):
     ops.PROFILE = None
     dist.barrier()
     dt = dist.max_over_ranks(dt, dev)
+    pipe.drain()
     res = {"dt": dt, "loss": float(last["loss"].item()), "grad_norm": float(norm.item()), "prof": prof,
+           "loss_step0": loss_step0, "state0": state0, "persist_status": ops.persist_status(),
            "step_us": step_us, "prof_steps": prof_steps,
            "params": int(flat_p.numel()), "Tp": Tp}
 
@@ -127,9 +144,11 @@ CPU_THREADS = 16  # best of {8, 16, 32, 64, 128} on the GPU box's 256 host threa
                   # 2.22, 1.84, 3.21, 7.87, 19.98 s/step) -- torch's default of 128 oversubscribes the small GRU GEMMs
 
 
-def cpu_baseline(steps=4):
+def cpu_baseline(steps=4, state0=None):
     """The reference's CPU path restated (oracle/torch_ref.py: the same torch.nn CPU modules + C CTC restatement),
-    timed on this box's host cores on a bounded sample: `steps` full B=32 train steps after one warm-up."""
+    timed on this box's host cores on a bounded sample: `steps` full B=32 train steps after one warm-up.
+    `state0`: the GPU leg's initial weights -- the warm-up step then starts from the same point and its loss is the
+    CPU side of the matched-loss check."""
     from oracle.torch_ref import TorchRefCTC, train_step
     threads = min(CPU_THREADS, os.cpu_count() or CPU_THREADS)
     prev = torch.get_num_threads()
@@ -137,11 +156,13 @@ def cpu_baseline(steps=4):
     try:
         torch.manual_seed(2017)
         model = TorchRefCTC(F, V, S_LIBRI)
+        if state0 is not None:
+            model.load_state_dict(state0)
         opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.0)
         x_h, lab_h = synthetic(0)
         x = torch.from_numpy(x_h)
         ll = np.full(B, L, np.int32)
-        train_step(model, opt, x, lab_h, ll, threads=threads)
+        loss0, _ = train_step(model, opt, x, lab_h, ll, threads=threads)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, _ = train_step(model, opt, x, lab_h, ll, threads=threads)
@@ -150,7 +171,7 @@ def cpu_baseline(steps=4):
         torch.set_num_threads(prev)
     return {"value": B / dt, "unit": "utt/s", "cores": threads, "kind": "port",
             "sample": "%d full train steps (B=32, T=1000) of oracle/torch_ref.py after 1 warm-up on %d threads; "
-                      "%.2f s/step" % (steps, threads, dt), "loss": loss}
+                      "%.2f s/step" % (steps, threads, dt), "loss": loss, "loss_step0": loss0}
 
 
 def roofline(prof, step_us, steps):
@@ -200,10 +221,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # run by hand: become the launcher (one rank per GPU over RCCL, rendezvous on the loopback address)
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     from speech_amd import dist
     world, rank, local = dist.init()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print("error: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     r = gpu_leg(args, world, rank, local)
     if rank != 0:
         return
@@ -218,12 +252,14 @@ def main():
                                "4xGRU-512 uni, fc->29, %d params" % (r["Tp"], r["params"]),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
         "ctc_loss_step_ms": r.get("ctc_ms"), "loss": r["loss"], "grad_norm": r["grad_norm"],
+        "loss_step0": r["loss_step0"], "loss_rel_err": None, "persist_status": r["persist_status"],
         "roofline": None,
         "kernel_time_ms_per_step": {k: v["ms"] / r["prof_steps"] for k, v in sorted(r["prof"].items())},
     }
     out["roofline"], out["roofline_other"] = roofline(r["prof"], r["step_us"], r["prof_steps"])
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cb = cpu_baseline(state0=r["state0"])
+        out["loss_rel_err"] = abs(r["loss_step0"] - cb["loss_step0"]) / abs(cb["loss_step0"])
     print(json.dumps(out))
 
 

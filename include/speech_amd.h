@@ -185,10 +185,24 @@ int sa_gru_profile_steps_per_launch(int kind);
  * as PERSISTENT chunk kernels whose sync groups are XCD-local (one (layer, batch tile) group per XCD, hand-off through
  * that XCD's L2; bit-identical to the step kernels; SA_GRU_PERSIST=0 switches them off).  A workgroup derives its
  * group from the XCC id it actually runs on, so a dispatcher that does not spread 32 workgroups per XCD -- or a
- * hand-off that times out -- cannot hang or silently corrupt: it raises the kernels' error word, which is copied to
- * the host asynchronously and makes the NEXT sa_gru_stack_* call return CTC_STATUS_EXECUTION_FAILED (and the path
- * switch itself off).  sa_gru_persist_status() waits for the latest word and returns it (0 = fine). */
+ * hand-off that times out -- cannot hang or silently corrupt: it ORs its code into the library's STICKY device error
+ * word (nothing but sa_gru_persist_reset() clears it).  Three things hang off that word:
+ *   - sa_gru_health_flag() writes 1.0f / 0.0f for word != 0 / == 0 to a device float, stream-ordered: the caller
+ *     appends that float to its gradient message and hands it to sa_clip_sgd_step() as d_skip_flag, so the optimiser
+ *     skips the update ON THE DEVICE (no host round trip between a failure and the update it must stop; summed by the
+ *     data-parallel all-reduce, one rank's failure stops every rank's update);
+ *   - every sa_gru_stack_* call copies the word to a ring of pinned host words; once a later call finds a non-zero
+ *     copy the persistent path is off for the process (every stack call from then on runs the step kernels).  The
+ *     calls themselves keep returning success -- data-parallel ranks must stay in lock-step, so the failure travels
+ *     through the gate above, not through one rank's return code; forward-only users call sa_gru_persist_status();
+ *   - sa_gru_persist_status() waits for every outstanding copy and returns the OR of the codes seen (0 = fine);
+ *     sa_gru_persist_reset() does the same, then clears the device word and the host state (the path stays off: the
+ *     caller re-runs the lost step on the step kernels).
+ * Tests: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave before its first step,
+ * SA_GRU_SPIN_LIMIT=n shortens the hand-off timeout (default 2^20 polls). */
 int sa_gru_persist_status(void);
+int sa_gru_persist_reset(void);
+ctcStatus_t sa_gru_health_flag(float* d_flag, void* stream);
 
 /* out[n] (+)= sum_m a[m * lda + n]  -- bias gradients; two deterministic stages through `workspace`. */
 size_t sa_colsum_workspace_bytes(int M, int N);
@@ -203,11 +217,14 @@ ctcStatus_t sa_add_rows_f32(const float* a, long lda, const float* b, long ldb, 
  * 5. Optimiser step on a flat fp32 parameter / gradient buffer (train.py:32 clip_grad_norm(params, 200) and
  *    train.py:35,95-97 SGD(lr, momentum)).  d_norm_out receives the pre-clip global L2 norm (device float).
  *    grad_scale multiplies the gradient first (1/world_size after the RCCL all-reduce).
+ *    d_skip_flag (or NULL): device float; non-zero = leave params / momentum untouched and write MINUS the norm to
+ *    d_norm_out (the health gate of sa_gru_health_flag above).
  * ----------------------------------------------------------------------------------------------------------------*/
 size_t sa_sgd_workspace_bytes(size_t n);
 ctcStatus_t sa_clip_sgd_step(float* params, float* grads, float* momentum_buf /* or NULL */, size_t n, float lr,
-                             float momentum, float max_norm, float grad_scale, float* d_norm_out, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             float momentum, float max_norm, float grad_scale, float* d_norm_out,
+                             const float* d_skip_flag /* or NULL */, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * 6. Featuriser: the log power spectrogram of speech/loader.py:156-166

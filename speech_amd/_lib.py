@@ -64,6 +64,8 @@ SIGNATURES = {
     "sa_gru_profile_read": (c_int, [c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "sa_gru_profile_steps_per_launch": (c_int, [c_int]),
     "sa_gru_persist_status": (c_int, []),
+    "sa_gru_persist_reset": (c_int, []),
+    "sa_gru_health_flag": (c_int, [c_void_p, c_void_p]),
     "sa_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
@@ -105,7 +107,7 @@ SIGNATURES = {
     "sa_argmax_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),
     "sa_clip_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_void_p,
-                                 c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _LIB = None

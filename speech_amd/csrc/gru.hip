@@ -206,7 +206,9 @@ struct PFwdJobs {
     unsigned* reg;       // [8] arrival counters, monotonic over the stack call
     unsigned reg_base;   // arrivals per counter before this launch
     unsigned long long* stamp;  // profiling: the (0, 0, 0) workgroup writes wall_clock64() at entry / exit (null: off)
-    unsigned* err;
+    unsigned* err;       // the library's STICKY error word (PersistHealth::dev): failures are OR-ed in, never cleared here
+    int spin_limit;      // polls before a hand-off counts as failed (SA_GRU_SPIN_LIMIT; default 1 << 20)
+    int fault;           // fault injection (SA_GRU_FAULT=1, tests only): unit tile 1 of group 0 leaves before its first step
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
     PFwdJob j[kMaxJobs];
 };
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         }
         __syncthreads();
         if (s_role[1] < 0 || s_role[1] >= 32) {  // more than 32 workgroups landed on this XCD
-            if (threadIdx.x == 0) atomicExch(P.err, 2u);
+            if (threadIdx.x == 0) atomicOr(P.err, 2u);
             return;
         }
         // an XCD hosts 32 / ntile_u groups (narrower layers: 16 or 8 unit tiles per group)
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         role_z = g / P.nbt;
         role_y = g - role_z * P.nbt;
         if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront, or fewer groups than slots
+        if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     }
     const PFwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                 int spins = 0;
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 22)) { dead = true; atomicExch(P.err, 1u); break; }
+                    if (++spins > 4 * P.spin_limit) { dead = true; atomicOr(P.err, 1u); break; }
                 }
             }
             __syncthreads();
@@ -331,11 +334,11 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
                                     : f32x4v{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (!P.flagless) break;
+                    if (!P.flagless || dead) break;  // after one timeout the wave stops polling (the step is lost anyway)
 #pragma unroll
                     for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;  // wave-uniform: the MFMAs below stay convergent
-                    if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
+                    if (spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
                 }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -432,6 +435,7 @@ struct PFusedFwd {
     unsigned* reg;
     unsigned reg_base;
     unsigned* err;
+    int spin_limit, fault;       // see PFwdJobs
     unsigned long long* stamp;
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
 };
@@ -446,12 +450,14 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     }
     __syncthreads();
     if (s_role[1] < 0 || s_role[1] >= 32) {
-        if (threadIdx.x == 0) atomicExch(P.err, 2u);
+        if (threadIdx.x == 0) atomicOr(P.err, 2u);
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
     const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt;
     if (l >= P.L) return;
+    if (P.fault && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
+    bool dead = false;  // a hand-off of this wave has timed out: stop waiting, the call is lost (error word is set)
     const int H = P.H, B = P.B, T = P.T;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
     if (stamper) P.stamp[0] = wall_clock64();
@@ -490,12 +496,12 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
 #pragma unroll
     for (int n = 0; n < 3; ++n) accg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto wait_lower = [&](int tt) {  // the lower layer has published step tt (every wave polls for itself)
-        if (avail >= (unsigned)(tt + 1)) return;
+        if (avail >= (unsigned)(tt + 1) || dead) return;
         int spins = 0;
         unsigned c;
         while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
                (unsigned)P.ntile_u * (unsigned)(tt + 1)) {
-            if (++spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
+            if (++spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
         }
         avail = c / (unsigned)P.ntile_u;
     };
@@ -601,10 +607,11 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
                                     : f32x4v{0.f, 0.f, 0.f, 0.f};
                     }
+                    if (dead) break;
 #pragma unroll
                     for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
+                    if (spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
                 }
                 SA_TICK(1)
                 if (prefetch) {  // the slow loads go out only now, behind the poll (H <= 512: this loop runs once)
@@ -805,6 +812,7 @@ struct PBwdJobs {
     unsigned reg_base;
     unsigned long long* stamp;
     unsigned* err;
+    int spin_limit, fault;  // see PFwdJobs
     PBwdJob j[kMaxJobs];
 };
 
@@ -818,12 +826,13 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     }
     __syncthreads();
     if (s_role[1] < 0 || s_role[1] >= 32) {
-        if (threadIdx.x == 0) atomicExch(P.err, 2u);
+        if (threadIdx.x == 0) atomicOr(P.err, 2u);
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
     const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt;
     if (role_z >= P.n) return;
+    if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     const PBwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B, H3 = 3 * P.H;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
@@ -871,7 +880,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                 const unsigned need = J.base + (unsigned)P.ntile_u * (unsigned)s;
                 int spins = 0;
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                    if (++spins > (1 << 22)) { dead = true; atomicExch(P.err, 1u); break; }
+                    if (++spins > 4 * P.spin_limit) { dead = true; atomicOr(P.err, 1u); break; }
                 }
             }
             __syncthreads();
@@ -890,11 +899,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
                                     : f32x4v{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (!P.flagless) break;
+                    if (!P.flagless || dead) break;
 #pragma unroll
                     for (int it = 0; it < 24; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > (1 << 20)) { if (lane == 0) atomicExch(P.err, 1u); break; }
+                    if (spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
                 }
 #pragma unroll
                 for (int it = 0; it < 24; ++it) {
@@ -1141,34 +1150,67 @@ struct StepProfiler {
     }
 };
 
-// Outcome of the XCD-local persistent kernels (the library's other piece of process-global state): their error word is
-// copied to pinned host memory at the end of every stack call and looked at when the NEXT call starts (or on demand by
-// sa_gru_persist_status), so a placement / hand-off failure is reported one call late instead of costing a sync.
+// Outcome of the XCD-local persistent kernels (the library's other piece of process-global state).
+//   * `dev` is a STICKY device error word: a kernel whose placement assumption or hand-off fails ORs its code in, and
+//     nothing but sa_gru_persist_reset() ever clears it -- a failure cannot be overwritten by a later, healthy launch.
+//   * the optimiser gates on it ON THE DEVICE: sa_gru_health_flag() turns the word into a float the caller appends to
+//     its gradient message, sa_clip_sgd_step() skips the update when that float is non-zero (and, summed by the
+//     gradient all-reduce, when ANY rank's is).  No host round trip sits between a failure and the update it must stop.
+//   * the host learns about it without a sync: every stack call copies the word into the next slot of a small ring of
+//     pinned words (one event each); a later call looks at whichever copies have landed.  sa_gru_persist_status()
+//     waits for all of them.
 struct PersistHealth {
+    static constexpr int kSlots = 8;
+    unsigned* dev = nullptr;
     unsigned* host = nullptr;
-    hipEvent_t ev = nullptr;
-    bool pending = false, broken = false;
+    hipEvent_t ev[kSlots];
+    bool pending[kSlots];
+    int next = 0;
+    unsigned code = 0;      // OR of every failure code seen since the last reset
+    bool disabled = false;  // a failure was seen at some point: the persistent path stays off for the process
+    bool ready = false;
     bool init() {
-        if (host) return true;
-        if (hipHostMalloc((void**)&host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { host = nullptr; return false; }
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-        *host = 0;
+        if (ready) return true;
+        if (hipMalloc((void**)&dev, 2 * sizeof(unsigned)) != hipSuccess) { dev = nullptr; return false; }
+        if (hipMemset(dev, 0, 2 * sizeof(unsigned)) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&host, kSlots * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { host = nullptr; return false; }
+        for (int i = 0; i < kSlots; ++i) {
+            host[i] = 0; pending[i] = false;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        ready = true;
         return true;
     }
-    void submit(const unsigned* dev_err, hipStream_t stream) {
-        if (!init()) return;
-        if (hipMemcpyAsync(host, dev_err, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-            hipEventRecord(ev, stream) == hipSuccess)
-            pending = true;
+    void harvest(int i) {
+        pending[i] = false;
+        if (host[i]) { code |= host[i]; disabled = true; }
     }
-    // 0 = fine (or nothing to report yet)
+    void submit(hipStream_t stream) {
+        if (!init()) return;
+        const int i = next;
+        next = (next + 1) % kSlots;
+        if (pending[i]) { if (hipEventSynchronize(ev[i]) == hipSuccess) harvest(i); }  // kSlots calls old: long done
+        if (hipMemcpyAsync(host + i, dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipEventRecord(ev[i], stream) == hipSuccess)
+            pending[i] = true;
+    }
+    // 0 = fine (or nothing has been reported yet)
     unsigned poll(bool wait) {
-        if (!pending) return 0;
-        if (wait) { if (hipEventSynchronize(ev) != hipSuccess) return 0; }
-        else if (hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        pending = false;
-        if (*host) broken = true;
-        return *host;
+        if (!ready) return 0;
+        for (int i = 0; i < kSlots; ++i) {
+            if (!pending[i]) continue;
+            if (wait) { if (hipEventSynchronize(ev[i]) != hipSuccess) continue; }
+            else if (hipEventQuery(ev[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+            harvest(i);
+        }
+        return code;
+    }
+    void reset() {
+        if (!ready) return;
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < kSlots; ++i) if (pending[i]) harvest(i);
+        (void)hipMemset(dev, 0, 2 * sizeof(unsigned));
+        code = 0;  // `disabled` stays
     }
 };
 PersistHealth g_health;
@@ -1216,6 +1258,27 @@ extern "C" int sa_gru_profile_steps_per_launch(int kind) { return kind == 0 || k
 
 extern "C" int sa_gru_persist_status(void) { return (int)g_health.poll(true); }
 
+extern "C" int sa_gru_persist_reset(void) {
+    const unsigned c = g_health.poll(true);
+    g_health.reset();
+    return (int)c;
+}
+
+namespace {
+__global__ void health_flag_kernel(const unsigned* __restrict__ err, float* __restrict__ out) {
+    out[0] = (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.0f : 0.0f;
+}
+}  // namespace
+
+extern "C" ctcStatus_t sa_gru_health_flag(float* d_flag, void* stream_) {
+    SA_CLEAR_ERR();
+    if (!d_flag) return CTC_STATUS_INVALID_VALUE;
+    if (!g_health.init()) return CTC_STATUS_MEMOPS_FAILED;
+    hipLaunchKernelGGL(health_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, (const unsigned*)g_health.dev, d_flag);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
 constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
 
 static int device_cus() {
@@ -1237,11 +1300,20 @@ static int device_cus() {
 static int persist_mode() {  // 2 XCD-local groups (default where eligible), 1 chip-wide groups, 0 off
     const char* e = getenv("SA_GRU_PERSIST");
     const int m = e ? (e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == '3') ? 2 : 0)) : 2;
-    return (m == 2 && g_health.broken) ? 0 : m;
+    return (m == 2 && g_health.disabled) ? 0 : m;
 }
 static bool flagless_mode() {  // the flag-less (sentinel) hand-off is the default; SA_GRU_PERSIST=2 keeps the counters
     const char* e = getenv("SA_GRU_PERSIST");
     return !e || e[0] == '3';
+}
+static int spin_limit() {
+    const char* e = getenv("SA_GRU_SPIN_LIMIT");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : (1 << 20);
+}
+static int fault_injection() {  // tests only: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave early
+    const char* e = getenv("SA_GRU_FAULT");
+    return (e && e[0] == '1') ? 1 : 0;
 }
 static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
     return hipMemsetD32Async((hipDeviceptr_t)p, (int)kSentinel, n, stream) == hipSuccess;
@@ -1253,7 +1325,7 @@ static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
 constexpr int kSyncErr = 200, kSyncReg = 201;  // word offsets in the sync page (counters occupy [0, 200))
 static bool xcd_shape_ok(int jobs, int B, int H) {
     const int ntile_u = H / 16;
-    if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256) return false;
+    if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256 || !g_health.init()) return false;
     return jobs * ((B + 15) / 16) <= 8 * (32 / ntile_u);
 }
 static size_t xcd_lds(size_t need) { return need < 84 * 1024 ? 84 * 1024 : need; }  // > half a CU's LDS: one per CU
@@ -1308,7 +1380,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
+    (void)g_health.poll(false);  // a failure seen by now switches the persistent path off (persist_mode() == 0)
     if (chunk <= 0 && n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H)) chunk = persistent_chunk(L, B, T, H);
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
@@ -1351,7 +1423,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
             if (bi_xcd) {  // ONE persistent launch runs both directions of the layer over all T steps
                 PFwdJobs Q;
-                Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + kSyncErr; Q.timing = nullptr;
+                Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.timing = nullptr;
                 Q.xcd_mode = 1; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
                 Q.flagless = flagless_mode() ? 1 : 0;
                 if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
@@ -1375,7 +1447,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
         }
         SA_CHECK_LAUNCH();
-        if (bi_xcd) g_health.submit(sync + kSyncErr, stream);
+        if (bi_xcd) g_health.submit(stream);
         return CTC_STATUS_SUCCESS;
     }
 
@@ -1390,7 +1462,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
     size_t plds = ((size_t)48 * (H + 4) + 2 * 4 * 3 * 256) * sizeof(float);
-    bool persist = persist_mode() != 0 && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
+    bool persist = persist_mode() != 0 && g_health.init() && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
                    (long)L * ntile_u * nbt <= device_cus() && L * nbt <= kSyncErr &&
                    (long)T * B * H * 4 < 0x7fffffffL;
     // XCD-local groups: 8 XCDs x 32 CUs, 32 / ntile_u (layer, batch tile) groups per XCD
@@ -1412,7 +1484,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 return CTC_STATUS_EXECUTION_FAILED;
             PFusedFwd Q;
             Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
-            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.reg_base = 0; Q.err = sync + kSyncErr;
+            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.reg_base = 0; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection();
             Q.stamp = g_prof.slot(0, true, false, T);
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
@@ -1422,7 +1494,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
             hipLaunchKernelGGL(gru_fwd_fused_kernel, dim3(256), dim3(256), flds, stream, Q);
             SA_CHECK_LAUNCH();
-            g_health.submit(sync + kSyncErr, stream);
+            g_health.submit(stream);
             return CTC_STATUS_SUCCESS;
         }
     }
@@ -1460,7 +1532,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         }
         if (persist) {  // ONE launch runs the whole chunk of every active layer
             PFwdJobs Q;
-            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = sync + kSyncErr;
+            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection();
             Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
             Q.flagless = flagless ? 1 : 0;
             Q.reg_base = persist_launches * 32u;
@@ -1505,7 +1577,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         ch.join();
     }
     SA_CHECK_LAUNCH();
-    if (xcd) g_health.submit(sync + kSyncErr, stream);
+    if (xcd) g_health.submit(stream);
     return CTC_STATUS_SUCCESS;
 }
 
@@ -1531,7 +1603,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (g_health.poll(false)) return CTC_STATUS_EXECUTION_FAILED;  // the previous call's persistent kernels failed
+    (void)g_health.poll(false);  // a failure seen by now switches the persistent path off (persist_mode() == 0)
     if (chunk <= 0 && n_aux <= 0 && D == 1 && xcd_shape_ok(L, B, H)) chunk = persistent_chunk(L, B, T, H);
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
@@ -1588,7 +1660,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                 if (Q.flagless)
                     for (int d = 0; d < 2; ++d)
                         if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = sync + kSyncErr; Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
                 Q.stamp = nullptr; Q.n = 2;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
@@ -1619,7 +1691,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                 }
         }
         SA_CHECK_LAUNCH();
-        if (bi_xcd) g_health.submit(sync + kSyncErr, stream);
+        if (bi_xcd) g_health.submit(stream);
         return CTC_STATUS_SUCCESS;
     }
 
@@ -1673,7 +1745,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
-            Q.err = sync + kSyncErr; Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
             ++persist_launches;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
@@ -1714,7 +1786,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         ch.join();
     }
     SA_CHECK_LAUNCH();
-    if (xcd) g_health.submit(sync + kSyncErr, stream);
+    if (xcd) g_health.submit(stream);
     if (dx) {
         st = sa_gemm_f32_impl(0, 0, T * B, I0, 3 * H, 1.f, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, nullptr,
                               nullptr, 0, stream);

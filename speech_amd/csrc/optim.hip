@@ -44,12 +44,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ mom, size_t n, float lr, float momentum,
                                                        float max_norm, float scale, const float* __restrict__ partials,
-                                                       int nparts, float* __restrict__ norm_out) {
+                                                       int nparts, float* __restrict__ norm_out,
+                                                       const float* __restrict__ skip_flag) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) acc += partials[i];
     const float total = sqrtf(block_sum(acc, red));
-    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
+    // the health gate (see sa_gru_health_flag): a non-zero flag -- this rank's, or any rank's after the gradient
+    // all-reduce summed them -- means some gradient of this step is garbage: leave the parameters alone and say so
+    const bool skip = skip_flag && *skip_flag != 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = skip ? -fmaxf(total, 1e-30f) : total;  // < 0 also for a zero or NaN norm
+    if (skip) return;
     float coef = max_norm / (total + 1e-6f);   // torch.nn.utils.clip_grad_norm_
     coef = coef < 1.0f ? coef : 1.0f;
     const float gs = scale * coef;
@@ -69,7 +74,8 @@ extern "C" size_t sa_sgd_workspace_bytes(size_t n) { (void)n; return kMaxPartial
 
 extern "C" ctcStatus_t sa_clip_sgd_step(float* params, float* grads, float* momentum_buf, size_t n, float lr,
                                         float momentum, float max_norm, float grad_scale, float* d_norm_out,
-                                        void* workspace, size_t workspace_bytes, void* stream_) {
+                                        const float* d_skip_flag, void* workspace, size_t workspace_bytes,
+                                        void* stream_) {
     SA_CLEAR_ERR();
     if (!params || !grads || !workspace || workspace_bytes < sa_sgd_workspace_bytes(n)) return CTC_STATUS_INVALID_VALUE;
     if (n == 0) return CTC_STATUS_SUCCESS;
@@ -83,7 +89,7 @@ extern "C" ctcStatus_t sa_clip_sgd_step(float* params, float* grads, float* mome
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(clip_sgd_kernel, dim3(grid), dim3(256), 0, stream, params, grads,
                        momentum != 0.f ? momentum_buf : nullptr, n, lr, momentum, max_norm, grad_scale, partials,
-                       nparts, d_norm_out);
+                       nparts, d_norm_out, d_skip_flag);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }

@@ -64,7 +64,9 @@ class EncoderFunction(torch.autograd.Function):
         b_ih = [P[off + 4 * k + 2] for k in range(L * D)]
         b_hh = [P[off + 4 * k + 3] for k in range(L * D)]
         fc_w, fc_b = P[off + 4 * L * D], P[off + 4 * L * D + 1]
-        need_grad = training and any(ctx.needs_input_grad[3:])
+        # gradients are wanted whenever a parameter requires them and grad mode is on (also after model.eval():
+        # fine-tuning / gradient checks with dropout off); `training` only selects dropout
+        need_grad = any(ctx.needs_input_grad[3:])
         p_drop = plan.dropout if training else 0.0
         B, T, F = x.shape
 

@@ -90,6 +90,13 @@ class Preprocessor:
         return text[s:e]
 
     def preprocess(self, wave_file, text):
+        """loader.py:65-69.  With `device_features` set (make_loader(..., device_features=True) sets it) the log
+        spectrogram and the z-normalisation run on the GPU (speech_amd.features.log_specgram -> sa_log_specgram) and
+        the features stay there as a float32 CUDA tensor: no host featuriser, no H2D copy of the features."""
+        if getattr(self, "device_features", False):
+            from . import features
+            audio, sr = array_from_wave(wave_file)
+            return features.log_specgram(audio, sr, mean=self.mean, std=self.std), self.encode(text)
         inputs = (log_specgram_from_file(wave_file) - self.mean) / self.std
         return inputs, self.encode(text)
 
@@ -127,29 +134,51 @@ class AudioDataset(tud.Dataset):
 
 
 class BatchRandomSampler(tud.sampler.Sampler):
-    """Consecutive batches, visited in random order without replacement (loader.py:120-137).  The shuffle uses
-    Python's `random`, which train.py seeds from the config: every data-parallel rank draws the same order."""
+    """Consecutive batches, visited in random order without replacement (loader.py:120-137).
 
-    def __init__(self, data_source, batch_size):
+    A BATCH sampler (it yields one list of dataset indices per batch) with two additions for data-parallel training
+    (SURVEY.md 8e):
+      * its own random.Random: the seed is drawn ONCE, at construction, from Python's global `random` (which
+        train.py seeds from the config, train.py:137), so every rank that builds its loaders in the same order visits
+        the batches in the same order in every epoch -- whatever else consumes the global RNG in between (rank 0's
+        dev-set pass, scheduled sampling);
+      * rank r of `world` is handed utterances [r*B/W, (r+1)*B/W) of every global batch only, so a rank reads and
+        featurises just its own shard (an empty list when the batch is smaller than the world).
+    """
+
+    def __init__(self, data_source, batch_size, world=1, rank=0, seed=None):
         it_end = len(data_source) - batch_size + 1
-        self.batches = [range(i, i + batch_size) for i in range(0, it_end, batch_size)]
+        self.batches = [list(range(i, i + batch_size)) for i in range(0, it_end, batch_size)]
         self.data_source = data_source
+        self.world, self.rank = int(world), int(rank)
+        self._rng = random.Random(random.getrandbits(64) if seed is None else seed)
 
     def __iter__(self):
-        random.shuffle(self.batches)
-        return (i for b in self.batches for i in b)
+        self._rng.shuffle(self.batches)
+        for b in self.batches:
+            base, rem = divmod(len(b), self.world)
+            lo = self.rank * base + min(self.rank, rem)
+            yield b[lo:lo + base + (1 if self.rank < rem else 0)]
 
     def __len__(self):
-        return len(self.data_source)
+        return len(self.batches)
 
 
 def _collate(batch):
+    if not batch:
+        return (), ()
     inputs, labels = zip(*batch)
     return inputs, labels
 
 
-def make_loader(dataset_json, preproc, batch_size, num_workers=4):
+def make_loader(dataset_json, preproc, batch_size, num_workers=4, world=1, rank=0, device_features=False):
+    """loader.py:139-150.  `world` / `rank`: this rank's shard of every global batch (see BatchRandomSampler).
+    `device_features`: featurise on the GPU in the loading process itself (num_workers is forced to 0: forked
+    DataLoader workers cannot use the device); batches then carry float32 CUDA tensors, which Model.collate pads on
+    the device."""
+    if device_features:
+        preproc.device_features = True
+        num_workers = 0
     dataset = AudioDataset(dataset_json, preproc, batch_size)
-    sampler = BatchRandomSampler(dataset, batch_size)
-    return tud.DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
-                          collate_fn=_collate, drop_last=True)
+    sampler = BatchRandomSampler(dataset, batch_size, world=world, rank=rank)
+    return tud.DataLoader(dataset, batch_sampler=sampler, num_workers=num_workers, collate_fn=_collate)

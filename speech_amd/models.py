@@ -54,6 +54,11 @@ class Model(nn.Module):
         self._encoder_dim = rnn_cfg["dim"]
         self._plan = EncoderPlan(input_dim, config)
         self.volatile = False
+        # data-parallel training (speech_amd.dist) describes the GLOBAL batch here so that a rank's shard is padded
+        # and normalised exactly as the single-process run of the whole batch would be: see set_global_batch()
+        self.loss_denominator = None
+        self.pad_frames = None
+        self.pad_labels = None
 
     # ---- reference API -------------------------------------------------------------------------------------------
     def conv_out_size(self, n, dim):
@@ -81,6 +86,27 @@ class Model(nn.Module):
     def set_train(self):
         self.train()
         self.volatile = False
+
+    def set_global_batch(self, size=None, max_frames=None, max_label_len=None):
+        """Data parallelism: this rank's batches are shards of a global batch of `size` utterances
+        whose longest input has `max_frames` frames and whose longest label sequence has `max_label_len` entries.
+        The reference scores the PADDED frames (every act_len is the padded length, ctc_model.py:43-45) and averages
+        over the batch, so a shard must be padded to the global maximum and its loss divided by the global size for
+        the summed shard gradients to equal the single-process gradient.  None (the default) = the batch is whole."""
+        self.loss_denominator = size
+        self.pad_frames = max_frames
+        self.pad_labels = max_label_len
+
+    def _healthy(self, fn):
+        """Forward-only use (infer, dev-set loss): there is no optimiser whose device-side gate would catch a failed
+        persistent-kernel hand-off, so ask the library once the results are on the host -- and, if it reports one,
+        reset it and recompute on the step kernels (include/speech_amd.h, sa_gru_persist_status)."""
+        from . import ops
+        out = fn()
+        if ops.persist_status():
+            ops.persist_reset()
+            out = fn()
+        return out
 
     @property
     def is_cuda(self):
@@ -118,12 +144,14 @@ class Model(nn.Module):
         """Re-home every parameter into ONE flat fp32 buffer and give each a slot in ONE flat gradient buffer: the
         fused clip+SGD step and the single RCCL all-reduce both operate on these.  Call after .cuda().
         Per step: p.grad = None for all p (model.zero_grad(set_to_none=True)); backward then fills every slot.
-        Returns (flat_params, flat_grads)."""
+        The gradient buffer has ONE extra trailing element, the health flag (ops.stamp_health / ops.clip_sgd_step):
+        it travels with the gradients through the all-reduce, so a failed persistent kernel on any rank stops every
+        rank's update on the device.  Returns (flat_params [n], flat_grads [n + 1])."""
         ps = [p for p in self.parameters()]
         n = sum(p.numel() for p in ps)
         dev = ps[0].device
         flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(n + 1, dtype=torch.float32, device=dev)
         off = 0
         for p in ps:
             k = p.numel()
@@ -190,14 +218,23 @@ class _LinearFunction(torch.autograd.Function):
         return dx, ops.gemm(dy, x, trans_a=True, out=ctx.slots[0]), ops.colsum(dy, out=ctx.slots[1])
 
 
-def zero_pad_concat(inputs):
-    """model.py:135-141"""
-    max_t = max(inp.shape[0] for inp in inputs)
+def zero_pad_concat(inputs, min_t=0):
+    """model.py:135-141.  `min_t`: pad at least this far (the global-batch maximum of a data-parallel shard).
+    Inputs that already live on the GPU (loader.make_loader(..., device_features=True)) are padded there and come back
+    as a float32 CUDA tensor; host arrays give the reference's float32 ndarray."""
+    max_t = max(max(inp.shape[0] for inp in inputs), int(min_t or 0))
     shape = (len(inputs), max_t, inputs[0].shape[1])
-    input_mat = np.zeros(shape, dtype=np.float32)
+    if torch.is_tensor(inputs[0]):
+        input_mat = torch.zeros(shape, dtype=torch.float32, device=inputs[0].device)
+    else:
+        input_mat = np.zeros(shape, dtype=np.float32)
     for e, inp in enumerate(inputs):
         input_mat[e, :inp.shape[0], :] = inp
     return input_mat
+
+
+def _as_tensor(x):
+    return x if torch.is_tensor(x) else torch.from_numpy(x)
 
 
 class CTC(Model):
@@ -207,7 +244,14 @@ class CTC(Model):
         # include the blank token (ctc_model.py:17-19): blank is the LAST class
         self.blank = output_dim
         self.fc = LinearND(self.encoder_dim, output_dim + 1)
-        self.ctc_denominator = None  # data-parallel training sets the GLOBAL batch size here (speech_amd.dist)
+
+    @property
+    def ctc_denominator(self):  # round-1 name of loss_denominator
+        return self.loss_denominator
+
+    @ctc_denominator.setter
+    def ctc_denominator(self, v):
+        self.loss_denominator = v
 
     def forward(self, batch):
         x, y, x_lens, y_lens = self.collate(*batch)
@@ -225,14 +269,14 @@ class CTC(Model):
         x, y, x_lens, y_lens = self.collate(*batch)
         with torch.set_grad_enabled(not self.volatile):
             out = self.forward_impl(x)
-            loss_fn = ctc.CTCLoss(denom=self.ctc_denominator)
+            loss_fn = ctc.CTCLoss(denom=self.loss_denominator)
             return loss_fn(out, y, x_lens, y_lens)
 
     def collate(self, inputs, labels):
-        max_t = max(i.shape[0] for i in inputs)
+        max_t = max(max(i.shape[0] for i in inputs), int(self.pad_frames or 0))
         max_t = self.conv_out_size(max_t, 0)
         x_lens = torch.IntTensor([max_t] * len(inputs))
-        x = torch.from_numpy(zero_pad_concat(inputs))
+        x = _as_tensor(zero_pad_concat(inputs, self.pad_frames))
         y_lens = torch.IntTensor([len(l) for l in labels])
         y = torch.IntTensor([int(l) for label in labels for l in label])
         return [x, y, x_lens, y_lens]
@@ -241,9 +285,12 @@ class CTC(Model):
         """ctc_model.py:55-60: prefix beam search with beam_size=1 over the full padded T' of every utterance --
         on the device, from the logits (the softmax of :30-31 is fused into the decode kernel)."""
         x, y, x_lens, y_lens = self.collate(*batch)
-        with torch.no_grad():
-            logits = self.forward_impl(x)
-            return decoder.beam_decode(logits, beam_size=1, blank=self.blank, input_is_logits=True)[0]
+
+        def run():
+            with torch.no_grad():
+                logits = self.forward_impl(x)
+                return decoder.beam_decode(logits, beam_size=1, blank=self.blank, input_is_logits=True)[0]
+        return self._healthy(run)
 
     @staticmethod
     def max_decode(pred, blank):
@@ -261,9 +308,10 @@ class CTC(Model):
 
 
 class Transducer(Model):
-    """transducer_model.py:14-113 on the HIP ops.  The joint lattice (B, T', U+1, H) is materialised (3.3 GB at
-    B=32, T'=498, U=100, H=512: sized for 288 GB of HBM); every product is sa_gemm_f32, the prediction network runs on
-    the GRU recurrence kernels, the loss is sa_transducer_loss."""
+    """transducer_model.py:14-113 on the HIP ops.  The prediction network runs on the GRU recurrence kernels, fc1 is one
+    sa_gemm_f32 over the stacked encoder / prediction rows, relu(xa + ya) -> fc2 -> log_softmax is ONE fused operator
+    (sa_joint_fused_*: the (B, T', U+1, H) joint tensor -- 3.3 GB at B=32, T'=498, U=100, H=512 -- exists only inside
+    its MFMA operands; shapes it does not take fall back to the unfused operators), the loss is sa_transducer_loss."""
 
     def __init__(self, freq_dim, vocab_size, config):
         super().__init__(freq_dim, config)
@@ -279,7 +327,6 @@ class Transducer(Model):
         self.blank = vocab_size
         self.fc1 = LinearND(rnn_dim, rnn_dim)
         self.fc2 = LinearND(rnn_dim, vocab_size + 1)
-        self.loss_denominator = None  # data-parallel training sets the GLOBAL batch size here (speech_amd.dist)
 
     def forward(self, batch):
         x, y, x_lens, y_lens = self.collate(*batch)
@@ -337,10 +384,10 @@ class Transducer(Model):
         return _tr.LogSoftmaxFunction.apply(out)
 
     def collate(self, inputs, labels):
-        max_t = max(i.shape[0] for i in inputs)
+        max_t = max(max(i.shape[0] for i in inputs), int(self.pad_frames or 0))
         max_t = self.conv_out_size(max_t, 0)
         x_lens = torch.IntTensor([max_t] * len(inputs))
-        x = torch.from_numpy(zero_pad_concat(inputs))
+        x = _as_tensor(zero_pad_concat(inputs, self.pad_frames))
         y_lens = torch.IntTensor([len(l) for l in labels])
         y = torch.IntTensor([int(l) for label in labels for l in label])
         return [x, y, x_lens, y_lens]
@@ -357,17 +404,21 @@ class Transducer(Model):
 
     def infer(self, batch, beam_size=4):
         """transducer_model.py:91-100: static beam search over each utterance's lattice out[e, :T, :len(l)+1]."""
-        with torch.no_grad():
-            out = self(batch)
         u1 = [len(l) + 1 for l in batch[1]]
-        return _tr.decode_static_batch(out, u1, beam_size=beam_size, blank=self.blank)[0]
+
+        def run():
+            with torch.no_grad():
+                out = self(batch)
+            return _tr.decode_static_batch(out, u1, beam_size=beam_size, blank=self.blank)[0]
+        return self._healthy(run)
 
 
-def end_pad_concat(labels):
-    """seq2seq.py:239-248: pad with the first utterance's last item (assumed to be the end token)."""
+def end_pad_concat(labels, min_len=0):
+    """seq2seq.py:239-248: pad with the first utterance's last item (assumed to be the end token).  `min_len`: pad at
+    least this far (the global-batch maximum of a data-parallel shard: the padded positions are scored, :61-63)."""
     batch_size = len(labels)
     end_tok = labels[0][-1]
-    max_len = max(len(l) for l in labels)
+    max_len = max(max(len(l) for l in labels), int(min_len or 0))
     cat_labels = np.full((batch_size, max_len), fill_value=end_tok, dtype=np.int64)
     for e, l in enumerate(labels):
         cat_labels[e, :len(l)] = l
@@ -446,7 +497,8 @@ class Seq2Seq(Model):
             batch_size, _, out_dim = out.size()
             out = out.reshape(-1, out_dim)
             tgt = y[:, 1:].contiguous().view(-1)
-            return _s2s.XentFunction.apply(out, tgt, 1.0 / batch_size)  # sum / batch_size (:61-63)
+            # sum / batch_size (:61-63); a data-parallel shard divides by the GLOBAL batch size
+            return _s2s.XentFunction.apply(out, tgt, 1.0 / (self.loss_denominator or batch_size))
 
     def forward_impl(self, x, y):
         x = self.encode(x)
@@ -496,11 +548,14 @@ class Seq2Seq(Model):
         """seq2seq.py:160-178: greedy decode from the start tokens (no beam search)."""
         x, y = self.collate(*batch)
         end_tok = int(y[0, -1])
-        with torch.no_grad():
-            x = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
-            y0 = y[:, 0:1].to(x.device)
-            _, argmaxs = self.infer_decode(x, y0, end_tok, max_len)
-        return [seq.tolist() for seq in argmaxs.cpu().numpy()]
+
+        def run():
+            with torch.no_grad():
+                enc = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
+                y0 = y[:, 0:1].to(enc.device)
+                _, argmaxs = self.infer_decode(enc, y0, end_tok, max_len)
+            return [seq.tolist() for seq in argmaxs.cpu().numpy()]
+        return self._healthy(run)
 
     def beam_search(self, batch, beam_size=10, max_len=200):
         """seq2seq.py:180-229 for a batch of ONE utterance, with the reference's py2 `filter(...)[:n]` (:211-212)
@@ -548,6 +603,6 @@ class Seq2Seq(Model):
         return [hyp]
 
     def collate(self, inputs, labels):
-        inputs = zero_pad_concat(inputs)
-        labels = end_pad_concat(labels)
-        return torch.from_numpy(inputs), torch.from_numpy(labels)
+        inputs = zero_pad_concat(inputs, self.pad_frames)
+        labels = end_pad_concat(labels, self.pad_labels)
+        return _as_tensor(inputs), torch.from_numpy(labels)

@@ -254,14 +254,77 @@ def add_rows(a, b, out=None):
 
 
 def clip_sgd_step(params, grads, momentum_buf, lr, momentum, max_norm, grad_scale=1.0, norm_out=None):
-    """Fused train.py:32,35 on flat buffers.  Returns the device scalar holding the pre-clip gradient norm."""
+    """Fused train.py:32,35 on flat buffers.  Returns the device scalar holding the pre-clip gradient norm.
+    `grads` may carry ONE extra trailing element (Model.flatten_parameters_ allocates it): the health flag written by
+    stamp_health() and summed by the gradient all-reduce.  When it is non-zero the update is skipped on the device
+    and the returned norm is NEGATIVE (see include/speech_amd.h, sa_gru_health_flag)."""
     _f32(params, "params"), _f32(grads, "grads")
     n = params.numel()
-    assert grads.numel() == n and params.is_contiguous() and grads.is_contiguous()
+    assert grads.numel() in (n, n + 1) and params.is_contiguous() and grads.is_contiguous()
+    flag = grads[n:] if grads.numel() == n + 1 else None
     if norm_out is None:
         norm_out = torch.empty(1, dtype=torch.float32, device=params.device)
     L = _lib.lib()
     ws = WORKSPACE.get(L.sa_sgd_workspace_bytes(n), params.device, "sgd")
     check(L.sa_clip_sgd_step(ptr(params), ptr(grads), ptr(momentum_buf), n, lr, momentum, max_norm, grad_scale,
-                             ptr(norm_out), ptr(ws), ws.numel(), cur_stream()), "sa_clip_sgd_step")
+                             ptr(norm_out), ptr(flag), ptr(ws), ws.numel(), cur_stream()), "sa_clip_sgd_step")
     return norm_out
+
+
+def stamp_health(grads_with_flag):
+    """Write the persistent kernels' health flag (0.0 fine, 1.0 failed) into the LAST element of the flat gradient
+    message, stream-ordered behind the backward pass: call it after loss.backward() and before the all-reduce."""
+    check(_lib.lib().sa_gru_health_flag(ptr(grads_with_flag[-1:]), cur_stream()), "sa_gru_health_flag")
+
+
+def persist_status(wait=True):
+    """OR of the persistent kernels' failure codes seen so far (0 = fine).  wait=True drains the outstanding copies."""
+    return int(_lib.lib().sa_gru_persist_status()) if wait else 0
+
+
+def persist_reset():
+    """After a failure: drain, clear the device error word and the host state.  The persistent path stays switched
+    off for the process; the caller re-runs the lost step (it goes to the step kernels).  Returns the failure code."""
+    return int(_lib.lib().sa_gru_persist_reset())
+
+
+class ScalarPipe:
+    """Device scalars to the host WITHOUT stalling the launch queue (the reference's loop reads loss.data[0] every
+    step, /root/reference/train.py:33: a full sync).  push(t) enqueues an async copy of the 1-element tensor into
+    pinned memory behind the work queued so far and returns the values of every EARLIER push whose copy has landed;
+    drain() waits for the rest.  Values come back in push order."""
+
+    def __init__(self, depth=4):
+        self._slots = [(torch.empty(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
+        self._pending = []  # (slot index, tag) in push order
+        self._n = 0
+
+    def _collect(self, wait):
+        out = []
+        while self._pending:
+            i, tag = self._pending[0]
+            buf, ev = self._slots[i]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                break
+            out.append((tag, float(buf[0])))
+            self._pending.pop(0)
+        return out
+
+    def push(self, t, tag=None):
+        done = self._collect(wait=False)
+        if len(self._pending) == len(self._slots):  # ring full: the oldest copy is `depth` steps old
+            i, tg = self._pending.pop(0)
+            self._slots[i][1].synchronize()
+            done.append((tg, float(self._slots[i][0][0])))
+        i = self._n % len(self._slots)
+        self._n += 1
+        buf, ev = self._slots[i]
+        buf.copy_(t.detach().reshape(1), non_blocking=True)
+        ev.record()
+        self._pending.append((i, tag))
+        return done
+
+    def drain(self):
+        return self._collect(wait=True)

@@ -1,8 +1,12 @@
-"""Data-parallel logic on CPU: 2 processes, gloo backend (the GPU path uses the same code with backend "nccl" = RCCL).
+"""Data-parallel logic on CPU: 2-3 processes, gloo backend (the GPU path runs the same code with backend "nccl" = RCCL).
 
-Checks the contract of speech_amd/dist.py: sharding a global batch over W ranks with the CTC loss divided by the
-GLOBAL batch size and a SUM all-reduce of the flat gradient buffer reproduces the single-process gradient of the same
-global batch.  The per-rank math is the CPU oracle (oracle/torch_ref.py) -- the HIP kernels need a GPU."""
+Checks the contract of speech_amd/dist.py on RAGGED batches: a global batch sharded over W
+ranks -- every shard zero-padded to the GLOBAL longest utterance, the CTC loss divided by the GLOBAL batch size -- and
+a SUM all-reduce of the flat gradient buffer reproduce the single-process gradient of the same global batch.  The
+reference scores the padded frames (every act_len is the padded length, /root/reference/speech/models/
+ctc_model.py:43-45), so padding a shard only to its own maximum would NOT (also asserted).
+The per-rank math is the CPU oracle (oracle/torch_ref.py) behind speech_amd.models.CTC's own host-side collate --
+the HIP kernels need a GPU."""
 import os
 import socket
 import sys
@@ -14,6 +18,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = {"dropout": 0.0, "encoder": {"conv": [[4, 5, 16, 2]], "rnn": {"dim": 8, "bidirectional": False, "layers": 2}}}
+LENS = [52, 40, 47, 33, 44]  # ragged: the longest utterance lives in rank 0's shard, rank 1's shard is shorter
 
 
 def _free_port():
@@ -24,27 +29,35 @@ def _free_port():
     return p
 
 
-def _make_batch():
+def _make_batch(lens=LENS):
     rng = np.random.RandomState(0)
-    inputs = tuple(rng.randn(40, 20).astype(np.float32) for _ in range(5))
-    labels = tuple(list(rng.randint(0, 6, 3)) for _ in range(5))
+    inputs = tuple(rng.randn(t, 20).astype(np.float32) for t in lens)
+    labels = tuple(list(rng.randint(0, 6, 2 + i % 3)) for i in range(len(lens)))
     return inputs, labels
 
 
-def _grad_of(batch, denom):
+def _grad_of(batch, shape):
+    """Flat gradient + loss of `batch` treated as a shard of a global batch of `shape` = (size, frames, label len).
+    Host side = the product's own collate (speech_amd.models.CTC.collate / set_global_batch); math = CPU oracle."""
     from oracle.torch_ref import TorchRefCTC, _CTCRef
+    from speech_amd.models import CTC
     torch.manual_seed(1)
-    model = TorchRefCTC(20, 6, CFG)
-    x = torch.from_numpy(np.stack(batch[0]))
-    logits = model(x)
-    B, Tp, _ = logits.shape
-    labs = np.concatenate([np.asarray(l, np.int32) for l in batch[1]]).astype(np.int32)
-    loss = _CTCRef.apply(logits, labs, np.full(B, Tp, np.int32), np.full(B, 3, np.int32), 6, 1) * (B / denom)
+    ref = TorchRefCTC(20, 6, CFG)
+    flat = torch.zeros(sum(p.numel() for p in ref.parameters()))
+    if len(batch[0]) == 0:
+        return flat, 0.0
+    host = CTC(20, 6, CFG)  # never computes: collate only
+    host.set_global_batch(*shape)
+    x, y, x_lens, y_lens = host.collate(*batch)
+    logits = ref(x)
+    assert logits.shape[1] == int(x_lens[0])
+    B = logits.shape[0]
+    loss = _CTCRef.apply(logits, y.numpy(), x_lens.numpy(), y_lens.numpy(), 6, 1) * (B / host.loss_denominator)
     loss.backward()
-    return torch.cat([p.grad.reshape(-1) for p in model.parameters()]), float(loss.item())
+    return torch.cat([p.grad.reshape(-1) for p in ref.parameters()]), float(loss.item())
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, lens, sharded_loader):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                       LOCAL_RANK=str(rank))
@@ -52,13 +65,19 @@ def _worker(rank, world, port, out):
     from speech_amd import dist
     w, r, _ = dist.init(backend="gloo")
     assert (w, r) == (world, rank)
-    shard, global_b = dist.shard_batch(_make_batch(), world, rank)
-    flat, loss = _grad_of(shard, global_b)
+    whole = _make_batch(lens)
+    if sharded_loader:  # the rank only ever sees its own utterances (loader.make_loader(world, rank)): agree by collective
+        lo, hi = dist.shard_bounds(len(lens), world, rank)
+        shard = (whole[0][lo:hi], whole[1][lo:hi])
+        shape = dist.global_shape(shard)
+    else:
+        shard, shape = dist.shard_batch(whole, world, rank)
+    flat, loss = _grad_of(shard, shape)
     dist.allreduce_gradients(flat)
-    total_loss = dist.max_over_ranks(loss, torch.device("cpu"))
+    total_loss = dist.allreduce_sum_host([loss])[0]
     dist.barrier()
     if rank == 0:
-        torch.save({"flat": flat, "n": len(shard[0]), "global_b": global_b, "max_loss": total_loss}, out)
+        torch.save({"flat": flat, "n": len(shard[0]), "shape": shape, "loss": total_loss}, out)
 
 
 def test_shard_bounds_cover_batch_exactly():
@@ -71,10 +90,30 @@ def test_shard_bounds_cover_batch_exactly():
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
 
 
-def test_two_rank_allreduce_equals_single_process(tmp_path):
+@pytest.mark.parametrize("sharded_loader", [False, True])
+def test_two_rank_allreduce_equals_single_process_on_a_ragged_batch(tmp_path, sharded_loader):
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, LENS, sharded_loader), nprocs=2, join=True)
     got = torch.load(out)
-    want, _ = _grad_of(_make_batch(), 5)
-    assert got["n"] == 3 and got["global_b"] == 5  # rank 0 takes the remainder utterance
-    torch.testing.assert_close(got["flat"], want, rtol=1e-5, atol=1e-7)
+    whole = _make_batch()
+    want, want_loss = _grad_of(whole, (5, max(LENS), 4))
+    assert got["n"] == 3 and tuple(got["shape"]) == (5, 52, 4)  # rank 0 takes the remainder utterance
+    torch.testing.assert_close(got["flat"], want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))  # fp32 sum order
+    assert abs(got["loss"] - want_loss) <= 1e-5 * abs(want_loss)
+    # the round-1 behaviour -- each shard padded to its OWN longest utterance -- is a different function
+    s1 = (whole[0][3:], whole[1][3:])
+    local, _ = _grad_of(s1, (5, max(LENS[3:]), 4))
+    glob, _ = _grad_of(s1, (5, max(LENS), 4))
+    assert float((local - glob).abs().max()) > 1e-4 * float(glob.abs().max())
+
+
+def test_global_batch_smaller_than_the_world(tmp_path):
+    """B < W: the trailing rank's shard is empty; it contributes zeros and still joins every collective."""
+    out = str(tmp_path / "r0.pt")
+    lens = LENS[:2]
+    mp.spawn(_worker, args=(3, _free_port(), out, lens, True), nprocs=3, join=True)
+    got = torch.load(out)
+    want, want_loss = _grad_of(_make_batch(lens), (2, max(lens), 3))
+    assert tuple(got["shape"]) == (2, 52, 3)
+    torch.testing.assert_close(got["flat"], want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))  # fp32 sum order
+    assert abs(got["loss"] - want_loss) <= 1e-5 * abs(want_loss)

@@ -1,0 +1,80 @@
+"""End-to-end parity AT the BASELINE configurations themselves: the full speech_amd.models.CTC
+(default kernel selection: fused forward wavefront + XCD-local persistent backward where eligible) against
+oracle/torch_ref.TorchRefCTC -- the reference's own torch.nn CPU modules (/root/reference/speech/models/model.py:12-79,
+ctc_model.py:17-40) + the C CTC restatement -- built from the SAME state dict, on the same seeded batch.
+
+  (i)   S-LIBRI headline (BASELINE.json metric config): conv [32,5,32,2], 4 x GRU-512 uni, F=80, |V|+1=29, B=32, T=1000
+  (ii)  the shipped TIMIT config (/root/reference/examples/timit/ctc_config.json:18-32): 2 convs, 4 x biGRU-256,
+        F=161, |V|+1=49, B=8, T=300
+  (iii) BASELINE config 2: 2 x GRU-256, F=40, |V|+1=62, B=32, T=1000
+
+Tolerances (fp32 HIP kernels vs fp32 torch CPU, both summing in different orders): loss rtol 1e-4 (north_star), every
+parameter gradient within 1e-3 of that tensor's max magnitude, logits within 2e-4 of the logit range."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "s_libri": dict(F=80, V=28, B=32, T=1000, L=100,
+                    cfg={"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]],
+                                                     "rnn": {"dim": 512, "layers": 4, "bidirectional": False}}}),
+    "timit_shipped": dict(F=161, V=48, B=8, T=300, L=40,
+                          cfg={"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2], [32, 5, 32, 1]],
+                                                           "rnn": {"dim": 256, "layers": 4, "bidirectional": True}}}),
+    "config2": dict(F=40, V=61, B=32, T=1000, L=100,
+                    cfg={"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]],
+                                                     "rnn": {"dim": 256, "layers": 2, "bidirectional": False}}}),
+}
+
+
+def _reference_step(case, state, x, labels, label_lens):
+    from oracle.torch_ref import TorchRefCTC, _CTCRef
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(16, prev))
+    try:
+        ref = TorchRefCTC(case["F"], case["V"], case["cfg"])
+        ref.load_state_dict(state)
+        logits = ref(torch.from_numpy(x))
+        B, Tp, _ = logits.shape
+        loss = _CTCRef.apply(logits, labels, np.full(B, Tp, np.int32), label_lens, ref.blank, 0)
+        loss.backward()
+        grads = {k: p.grad.detach().numpy() for k, p in ref.named_parameters()}
+        return float(loss.item()), logits.detach().numpy(), grads
+    finally:
+        torch.set_num_threads(prev)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_loss_and_gradients_at_baseline_config(name):
+    from speech_amd import _lib
+    from speech_amd.models import CTC
+    case = CASES[name]
+    F, V, B, T, L = case["F"], case["V"], case["B"], case["T"], case["L"]
+    torch.manual_seed(2017)
+    model = CTC(F, V, case["cfg"])
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    rng = np.random.RandomState(2017)
+    x = rng.randn(B, T, F).astype(np.float32)
+    labels = tuple(rng.randint(0, V, L) for _ in range(B))
+    batch = (tuple(x[b] for b in range(B)), labels)
+    model.set_train()
+    out = model(batch)
+    loss = model.loss(batch)
+    loss.backward()
+    assert _lib.lib().sa_gru_persist_status() == 0  # the XCD-local persistent kernels ran clean
+    flat = np.concatenate(labels).astype(np.int32)
+    want_loss, want_logits, want_grads = _reference_step(case, state, x, flat, np.full(B, L, np.int32))
+    got_logits = out.detach().cpu().numpy()
+    assert got_logits.shape == want_logits.shape
+    span = float(want_logits.max() - want_logits.min())
+    assert np.abs(got_logits - want_logits).max() <= 2e-4 * span
+    assert abs(float(loss.item()) - want_loss) <= 1e-4 * abs(want_loss), (float(loss.item()), want_loss)
+    assert set(want_grads) == {k for k, _ in model.named_parameters()}
+    for k, p in model.named_parameters():
+        got = p.grad.cpu().numpy()
+        scale = max(float(np.abs(want_grads[k]).max()), 1e-10)
+        err = float(np.abs(got - want_grads[k]).max())
+        assert err <= 1e-3 * scale, (name, k, err, scale)

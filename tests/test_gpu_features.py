@@ -43,3 +43,47 @@ def test_shapes_rates_and_normalisation(n, sr, win, step):
     ref = features_ref.normalise(want, mean, std)
     strong = want > want.max() - 25.0
     np.testing.assert_allclose(got[strong], ref[strong], rtol=0, atol=2e-2)
+
+
+def test_loader_device_feed_matches_the_host_featuriser(tmp_path):
+    """/root/reference/speech/loader.py:65-69 with the featuriser on the data path (VERDICT r01 missing #5):
+    make_loader(device_features=True) yields float32 CUDA features (log spectrogram + z-normalisation on the GPU) that
+    agree with the reference's scipy path within the featuriser tolerance above, and the model consumes them as they
+    are (collate pads on the device)."""
+    import json
+    import random
+    import scipy.io.wavfile
+    import speech.loader as loader
+    from speech_amd.models import CTC
+    rng = np.random.RandomState(0)
+    lines = []
+    for i, n in enumerate([17622, 25130, 20111, 17622]):
+        t = np.arange(n) / 16000.0
+        audio = (3000 * np.sin(2 * np.pi * (200 + 150 * i) * t) + 300 * rng.randn(n)).astype(np.int16)
+        path = str(tmp_path / ("utt%d.wav" % i))
+        scipy.io.wavfile.write(path, 16000, audio)
+        lines.append({"text": list("hello world"), "duration": n / 16000.0, "audio": path})
+    js = str(tmp_path / "data.json")
+    with open(js, "w") as fid:
+        fid.writelines(json.dumps(l) + "\n" for l in lines)
+    random.seed(0)
+    preproc = loader.Preprocessor(js, start_and_end=False)
+    random.seed(1)
+    host = list(loader.make_loader(js, preproc, 2, num_workers=0))
+    random.seed(1)
+    dev = list(loader.make_loader(js, preproc, 2, device_features=True))
+    preproc.device_features = False
+    assert len(host) == len(dev) == 2
+    for (hi, hl), (di, dl) in zip(host, dev):
+        assert hl == dl
+        for h, d in zip(hi, di):
+            assert d.is_cuda and d.dtype == torch.float32 and tuple(d.shape) == h.shape
+            raw = h * preproc.std + preproc.mean          # un-normalised log power of the host path
+            strong = raw > raw.max() - 25.0
+            np.testing.assert_allclose(d.cpu().numpy()[strong], h[strong], rtol=0, atol=2e-2)
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 32, 2]], "rnn": {"dim": 16, "bidirectional": False, "layers": 1}}}
+    torch.manual_seed(0)
+    model = CTC(preproc.input_dim, preproc.vocab_size, cfg).cuda()
+    a, b = model.loss(dev[0]), model.loss(host[0])
+    assert abs(float(a.item()) - float(b.item())) <= 2e-3 * abs(float(b.item()))
+    assert model.infer(dev[1]) is not None

@@ -50,7 +50,7 @@ def test_train_then_eval(tmp_path, monkeypatch):
     train = _load("train")
     import speech.loader as loader
     real = loader.make_loader
-    monkeypatch.setattr(loader, "make_loader", lambda j, p, b, num_workers=4: real(j, p, b, num_workers=0))
+    monkeypatch.setattr(loader, "make_loader", lambda *a, **k: real(*a, **dict(k, num_workers=0)))
     train.run(cfg)
     assert os.path.exists(os.path.join(cfg["save_path"], "model")) and os.path.exists(
         os.path.join(cfg["save_path"], "best_model"))
@@ -84,7 +84,7 @@ def test_other_model_families_train_then_eval(tmp_path, monkeypatch, model_cfg, 
     train = _load("train")
     import speech.loader as loader
     real = loader.make_loader
-    monkeypatch.setattr(loader, "make_loader", lambda j, p, b, num_workers=4: real(j, p, b, num_workers=0))
+    monkeypatch.setattr(loader, "make_loader", lambda *a, **k: real(*a, **dict(k, num_workers=0)))
     train.run(cfg)
     assert os.path.exists(os.path.join(cfg["save_path"], "best_model"))
     ev = _load("eval")

@@ -143,3 +143,54 @@ def test_transducer_and_seq2seq_host_methods_and_cpu_refusal():
         s.loss((inputs, seqs))
     with pytest.raises(AssertionError):   # the context vector is added to the embedding: the two widths must match
         Seq2Seq(40, 11, dict(cfg, decoder={"embedding_dim": 8, "layers": 1}))
+
+
+def test_batch_sampler_is_private_sharded_and_in_step(tiny_dataset):
+    """Data-parallel contract of loader.BatchRandomSampler (batch order must not depend on the global RNG
+    after construction; SURVEY 8e: rank r takes utterances [r*B/W, (r+1)*B/W) of every global batch)."""
+    import random
+    import speech.loader as loader
+    random.seed(2017)
+    preproc = loader.Preprocessor(tiny_dataset)
+    ds = loader.AudioDataset(tiny_dataset, preproc, 4)
+
+    def as_process(**kw):
+        random.seed(99)  # every rank is its own process, seeds alike (train.py:137) and builds its loaders alike
+        return loader.BatchRandomSampler(ds, 3, **kw)
+    r0, r1, whole = as_process(world=2, rank=0), as_process(world=2, rank=1), as_process()
+    for epoch in range(3):
+        if epoch == 1:
+            random.random()  # rank 0 alone consumes the global RNG (its dev pass): must not matter
+        a = list(r0)
+        random.seed(epoch)   # ... nor must anything else that happens to it
+        b, w = list(r1), list(whole)
+        assert len(a) == len(b) == len(w) == len(whole) == 2
+        for sa, sb, sw in zip(a, b, w):
+            assert sa + sb == sw and len(sa) == 2 and len(sb) == 1  # remainder goes to the first ranks
+    # a global batch smaller than the world: trailing ranks get an empty shard and the loader still yields it
+    tiny = loader.BatchRandomSampler(ds, 2, world=4, rank=3)
+    assert all(s == [] for s in tiny)
+    ldr = loader.make_loader(tiny_dataset, preproc, batch_size=2, num_workers=0, world=4, rank=3)
+    assert [b for b in ldr] == [((), ())] * 4
+
+
+def test_collate_pads_to_the_global_batch_shape():
+    from speech_amd.models import CTC, Seq2Seq, zero_pad_concat, end_pad_concat
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 32, 2]], "rnn": {"dim": 16, "bidirectional": False, "layers": 1}},
+           "decoder": {"embedding_dim": 16, "layers": 1}}
+    inputs = (np.ones((30, 40), np.float32), np.ones((25, 40), np.float32))
+    labels = ([1, 2, 3], [4, 5])
+    model = CTC(40, 10, cfg)
+    x, y, xl, yl = model.collate(inputs, labels)
+    assert x.shape == (2, 30, 40) and xl.tolist() == [13, 13]
+    model.set_global_batch(8, 41, 7)     # the global batch's longest utterance has 41 frames
+    x, y, xl, yl = model.collate(inputs, labels)
+    assert x.shape == (2, 41, 40) and xl.tolist() == [model.conv_out_size(41, 0)] * 2 and float(x[:, 30:].abs().sum()) == 0
+    assert model.loss_denominator == 8 == model.ctc_denominator
+    model.set_global_batch()
+    assert model.collate(inputs, labels)[0].shape == (2, 30, 40) and model.loss_denominator is None
+    s2s = Seq2Seq(40, 12, cfg)
+    s2s.set_global_batch(8, 41, 7)
+    xs, ys = s2s.collate(inputs, ([11, 1, 2, 10], [11, 3, 10]))
+    assert xs.shape == (2, 41, 40) and ys.shape == (2, 7) and ys[1].tolist() == [11, 3, 10, 10, 10, 10, 10]
+    assert zero_pad_concat(inputs, 0).shape == (2, 30, 40) and end_pad_concat(([1, 2], [3]), 0).shape == (2, 2)

@@ -3,12 +3,20 @@
 
 Same CLI (`python train.py config.json [--deterministic]`), same JSON config schema (train.py:72-97), same loop
 (run_epoch :21-49, eval_dev :51-70, checkpoint every epoch + "best" :115-121).  Differences:
-  * data parallel: launched under torch.distributed.run it shards every global batch over the ranks and SUM
-    all-reduces the flat gradient buffer (RCCL) between backward and the clip (speech_amd/dist.py);
+  * data parallel: launched under torch.distributed.run every rank loads ITS shard of each global batch
+    (loader.make_loader(world, rank)), pads it to the global batch's shape (Model.set_global_batch) and SUM
+    all-reduces the flat gradient buffer (RCCL) between backward and the clip (speech_amd/dist.py); the dev set is
+    evaluated by all ranks on their shards and the totals are summed, so no rank idles in a collective;
   * clip_grad_norm(200) + SGD run as the fused flat-buffer kernel (speech_amd.ops.clip_sgd_step);
-  * py3 / torch-2 fixes of SURVEY.md App. C (loss.item(), materialised batches, tensorboard optional).
+  * the loss / gradient norm of a step are read back asynchronously (ops.ScalarPipe) instead of with the reference's
+    per-step `loss.data[0]` sync (train.py:33): the progress bar shows them one or two steps late and the launch
+    queue never drains;
+  * a failed persistent-kernel hand-off cannot reach the parameters: the optimiser skips the update on the device
+    (negative norm), this loop then resets the library and replays the lost batches on the step kernels;
+  * py3 / torch-2 fixes of SURVEY.md App. C (materialised batches, tensorboard optional).
 """
 import argparse
+import collections
 import json
 import random
 import time
@@ -19,7 +27,7 @@ import tqdm
 import speech
 import speech.loader as loader
 import speech.models as models
-from speech_amd import dist, ops
+from speech_amd import dist, io as sa_io, ops
 
 try:
     import tensorboard_logger as tb
@@ -27,50 +35,91 @@ except ImportError:  # optional, as in requirements.txt of the reference
     tb = None
 
 
-def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank):
+def train_step(model, flat, opt_cfg, batch):
+    """One train.py:28-35 step on this rank's shard.  Returns (loss tensor or None for an empty shard, norm tensor)."""
     flat_p, flat_g, mom = flat
+    model.set_global_batch(*dist.global_shape(batch))
+    model.zero_grad(set_to_none=True)
+    loss = None
+    if len(batch[0]) == 0:
+        flat_g.zero_()  # global batch smaller than the world: this rank adds nothing but still joins the collective
+    else:
+        loss = model.loss(batch)
+        loss.backward()
+    ops.stamp_health(flat_g)
+    dist.allreduce_gradients(flat_g)
+    norm = ops.clip_sgd_step(flat_p, flat_g, mom, opt_cfg["learning_rate"], opt_cfg["momentum"], 200.0)
+    return loss, norm
+
+
+def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank):
     model_t = 0.0
     data_t = 0.0
     end_t = time.time()
     tq = tqdm.tqdm(train_ldr, disable=rank != 0)
+    losses, norms = ops.ScalarPipe(), ops.ScalarPipe()
+    recent = collections.deque(maxlen=8)  # batches whose update has not been confirmed yet
+    zero = torch.zeros(1, device=flat[0].device)
+    shown = {"loss": 0.0, "norm": 0.0}
+
+    def consume(done_losses, done_norms):
+        nonlocal avg_loss
+        for tag, v in done_losses:
+            shown["loss"] = v
+            avg_loss = 0.99 * avg_loss + 0.01 * v
+            if tb is not None and rank == 0:
+                tb.log_value("train_loss", v, tag)
+        lost = None
+        for tag, v in done_norms:
+            shown["norm"] = abs(v)
+            if v < 0 and lost is None:
+                lost = tag  # the optimiser skipped this step: a persistent kernel reported a failure
+        return lost
+
     for batch in tq:
         start_t = time.time()
-        batch, global_b = dist.shard_batch(batch, world, rank)
-        model.ctc_denominator = model.loss_denominator = global_b  # CTC / Transducer: mean over the GLOBAL batch
-        model.zero_grad(set_to_none=True)
-        loss = model.loss(batch)
-        loss.backward()
-        dist.allreduce_gradients(flat_g)
-        grad_norm = ops.clip_sgd_step(flat_p, flat_g, mom, opt_cfg["learning_rate"], opt_cfg["momentum"], 200.0)
-        loss = float(loss.item())  # this rank's share of the global-mean loss
+        recent.append((it, batch))
+        loss, norm = train_step(model, flat, opt_cfg, batch)
+        lost = consume(losses.push(loss if loss is not None else zero, it), norms.push(norm, it))
+        if lost is not None:
+            consume(losses.drain(), norms.drain())
+            code = ops.persist_reset()
+            print("persistent GRU kernels failed (code %d) at iteration %d: replaying from there on the step kernels"
+                  % (code, lost))
+            for tag, b in [rb for rb in recent if rb[0] >= lost]:
+                l2, n2 = train_step(model, flat, opt_cfg, b)
+                consume(losses.push(l2 if l2 is not None else zero, tag), norms.push(n2, tag))
         prev_end_t = end_t
         end_t = time.time()
         model_t += end_t - start_t
         data_t += start_t - prev_end_t
-        exp_w = 0.99
-        avg_loss = exp_w * avg_loss + (1 - exp_w) * loss
-        if tb is not None and rank == 0:
-            tb.log_value("train_loss", loss, it)
-        tq.set_postfix(iter=it, loss=loss, avg_loss=avg_loss, grad_norm=float(grad_norm), model_time=model_t,
+        tq.set_postfix(iter=it, loss=shown["loss"], avg_loss=avg_loss, grad_norm=shown["norm"], model_time=model_t,
                        data_time=data_t)
         it += 1
+    consume(losses.drain(), norms.drain())
     return it, avg_loss
 
 
-def eval_dev(model, ldr, preproc):
-    losses, all_preds, all_labels = [], [], []
+def eval_dev(model, ldr, preproc, rank=0):
+    """train.py:51-70 on this rank's shards; loss and CER totals are summed over the ranks."""
+    loss_sum, n_batches, results = 0.0, 0, []
     model.set_eval()
-    model.ctc_denominator = model.loss_denominator = None
-    for batch in tqdm.tqdm(ldr):
+    for batch in tqdm.tqdm(ldr, disable=rank != 0):
+        model.set_global_batch(*dist.global_shape(batch))
+        n_batches += 1
+        if len(batch[0]) == 0:
+            continue
         preds = model.infer(batch)
-        losses.append(float(model.loss(batch).item()))
-        all_preds.extend(preds)
-        all_labels.extend(batch[1])
+        loss_sum += float(model.loss(batch).item())  # this rank's share of the global-mean loss
+        results.extend((preproc.decode(l), preproc.decode(p)) for l, p in zip(batch[1], preds))
     model.set_train()
-    loss = sum(losses) / len(losses)
-    results = [(preproc.decode(l), preproc.decode(p)) for l, p in zip(all_labels, all_preds)]
-    cer = speech.compute_cer(results)
-    print("Dev: Loss {:.3f}, CER {:.3f}".format(loss, cer))
+    model.set_global_batch()
+    edits, length = sa_io.cer_counts(results)
+    loss_sum, edits, length = dist.allreduce_sum_host([loss_sum, edits, length])
+    loss = loss_sum / max(n_batches, 1)
+    cer = edits / max(length, 1)
+    if rank == 0:
+        print("Dev: Loss {:.3f}, CER {:.3f}".format(loss, cer))
     return loss, cer
 
 
@@ -79,8 +128,11 @@ def run(config):
     opt_cfg, data_cfg, model_cfg = config["optimizer"], config["data"], config["model"]
     batch_size = opt_cfg["batch_size"]
     preproc = loader.Preprocessor(data_cfg["train_set"], start_and_end=data_cfg["start_and_end"])
-    train_ldr = loader.make_loader(data_cfg["train_set"], preproc, batch_size)
-    dev_ldr = loader.make_loader(data_cfg["dev_set"], preproc, batch_size)
+    device_features = bool(data_cfg.get("device_features", False))  # featurise on the GPU (speech_amd.features)
+    train_ldr = loader.make_loader(data_cfg["train_set"], preproc, batch_size, world=world, rank=rank,
+                                   device_features=device_features)
+    dev_ldr = loader.make_loader(data_cfg["dev_set"], preproc, batch_size, world=world, rank=rank,
+                                 device_features=device_features)
     model_class = getattr(models, model_cfg["class"])
     model = model_class(preproc.input_dim, preproc.vocab_size, model_cfg)
     model.cuda()  # there is no CPU path
@@ -91,10 +143,11 @@ def run(config):
     for e in range(opt_cfg["epochs"]):
         start = time.time()
         run_state = run_epoch(model, (flat_p, flat_g, mom), opt_cfg, train_ldr, *run_state, world, rank)
+        if rank == 0:
+            print("Epoch {} completed in {:.2f} (s).".format(e, time.time() - start))
+        dev_loss, dev_cer = eval_dev(model, dev_ldr, preproc, rank)
         if rank != 0:
             continue
-        print("Epoch {} completed in {:.2f} (s).".format(e, time.time() - start))
-        dev_loss, dev_cer = eval_dev(model, dev_ldr, preproc)
         if tb is not None:
             tb.log_value("dev_loss", dev_loss, e)
             tb.log_value("dev_cer", dev_cer, e)
