@@ -169,6 +169,21 @@ ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, con
                              const float* const* w_hh, float* const* dai, float* const* dah, float* dx, int I0, int L,
                              int D, int B, int T, int H, int chunk, void* workspace, size_t workspace_bytes,
                              void* stream, void* const* aux_streams, int n_aux);
+/* The same backward pass, plus the stack's PARAMETER gradients (what autograd derives for nn.GRU, train.py:30):
+ *   dw_ih[l*D+d] (3H, I_l) = dai^T in_l (in_0 = x (T, B, I0), in_l = h_out[l-1] (T, B, D*H)),  db_ih = column sums of dai,
+ *   dw_hh[l*D+d] (3H, H)   = dah^T h_prev (the stash's fifth block),                            db_hh = column sums of dah.
+ * The library schedules them: as soon as a span of time steps of a layer is final its products are handed to a
+ * library-owned side stream as one-block-per-CU GEMM launches (bias gradients fused into the same launches) that
+ * run BESIDE the latency-bound persistent recurrence kernels, on the matrix-pipe cycles those leave idle; the call
+ * joins the side stream before it returns (stream-ordered: everything is complete when `stream` reaches the end of
+ * the call's work).  Deterministic: fixed hand-over points, fixed accumulation order.  SA_GRU_OVERLAP=0: the same
+ * products on `stream` after the recurrence; SA_GRU_WG_EVERY=n: persistent launches between hand-overs (default 4). */
+ctcStatus_t sa_gru_stack_bwd_wgrad(const float* dh_top, const float* const* stash, const float* const* w_ih,
+                                   const float* const* w_hh, float* const* dai, float* const* dah, float* dx, int I0,
+                                   int L, int D, int B, int T, int H, int chunk, const float* x,
+                                   const float* const* h_out, float* const* dw_ih, float* const* dw_hh,
+                                   float* const* db_ih, float* const* db_hh, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 
 /* Opt-in launch profiler for the stack entry points (bench.py): after sa_gru_profile_configure(1), block 0 of every
  * step launch stamps the 100 MHz wall clock at entry and exit into a device ring (16 K launches).

@@ -44,6 +44,12 @@ struct GemmArgs {
     long s_outer, s_mid, col_stride;
     int relu;
     float* partial;   // split-K workspace [nprob][splits][M][N] or null
+    // optional fused column sums of A (TA products only: A is stored (K, M), so these are the bias gradients that
+    // belong to a weight gradient dW = dA^T X): colsum[m] = (beta != 0 ? colsum[m] : 0) + sum_k A[k][m], computed by
+    // the blocks of the first column tile from the A tiles they stage anyway.  Under split-K the per-split sums go to
+    // cs_partial [nprob][splits][M] and the reduce kernel folds them with the products.
+    float* colsumg[kMaxGroup];
+    float* cs_partial;
 };
 
 __device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
@@ -146,7 +152,8 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ a_s, const fl
 template <bool TA, bool TB>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __restrict__ gA,
                                               const float* __restrict__ gB, float* smem, int m0, int n0, int kbeg,
-                                              int kend, int tid, bool fast, f32x16 (&acc)[2][2]) {
+                                              int kend, int tid, bool fast, f32x16 (&acc)[2][2], bool do_colsum,
+                                              float4& csum) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = (kend - kbeg + BK - 1) / BK;
@@ -164,8 +171,16 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
             load_tile<TB, false>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
         }
     };
+    // TA: a thread's NL float4 of an A tile are 4 consecutive m at NL different k -> its share of the column sums
+    auto colsum_acc = [&]() {
+        if (TA && do_colsum) {
+#pragma unroll
+            for (int p = 0; p < NL; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+        }
+    };
     if (ntiles > 0) {
         load(0);
+        colsum_acc();
         store_tile<!TA>(As(0), tid, ra);
         store_tile<TB>(Bs(0), tid, rb);
     }
@@ -176,6 +191,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
         if (more) load(it + 1);
         mma_tile(As(cur) + frag + wm * 64, Bs(cur) + frag + wn * 64, acc);
         if (more) {
+            colsum_acc();
             store_tile<!TA>(As(cur ^ 1), tid, ra);
             store_tile<TB>(Bs(cur ^ 1), tid, rb);
         }
@@ -208,7 +224,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const bool fast = g.vecA && g.vecB && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
-    gemm_mainloop<TA, TB>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, fast, acc);
+    const bool do_colsum = TA && g.colsumg[prob] != nullptr && blockIdx.x == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    gemm_mainloop<TA, TB>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, fast, acc, do_colsum, csum);
+    if (do_colsum) {  // fold the 8 k-rows of threads (tid >> 5) that share 4 columns; fixed order: deterministic
+        float* cs = smem;  // the mainloop's last barrier has released the tiles
+        *reinterpret_cast<float4*>(&cs[(tid >> 5) * BM + 4 * (tid & 31)]) = csum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += cs[r * BM + tid];
+            if (g.partial) {
+                g.cs_partial[(long)blockIdx.z * g.M + m0 + tid] = t;
+            } else {
+                float* o = g.colsumg[prob] + m0 + tid;
+                *o = g.beta != 0.f ? g.beta * *o + t : t;
+            }
+        }
+    }
 
     // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool splitk = g.partial != nullptr;
@@ -244,9 +278,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int splits) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)g.M * g.N;
-    if (idx >= total) return;
-    const int row = (int)(idx / g.N), col = (int)(idx % g.N);
     const int prob = blockIdx.y;
+    if (idx >= total) {  // the tail threads fold the fused column sums
+        const long m = idx - total;
+        if (m < g.M && g.colsumg[prob]) {
+            float t = 0.f;
+            for (int z = 0; z < splits; ++z) t += g.cs_partial[((long)prob * splits + z) * g.M + m];
+            float* o = g.colsumg[prob] + m;
+            *o = g.beta != 0.f ? g.beta * *o + t : t;
+        }
+        return;
+    }
+    const int row = (int)(idx / g.N), col = (int)(idx % g.N);
     float s = 0.f;
     for (int z = 0; z < splits; ++z)
         s += g.partial[((long)prob * splits + z) * total + idx];  // fixed order: deterministic
@@ -286,8 +329,10 @@ int choose_splits(int M, int N, int K, int nprob = 1) {
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
                                    const float* const* A, long lda, const float* const* B, long ldb, float beta,
                                    float* const* C, long ldc, const float* const* bias, const SaGemmEpilogue* ep,
-                                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                   void* workspace, size_t workspace_bytes, hipStream_t stream,
+                                   const SaGemmOpts* opts) {
     SA_CLEAR_ERR();
+    if (opts && opts->colsum && (!trans_a || alpha != 1.f)) return CTC_STATUS_INVALID_VALUE;
     if (M < 0 || N < 0 || K < 0 || nprob < 1 || nprob > kMaxGroup) return CTC_STATUS_INVALID_VALUE;
     if (M == 0 || N == 0) return CTC_STATUS_SUCCESS;
     GemmArgs g;
@@ -297,6 +342,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     for (int p = 0; p < nprob; ++p) {
         if (!A[p] || !B[p] || !C[p]) return CTC_STATUS_INVALID_VALUE;
         g.Ag[p] = A[p]; g.Bg[p] = B[p]; g.Cg[p] = C[p]; g.biasg[p] = bias ? bias[p] : nullptr;
+        g.colsumg[p] = (opts && opts->colsum) ? opts->colsum[p] : nullptr;
         g.vecA = g.vecA && (((uintptr_t)A[p] & 15) == 0);
         g.vecB = g.vecB && (((uintptr_t)B[p] & 15) == 0);
     }
@@ -310,8 +356,9 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.col_stride = ep ? ep->col_stride : 1;
     g.relu = ep ? ep->relu : 0;
     int splits = choose_splits(M, N, K, nprob);
+    if (opts && opts->no_split) splits = 1;
     if (splits > 1) {
-        const size_t need = (size_t)nprob * splits * M * N * sizeof(float);
+        const size_t need = (size_t)nprob * splits * ((size_t)M * N + M) * sizeof(float);
         if (!workspace || workspace_bytes < need) splits = 1;  // no room: fall back to one pass (still correct)
     }
     int kps = (K + splits - 1) / splits;
@@ -321,17 +368,34 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.k_per_split = kps;
     g.splits = splits;
     g.partial = splits > 1 ? (float*)workspace : nullptr;
+    g.cs_partial = splits > 1 ? (float*)workspace + (size_t)nprob * splits * M * N : nullptr;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
+    // "polite" launches (opts->pad_lds): dynamic LDS on top of the kernel's 66 KB so that a CU admits ONE block of this
+    // launch -- what a side-stream GEMM wants while a persistent recurrence kernel holds every CU (gru.hip): the
+    // recurrence blocks then always find room, before and after this launch's blocks arrive.
+    size_t dyn = 0;
+    if (opts && opts->pad_lds) {
+        static bool attr_set = false;
+        dyn = 81 * 1024 - sizeof(float) * 2 * 2 * BK * LDT;
+        if (!attr_set) {
+            const void* fns[4] = {(const void*)gemm_f32_kernel<true, true>, (const void*)gemm_f32_kernel<true, false>,
+                                  (const void*)gemm_f32_kernel<false, true>, (const void*)gemm_f32_kernel<false, false>};
+            for (int i = 0; i < 4; ++i)
+                if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
+                    return CTC_STATUS_EXECUTION_FAILED;
+            attr_set = true;
+        }
+    }
     if (trans_a) {
-        if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, g);
+        if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), dyn, stream, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), dyn, stream, g);
     } else {
-        if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, g);
+        if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), dyn, stream, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), dyn, stream, g);
     }
     SA_CHECK_LAUNCH();
     if (splits > 1) {
-        const long total = (long)M * N;
+        const long total = (long)M * N + M;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), nprob), dim3(256), 0,
                            stream, g, splits);
         SA_CHECK_LAUNCH();
@@ -342,7 +406,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
 size_t sa_gemm_group_workspace_bytes(int nprob, int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || nprob <= 0) return 0;
     const int s = choose_splits(M, N, K, nprob);
-    return s > 1 ? (size_t)nprob * s * M * N * sizeof(float) : 0;
+    return s > 1 ? (size_t)nprob * s * ((size_t)M * N + M) * sizeof(float) : 0;
 }
 
 ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
@@ -350,13 +414,13 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
                              const SaGemmEpilogue* ep, void* workspace, size_t workspace_bytes,
                              hipStream_t stream) {
     return sa_gemm_f32_group_impl(1, trans_a, trans_b, M, N, K, alpha, &A, lda, &B, ldb, beta, &C, ldc, &bias, ep,
-                                  workspace, workspace_bytes, stream);
+                                  workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int s = choose_splits(M, N, K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    return s > 1 ? (size_t)s * ((size_t)M * N + M) * sizeof(float) : 0;
 }
 
 extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,

@@ -37,9 +37,12 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // 4 consecutive k (one float4) from its row and feeds 4 MFMAs, the four 16-lane groups cover 16 consecutive k.
 // The loop is a dependent-latency problem (L2 round trip ~0.5 us per trip if loads and MFMAs alternate), so operands
 // are fetched U iterations at a time -- U * (1 + NT) independent 16-byte loads in flight -- before their MFMAs issue.
-template <int NT, int U>
+// DUAL (U even): k-groups alternate between acc and acc2 (the caller adds them): one accumulator is a chain of
+// dependent 16x16x4 MFMAs (40-cycle dependent latency against a 32-cycle issue interval), two run at the issue rate.
+template <int NT, int U, bool DUAL = false>
 __device__ __forceinline__ void smallm_mfma(const float* __restrict__ a_row, const float* const (&b_row)[NT],
-                                            int kbeg, int kend, int K, f32x4 (&acc)[NT], int g) {
+                                            int kbeg, int kend, int K, f32x4 (&acc)[NT], int g,
+                                            f32x4* acc2 = nullptr) {
     for (int kk0 = kbeg; kk0 < kend; kk0 += 16 * U) {  // wave-uniform trip counts (MFMA must not sit in divergent flow)
         float4 a[U];
         float4 b[U][NT];
@@ -72,10 +75,11 @@ __device__ __forceinline__ void smallm_mfma(const float* __restrict__ a_row, con
             if (kk0 + 16 * it < kend) {  // wave-uniform
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, b[it][n].x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, b[it][n].y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, b[it][n].z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, b[it][n].w, acc[n], 0, 0, 0);
+                    f32x4& d = (DUAL && (it & 1)) ? acc2[n] : acc[n];
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, b[it][n].x, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, b[it][n].y, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, b[it][n].z, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, b[it][n].w, d, 0, 0, 0);
                 }
             }
         }
@@ -219,6 +223,18 @@ __device__ __forceinline__ bool has_sentinel(f32x4v v) {
            __builtin_bit_cast(unsigned, v.z) == kSentinel || __builtin_bit_cast(unsigned, v.w) == kSentinel;
 }
 
+// One XCD-local persistent workgroup per CU, by construction: the empty asm clobbers v255 and a7, which pins the
+// kernel's register allocation at >= 264 of the 512 registers a SIMD lane owns -- two such workgroups can never share a
+// CU, whatever the compiler's own count.  (Round 1 got the same exclusivity from an 84 KB LDS request; registers leave
+// the LDS free, so that a side-stream GEMM block -- 152 registers, 81 KB of LDS -- FITS beside the recurrence block and
+// uses the matrix-pipe cycles the latency-bound recurrence leaves idle.)  The recurrence waves run at raised priority:
+// whenever they are ready to issue they go first.
+#define SA_PERSIST_EXCLUSIVE()                      \
+    do {                                            \
+        asm volatile("" ::: "v255", "a7");          \
+        __builtin_amdgcn_s_setprio(3);              \
+    } while (0)
+
 __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
     return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;
 }
@@ -226,6 +242,7 @@ __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID =
 template <bool WREG>  // W_hh fragments resident in registers (XCD-local mode, H <= 512) instead of LDS
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
+    if (WREG) SA_PERSIST_EXCLUSIVE();
     int role_x = blockIdx.x, role_y = blockIdx.y, role_z = blockIdx.z;
     if (P.xcd_mode) {
         __shared__ int s_role[2];
@@ -253,8 +270,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     const bool stamper = P.xcd_mode && P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
     if (stamper) P.stamp[0] = wall_clock64();
     const int LDW = H + 4;                       // padded row pitch: 16-byte aligned, spreads the fragment reads
-    float* Wl = psm;                             // [48][LDW]: rows u0.., H+u0.., 2H+u0.. of W_hh
-    float* red = psm + 48 * LDW;                 // [4][3][256]
+    float* Wl = psm;                             // [48][LDW]: rows u0.., H+u0.., 2H+u0.. of W_hh (not with WREG)
+    float* red = psm + (WREG ? 0 : 48 * LDW);    // [2][4][3][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ntile_u = P.xcd_mode ? P.ntile_u : (int)gridDim.x;
@@ -443,6 +460,7 @@ struct PFusedFwd {
 __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE();
     if (threadIdx.x == 0) {
         const int x = xcc_id();
         s_role[0] = x;
@@ -765,11 +783,11 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(BwdJobs P) {
         const int urow = min(u0 + i, H - 1);
         const float* a_row = J.dah + ((long)brow * P.rb + (long)J.t_next * P.rt) * H3;
         const float* b_rows[1] = {J.w_hh_t + (long)urow * H3};
-        f32x4 acc[1];
-        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        smallm_mfma<1, 12>(a_row, b_rows, kbeg, kend, H3, acc, g);
+        f32x4 acc[1], acc2[1];
+        acc[0] = acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        smallm_mfma<1, 12, true>(a_row, b_rows, kbeg, kend, H3, acc, g, acc2);  // same order as the persistent kernel
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) red[wave][(g * 4 + rr) * 16 + i] = acc[0][rr];
+        for (int rr = 0; rr < 4; ++rr) red[wave][(g * 4 + rr) * 16 + i] = acc[0][rr] + acc2[0][rr];
     }
     __syncthreads();
     if (!live) { if (stamper) P.stamp[1] = wall_clock64(); return; }
@@ -819,6 +837,7 @@ struct PBwdJobs {
 __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE();
     if (threadIdx.x == 0) {
         const int x = xcc_id();
         s_role[0] = x;
@@ -886,7 +905,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
             __syncthreads();
         }
         if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // even / odd k-groups
             const int abase = (int)((((long)brow * P.rb + (long)(t - J.dt) * P.rt) * H3) * 4);  // byte offset of the row
             for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 384) {  // H = 512: the whole k-slice in ONE round trip
                 f32x4v a[24];
@@ -909,16 +928,17 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                 for (int it = 0; it < 24; ++it) {
                     if (kk0 + 16 * it < kbeg + kslice) {
                         const float4 w = wr[it];  // H <= 512: the k loop runs once, `it` indexes the resident fragments
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, acc, 0, 0, 0);
+                        f32x4& d = (it & 1) ? acc1 : acc;  // two chains: the 40-cycle dependent latency is hidden
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, d, 0, 0, 0);
                     }
                 }
             }
             float* rd = red + (P.flagless ? (s & 1) * 1024 : 0);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr];
+            for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr] + acc1[rr];
         }
         __syncthreads();
         if (live) {
@@ -1328,7 +1348,9 @@ static bool xcd_shape_ok(int jobs, int B, int H) {
     if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256 || !g_health.init()) return false;
     return jobs * ((B + 15) / 16) <= 8 * (32 / ntile_u);
 }
-static size_t xcd_lds(size_t need) { return need < 84 * 1024 ? 84 * 1024 : need; }  // > half a CU's LDS: one per CU
+// XCD-local kernels are one-per-CU through their register reservation (SA_PERSIST_EXCLUSIVE), so they ask for the LDS
+// they use and nothing more: <= 79 KB leaves room for one "polite" (81 KB) side-stream GEMM block beside them
+static size_t xcd_lds(size_t need) { return need; }
 
 static int clamp_chunk(int chunk, int T) {
     // measured on MI355X at S-LIBRI, whole train step: step kernels 16 -> 19.6 ms, 32 -> 19.9, 8 -> 20.5;
@@ -1404,7 +1426,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
                    // the two directions of a layer share every launch
         const int bi_nbt = (B + 15) / 16;
-        const size_t bi_lds = xcd_lds(((size_t)48 * (H + 4) + 2 * 4 * 3 * 256) * sizeof(float));
+        const size_t bi_lds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * DH * 4 < 0x7fffffffL;
         if (bi_xcd) {
@@ -1468,7 +1490,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     // XCD-local groups: 8 XCDs x 32 CUs, 32 / ntile_u (layer, batch tile) groups per XCD
     const bool xcd = persist && xcd_shape_ok(L, B, H);
     if (persist_mode() == 2 && !xcd) persist = false;
-    if (xcd) plds = xcd_lds(plds);
+    if (xcd) plds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
     unsigned persist_launches = 0;
     const bool flagless = xcd && flagless_mode();
     if (flagless)
@@ -1581,6 +1603,19 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     return CTC_STATUS_SUCCESS;
 }
 
+// split-K workspace of the weight-gradient products (one region: the products of a call run on ONE stream, in order)
+static size_t wgrad_ws_bytes(int D, int B, int T, int H, int I0) {
+    const int nmax = I0 > D * H ? I0 : D * H;
+    size_t w = 0;
+    for (int np = 1; np <= 2 * D && np <= kMaxJobs; ++np) {
+        const size_t a = sa_gemm_group_workspace_bytes(np, 3 * H, nmax, T * B);
+        const size_t b = sa_gemm_group_workspace_bytes(np, 3 * H, H, T * B);
+        if (a > w) w = a;
+        if (b > w) w = b;
+    }
+    return sa_align_up(w, 256);
+}
+
 extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, int H, int I0) {
     if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +      // dh ping-pong
@@ -1588,15 +1623,133 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
-    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw + kSyncBytes;
+    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw + wgrad_ws_bytes(D, B, T, H, I0) +
+           kSyncBytes;
 }
 
 // dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d] (T, B, 3H) for every layer and
 // direction, and dx (T, B, I0) = gradient wrt the stack input (may be NULL).
-extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, const float* const* w_ih,
-                                        const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
-                                        int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
-                                        size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux) {
+namespace {
+// Parameter gradients of the stack, produced INSIDE the backward call so that the library can schedule them:
+//   dW_ih[l,d] = dai[l,d]^T in_l      (in_0 = x, in_l = h_out[l-1])        db_ih[l,d] = column sums of dai[l,d]
+//   dW_hh[l,d] = dah[l,d]^T h_prev    (h_prev = stash[l,d][:, 4H:5H])      db_hh[l,d] = column sums of dah[l,d]
+// As soon as a span of time steps of a layer is final (its persistent launch has retired) these products go out on a
+// SIDE stream as "polite" GEMM launches (one block per CU, bias gradients fused in): the recurrence kernels are
+// latency-bound -- their blocks use ~20 % of a CU's matrix-pipe time and 264 of its 512 registers per lane -- so a GEMM
+// block fits beside each of them and the weight gradients ride on the idle MFMA cycles instead of queueing behind the
+// whole backward pass (2.8 ms of 12.4 at S-LIBRI in round 1).  SA_GRU_OVERLAP=0: same products, issued on the
+// caller's stream after the recurrence.
+struct WGrad {
+    const float* x;               // (T, B, I0)
+    const float* const* h_out;    // [L] (T, B, D*H)
+    float* const* dw_ih;          // [L*D] (3H, I_l)
+    float* const* dw_hh;          // [L*D] (3H, H)
+    float* const* db_ih;          // [L*D] (3H)
+    float* const* db_hh;          // [L*D] (3H)
+};
+
+struct SideStream {
+    static constexpr int kEvents = 64;
+    hipStream_t s = nullptr;
+    hipEvent_t ev[kEvents];
+    int next = 0;
+    bool ready = false;
+    bool init() {
+        if (ready) return true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < kEvents; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        ready = true;
+        return true;
+    }
+    // `waiter` will not start work queued after this call before everything queued on `signaller` so far is done
+    bool order(hipStream_t signaller, hipStream_t waiter) {
+        hipEvent_t e = ev[next];
+        next = (next + 1) % kEvents;
+        return hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
+    }
+};
+SideStream g_side;
+
+int wgrad_every() {  // persistent launches between two hand-overs of weight-gradient work to the side stream
+    const char* e = getenv("SA_GRU_WG_EVERY");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4;
+}
+
+bool overlap_enabled() {
+    const char* e = getenv("SA_GRU_OVERLAP");
+    return !(e && e[0] == '0');
+}
+
+// Issues the weight-gradient products of layer-direction k = l*D+d over the time steps [t0, t1) on `stream`.
+// `first[k]` tracks whether the slot has been written yet (beta = 0 the first time, 1 afterwards).
+struct WGradIssuer {
+    WGrad wg;
+    const float* const* stash;
+    float* const* dai;
+    float* const* dah;
+    int L, D, B, T, H, I0;
+    bool polite;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    bool first_ih[2 * kMaxJobs], first_hh[2 * kMaxJobs];
+    WGradIssuer(const WGrad& w, const float* const* st, float* const* da, float* const* dh, int L_, int D_, int B_,
+                int T_, int H_, int I0_, bool pol)
+        : wg(w), stash(st), dai(da), dah(dh), L(L_), D(D_), B(B_), T(T_), H(H_), I0(I0_), polite(pol) {
+        for (int i = 0; i < 2 * kMaxJobs; ++i) first_ih[i] = first_hh[i] = true;
+    }
+    // spans[k] = {t0, t1} (t1 <= t0: nothing).  Same-shaped problems share a grouped launch.
+    ctcStatus_t issue(const int (*spans)[2], hipStream_t stream, bool allow_split) {
+        const int n = L * D;
+        bool done_ih[2 * kMaxJobs], done_hh[2 * kMaxJobs];
+        for (int k = 0; k < n; ++k) done_ih[k] = done_hh[k] = spans[k][1] <= spans[k][0];
+        SaGemmOpts o;
+        o.no_split = allow_split ? 0 : 1; o.pad_lds = polite ? 1 : 0;
+        for (int pass = 0; pass < 2; ++pass) {      // 0: dW_hh (N = H, B operand = stash h_prev), 1: dW_ih
+            bool* done = pass == 0 ? done_hh : done_ih;
+            bool* first = pass == 0 ? first_hh : first_ih;
+            for (int k0 = 0; k0 < n; ++k0) {
+                if (done[k0]) continue;
+                const int rows = (spans[k0][1] - spans[k0][0]) * B;
+                const int N0 = pass == 0 ? H : (k0 / D == 0 ? I0 : D * H);
+                const float* gA[kMaxJobs]; const float* gB[kMaxJobs]; float* gC[kMaxJobs]; float* gS[kMaxJobs];
+                int ng = 0;
+                for (int k = k0; k < n && ng < kMaxJobs; ++k) {
+                    if (done[k]) continue;
+                    const int Nk = pass == 0 ? H : (k / D == 0 ? I0 : D * H);
+                    if ((spans[k][1] - spans[k][0]) * B != rows || Nk != N0 || first[k] != first[k0]) continue;
+                    const long r0 = (long)spans[k][0] * B;
+                    const int l = k / D;
+                    if (pass == 0) {
+                        gA[ng] = dah[k] + r0 * 3 * H; gB[ng] = stash[k] + r0 * 5 * H + 4 * H;
+                        gC[ng] = wg.dw_hh[k]; gS[ng] = wg.db_hh[k];
+                    } else {
+                        gA[ng] = dai[k] + r0 * 3 * H; gB[ng] = (l == 0 ? wg.x : wg.h_out[l - 1]) + r0 * N0;
+                        gC[ng] = wg.dw_ih[k]; gS[ng] = wg.db_ih[k];
+                    }
+                    done[k] = true;
+                    ++ng;
+                }
+                o.colsum = gS;
+                const float beta = first[k0] ? 0.f : 1.f;
+                const ctcStatus_t st = sa_gemm_f32_group_impl(ng, 1, 0, 3 * H, N0, rows, 1.f, gA, 3 * H, gB,
+                                                              pass == 0 ? 5 * H : N0, beta, gC, N0, nullptr, nullptr,
+                                                              ws, ws_bytes, stream, &o);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
+            for (int k = 0; k < n; ++k)
+                if (spans[k][1] > spans[k][0]) first[k] = false;
+        }
+        return CTC_STATUS_SUCCESS;
+    }
+};
+
+ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const float* const* w_ih,
+                           const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
+                           int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
+                           size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux,
+                           const WGrad* wg) {
     SA_CLEAR_ERR();
     if (!dh_top || !stash || !w_ih || !w_hh || !dai || !dah || !workspace) return CTC_STATUS_INVALID_VALUE;
     if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
@@ -1612,7 +1765,21 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     char* ws = (char*)workspace;
     const size_t fixed_bytes = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
     char* gws = ws + fixed_bytes;
-    const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes;
+    const size_t wws_bytes = wgrad_ws_bytes(D, B, T, H, I0);
+    const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes - wws_bytes;
+    char* wws = gws + gws_bytes;
+    WGradIssuer issuer(wg ? *wg : WGrad{}, stash, dai, dah, L, D, B, T, H, I0, false);
+    issuer.ws = wws; issuer.ws_bytes = wws_bytes;
+    // everything that is still owed when the recurrence is done goes out on the caller's stream (the fallback path)
+    int wg_hi[2 * kMaxJobs];
+    for (int k = 0; k < L * D; ++k) wg_hi[k] = T;
+    auto wgrad_rest = [&]() -> ctcStatus_t {
+        if (!wg) return CTC_STATUS_SUCCESS;
+        int spans[2 * kMaxJobs][2];
+        for (int k = 0; k < L * D; ++k) { spans[k][0] = 0; spans[k][1] = wg_hi[k]; wg_hi[k] = 0; }
+        issuer.polite = false;
+        return issuer.issue(spans, stream, true);
+    };
     unsigned* sync = (unsigned*)(ws + workspace_bytes - kSyncBytes);
     auto dh_buf = [&](int l, int d, int which) {
         return (float*)(ws + (size_t)(l * D + d) * per_dir) + (size_t)which * B * H;
@@ -1646,6 +1813,7 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         const size_t bi_lds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
+        const bool bi_side = wg && bi_xcd && overlap_enabled() && g_side.init();
         if (bi_xcd) {
             if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
             if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1672,6 +1840,17 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                     J.dt = d ? 1 : -1; J.t0 = J.t_first = d ? 0 : T - 1;   // the reverse chain unwinds forward in time
                 }
                 hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(256), dim3(256), bi_lds, stream, Q);
+                if (wg && bi_side) {
+                    // this layer's weight gradients: on the side stream, beside the input-gradient products below
+                    // and the NEXT layer's persistent launch
+                    int spans[2 * kMaxJobs][2];
+                    for (int k = 0; k < L * 2; ++k) { spans[k][0] = spans[k][1] = 0; }
+                    for (int d = 0; d < 2; ++d) { spans[l * 2 + d][1] = T; wg_hi[l * 2 + d] = 0; }
+                    if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
+                    issuer.polite = true;
+                    st = issuer.issue(spans, g_side.s, true);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
             } else {
             P.n = 2; grid.z = 2;
             for (int s = 0; s < T; ++s) {
@@ -1692,7 +1871,8 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
         }
         SA_CHECK_LAUNCH();
         if (bi_xcd) g_health.submit(stream);
-        return CTC_STATUS_SUCCESS;
+        if (bi_side && !g_side.order(g_side.s, stream)) return CTC_STATUS_EXECUTION_FAILED;  // join
+        return wgrad_rest();
     }
 
     // unidirectional: the wavefront runs top layer first, time chunks from the end
@@ -1710,6 +1890,10 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
     if (flagless)
         for (int l = 0; l < L; ++l)
             if (!sentinel_fill(dah[l], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+    // weight gradients ride beside the persistent launches: every kWgEvery launches, the time steps that have become
+    // final since the last hand-over go to the side stream
+    const bool side = wg && xcd && overlap_enabled() && g_side.init();
+    const int wg_every = wgrad_every();
     if (xcd) {
         if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1762,6 +1946,24 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
             Q.n = n;
             Q.stamp = g_prof.slot(1, n == L, false, chunk);
             hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(256), dim3(256), plds, stream, Q);
+            if (side && ((w + 1) % wg_every == 0 || w == nch + L - 2)) {
+                int spans[2 * kMaxJobs][2];
+                bool any = false;
+                for (int l = 0; l < L; ++l) {
+                    int cc = w - (L - 1 - l);           // chunks 0 .. cc (counted from the end) of layer l are final
+                    if (cc > nch - 1) cc = nch - 1;
+                    const int lo = cc >= 0 ? (nch - 1 - cc) * chunk : T;
+                    spans[l][0] = lo; spans[l][1] = wg_hi[l];
+                    any = any || lo < wg_hi[l];
+                    wg_hi[l] = lo;
+                }
+                if (any) {
+                    if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
+                    issuer.polite = true;
+                    st = issuer.issue(spans, g_side.s, false);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
+            }
             continue;
         }
         ch.fork();
@@ -1792,7 +1994,32 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                               nullptr, 0, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
     }
-    return CTC_STATUS_SUCCESS;
+    if (side && !g_side.order(g_side.s, stream)) return CTC_STATUS_EXECUTION_FAILED;  // join
+    return wgrad_rest();
+}
+}  // namespace
+
+extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, const float* const* w_ih,
+                                        const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
+                                        int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
+                                        size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux) {
+    return stack_bwd_impl(dh_top, stash, w_ih, w_hh, dai, dah, dx, I0, L, D, B, T, H, chunk, workspace,
+                          workspace_bytes, stream_, aux_streams, n_aux, nullptr);
+}
+
+extern "C" ctcStatus_t sa_gru_stack_bwd_wgrad(const float* dh_top, const float* const* stash,
+                                              const float* const* w_ih, const float* const* w_hh, float* const* dai,
+                                              float* const* dah, float* dx, int I0, int L, int D, int B, int T, int H,
+                                              int chunk, const float* x, const float* const* h_out,
+                                              float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
+                                              float* const* db_hh, void* workspace, size_t workspace_bytes,
+                                              void* stream_) {
+    if (!x || !h_out || !dw_ih || !dw_hh || !db_ih || !db_hh) return CTC_STATUS_INVALID_VALUE;
+    for (int k = 0; k < L * D && k < 2 * kMaxJobs; ++k)
+        if (!dw_ih[k] || !dw_hh[k] || !db_ih[k] || !db_hh[k]) return CTC_STATUS_INVALID_VALUE;
+    WGrad wg{x, h_out, dw_ih, dw_hh, db_ih, db_hh};
+    return stack_bwd_impl(dh_top, stash, w_ih, w_hh, dai, dah, dx, I0, L, D, B, T, H, chunk, workspace,
+                          workspace_bytes, stream_, nullptr, 0, &wg);
 }
 
 extern "C" size_t sa_colsum_workspace_bytes(int M, int N) {

@@ -138,21 +138,25 @@ class EncoderFunction(torch.autograd.Function):
                 dtop = dtop * mask
             sel = [l * D + d for l in grp for d in range(D)]
             I0 = inp.shape[2]
+            # the library computes the stack's parameter gradients itself (and overlaps them with the recurrence):
+            # hand it the slots of the flat gradient buffer, or fresh tensors for parameters that have none
+            outs = []
+            for j, l in enumerate(grp):
+                for d in range(D):
+                    gi = 2 * nconv + 4 * (l * D + d)
+                    for q in range(4):
+                        slot = slots[gi + q]
+                        if slot is None:
+                            ref = (ctx.w_ih, ctx.w_hh)[q][l * D + d] if q < 2 else None
+                            slot = torch.empty_like(ref) if ref is not None else \
+                                torch.empty(3 * H, dtype=torch.float32, device=dtop.device)
+                        grads[gi + q] = slot
+                    outs.append(gi)
+            wg = (inp, h_out, [grads[g] for g in outs], [grads[g + 1] for g in outs], [grads[g + 2] for g in outs],
+                  [grads[g + 3] for g in outs])
             dai, dah, dx = ops.gru_stack_bwd(dtop.contiguous(), stash, [ctx.w_ih[k] for k in sel],
                                              [ctx.w_hh[k] for k in sel], len(grp), D, H, I0, want_dx=True,
-                                             chunk=plan.chunk)
-            for j, l in enumerate(grp):
-                lay_in = inp if j == 0 else h_out[j - 1]
-                lay_in2 = lay_in.view(Tp * B, lay_in.shape[2])
-                for d in range(D):
-                    k = j * D + d
-                    gi = 2 * nconv + 4 * (l * D + d)
-                    dai2, dah2 = dai[k].view(Tp * B, 3 * H), dah[k].view(Tp * B, 3 * H)
-                    grads[gi] = ops.gemm(dai2, lay_in2, trans_a=True, out=slots[gi])
-                    grads[gi + 1] = ops.gemm(dah2, stash[k].view(Tp * B, 5 * H)[:, 4 * H:], trans_a=True,
-                                             out=slots[gi + 1])
-                    grads[gi + 2] = ops.colsum(dai2, out=slots[gi + 2])
-                    grads[gi + 3] = ops.colsum(dah2, out=slots[gi + 3])
+                                             chunk=plan.chunk, wgrad=wg)
             dtop = dx
         # conv stack
         dy = dtop

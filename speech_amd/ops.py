@@ -224,8 +224,11 @@ def gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash, chunk=0):
     return h_out, stash
 
 
-def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0):
-    """dh_top (T, B, D*H).  Returns (dai list, dah list of L*D (T, B, 3H) tensors, dx (T, B, I0) or None)."""
+def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0, wgrad=None):
+    """dh_top (T, B, D*H).  Returns (dai list, dah list of L*D (T, B, 3H) tensors, dx (T, B, I0) or None).
+    wgrad = (x, h_out, dw_ih, dw_hh, db_ih, db_hh): the stack input (T, B, I0), the L layer outputs of the forward
+    pass, and L*D output tensors each for the weight / bias gradients -- the library then computes them itself and
+    overlaps them with the recurrence (sa_gru_stack_bwd_wgrad: side-stream GEMMs beside the persistent kernels)."""
     T, B, _ = dh_top.shape
     dev = dh_top.device
     assert dh_top.is_contiguous()
@@ -236,10 +239,23 @@ def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0)
     ws = WORKSPACE.get(lib.sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0), dev, "gru_stack_bwd")
     launches = (T + L - 1 if D == 1 else L * T)
     with _span("gru_bwd_stack", launches, 4.0 * B * H * 17 * T * L * D):
-        check(lib.sa_gru_stack_bwd(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
-                                   _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk, ptr(ws),
-                                   ws.numel(), cur_stream(), _aux_streams(dev, N_CHAINS - 1), N_CHAINS - 1),
-              "sa_gru_stack_bwd")
+        if wgrad is None:
+            check(lib.sa_gru_stack_bwd(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
+                                       _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk, ptr(ws),
+                                       ws.numel(), cur_stream(), _aux_streams(dev, N_CHAINS - 1), N_CHAINS - 1),
+                  "sa_gru_stack_bwd")
+        else:
+            x, h_out, dw_ih, dw_hh, db_ih, db_hh = wgrad
+            assert x.is_contiguous() and x.shape == (T, B, I0) and len(h_out) == L
+            for k in range(L * D):
+                I = I0 if k // D == 0 else D * H
+                assert dw_ih[k].is_contiguous() and dw_ih[k].shape == (3 * H, I) and dw_hh[k].is_contiguous()
+                assert dw_hh[k].shape == (3 * H, H) and db_ih[k].numel() == 3 * H and db_hh[k].numel() == 3 * H
+            check(lib.sa_gru_stack_bwd_wgrad(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
+                                             _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk,
+                                             ptr(x), _ptr_array(h_out), _ptr_array(dw_ih), _ptr_array(dw_hh),
+                                             _ptr_array(db_ih), _ptr_array(db_hh), ptr(ws), ws.numel(), cur_stream()),
+                  "sa_gru_stack_bwd_wgrad")
     return dai, dah, dx
 
 
