@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspeech_amd.so")
+LIB_PATH = os.environ.get("SPEECH_AMD_LIB") or os.path.join(_HERE, "libspeech_amd.so")  # override: experiment builds
 
 STATUS_NAMES = {0: "CTC_STATUS_SUCCESS", 1: "CTC_STATUS_MEMOPS_FAILED", 2: "CTC_STATUS_INVALID_VALUE",
                 3: "CTC_STATUS_EXECUTION_FAILED", 4: "CTC_STATUS_UNKNOWN_ERROR"}

@@ -5,11 +5,23 @@
 //   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ beta * C)
 //
 // Tiling (CDNA4): 128x128 block tile, BK = 32, 256 threads = 4 waves as 2x2, each wave a 64x64 sub-tile =
-// 2x2 MFMA 32x32 tiles (4 x 16 accumulator VGPRs).  Operand tiles are staged in LDS k-major ([k][m], [k][n]):
-// an MFMA fragment read is then 32 consecutive floats per half-wave (conflict-free ds_read_b32).  An operand that
-// is k-contiguous in memory (A of an NT product, nn.Linear weights) is transposed on the way into LDS; an operand
-// that is m/n-contiguous is copied with 16-byte accesses.  Global loads for tile i+1 are issued before the MFMAs of
-// tile i (register staging, double-buffered LDS, one barrier per K tile).
+// 2x2 MFMA 32x32 tiles (4 x 16 accumulator registers).
+// Round 2 main loop (round 1 read one float per MFMA operand from a k-major LDS tile right before using it; with one
+// block on a CU -- the small per-chunk products of the GRU wavefront, or a block sharing its CU with a persistent
+// recurrence block -- every k-step then exposed an LDS round trip and the kernel ran at ~40 % of the matrix pipe):
+//   * the MFMA's two k-lanes are fed k = j and k = j + 16 of the tile (the same permutation on both operands, so the
+//     product is unchanged).  An operand that is k-contiguous in memory sits in LDS ROW-major, [row][k] with a 36-float
+//     pitch: lane (h, r) then needs 16 CONSECUTIVE floats of row r -- four conflict-free ds_read_b128 -- for all 16
+//     MFMAs of the k-tile.  An operand that is m/n-contiguous in memory keeps that orientation in LDS, [k][row] with a
+//     132-float pitch, and its fragments are 16 ds_read_b32 (32 consecutive floats per half-wave: conflict-free).
+//     Either way the tile goes into LDS with 16-byte stores and NO transpose -- transposing stores of 4-row-strided
+//     floats into a 16-byte-aligned pitch land on 2 of the 32 banks (measured: 88 % of the LDS cycles of the
+//     weight-gradient product were bank-conflict cycles);
+//   * a k-tile is consumed in four quarters of 16 MFMAs per wave with every operand already in registers: the
+//     fragments of the next quarter are fetched from LDS while the current one's MFMAs run.  Global loads run TWO
+//     tiles ahead through two register stages; a staged tile's 16-byte LDS stores are slipped in between the MFMAs
+//     of the first two quarters.  One barrier per k-tile, no LDS or memory latency inside an MFMA run;
+//   * interior blocks (full tiles, aligned operands) run a guard-free instance of the loop; edge blocks a guarded one.
 // Tall-K products with few output tiles (dW = dA^T X, K = B*T' ~ 16k) are split along K across blockIdx.z into a
 // workspace and reduced by a second kernel in a fixed order (deterministic, unlike atomics).
 #include "common.h"
@@ -20,7 +32,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDT = 132;  // LDS row pitch in floats (128 + 4): keeps 16-byte alignment, spreads transposed writes
+constexpr int PITCH = 36;            // [row][k] tiles: row pitch in floats (16-byte aligned rows, conflict-free b128 reads)
+constexpr int KPITCH = 132;          // [k][row] tiles: k pitch in floats
+constexpr int TILE_F = BM * PITCH;   // floats reserved per operand tile (>= BK * KPITCH)
 
 constexpr int kMaxGroup = 8;
 
@@ -57,7 +71,7 @@ __device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
     return (long)(q / g.m_mid) * g.s_outer + (long)(q % g.m_mid) * g.s_mid + (row % g.m_inner);
 }
 
-// Load this thread's slice of one operand tile (128 x BK) into registers: NL = 4 float4 per thread.
+// Load this thread's slice of one operand tile (128 rows x BK) into registers: NL = 4 float4 per thread.
 // KCONTIG: memory is [rows][k] (k contiguous)  -> row = tid/8 + 32p, k = 4*(tid%8)      (128 B per row: full lines)
 // else:    memory is [k][cols] (cols contiguous) -> k = tid/32 + 8p, col = 4*(tid%32)
 // FAST: the block's tile is interior, K-tiles are full and 16-byte loads are legal: no guards, no branches.
@@ -67,15 +81,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
                                           int vec, int tid, float4 (&v)[NL]) {
 #pragma unroll
     for (int p = 0; p < NL; ++p) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (FAST) {
             if (KCONTIG)
-                v[p] = *reinterpret_cast<const float4*>(P + (long)(r0 + (tid >> 3) + 32 * p) * ld + k0 + 4 * (tid & 7));
+                x = *reinterpret_cast<const float4*>(P + (long)(r0 + (tid >> 3) + 32 * p) * ld + k0 + 4 * (tid & 7));
             else
-                v[p] = *reinterpret_cast<const float4*>(P + (long)(k0 + (tid >> 5) + 8 * p) * ld + r0 + 4 * (tid & 31));
-            continue;
-        }
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KCONTIG) {
+                x = *reinterpret_cast<const float4*>(P + (long)(k0 + (tid >> 5) + 8 * p) * ld + r0 + 4 * (tid & 31));
+        } else if (KCONTIG) {
             const int row = r0 + (tid >> 3) + 32 * p;
             const int k = k0 + 4 * (tid & 7);
             if (row < R) {
@@ -108,102 +120,171 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
     }
 }
 
+// registers -> LDS tile: S[row][k] (pitch PITCH) for a k-contiguous operand, S[k][row] (pitch KPITCH) otherwise
 template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ S /* [BK][LDT] */, int tid, const float4 (&v)[NL]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 (&v)[NL]) {
 #pragma unroll
     for (int p = 0; p < NL; ++p) {
-        if (KCONTIG) {
-            const int row = (tid >> 3) + 32 * p;
-            const int k = 4 * (tid & 7);
-            S[(k + 0) * LDT + row] = v[p].x;
-            S[(k + 1) * LDT + row] = v[p].y;
-            S[(k + 2) * LDT + row] = v[p].z;
-            S[(k + 3) * LDT + row] = v[p].w;
-        } else {
-            const int k = (tid >> 5) + 8 * p;
-            const int col = 4 * (tid & 31);
-            *reinterpret_cast<float4*>(&S[k * LDT + col]) = v[p];
-        }
+        if (KCONTIG) *reinterpret_cast<float4*>(&S[((tid >> 3) + 32 * p) * PITCH + 4 * (tid & 7)]) = v[p];
+        else *reinterpret_cast<float4*>(&S[((tid >> 5) + 8 * p) * KPITCH + 4 * (tid & 31)]) = v[p];
     }
 }
 
-// 32 MFMAs of one K tile.  Fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued.
-__device__ __forceinline__ void mma_tile(const float* __restrict__ a_s, const float* __restrict__ b_s,
-                                         f32x16 (&acc)[2][2]) {
-    float a0 = a_s[0], a1 = a_s[32], b0 = b_s[0], b1 = b_s[32];
+// The fragments of a QUARTER of a k-tile for this lane: per operand 2 MFMA tiles x 4 k-steps.  Element (t, j) feeds
+// k-step j (of the quarter q) of tile t: k_local = 4 q + j + 16 h for lane (h = lane >> 5, r = lane & 31).
+struct QFrag { float a[2][4], b[2][4]; };
+// `s` points at the lane's first element: [row][k] tiles  S[(row0 + r) * PITCH + 16 h + 4 q],
+//                                         [k][row] tiles  S[(16 h + 4 q) * KPITCH + row0 + r]
+template <bool KCONTIG>
+__device__ __forceinline__ void read_frag(const float* __restrict__ s, float (&f)[2][4]) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        if (ks + 1 < BK / 2) {
-            na0 = a_s[(2 * ks + 2) * LDT]; na1 = a_s[(2 * ks + 2) * LDT + 32];
-            nb0 = b_s[(2 * ks + 2) * LDT]; nb1 = b_s[(2 * ks + 2) * LDT + 32];
+    for (int t = 0; t < 2; ++t) {
+        if (KCONTIG) {
+            const float4 v = *reinterpret_cast<const float4*>(s + t * 32 * PITCH);
+            f[t][0] = v.x; f[t][1] = v.y; f[t][2] = v.z; f[t][3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[t][j] = s[j * KPITCH + t * 32];
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+}
+__device__ __forceinline__ void mma_step(const QFrag& f, int j, f32x16 (&acc)[2][2]) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][j], f.b[0][j], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][j], f.b[1][j], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][j], f.b[0][j], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][j], f.b[1][j], acc[1][1], 0, 0, 0);
+}
+// 16 MFMAs: 4 k-steps x (2 x 2) tiles, all operands in registers
+__device__ __forceinline__ void mma_quarter(const QFrag& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mma_step(f, j, acc);
+}
+// the same 16 MFMAs with 4 of the 2 x NL 16-byte LDS stores of a staged tile slipped in between them (PART 0: the A
+// tile, PART 1: the B tile): a store issues while the MFMA before it executes, so staging costs no matrix-pipe time
+template <bool KCONTIG>
+__device__ __forceinline__ void mma_quarter_store(const QFrag& f, f32x16 (&acc)[2][2], float* __restrict__ S, int tid,
+                                                  const float4 (&r)[NL]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mma_step(f, j, acc);
+        if (KCONTIG) *reinterpret_cast<float4*>(&S[((tid >> 3) + 32 * j) * PITCH + 4 * (tid & 7)]) = r[j];
+        else *reinterpret_cast<float4*>(&S[((tid >> 5) + 8 * j) * KPITCH + 4 * (tid & 31)]) = r[j];
     }
 }
 
-// The K loop: register-staged, double-buffered LDS, one barrier per K tile.  The next tile's global loads are issued
-// before this tile's 64 MFMAs per wave (4096 matrix-pipe cycles ~ 1.8 us: a block that sits alone on its CU -- the
-// small per-chunk GEMMs of the GRU wavefront -- still covers an L2/HBM round trip with them).
-template <bool TA, bool TB>
+// One k-tile of the steady state, in four quarters of 16 MFMAs per wave.  On entry: LDS buffer `cur` holds tile `it`,
+// fx its first quarter's fragments, (sa, sb) the staged registers of tile it + 1 (their loads were issued a whole tile
+// ago).  LOAD: issue the global loads of tile it + 2 into (na, nb).  STORE: tile it + 1 goes to the other LDS buffer
+// between the MFMAs of quarters 0 and 1.  The barrier sits before quarter 3: by then every wave has READ its last
+// fragments of buffer `cur` (the next tile's stores may overwrite it) and the other buffer is complete; the next
+// tile's first fragments are fetched right behind it and land during quarter 3.
+template <bool TA, bool TB, bool FAST, bool LOAD, bool STORE>
+__device__ __forceinline__ void gemm_ktile(const GemmArgs& g, const float* __restrict__ gA,
+                                           const float* __restrict__ gB, float* smem, int m0, int n0, int k_next2,
+                                           int kend, int tid, int cur, int fa, int fb, f32x16 (&acc)[2][2],
+                                           QFrag& fx, QFrag& fy, float4 (&sa)[NL], float4 (&sb)[NL],
+                                           float4 (&na)[NL], float4 (&nb)[NL], bool do_colsum, float4& csum) {
+    constexpr bool AK = !TA, BKC = TB;
+    constexpr int qa = AK ? 4 : 4 * KPITCH, qb = BKC ? 4 : 4 * KPITCH;  // step from one quarter to the next
+    float* Ac = smem + cur * (2 * TILE_F);
+    float* Bc = Ac + TILE_F;
+    float* An = smem + (cur ^ 1) * (2 * TILE_F);
+    float* Bn = An + TILE_F;
+    if (LOAD) {
+        load_tile<!TA, FAST>(gA, g.lda, m0, g.M, k_next2, kend, g.vecA, tid, na);
+        load_tile<TB, FAST>(gB, g.ldb, n0, g.N, k_next2, kend, g.vecB, tid, nb);
+    }
+    read_frag<AK>(Ac + fa + qa, fy.a);
+    read_frag<BKC>(Bc + fb + qb, fy.b);
+    if (STORE) {
+        if (TA && do_colsum) {  // a thread's NL float4 of an A tile are 4 consecutive m at NL different k
+#pragma unroll
+            for (int p = 0; p < NL; ++p) { csum.x += sa[p].x; csum.y += sa[p].y; csum.z += sa[p].z; csum.w += sa[p].w; }
+        }
+        mma_quarter_store<AK>(fx, acc, An, tid, sa);
+    } else {
+        mma_quarter(fx, acc);
+    }
+    read_frag<AK>(Ac + fa + 2 * qa, fx.a);
+    read_frag<BKC>(Bc + fb + 2 * qb, fx.b);
+    if (STORE) mma_quarter_store<BKC>(fy, acc, Bn, tid, sb);
+    else mma_quarter(fy, acc);
+    read_frag<AK>(Ac + fa + 3 * qa, fy.a);
+    read_frag<BKC>(Bc + fb + 3 * qb, fy.b);
+    mma_quarter(fx, acc);
+    __syncthreads();
+    if (STORE) {
+        read_frag<AK>(An + fa, fx.a);
+        read_frag<BKC>(Bn + fb, fx.b);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the barrier BEFORE the last quarter's MFMAs
+    mma_quarter(fy, acc);
+}
+
+// The K loop (see the file header).  LDS: stage s holds the A tile at smem + s * 2 * TILE_F and the B tile behind it.
+// Global loads run TWO tiles ahead of the MFMAs (two register stages, the loop is unrolled by two so that they swap
+// roles without moves): a load has a whole k-tile (>= 4096 matrix-pipe cycles) to land before its LDS store.
+template <bool TA, bool TB, bool FAST>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __restrict__ gA,
                                               const float* __restrict__ gB, float* smem, int m0, int n0, int kbeg,
-                                              int kend, int tid, bool fast, f32x16 (&acc)[2][2], bool do_colsum,
-                                              float4& csum) {
+                                              int kend, int tid, f32x16 (&acc)[2][2], bool do_colsum, float4& csum) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = (kend - kbeg + BK - 1) / BK;
-    auto As = [&](int i) { return smem + i * (BK * LDT); };
-    auto Bs = [&](int i) { return smem + (2 + i) * (BK * LDT); };
-    const int frag = (lane >> 5) * LDT + (lane & 31);
-    float4 ra[NL], rb[NL];
-    auto load = [&](int tile) {
-        const int k0 = kbeg + tile * BK;
-        if (fast) {  // block-uniform: only the loads differ
-            load_tile<!TA, true>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-            load_tile<TB, true>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-        } else {
-            load_tile<!TA, false>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-            load_tile<TB, false>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-        }
-    };
-    // TA: a thread's NL float4 of an A tile are 4 consecutive m at NL different k -> its share of the column sums
-    auto colsum_acc = [&]() {
-        if (TA && do_colsum) {
+    // this lane's first fragment element (half 0) in an A tile / a B tile
+    constexpr bool AK = !TA, BKC = TB;  // operand is k-contiguous in memory -> [row][k] tile
+    const int fa = AK ? (wm * 64 + (lane & 31)) * PITCH + 16 * (lane >> 5) : 16 * (lane >> 5) * KPITCH + wm * 64 + (lane & 31);
+    const int fb = BKC ? (wn * 64 + (lane & 31)) * PITCH + 16 * (lane >> 5) : 16 * (lane >> 5) * KPITCH + wn * 64 + (lane & 31);
+    float4 ra[NL], rb[NL], qa[NL], qb[NL];
+    if (ntiles <= 0) return;
+    load_tile<!TA, FAST>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+    load_tile<TB, FAST>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+    if (TA && do_colsum) {
 #pragma unroll
-            for (int p = 0; p < NL; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
-        }
-    };
-    if (ntiles > 0) {
-        load(0);
-        colsum_acc();
-        store_tile<!TA>(As(0), tid, ra);
-        store_tile<TB>(Bs(0), tid, rb);
+        for (int p = 0; p < NL; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+    }
+    store_tile<!TA>(smem, tid, ra);
+    store_tile<TB>(smem + TILE_F, tid, rb);
+    if (ntiles > 1) {  // tile 1 -> stage (ra, rb)
+        load_tile<!TA, FAST>(gA, g.lda, m0, g.M, kbeg + BK, kend, g.vecA, tid, ra);
+        load_tile<TB, FAST>(gB, g.ldb, n0, g.N, kbeg + BK, kend, g.vecB, tid, rb);
     }
     __syncthreads();
-    for (int it = 0; it < ntiles; ++it) {
-        const int cur = it & 1;
-        const bool more = it + 1 < ntiles;
-        if (more) load(it + 1);
-        mma_tile(As(cur) + frag + wm * 64, Bs(cur) + frag + wn * 64, acc);
-        if (more) {
-            colsum_acc();
-            store_tile<!TA>(As(cur ^ 1), tid, ra);
-            store_tile<TB>(Bs(cur ^ 1), tid, rb);
-        }
-        __syncthreads();
+    QFrag f0, f1;
+    read_frag<AK>(smem + fa, f0.a);
+    read_frag<BKC>(smem + TILE_F + fb, f0.b);
+    int it = 0;
+    for (; it + 3 < ntiles; it += 2) {  // steady state: tiles it, it + 1 (loads of it + 2, it + 3 go out)
+        gemm_ktile<TA, TB, FAST, true, true>(g, gA, gB, smem, m0, n0, kbeg + (it + 2) * BK, kend, tid, 0, fa, fb, acc, f0,
+                                             f1, ra, rb, qa, qb, do_colsum, csum);
+        gemm_ktile<TA, TB, FAST, true, true>(g, gA, gB, smem, m0, n0, kbeg + (it + 3) * BK, kend, tid, 1, fa, fb, acc, f0,
+                                             f1, qa, qb, ra, rb, do_colsum, csum);
+    }
+    // the last 1..3 tiles (`it` is even: LDS buffer 0 holds tile `it`, (ra, rb) stage tile it + 1)
+    const int left = ntiles - it;
+    if (left == 3) {
+        gemm_ktile<TA, TB, FAST, true, true>(g, gA, gB, smem, m0, n0, kbeg + (it + 2) * BK, kend, tid, 0, fa, fb, acc, f0,
+                                             f1, ra, rb, qa, qb, do_colsum, csum);
+        gemm_ktile<TA, TB, FAST, false, true>(g, gA, gB, smem, m0, n0, 0, kend, tid, 1, fa, fb, acc, f0, f1, qa, qb, ra,
+                                              rb, do_colsum, csum);
+        gemm_ktile<TA, TB, FAST, false, false>(g, gA, gB, smem, m0, n0, 0, kend, tid, 0, fa, fb, acc, f0, f1, ra, rb, qa,
+                                               qb, do_colsum, csum);
+    } else if (left == 2) {
+        gemm_ktile<TA, TB, FAST, false, true>(g, gA, gB, smem, m0, n0, 0, kend, tid, 0, fa, fb, acc, f0, f1, ra, rb, qa,
+                                              qb, do_colsum, csum);
+        gemm_ktile<TA, TB, FAST, false, false>(g, gA, gB, smem, m0, n0, 0, kend, tid, 1, fa, fb, acc, f0, f1, qa, qb, ra,
+                                               rb, do_colsum, csum);
+    } else {
+        gemm_ktile<TA, TB, FAST, false, false>(g, gA, gB, smem, m0, n0, 0, kend, tid, 0, fa, fb, acc, f0, f1, ra, rb, qa,
+                                               qb, do_colsum, csum);
     }
 }
 
 // TA: A is stored (K, M) (m-contiguous);  !TA: A is stored (M, K) (k-contiguous)
 // TB: B is stored (N, K) (k-contiguous);  !TB: B is stored (K, N) (n-contiguous)
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -226,7 +307,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const bool fast = g.vecA && g.vecB && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
     const bool do_colsum = TA && g.colsumg[prob] != nullptr && blockIdx.x == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    gemm_mainloop<TA, TB>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, fast, acc, do_colsum, csum);
+    if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
+    else gemm_mainloop<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
     if (do_colsum) {  // fold the 8 k-rows of threads (tid >> 5) that share 4 columns; fixed order: deterministic
         float* cs = smem;  // the mainloop's last barrier has released the tiles
         *reinterpret_cast<float4*>(&cs[(tid >> 5) * BM + 4 * (tid & 31)]) = csum;
@@ -303,23 +385,25 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
 }
 
 int choose_splits(int M, int N, int K, int nprob = 1) {
-    // Blocks of this kernel sit 2-3 per CU and share each SIMD's matrix pipe, so the launch is balanced when the block
-    // count is just under a multiple of the CU count: pick the split (>= 4 K-tiles each) whose tiles * split fills
-    // 256 / 512 / 768 slots best, preferring fewer splits on ties (less partial-sum traffic).
+    // Cost model in units of one k-tile of a block that shares its CU with a second block (two blocks per CU keep each
+    // other's matrix pipe busy; measured ~3.9 us).  A launch of `blocks` blocks takes ceil(blocks / 512) rounds of
+    // (k-tiles per block + ~6 tiles of prologue / epilogue); a block that has its CU to itself (<= 256 blocks) runs
+    // its tiles ~0.6 x as long.  Splitting K adds the reduce launch: ~2 tiles of launch gap + its traffic at ~3 TB/s.
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nprob;
-    if (tiles >= 192 || K < 8 * BK) return 1;
-    int max_s = K / (4 * BK);
+    const int ktiles = (K + BK - 1) / BK;
+    if (ktiles < 8) return 1;
+    int max_s = ktiles / 4;
     if (max_s > 128) max_s = 128;
-    if (max_s < 1) return 1;
     int best = 1;
-    double best_score = 0.0;
+    double best_cost = 1e30;
     for (int s = 1; s <= max_s; ++s) {
         const long blocks = tiles * s;
-        if (blocks > 768) break;
-        const long slots = ((blocks + 255) / 256) * 256;
-        double score = (double)blocks / (double)slots;          // fill of the last round
-        score *= blocks >= 512 ? 1.0 : (blocks >= 256 ? 0.92 : 0.5 * blocks / 256.0 + 0.3);  // want >= 2 blocks per CU
-        if (score > best_score + 0.02) { best_score = score; best = s; }
+        if (blocks > 4096 && s > 1) break;
+        const double rounds = (double)((blocks + 511) / 512);
+        const double per_tile = blocks <= 256 ? 0.6 : 1.0;
+        double cost = rounds * ((double)((ktiles + s - 1) / s) + 6.0) * per_tile;
+        if (s > 1) cost += 2.0 + (double)s * M * N * nprob * 4.0 / 3.0e12 / 3.9e-6;
+        if (cost < best_cost * 0.97) { best_cost = cost; best = s; }  // prefer fewer splits unless clearly better
     }
     return best;
 }
@@ -376,7 +460,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     size_t dyn = 0;
     if (opts && opts->pad_lds) {
         static bool attr_set = false;
-        dyn = 81 * 1024 - sizeof(float) * 2 * 2 * BK * LDT;
+        dyn = 81 * 1024 - sizeof(float) * 2 * 2 * TILE_F;
         if (!attr_set) {
             const void* fns[4] = {(const void*)gemm_f32_kernel<true, true>, (const void*)gemm_f32_kernel<true, false>,
                                   (const void*)gemm_f32_kernel<false, true>, (const void*)gemm_f32_kernel<false, false>};

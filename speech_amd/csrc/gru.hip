@@ -211,6 +211,7 @@ struct PFwdJobs {
     unsigned reg_base;   // arrivals per counter before this launch
     unsigned long long* stamp;  // profiling: the (0, 0, 0) workgroup writes wall_clock64() at entry / exit (null: off)
     unsigned* err;       // the library's STICKY error word (PersistHealth::dev): failures are OR-ed in, never cleared here
+    int prio;            // raise the waves' issue priority (they share their CU with side-stream GEMM blocks)
     int spin_limit;      // polls before a hand-off counts as failed (SA_GRU_SPIN_LIMIT; default 1 << 20)
     int fault;           // fault injection (SA_GRU_FAULT=1, tests only): unit tile 1 of group 0 leaves before its first step
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
@@ -229,10 +230,10 @@ __device__ __forceinline__ bool has_sentinel(f32x4v v) {
 // the LDS free, so that a side-stream GEMM block -- 152 registers, 81 KB of LDS -- FITS beside the recurrence block and
 // uses the matrix-pipe cycles the latency-bound recurrence leaves idle.)  The recurrence waves run at raised priority:
 // whenever they are ready to issue they go first.
-#define SA_PERSIST_EXCLUSIVE()                      \
-    do {                                            \
-        asm volatile("" ::: "v255", "a7");          \
-        __builtin_amdgcn_s_setprio(3);              \
+#define SA_PERSIST_EXCLUSIVE(prio_)                        \
+    do {                                                   \
+        asm volatile("" ::: "v255", "a7");                 \
+        if (prio_) __builtin_amdgcn_s_setprio(3);          \
     } while (0)
 
 __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
@@ -242,7 +243,7 @@ __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID =
 template <bool WREG>  // W_hh fragments resident in registers (XCD-local mode, H <= 512) instead of LDS
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
-    if (WREG) SA_PERSIST_EXCLUSIVE();
+    if (WREG) SA_PERSIST_EXCLUSIVE(P.prio);
     int role_x = blockIdx.x, role_y = blockIdx.y, role_z = blockIdx.z;
     if (P.xcd_mode) {
         __shared__ int s_role[2];
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     const int brow = min(b0 + i, B - 1);
     __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)J.h_out, 0, 0x7fffffff, 0x00020000);
     bool dead = false;
+    int budget = P.spin_limit;
     // XCD-local mode, H <= 512: the W_hh fragments this lane feeds to its MFMAs (3 gates x up to 8 k-groups x 4 floats)
     // are the same every step -- resident in registers instead of re-read from LDS
     float4 wr[8][3];
@@ -351,11 +353,12 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
                                     : f32x4v{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (!P.flagless || dead) break;  // after one timeout the wave stops polling (the step is lost anyway)
+                    if (!P.flagless) break;
 #pragma unroll
                     for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;  // wave-uniform: the MFMAs below stay convergent
-                    if (spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
+                    // budget: a wave-uniform scalar; after one timeout it is 0, so a lost call drains quickly
+                    if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
                 }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -452,7 +455,7 @@ struct PFusedFwd {
     unsigned* reg;
     unsigned reg_base;
     unsigned* err;
-    int spin_limit, fault;       // see PFwdJobs
+    int spin_limit, fault, prio; // see PFwdJobs
     unsigned long long* stamp;
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
 };
@@ -460,7 +463,7 @@ struct PFusedFwd {
 __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
-    SA_PERSIST_EXCLUSIVE();
+    SA_PERSIST_EXCLUSIVE(P.prio);
     if (threadIdx.x == 0) {
         const int x = xcc_id();
         s_role[0] = x;
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt;
     if (l >= P.L) return;
     if (P.fault && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
-    bool dead = false;  // a hand-off of this wave has timed out: stop waiting, the call is lost (error word is set)
+    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
     const int H = P.H, B = P.B, T = P.T;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
     if (stamper) P.stamp[0] = wall_clock64();
@@ -514,12 +517,12 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
 #pragma unroll
     for (int n = 0; n < 3; ++n) accg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto wait_lower = [&](int tt) {  // the lower layer has published step tt (every wave polls for itself)
-        if (avail >= (unsigned)(tt + 1) || dead) return;
+        if (avail >= (unsigned)(tt + 1)) return;
         int spins = 0;
         unsigned c;
         while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
                (unsigned)P.ntile_u * (unsigned)(tt + 1)) {
-            if (++spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
+            if (++spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
         }
         avail = c / (unsigned)P.ntile_u;
     };
@@ -625,11 +628,10 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
                                     : f32x4v{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (dead) break;
 #pragma unroll
                     for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
+                    if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
                 }
                 SA_TICK(1)
                 if (prefetch) {  // the slow loads go out only now, behind the poll (H <= 512: this loop runs once)
@@ -830,14 +832,22 @@ struct PBwdJobs {
     unsigned reg_base;
     unsigned long long* stamp;
     unsigned* err;
-    int spin_limit, fault;  // see PFwdJobs
+    int spin_limit, fault, prio;  // see PFwdJobs
     PBwdJob j[kMaxJobs];
 };
 
+// POLL = 0: every polling trip re-reads the wave's whole k-slice (24 x 16 B per lane at H = 512) until it holds no
+//           sentinel -- the data is its own flag, but a waiting block keeps its CU's vector-memory path saturated
+//           (4 waves x 24 KB per trip), which starves a side-stream GEMM block sharing the CU.
+// POLL = 1: light trips first -- the four lanes that share a batch row split the producers' 16-column pieces between
+//           them (lane g reads float4 #g of the pieces it = g mod 4: a quarter of the bytes, every (row, piece)
+//           still probed) -- then ONE full trip, checked in full (a torn piece just sends the wave back to polling).
+// SLEEP: s_sleep between failed trips (64-cycle units): yields issue slots and memory bandwidth to the co-resident block.
+template <int POLL, int SLEEP>
 __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
-    SA_PERSIST_EXCLUSIVE();
+    SA_PERSIST_EXCLUSIVE(P.prio);
     if (threadIdx.x == 0) {
         const int x = xcc_id();
         s_role[0] = x;
@@ -869,6 +879,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         z_next = J.stash[((long)b * P.rb + (long)(J.t0 - J.dt) * P.rt) * 5 * H + H + u];
     }
     unsigned* counter = J.counters + role_y;
+    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
     const int kslice = H3 / 4, kbeg = wave * kslice;  // 3H % 64 == 0 (checked by the host)
     const int brow = min(b0 + i, B - 1);
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.dah, 0, 0x7fffffff, 0x00020000);
@@ -911,6 +922,23 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                 f32x4v a[24];
                 for (int spins = 0;; ++spins) {
                     bool stale = false;
+                    if (POLL == 1 && P.flagless) {  // light trips: 6 probes per lane
+                        for (;; ++spins) {
+                            f32x4v pr[6];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) {
+                                const int k = kk0 + 16 * (4 * j + g) + 4 * g;
+                                pr[j] = kk0 + 16 * (4 * j + g) < kbeg + kslice
+                                            ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
+                                            : f32x4v{0.f, 0.f, 0.f, 0.f};
+                            }
+                            bool st = false;
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) st |= has_sentinel(pr[j]);
+                            if (__builtin_amdgcn_ballot_w64(st) == 0 || spins > budget) break;
+                            if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+                        }
+                    }
 #pragma unroll
                     for (int it = 0; it < 24; ++it) {
                         const int k = kk0 + 16 * it + 4 * g;
@@ -918,11 +946,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                                     ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase + 4 * k, 0, 16))
                                     : f32x4v{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (!P.flagless || dead) break;
+                    if (!P.flagless) break;
 #pragma unroll
                     for (int it = 0; it < 24; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > P.spin_limit) { if (lane == 0) atomicOr(P.err, 1u); dead = true; break; }
+                    if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
+                    if (POLL == 0 && SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
                 }
 #pragma unroll
                 for (int it = 0; it < 24; ++it) {
@@ -1350,7 +1379,23 @@ static bool xcd_shape_ok(int jobs, int B, int H) {
 }
 // XCD-local kernels are one-per-CU through their register reservation (SA_PERSIST_EXCLUSIVE), so they ask for the LDS
 // they use and nothing more: <= 79 KB leaves room for one "polite" (81 KB) side-stream GEMM block beside them
-static size_t xcd_lds(size_t need) { return need; }
+static size_t xcd_lds(size_t need) {
+    const char* e = getenv("SA_GRU_LDS_KB");  // experiment: a floor on the request
+    const size_t fl = e ? (size_t)atoi(e) * 1024 : 0;
+    return need < fl ? fl : need;
+}
+typedef void (*BwdPersistFn)(PBwdJobs);
+static BwdPersistFn bwd_persist_fn() {  // SA_GRU_POLL = 0 / 1 (light trips), SA_GRU_SLEEP = 0 / 1 / 2
+    const char* pe = getenv("SA_GRU_POLL");
+    const char* se = getenv("SA_GRU_SLEEP");
+    const int poll = pe ? atoi(pe) : 0, sl = se ? atoi(se) : 0;  // measured: light trips cost 17 % (r2c)
+    if (poll == 0) return sl >= 1 ? gru_bwd_persist_kernel<0, 1> : gru_bwd_persist_kernel<0, 0>;
+    return sl >= 2 ? gru_bwd_persist_kernel<1, 2> : (sl == 1 ? gru_bwd_persist_kernel<1, 1> : gru_bwd_persist_kernel<1, 0>);
+}
+static int persist_prio() {
+    const char* e = getenv("SA_GRU_PRIO");
+    return e ? atoi(e) : 1;
+}
 
 static int clamp_chunk(int chunk, int T) {
     // measured on MI355X at S-LIBRI, whole train step: step kernels 16 -> 19.6 ms, 32 -> 19.9, 8 -> 20.5;
@@ -1445,7 +1490,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             }
             if (bi_xcd) {  // ONE persistent launch runs both directions of the layer over all T steps
                 PFwdJobs Q;
-                Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.timing = nullptr;
+                Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.timing = nullptr;
                 Q.xcd_mode = 1; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
                 Q.flagless = flagless_mode() ? 1 : 0;
                 if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
@@ -1506,7 +1551,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 return CTC_STATUS_EXECUTION_FAILED;
             PFusedFwd Q;
             Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
-            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.reg_base = 0; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection();
+            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.reg_base = 0; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
             Q.stamp = g_prof.slot(0, true, false, T);
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
@@ -1554,7 +1599,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         }
         if (persist) {  // ONE launch runs the whole chunk of every active layer
             PFwdJobs Q;
-            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection();
+            Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
             Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
             Q.flagless = flagless ? 1 : 0;
             Q.reg_base = persist_launches * 32u;
@@ -1604,10 +1649,10 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
 }
 
 // split-K workspace of the weight-gradient products (one region: the products of a call run on ONE stream, in order)
-static size_t wgrad_ws_bytes(int D, int B, int T, int H, int I0) {
+static size_t wgrad_ws_bytes(int L, int D, int B, int T, int H, int I0) {
     const int nmax = I0 > D * H ? I0 : D * H;
     size_t w = 0;
-    for (int np = 1; np <= 2 * D && np <= kMaxJobs; ++np) {
+    for (int np = 1; np <= L * D && np <= kMaxJobs; ++np) {  // same-shaped products of all layers share a launch
         const size_t a = sa_gemm_group_workspace_bytes(np, 3 * H, nmax, T * B);
         const size_t b = sa_gemm_group_workspace_bytes(np, 3 * H, H, T * B);
         if (a > w) w = a;
@@ -1623,7 +1668,7 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
-    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw + wgrad_ws_bytes(D, B, T, H, I0) +
+    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw + wgrad_ws_bytes(L, D, B, T, H, I0) +
            kSyncBytes;
 }
 
@@ -1677,9 +1722,15 @@ int wgrad_every() {  // persistent launches between two hand-overs of weight-gra
     return v > 0 ? v : 4;
 }
 
-bool overlap_enabled() {
+// uni = the layer wavefront of a unidirectional stack (all 8 XCDs busy: the GEMM blocks share CUs with recurrence
+// blocks); bidirectional layers keep half the chip idle.  Measured at S-LIBRI (profiles/r02_overlap_*): beside a GEMM
+// block a recurrence launch takes 230-310 us instead of 169 (its MFMAs queue behind the GEMM's 64-cycle ones, its
+// exchange loads behind the GEMM's tile loads) and the GEMM runs at a third of its speed -- 15.4 ms per step against
+// 12.1 -- so the unidirectional default is OFF (SA_GRU_OVERLAP=1 switches it on).
+bool overlap_enabled(bool uni) {
     const char* e = getenv("SA_GRU_OVERLAP");
-    return !(e && e[0] == '0');
+    if (e) return e[0] != '0';
+    return !uni;
 }
 
 // Issues the weight-gradient products of layer-direction k = l*D+d over the time steps [t0, t1) on `stream`.
@@ -1765,7 +1816,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     char* ws = (char*)workspace;
     const size_t fixed_bytes = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
     char* gws = ws + fixed_bytes;
-    const size_t wws_bytes = wgrad_ws_bytes(D, B, T, H, I0);
+    const size_t wws_bytes = wgrad_ws_bytes(L, D, B, T, H, I0);
     const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes - wws_bytes;
     char* wws = gws + gws_bytes;
     WGradIssuer issuer(wg ? *wg : WGrad{}, stash, dai, dah, L, D, B, T, H, I0, false);
@@ -1813,10 +1864,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         const size_t bi_lds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
-        const bool bi_side = wg && bi_xcd && overlap_enabled() && g_side.init();
+        const bool bi_side = wg && bi_xcd && overlap_enabled(false) && g_side.init();
         if (bi_xcd) {
             if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
-            if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)bi_lds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
         }
@@ -1828,7 +1879,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 if (Q.flagless)
                     for (int d = 0; d < 2; ++d)
                         if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
                 Q.stamp = nullptr; Q.n = 2;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
@@ -1839,7 +1890,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     J.nsteps = T; J.base = 0;
                     J.dt = d ? 1 : -1; J.t0 = J.t_first = d ? 0 : T - 1;   // the reverse chain unwinds forward in time
                 }
-                hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(256), dim3(256), bi_lds, stream, Q);
+                hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
                 if (wg && bi_side) {
                     // this layer's weight gradients: on the side stream, beside the input-gradient products below
                     // and the NEXT layer's persistent launch
@@ -1892,11 +1943,11 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             if (!sentinel_fill(dah[l], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
     // weight gradients ride beside the persistent launches: every kWgEvery launches, the time steps that have become
     // final since the last hand-over go to the side stream
-    const bool side = wg && xcd && overlap_enabled() && g_side.init();
+    const bool side = wg && xcd && overlap_enabled(true) && g_side.init();
     const int wg_every = wgrad_every();
     if (xcd) {
         if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
-        if (hipFuncSetAttribute((const void*)gru_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
     }
@@ -1929,7 +1980,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
             ++persist_launches;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
@@ -1945,7 +1996,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             }
             Q.n = n;
             Q.stamp = g_prof.slot(1, n == L, false, chunk);
-            hipLaunchKernelGGL(gru_bwd_persist_kernel, dim3(256), dim3(256), plds, stream, Q);
+            hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
             if (side && ((w + 1) % wg_every == 0 || w == nch + L - 2)) {
                 int spans[2 * kMaxJobs][2];
                 bool any = false;
