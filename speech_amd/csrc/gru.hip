@@ -202,6 +202,9 @@ struct PFwdJobs {
     // from the XCC id it actually runs on and its unit tile from an arrival counter, so a sync group never spans
     // XCDs whatever the dispatcher did (a group short of members times out into `err`, it cannot hang or corrupt).
     int xcd_mode, nbt, ntile_u;
+    // batches wider than the XCD groups can host are walked in PASSES of `nbt` batch tiles: this launch handles tiles
+    // [bt0, bt0 + nbt) of nbt_all (the recurrences of different batch rows are independent)
+    int bt0, nbt_all;
     // flag-less hand-off (XCD-local mode only): h_out is pre-filled with a NaN sentinel by the host; a consumer wave
     // simply re-reads the rows it needs (sc1 loads, served by the XCD's L2) until no element is the sentinel any more.
     // No arrival counter, no store acknowledgement wait, no workgroup barrier before the MFMAs: a wave starts as soon
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         const int sub = s_role[1] / P.ntile_u, g = s_role[0] * (32 / P.ntile_u) + sub;
         role_x = s_role[1] - sub * P.ntile_u;
         role_z = g / P.nbt;
-        role_y = g - role_z * P.nbt;
+        role_y = g - role_z * P.nbt + P.bt0;
         if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront, or fewer groups than slots
         if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     }
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         SA_TICK(3)
     }
     if (timed) {
-        unsigned long long* o = P.timing + 4 * ((role_z * (P.xcd_mode ? P.nbt : (int)gridDim.y) + role_y) * ntile_u + role_x);
+        unsigned long long* o = P.timing + 4 * ((role_z * (P.xcd_mode ? P.nbt : (int)gridDim.y) + role_y - P.bt0) * ntile_u + role_x);
         for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
     }
     if (stamper) P.stamp[1] = wall_clock64();
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
 // satisfied) and its step-t barrier -- the consumer layer therefore trails by one step more than it strictly must.
 struct PFusedFwd {
     int L, B, H, T, nbt, ntile_u;
+    int bt0, nbt_all;            // see PFwdJobs
     long rb, rt;
     const float* ai0;            // (T*B, 3H): layer 0's input projection incl. bias (one GEMM before the launch)
     const float* w_ih[kMaxJobs]; // l >= 1: (3H, H)
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
-    const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt;
+    const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt + P.bt0;
     if (l >= P.L) return;
     if (P.fault && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
     int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
@@ -501,8 +505,8 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)h_out, 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)(l > 0 ? P.h_out[l - 1] : h_out), 0, 0x7fffffff,
                                                                     0x00020000);
-    unsigned* my_prog = P.prog + l * P.nbt + role_y;
-    const unsigned* lower_prog = P.prog + (l > 0 ? l - 1 : 0) * P.nbt + role_y;
+    unsigned* my_prog = P.prog + l * P.nbt_all + role_y;
+    const unsigned* lower_prog = P.prog + (l > 0 ? l - 1 : 0) * P.nbt_all + role_y;
     const float* w_ih = l > 0 ? P.w_ih[l] : nullptr;
     unsigned avail = 0;  // steps of the lower layer known to be published
     float hp = 0.f;
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
         SA_TICK(3)
     }
     if (timed) {
-        unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y) * P.ntile_u + role_x);
+        unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
         for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
     }
 #undef SA_TICK
@@ -827,6 +831,7 @@ struct PBwdJob {
 };
 struct PBwdJobs {
     int n, B, H, nbt, ntile_u, flagless;
+    int bt0, nbt_all;  // see PFwdJobs
     long rb, rt;
     unsigned* reg;
     unsigned reg_base;
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
-    const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt;
+    const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
     if (role_z >= P.n) return;
     if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     const PBwdJob& J = P.j[role_z];
@@ -1375,8 +1380,11 @@ constexpr int kSyncErr = 200, kSyncReg = 201;  // word offsets in the sync page 
 static bool xcd_shape_ok(int jobs, int B, int H) {
     const int ntile_u = H / 16;
     if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256 || !g_health.init()) return false;
-    return jobs * ((B + 15) / 16) <= 8 * (32 / ntile_u);
+    (void)B;
+    return jobs <= 8 * (32 / ntile_u);  // at least one batch tile per pass (see tiles_per_pass)
 }
+// batch tiles one persistent launch can host next to `jobs` concurrent jobs: 8 XCDs x (32 / ntile_u) groups
+static int tiles_per_pass(int jobs, int H) { return (8 * (32 / (H / 16))) / jobs; }
 // XCD-local kernels are one-per-CU through their register reservation (SA_PERSIST_EXCLUSIVE), so they ask for the LDS
 // they use and nothing more: <= 79 KB leaves room for one "polite" (81 KB) side-stream GEMM block beside them
 static size_t xcd_lds(size_t need) {
@@ -1470,7 +1478,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
 
     if (D == 2) {  // bidirectional: a layer needs both directions of the layer below -> layers in sequence,
                    // the two directions of a layer share every launch
-        const int bi_nbt = (B + 15) / 16;
+        const int bi_nbt = (B + 15) / 16, bi_tpp = tiles_per_pass(2, H);
+        unsigned bi_launches = 0;
         const size_t bi_lds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * DH * 4 < 0x7fffffffL;
@@ -1491,10 +1500,10 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             if (bi_xcd) {  // ONE persistent launch runs both directions of the layer over all T steps
                 PFwdJobs Q;
                 Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.timing = nullptr;
-                Q.xcd_mode = 1; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
+                Q.xcd_mode = 1; Q.nbt_all = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
                 Q.flagless = flagless_mode() ? 1 : 0;
                 if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
-                Q.reg_base = (unsigned)l * 32u; Q.stamp = nullptr; Q.n = 2;
+                Q.stamp = nullptr; Q.n = 2;
                 for (int d = 0; d < 2; ++d) {
                     PFwdJob& J = Q.j[d];
                     J.ai = ai_of(l, d); J.w_hh = w_hh[l * 2 + d]; J.b_hh = b_hh[l * 2 + d];
@@ -1503,7 +1512,11 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                     J.hs_b = DH; J.hs_t = (long)B * DH; J.nsteps = T; J.base = 0;
                     J.dt = d ? -1 : 1; J.t0 = J.t_first = d ? T - 1 : 0;
                 }
-                hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
+                for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
+                    Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
+                    Q.reg_base = bi_launches++ * 32u;
+                    hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
+                }
                 continue;
             }
             P.n = 2; grid.z = 2;
@@ -1550,8 +1563,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                                     (int)flds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
             PFusedFwd Q;
-            Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
-            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.reg_base = 0; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
+            Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
+            Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
             Q.stamp = g_prof.slot(0, true, false, T);
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
@@ -1559,7 +1572,14 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 Q.w_ih[l] = w_ih[l]; Q.b_ih[l] = b_ih[l]; Q.w_hh[l] = w_hh[l]; Q.b_hh[l] = b_hh[l];
                 Q.h_out[l] = h_out[l]; Q.stash[l] = stash ? stash[l] : nullptr;
             }
-            hipLaunchKernelGGL(gru_fwd_fused_kernel, dim3(256), dim3(256), flds, stream, Q);
+            const int tpp = tiles_per_pass(L, H);
+            unsigned launches = 0;
+            for (int bt0 = 0; bt0 < nbt; bt0 += tpp) {  // passes over the batch tiles (one pass up to B = 32 at L = 4)
+                Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
+                Q.reg_base = launches++ * 32u;
+                if (bt0 > 0) Q.stamp = nullptr;
+                hipLaunchKernelGGL(gru_fwd_fused_kernel, dim3(256), dim3(256), flds, stream, Q);
+            }
             SA_CHECK_LAUNCH();
             g_health.submit(stream);
             return CTC_STATUS_SUCCESS;
@@ -1600,10 +1620,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         if (persist) {  // ONE launch runs the whole chunk of every active layer
             PFwdJobs Q;
             Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
-            Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
+            Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.nbt_all = nbt; Q.bt0 = 0; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
             Q.flagless = flagless ? 1 : 0;
-            Q.reg_base = persist_launches * 32u;
-            ++persist_launches;
             Q.stamp = nullptr;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;  // 3 KB of the sync page
             int n = 0;
@@ -1618,9 +1636,18 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 J.base = (unsigned)ntile_u * (unsigned)J.t0;
             }
             Q.n = n;
-            if (xcd) Q.stamp = g_prof.slot(0, n == L, false, chunk);
-            if (xcd) hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), plds, stream, Q);
-            else hipLaunchKernelGGL(gru_fwd_persist_kernel<false>, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
+            if (xcd) {
+                Q.stamp = g_prof.slot(0, n == L, false, chunk);
+                const int tpp = tiles_per_pass(L, H);
+                for (int bt0 = 0; bt0 < nbt; bt0 += tpp) {  // passes over the batch tiles
+                    Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
+                    Q.reg_base = persist_launches++ * 32u;
+                    if (bt0 > 0) Q.stamp = nullptr;
+                    hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), plds, stream, Q);
+                }
+            } else {
+                hipLaunchKernelGGL(gru_fwd_persist_kernel<false>, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
+            }
             continue;
         }
         ch.fork();
@@ -1860,7 +1887,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     };
 
     if (D == 2) {
-        const int bi_nbt = (B + 15) / 16;
+        const int bi_nbt = (B + 15) / 16, bi_tpp = tiles_per_pass(2, H);
+        unsigned bi_launches = 0;
         const size_t bi_lds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
@@ -1874,12 +1902,12 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         for (int l = L - 1; l >= 0; --l) {
             if (bi_xcd) {  // ONE persistent launch unwinds both directions of the layer over all T steps
                 PBwdJobs Q;
-                Q.B = B; Q.H = H; Q.nbt = bi_nbt; Q.ntile_u = H / 16; Q.rb = 1; Q.rt = B;
+                Q.B = B; Q.H = H; Q.nbt_all = bi_nbt; Q.ntile_u = H / 16; Q.rb = 1; Q.rt = B;
                 Q.flagless = flagless_mode() ? 1 : 0;
                 if (Q.flagless)
                     for (int d = 0; d < 2; ++d)
                         if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg; Q.reg_base = (unsigned)(L - 1 - l) * 32u;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
@@ -1890,7 +1918,11 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     J.nsteps = T; J.base = 0;
                     J.dt = d ? 1 : -1; J.t0 = J.t_first = d ? 0 : T - 1;   // the reverse chain unwinds forward in time
                 }
-                hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
+                for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
+                    Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
+                    Q.reg_base = bi_launches++ * 32u;
+                    hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
+                }
                 if (wg && bi_side) {
                     // this layer's weight gradients: on the side stream, beside the input-gradient products below
                     // and the NEXT layer's persistent launch
@@ -1979,9 +2011,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         }
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
-            Q.B = B; Q.H = H; Q.nbt = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg; Q.reg_base = persist_launches * 32u;
-            ++persist_launches;
+            Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
@@ -1996,7 +2027,15 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             }
             Q.n = n;
             Q.stamp = g_prof.slot(1, n == L, false, chunk);
-            hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
+            {
+                const int tpp = tiles_per_pass(L, H);
+                for (int bt0 = 0; bt0 < nbt; bt0 += tpp) {  // passes over the batch tiles
+                    Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
+                    Q.reg_base = persist_launches++ * 32u;
+                    if (bt0 > 0) Q.stamp = nullptr;
+                    hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
+                }
+            }
             if (side && ((w + 1) % wg_every == 0 || w == nch + L - 2)) {
                 int spans[2 * kMaxJobs][2];
                 bool any = false;

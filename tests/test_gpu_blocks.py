@@ -325,7 +325,10 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     for other in res[1:]:
         assert len(res[0]) == len(other) and all(torch.equal(a, b) for a, b in zip(res[0], other))
     # narrower layers share an XCD (H = 256: two groups per XCD, H = 128: four), fewer groups than slots idle
-    for shape in ("2, 20, 33, 48, 512", "2, 32, 45, 40, 256", "3, 16, 37, 24, 128", "4, 64, 21, 24, 256"):
+    # ... and batches wider than the groups can host are walked in passes of batch tiles (4 x 512 at B = 48: 3 tiles,
+    # 2 per pass; 4 x 256 at B = 80: 5 tiles, 4 per pass)
+    for shape in ("2, 20, 33, 48, 512", "2, 32, 45, 40, 256", "3, 16, 37, 24, 128", "4, 64, 21, 24, 256",
+                  "4, 48, 37, 40, 512", "4, 80, 19, 24, 256"):
         code2 = code.replace("L, B, T, I0, H = 4, 32, 70, 48, 512", "L, B, T, I0, H = " + shape)
         res = []
         for mode in ("0", "2", "3"):
@@ -400,10 +403,13 @@ def test_fused_forward_wavefront_matches_oracle_and_default():
             "dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0)\n"
             "torch.cuda.synchronize()\nassert _lib.lib().sa_gru_persist_status() == 0\n"
             "torch.save([t.cpu() for t in h + [dx]], sys.argv[1])\n") % (root, root)
-    res = []
-    for fused in ("0", "1"):
-        out = "/tmp/sa_fused_%s.pt" % fused
-        subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, SA_GRU_FUSED=fused), check=True, timeout=180)
-        res.append(torch.load(out))
-    for a, b in zip(*res):
-        assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max()))
+    for shape in ("4, 32, 90, 48, 512", "4, 64, 40, 48, 512"):  # B = 64: two passes of two batch tiles each
+        code2 = code.replace("L, B, T, I0, H = 4, 32, 90, 48, 512", "L, B, T, I0, H = " + shape)
+        res = []
+        for fused in ("0", "1"):
+            out = "/tmp/sa_fused_%s.pt" % fused
+            subprocess.run([sys.executable, "-c", code2, out], env=dict(os.environ, SA_GRU_FUSED=fused), check=True,
+                           timeout=180)
+            res.append(torch.load(out))
+        for a, b in zip(*res):
+            assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max())), shape
