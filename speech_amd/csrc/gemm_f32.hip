@@ -64,6 +64,14 @@ struct GemmArgs {
     // cs_partial [nprob][splits][M] and the reduce kernel folds them with the products.
     float* colsumg[kMaxGroup];
     float* cs_partial;
+    // XCD-filtered persistent mode (xcc_mask != 0): the launch is 512 blocks; a block that finds itself on an XCD outside
+    // the mask leaves at once, the others pull tiles off `tile_counter` (zeroed by the host) until none is left.  A
+    // side-stream GEMM can so be kept OFF the XCDs a persistent recurrence launch occupies (a bidirectional layer's
+    // groups sit on XCDs 0 .. u-1): no shared CUs, no interference -- hipExtStreamCreateWithCUMask cannot express this
+    // (measured: its bits select CUs inside every XCD alike, tools/ubench/cumask_probe.hip).
+    unsigned xcc_mask;
+    unsigned* tile_counter;
+    int grid_x, grid_y, grid_z;
 };
 
 __device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
@@ -283,14 +291,13 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
 // TA: A is stored (K, M) (m-contiguous);  !TA: A is stored (M, K) (k-contiguous)
 // TB: B is stored (N, K) (k-contiguous);  !TB: B is stored (K, N) (n-contiguous)
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+__device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int bx, int by, int bz) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int prob = blockIdx.z / g.splits, split = blockIdx.z - prob * g.splits;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int prob = bz / g.splits, split = bz - prob * g.splits;
     const float* __restrict__ gA = g.Ag[prob];
     const float* __restrict__ gB = g.Bg[prob];
     const int kbeg = split * g.k_per_split;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const bool fast = g.vecA && g.vecB && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
-    const bool do_colsum = TA && g.colsumg[prob] != nullptr && blockIdx.x == 0;
+    const bool do_colsum = TA && g.colsumg[prob] != nullptr && bx == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
     else gemm_mainloop<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += cs[r * BM + tid];
             if (g.partial) {
-                g.cs_partial[(long)blockIdx.z * g.M + m0 + tid] = t;
+                g.cs_partial[(long)bz * g.M + m0 + tid] = t;
             } else {
                 float* o = g.colsumg[prob] + m0 + tid;
                 *o = g.beta != 0.f ? g.beta * *o + t : t;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= g.M) continue;
                 if (splitk) {
-                    g.partial[((long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                    g.partial[((long)bz * g.M + row) * g.N + col] = acc[i][j][r];
                 } else {
                     float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride
                                              : gC + (long)row * g.ldc + col;
@@ -354,6 +361,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                 }
             }
         }
+    }
+}
+
+__device__ __forceinline__ int gemm_xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
+    if (g.xcc_mask == 0) {
+        gemm_block<TA, TB>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+        return;
+    }
+    if (!((g.xcc_mask >> gemm_xcc_id()) & 1u)) return;
+    __shared__ int s_tile;
+    const int total = g.grid_x * g.grid_y * g.grid_z;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = (int)atomicAdd(g.tile_counter, 1u);
+        __syncthreads();
+        const int tile = s_tile;
+        __syncthreads();  // s_tile may be rewritten; also separates this tile's LDS use from the previous one's
+        if (tile >= total) return;
+        const int bx = tile % g.grid_x, r = tile / g.grid_x;
+        gemm_block<TA, TB>(g, smem, bx, r % g.grid_y, r / g.grid_y);
     }
 }
 
@@ -454,6 +486,12 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.partial = splits > 1 ? (float*)workspace : nullptr;
     g.cs_partial = splits > 1 ? (float*)workspace + (size_t)nprob * splits * M * N : nullptr;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
+    g.xcc_mask = 0; g.tile_counter = nullptr;
+    g.grid_x = (int)grid.x; g.grid_y = (int)grid.y; g.grid_z = (int)grid.z;
+    if (opts && opts->xcc_mask && opts->tile_counter) {
+        g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter;
+        grid = dim3(512, 1, 1);
+    }
     // "polite" launches (opts->pad_lds): dynamic LDS on top of the kernel's 66 KB so that a CU admits ONE block of this
     // launch -- what a side-stream GEMM wants while a persistent recurrence kernel holds every CU (gru.hip): the
     // recurrence blocks then always find room, before and after this launch's blocks arrive.

@@ -1377,6 +1377,7 @@ static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
 // H / 16 = 32, 16 or 8 unit tiles, so an XCD hosts 1, 2 or 4 groups.  jobs = layers in flight (unidirectional layer
 // wavefront) or the 2 directions of one bidirectional layer.
 constexpr int kSyncErr = 200, kSyncReg = 201;  // word offsets in the sync page (counters occupy [0, 200))
+constexpr int kSyncTiles = 210, kSyncTileWords = 46;  // tile counters of XCD-filtered GEMM launches: words [210, 256)
 static bool xcd_shape_ok(int jobs, int B, int H) {
     const int ntile_u = H / 16;
     if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256 || !g_health.init()) return false;
@@ -1754,10 +1755,16 @@ int wgrad_every() {  // persistent launches between two hand-overs of weight-gra
 // block a recurrence launch takes 230-310 us instead of 169 (its MFMAs queue behind the GEMM's 64-cycle ones, its
 // exchange loads behind the GEMM's tile loads) and the GEMM runs at a third of its speed -- 15.4 ms per step against
 // 12.1 -- so the unidirectional default is OFF (SA_GRU_OVERLAP=1 switches it on).
+// Bidirectional layers leave XCDs idle, and XCD-FILTERED side GEMMs keep off the busy ones -- but the workgroup
+// dispatcher walks a grid in order: the next layer's persistent launch cannot place its (exit-at-once) workgroups on
+// XCDs whose CUs are full of resident GEMM blocks, and nothing behind them is dispatched until it can, so the
+// recurrence starts only when the GEMM launch before it has drained (profiles/r02_bidirectional_overlap_trace.txt:
+// 0.9 ms late per layer).  Net at bidirectional S-LIBRI 36.1 -> 35.5 ms, at the shipped TIMIT shapes 8.2 -> 8.3 ms:
+// OFF by default here too.
 bool overlap_enabled(bool uni) {
+    (void)uni;
     const char* e = getenv("SA_GRU_OVERLAP");
-    if (e) return e[0] != '0';
-    return !uni;
+    return e && e[0] != '0';
 }
 
 // Issues the weight-gradient products of layer-direction k = l*D+d over the time steps [t0, t1) on `stream`.
@@ -1769,6 +1776,9 @@ struct WGradIssuer {
     float* const* dah;
     int L, D, B, T, H, I0;
     bool polite;
+    unsigned xcc_mask = 0;        // != 0: the launches keep to these XCDs (the ones the recurrence leaves idle)
+    unsigned* counters = nullptr; // zeroed device words, one per filtered launch
+    int next_counter = 0, max_counters = 0;
     void* ws = nullptr;
     size_t ws_bytes = 0;
     bool first_ih[2 * kMaxJobs], first_hh[2 * kMaxJobs];
@@ -1784,6 +1794,7 @@ struct WGradIssuer {
         for (int k = 0; k < n; ++k) done_ih[k] = done_hh[k] = spans[k][1] <= spans[k][0];
         SaGemmOpts o;
         o.no_split = allow_split ? 0 : 1; o.pad_lds = polite ? 1 : 0;
+        o.xcc_mask = 0; o.tile_counter = nullptr;
         for (int pass = 0; pass < 2; ++pass) {      // 0: dW_hh (N = H, B operand = stash h_prev), 1: dW_ih
             bool* done = pass == 0 ? done_hh : done_ih;
             bool* first = pass == 0 ? first_hh : first_ih;
@@ -1810,6 +1821,11 @@ struct WGradIssuer {
                     ++ng;
                 }
                 o.colsum = gS;
+                if (xcc_mask && counters && next_counter < max_counters) {
+                    o.xcc_mask = xcc_mask; o.tile_counter = counters + next_counter++; o.pad_lds = 0;
+                } else {
+                    o.xcc_mask = 0; o.tile_counter = nullptr;
+                }
                 const float beta = first[k0] ? 0.f : 1.f;
                 const ctcStatus_t st = sa_gemm_f32_group_impl(ng, 1, 0, 3 * H, N0, rows, 1.f, gA, 3 * H, gB,
                                                               pass == 0 ? 5 * H : N0, beta, gC, N0, nullptr, nullptr,
@@ -1892,7 +1908,12 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         const size_t bi_lds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
-        const bool bi_side = wg && bi_xcd && overlap_enabled(false) && g_side.init();
+        // a layer's groups (2 directions x the batch tiles of a pass) sit on XCDs 0 .. used-1: the weight gradients of
+        // the layer above run on the OTHER XCDs meanwhile (XCD-filtered persistent-tile GEMM launches on the side stream)
+        const int bi_used = (2 * min(bi_tpp, bi_nbt) + (32 / (H / 16)) - 1) / (32 / (H / 16));
+        const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
+        const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled(false) && g_side.init();
+        issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords;
         if (bi_xcd) {
             if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
             if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1923,17 +1944,6 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     Q.reg_base = bi_launches++ * 32u;
                     hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
                 }
-                if (wg && bi_side) {
-                    // this layer's weight gradients: on the side stream, beside the input-gradient products below
-                    // and the NEXT layer's persistent launch
-                    int spans[2 * kMaxJobs][2];
-                    for (int k = 0; k < L * 2; ++k) { spans[k][0] = spans[k][1] = 0; }
-                    for (int d = 0; d < 2; ++d) { spans[l * 2 + d][1] = T; wg_hi[l * 2 + d] = 0; }
-                    if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
-                    issuer.polite = true;
-                    st = issuer.issue(spans, g_side.s, true);
-                    if (st != CTC_STATUS_SUCCESS) return st;
-                }
             } else {
             P.n = 2; grid.z = 2;
             for (int s = 0; s < T; ++s) {
@@ -1951,6 +1961,20 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                           d ? 1.f : 0.f, din, I, nullptr, nullptr, nullptr, 0, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
                 }
+            if (bi_xcd && wg && bi_side) {
+                // this layer's weight gradients go to the side stream NOW, behind the input-gradient products above
+                // (those are on the critical path and need the whole chip: a persistent side GEMM started earlier
+                // would hold the idle XCDs' CUs and stall their share of the tiles): they run beside the NEXT layer's
+                // persistent launch, on the XCDs it leaves idle
+                int spans[2 * kMaxJobs][2];
+                for (int k = 0; k < L * 2; ++k) { spans[k][0] = spans[k][1] = 0; }
+                for (int d = 0; d < 2; ++d) { spans[l * 2 + d][1] = T; wg_hi[l * 2 + d] = 0; }
+                if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
+                issuer.polite = false; issuer.xcc_mask = bi_mask;
+                st = issuer.issue(spans, g_side.s, true);
+                issuer.xcc_mask = 0;
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
         }
         SA_CHECK_LAUNCH();
         if (bi_xcd) g_health.submit(stream);

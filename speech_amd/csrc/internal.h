@@ -18,6 +18,8 @@ struct SaGemmOpts {
     int no_split;           // never split K (no workspace, no reduce launch)
     int pad_lds;            // one block of this launch per CU (side-stream launches beside a persistent kernel)
     float* const* colsum;   // trans_a products: per problem, also write the column sums of A (K x M) -> [M]; or null
+    unsigned xcc_mask;      // != 0: run only on the XCDs in the mask (persistent tile loop); needs tile_counter
+    unsigned* tile_counter; // device word, zero before the launch
 };
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
                                    const float* const* A, long lda, const float* const* B, long ldb, float beta,
