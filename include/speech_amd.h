@@ -114,6 +114,9 @@ ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alp
  *     y[b * ys_b + c * ys_c + t * ys_t + f].
  * workspace >= sa_conv2d_fwd_workspace_bytes() holds the im2col matrix; if keep_cols != NULL the im2col matrix
  * ((B*T'*F') x (in_c*kh*kw) floats) is written there instead, for sa_conv2d_relu_bwd(fwd_cols) to reuse. */
+/* 1 when this shape runs the direct kernels (one input channel, <= 32 output channels, even kh * kw <= 224: the first
+ * conv of every shipped config): no im2col matrix exists, keep_cols / fwd_cols are ignored and may be NULL. */
+int sa_conv2d_is_direct(int in_c, int F, int out_c, int kh, int kw, int s);
 size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s);
 ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in_c, int T,
                                int F, int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t,

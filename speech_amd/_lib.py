@@ -44,6 +44,7 @@ SIGNATURES = {
     "sa_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sa_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_float,
                             c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_conv2d_is_direct": (c_int, [c_int] * 6),
     "sa_conv2d_fwd_workspace_bytes": (c_size_t, [c_int] * 8),
     "sa_conv2d_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),

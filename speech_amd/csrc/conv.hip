@@ -239,6 +239,201 @@ __global__ __launch_bounds__(256) void conv_dw_final_kernel(const float* __restr
     dw[idx] = s0 + s1;
 }
 
+// ------------------------------------------------------------------------------------------ direct first convolution
+// The first conv of every shipped config has ONE input channel (the spectrogram) and at most 32 output channels
+// ([32, 5, 32, 2]): its im2col matrix is 160 columns of re-arranged input -- 255 MB written and read back at S-LIBRI for
+// 10 MB of features -- and as a GEMM it fills a quarter of a 128-wide tile.  The direct kernels below never build it:
+// a block stages the input rows its output frames touch in LDS (a slab of (TT - 1) s + kh rows x F floats) and feeds
+// v_mfma_f32_32x32x2_f32 with operands gathered from that slab.
+//   forward : D[channel][position] += W[channel][tap] * x[window(position)][tap]      (M = 32 channels, N = positions)
+//             rows = channels so that a register of the accumulator tile holds 32 CONSECUTIVE positions of one channel:
+//             the epilogue (bias, ReLU, the caller's layout) writes contiguous segments.
+//   backward: dW[channel][tap] += dyp[position][channel] * x[window(position)][tap]   (reduction over positions),
+//             tap tiles of 32 plus one column of ones (-> the bias gradient); a block walks several slabs with its
+//             partial sums in registers, the per-block partials are folded in a fixed order (conv_dw_final_kernel).
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+constexpr int kDirMaxTT = 16;  // output frames per slab, at most
+
+// frames per slab: the most (<= 16) whose LDS footprint stays <= 64 KB in both kernels (2+ blocks per CU)
+__host__ __device__ inline int conv_direct_tt(int kh, int kw, int s, int F, int Fo) {
+    for (int tt = kDirMaxTT; tt >= 1; tt >>= 1) {
+        const long rows = (long)(tt - 1) * s + kh;
+        const long fwd = rows * F + (long)kh * kw * 32, bwd = rows * F + (long)tt * Fo * 33;
+        if ((fwd > bwd ? fwd : bwd) * 4 <= 64 * 1024) return tt;
+    }
+    return 0;
+}
+__host__ __device__ inline bool conv_direct_ok(int C, int O, int kh, int kw, int s, int F, int Fo) {
+    const int K = kh * kw;
+    return C == 1 && O <= 32 && (K & 1) == 0 && K <= 224 && conv_direct_tt(kh, kw, s, F, Fo) > 0;
+}
+
+struct DirGeom {
+    int B, T, F, O, kh, kw, s, To, Fo, K, TT;
+    long ys_b, ys_c, ys_t;
+};
+
+// Stage the slab of input rows [s * t0, s * t0 + rows) of utterance b (zero beyond T) into xs[rows][F].
+__device__ __forceinline__ void dir_stage_x(const float* __restrict__ x, float* __restrict__ xs, const DirGeom& g, int b,
+                                            int t0, int rows) {
+    const float* src = x + ((long)b * g.T + (long)g.s * t0) * g.F;
+    const int n = rows * g.F;
+    const int valid = max(0, min(rows, g.T - g.s * t0)) * g.F;
+    for (int i = threadIdx.x; i < n; i += 256) xs[i] = i < valid ? src[i] : 0.f;
+}
+
+// grid (ceil(To / g.TT), B).  LDS: xs[rows][F] | ws[K][32] (tap-major weights, channels >= O zero).
+__global__ __launch_bounds__(256) void conv1_fwd_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              DirGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int rows = (g.TT - 1) * g.s + g.kh;
+    float* xs = dsm;
+    float* ws = dsm + rows * g.F;
+    const int b = blockIdx.y, t0 = blockIdx.x * g.TT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dir_stage_x(x, xs, g, b, t0, rows);
+    for (int i = tid; i < g.K * 32; i += 256) {
+        const int k = i >> 5, c = i & 31;
+        ws[i] = c < g.O ? w[(long)c * g.K + k] : 0.f;
+    }
+    __syncthreads();
+    const int nt = min(g.TT, g.To - t0);
+    const int npos = nt * g.Fo;
+    const int h = lane >> 5, r = lane & 31;
+    for (int tile = wave; tile * 32 < npos; tile += 4) {
+        const int p = tile * 32 + r;
+        const bool pv = p < npos;
+        const int tl = pv ? p / g.Fo : 0, fo = pv ? p - tl * g.Fo : 0;
+        const float* xb = xs + (g.s * tl) * g.F + g.s * fo;       // + i * F + j for tap k = i * kw + j (k = 2 ks + h)
+        const float* wb = ws + h * 32 + r;                          // + 64 ks
+        f32x16c acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        int j0 = 0, roff = 0;  // tap 2 ks = (roff / F, j0): kw is not assumed even, so a pair may straddle a row
+        for (int ks0 = 0; ks0 < g.K / 2; ks0 += 4) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool on = ks0 + u < g.K / 2;
+                int jj = j0 + h, ro = roff;
+                if (jj >= g.kw) { jj -= g.kw; ro += g.F; }
+                av[u] = on ? wb[64 * (ks0 + u)] : 0.f;
+                bv[u] = on ? xb[ro + jj] : 0.f;
+                j0 += 2;
+                if (j0 >= g.kw) { j0 -= g.kw; roff += g.F; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        // C/D layout: column (position) = lane & 31, row (channel) = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
+        if (pv) {
+            float* yo = y + (long)b * g.ys_b + (long)(t0 + tl) * g.ys_t + fo;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (c < g.O) yo[(long)c * g.ys_c] = fmaxf(acc[q] + bias[c], 0.f);
+            }
+        }
+    }
+}
+
+// Weight / bias gradient of the same conv.  grid = nblocks persistent blocks walking the (b, slab) list; LDS:
+// xs[rows][F] | dyp[g.TT * Fo][33] (dy masked by y > 0; pitch 33: the A fragment reads 32 channels of one position).
+// Each wave takes every 4th PAIR of positions of a slab (the MFMA's k = 2 lanes) and keeps NT tap tiles of 16 registers;
+// tile n covers taps 32 n .. 32 n + 31, column K of the last tile multiplies by 1 (the bias gradient).
+template <int NT>
+__global__ __launch_bounds__(256) void conv1_dw_direct_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, float* __restrict__ part,
+                                                             DirGeom g, int nslab_t) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int rows = (g.TT - 1) * g.s + g.kh;
+    float* xs = dsm;
+    float* dyp = dsm + rows * g.F;                 // [g.TT * Fo][33]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    f32x16c acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
+    // this lane's tap per tile: k = 32 n + r -> offset i * F + j in the slab; tap == K: the constant 1; beyond: 0
+    int toff[NT];
+    float tone[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int k = 32 * n + r;
+        toff[n] = k < g.K ? (k / g.kw) * g.F + (k % g.kw) : -1;
+        tone[n] = k == g.K ? 1.f : 0.f;
+    }
+    const int nslabs = g.B * nslab_t;
+    for (int slab = blockIdx.x; slab < nslabs; slab += gridDim.x) {
+        const int b = slab / nslab_t, t0 = (slab - b * nslab_t) * g.TT;
+        const int nt = min(g.TT, g.To - t0);
+        const int npos = nt * g.Fo;
+        __syncthreads();  // the previous slab's readers are done
+        dir_stage_x(x, xs, g, b, t0, rows);
+        for (int i = tid; i < npos * 32; i += 256) {  // (channel, frame, f') with f' fastest: the caller's layout is f'-contiguous
+            const int fo = i % g.Fo, q = i / g.Fo;
+            const int tl = q % nt, c = q / nt;
+            float v = 0.f;
+            if (c < g.O) {
+                const long o = (long)b * g.ys_b + (long)c * g.ys_c + (long)(t0 + tl) * g.ys_t + fo;
+                v = y[o] > 0.f ? dy[o] : 0.f;
+            }
+            dyp[(tl * g.Fo + fo) * 33 + c] = v;
+        }
+        __syncthreads();
+        for (int p0 = 2 * wave; p0 < npos; p0 += 8) {
+            const int p = p0 + h;
+            const bool pv = p < npos;
+            const int tl = pv ? p / g.Fo : 0, fo = pv ? p - tl * g.Fo : 0;
+            const float a = pv ? dyp[p * 33 + r] : 0.f;
+            const float* xb = xs + (g.s * tl) * g.F + g.s * fo;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bvv = toff[n] >= 0 ? xb[toff[n]] : tone[n];
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pv ? bvv : 0.f, acc[n], 0, 0, 0);
+            }
+        }
+    }
+    // fold the 4 waves in wave order (fixed: deterministic) through one [32][32 NT] LDS tile, write the block's partial
+    float* red = dsm;  // 32 * 32 NT floats <= the LDS request (checked by the host)
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
+                    float* o = &red[c * (32 * NT) + 32 * n + r];
+                    *o = wv == 0 ? acc[n][q] : *o + acc[n][q];
+                }
+        }
+    }
+    __syncthreads();
+    float* out = part + (long)blockIdx.x * 32 * (32 * NT);
+    for (int i = tid; i < 32 * 32 * NT; i += 256) out[i] = red[i];
+}
+
+// dw[c][k] (c < O, k < K) and dbias[c] = the fixed-order sum of the per-block partials [nb][32][NTK]
+__global__ __launch_bounds__(256) void conv1_dw_fold_kernel(const float* __restrict__ part, int nb, int NTK, int O, int K,
+                                                           float* __restrict__ dw, float* __restrict__ dbias) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= O * (K + 1)) return;
+    const int c = idx / (K + 1), k = idx - c * (K + 1);
+    const float* p = part + (long)c * NTK + k;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 1 < nb; b += 2) { s0 += p[(long)b * 32 * NTK]; s1 += p[(long)(b + 1) * 32 * NTK]; }
+    if (b < nb) s0 += p[(long)b * 32 * NTK];
+    if (k < K) dw[(long)c * K + k] = s0 + s1;
+    else dbias[c] = s0 + s1;
+}
+
+constexpr int kDirDwBlocks = 512;
+
 constexpr int kDwBlocks = 512;
 
 bool make_geom(ConvGeom* g, int B, int C, int T, int F, int O, int kh, int kw, int s) {
@@ -255,9 +450,30 @@ int grid_for(long total) {
 
 }  // namespace
 
+static DirGeom dir_geom(const ConvGeom& g, long ys_b, long ys_c, long ys_t) {
+    DirGeom d;
+    d.B = g.B; d.T = g.T; d.F = g.F; d.O = g.O; d.kh = g.kh; d.kw = g.kw; d.s = g.s; d.To = g.To; d.Fo = g.Fo; d.K = g.K;
+    d.ys_b = ys_b; d.ys_c = ys_c; d.ys_t = ys_t;
+    d.TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
+    return d;
+}
+static int dir_nt(int K) { const int need = (K + 1 + 31) / 32; return need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 4 ? 4 : (need <= 6 ? 6 : 8))); }
+static size_t dir_dw_lds(const ConvGeom& g) {
+    const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
+    const size_t stage = ((size_t)((TT - 1) * g.s + g.kh) * g.F + (size_t)TT * g.Fo * 33) * sizeof(float);
+    const size_t fold = (size_t)32 * 32 * dir_nt(g.K) * sizeof(float);
+    return stage > fold ? stage : fold;
+}
+
+extern "C" int sa_conv2d_is_direct(int in_c, int F, int out_c, int kh, int kw, int s) {
+    const int Fo = conv_out(F, kw, s);
+    return Fo > 0 && conv_direct_ok(in_c, out_c, kh, kw, s, F, Fo) ? 1 : 0;
+}
+
 extern "C" size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s) {
     ConvGeom g;
     if (!make_geom(&g, B, in_c, T, F, out_c, kh, kw, s)) return 0;
+    if (conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo)) return 256;  // the direct kernel needs none
     const long npos = (long)g.B * g.To * g.Fo;
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +
            sa_align_up(sa_gemm_workspace_bytes((int)npos, g.O, g.K), 256);
@@ -273,6 +489,17 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_conv2d_fwd_workspace_bytes(B, in_c, T, F, out_c, kh, kw, s)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo)) {  // no im2col matrix at all (keep_cols is not filled)
+        const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
+        const size_t lds = ((size_t)((TT - 1) * g.s + g.kh) * g.F + (size_t)g.K * 32) * sizeof(float);
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)conv1_fwd_direct_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return CTC_STATUS_EXECUTION_FAILED;
+        hipLaunchKernelGGL(conv1_fwd_direct_kernel, dim3((g.To + TT - 1) / TT, g.B), dim3(256), lds, stream, x, w,
+                           bias, y, dir_geom(g, ys_b, ys_c, ys_t));
+        SA_CHECK_LAUNCH();
+        return CTC_STATUS_SUCCESS;
+    }
     const long npos = (long)g.B * g.To * g.Fo;
     float* cols = keep_cols ? keep_cols : (float*)workspace;  // keep_cols: caller-owned (npos x K) buffer reused by bwd
     char* gws = (char*)workspace + sa_align_up((size_t)npos * g.K * sizeof(float), 256);
@@ -295,6 +522,8 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
     if (gw3 > gw) gw = gw3;
     const size_t gw4 = (size_t)kDwBlocks * g.O * g.K * sizeof(float);  // conv_dw_partial_kernel
     if (conv_dw_fits(g.O, g.K) && gw4 > gw) gw = gw4;
+    const size_t gw5 = (size_t)kDirDwBlocks * 32 * 32 * 8 * sizeof(float);  // conv1_dw_direct_kernel partials
+    if (conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo) && gw5 > gw) gw = gw5;
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +   // cols, reused for dcols
            sa_align_up((size_t)npos * g.O * sizeof(float), 256) +   // dyp
            sa_align_up(gw, 256);
@@ -315,6 +544,27 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
     float* dyp = (float*)((char*)cols + sa_align_up((size_t)npos * g.K * sizeof(float), 256));
     char* gws = (char*)dyp + sa_align_up((size_t)npos * g.O * sizeof(float), 256);
     const size_t gws_bytes = workspace_bytes - (size_t)(gws - (char*)workspace);
+    if (!dx && conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo)) {  // direct weight / bias gradient
+        const int NT = dir_nt(g.K);
+        const size_t lds = dir_dw_lds(g);
+        const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
+        const int nslab_t = (g.To + TT - 1) / TT;
+        int nb = g.B * nslab_t;
+        if (nb > kDirDwBlocks) nb = kDirDwBlocks;
+        if (gws_bytes < (size_t)nb * 32 * 32 * NT * sizeof(float)) return CTC_STATUS_INVALID_VALUE;
+        void (*fn)(const float*, const float*, const float*, float*, DirGeom, int) =
+            NT == 2 ? conv1_dw_direct_kernel<2> : NT == 3 ? conv1_dw_direct_kernel<3> : NT == 4 ? conv1_dw_direct_kernel<4>
+            : NT == 6 ? conv1_dw_direct_kernel<6> : conv1_dw_direct_kernel<8>;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return CTC_STATUS_EXECUTION_FAILED;
+        hipLaunchKernelGGL(fn, dim3(nb), dim3(256), lds, stream, x, y, dy, (float*)gws, dir_geom(g, ys_b, ys_c, ys_t),
+                           nslab_t);
+        hipLaunchKernelGGL(conv1_dw_fold_kernel, dim3((g.O * (g.K + 1) + 255) / 256), dim3(256), 0, stream,
+                           (const float*)gws, nb, 32 * NT, g.O, g.K, dw, dbias);
+        SA_CHECK_LAUNCH();
+        return CTC_STATUS_SUCCESS;
+    }
     if (fwd_cols && !dx) {
         cols = const_cast<float*>(fwd_cols);  // the forward pass's im2col matrix, kept by the caller (read only here)
     } else {

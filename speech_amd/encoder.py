@@ -112,6 +112,7 @@ class EncoderFunction(torch.autograd.Function):
             # parameters re-homed by Model.flatten_parameters_() carry a `_grad_slot` view of the flat gradient
             # buffer: backward writes each gradient there and hands the view to autograd
             ctx.slots = [getattr(p, "_grad_slot", None) for p in params]
+            ctx.param_refs = params
             ctx.plan = plan
             ctx.conv_p, ctx.w_ih, ctx.w_hh, ctx.fc_w = conv_p, w_ih, w_hh, fc_w
             ctx.conv_saved, ctx.gru_saved, ctx.enc = conv_saved, gru_saved, enc
@@ -169,4 +170,18 @@ class EncoderFunction(torch.autograd.Function):
                                              dw=slots[2 * i], db=slots[2 * i + 1], cols=cols)
             grads[2 * i], grads[2 * i + 1] = dw, db
             dy = dx
-        return (None, None, None) + tuple(grads)
+        # A gradient that sits in its slot of the flat buffer is handed over by reference: autograd's accumulator would
+        # otherwise CLONE every returned view into a fresh p.grad (20 device copies per step, and a second copy of the
+        # whole gradient in memory).  A parameter whose .grad already IS its slot (no zero_grad in between) simply
+        # sees the fresh gradient there -- the flat buffer holds the LATEST gradient, it does not accumulate; one that
+        # holds some other gradient tensor takes the ordinary (accumulating) path.
+        out = list(grads)
+        for i, (p, slot) in enumerate(zip(ctx.param_refs, slots)):
+            if slot is None or out[i] is not slot or not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = slot
+                out[i] = None
+            elif p.grad.data_ptr() == slot.data_ptr():
+                out[i] = None
+        return (None, None, None) + tuple(out)

@@ -109,11 +109,16 @@ def conv2d_relu_fwd(x, w, bias, s, layout="nchw", keep_cols=False):
     L = _lib.lib()
     nbytes = L.sa_conv2d_fwd_workspace_bytes(B, C, T, F, O, kh, kw, s)
     ws = WORKSPACE.get(nbytes, x.device, "conv")
+    if keep_cols and L.sa_conv2d_is_direct(C, F, O, kh, kw, s):
+        keep_cols = False  # the direct first-conv kernels build no im2col matrix: nothing to keep
+        direct = True
+    else:
+        direct = False
     cols = torch.empty(B * To * Fo, C * kh * kw, dtype=torch.float32, device=x.device) if keep_cols else None
     with _span("conv_fwd", 2, 2.0 * B * To * Fo * O * C * kh * kw):
         check(L.sa_conv2d_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1], ys[2],
                                    ptr(cols), ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
-    if keep_cols:
+    if keep_cols or direct:
         return y, ys, cols
     return y, ys
 

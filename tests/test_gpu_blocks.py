@@ -99,6 +99,38 @@ def test_conv_relu_fwd_bwd(B, C, T, F, O, kh, kw, s, feature_layout):
     close(dx, dx_ref, rtol=2e-5, atol_scale=1e-5)
 
 
+@pytest.mark.parametrize("B,T,F,O,kh,kw,s", [(2, 70, 80, 32, 5, 32, 2),    # the first conv of every shipped config
+                                             (1, 300, 161, 32, 5, 32, 2),  # ... at the TIMIT feature width
+                                             (3, 41, 40, 8, 5, 11, 2),     # kw odd, kh * kw odd -> generic path
+                                             (2, 37, 33, 16, 4, 7, 1),     # tap pairs straddle window rows
+                                             (2, 19, 50, 5, 2, 9, 3)])
+@pytest.mark.parametrize("layout", ["nchw", "btf", "tbf"])
+def test_first_conv_direct_kernels(B, T, F, O, kh, kw, s, layout):
+    """One input channel: the direct MFMA kernels (no im2col matrix), forward and weight / bias gradient (need_dx=False,
+    as the encoder calls the first conv), every output layout; shapes they do not take fall back to the generic path."""
+    from speech_amd import ops, _lib
+    rng = np.random.RandomState(T + F)
+    x = rng.randn(B, 1, T, F)
+    w = rng.randn(O, 1, kh, kw) / np.sqrt(kh * kw)
+    b = rng.randn(O) * 0.1
+    y_ref, cols = E.conv_relu_fwd(x, w, b, s)
+    _, _, To, Fo = y_ref.shape
+    assert bool(_lib.lib().sa_conv2d_is_direct(1, F, O, kh, kw, s)) == ((kh * kw) % 2 == 0)
+    res = ops.conv2d_relu_fwd(dev(x), dev(w), dev(b), s, layout, keep_cols=True)
+    y, ys = res[0], res[1]
+    to_nchw = {"nchw": lambda t: t, "btf": lambda t: t.view(B, To, O, Fo).permute(0, 2, 1, 3),
+               "tbf": lambda t: t.view(To, B, O, Fo).permute(1, 2, 0, 3)}[layout]
+    close(to_nchw(y), y_ref, rtol=1e-5, atol_scale=2e-6)
+    dy = rng.randn(*y_ref.shape)
+    _, dw_ref, db_ref = E.conv_relu_bwd(dy, y_ref, cols, x.shape, w, s, need_dx=False)
+    dy_l = {"nchw": dy, "btf": dy.transpose(0, 2, 1, 3).reshape(B, To, O * Fo),
+            "tbf": dy.transpose(2, 0, 1, 3).reshape(To, B, O * Fo)}[layout]
+    dx, dw, db = ops.conv2d_relu_bwd(dev(x), dev(w), y, dev(dy_l), ys, s, need_dx=False, cols=res[2])
+    assert dx is None
+    close(dw, dw_ref, rtol=2e-5, atol_scale=1e-5)
+    close(db, db_ref, rtol=2e-5, atol_scale=1e-5)
+
+
 # -------------------------------------------------------------------------------------------------------------- GRU
 def gru_case(B, T, I, H, reverse, seed):
     rng = np.random.RandomState(seed)
