@@ -838,6 +838,8 @@ struct PBwdJobs {
     unsigned long long* stamp;
     unsigned* err;
     int spin_limit, fault, prio;  // see PFwdJobs
+    unsigned long long* timing;   // debug (SA_GRU_TIMING=1): per block {poll+load, mfma, reduce+barrier, gates+publish} in
+                                  // 10 ns ticks and the number of polling trips; else null
     PBwdJob j[kMaxJobs];
 };
 
@@ -899,6 +901,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    const bool timed = P.timing != nullptr && tid == 0;
+    if (timed) tprev = wall_clock64();
+#define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
 
     for (int s = 0; s < J.nsteps; ++s) {
         const int t = J.t0 + s * J.dt;
@@ -954,10 +960,12 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                     if (!P.flagless) break;
 #pragma unroll
                     for (int it = 0; it < 24; ++it) stale |= has_sentinel(a[it]);
+                    if (timed) ++tacc[4];
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
                     if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
                     if (POLL == 0 && SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
                 }
+                SA_TICK(0)
 #pragma unroll
                 for (int it = 0; it < 24; ++it) {
                     if (kk0 + 16 * it < kbeg + kslice) {
@@ -973,8 +981,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
             float* rd = red + (P.flagless ? (s & 1) * 1024 : 0);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr] + acc1[rr];
+            SA_TICK(1)
         }
         __syncthreads();
+        SA_TICK(2)
         if (live) {
             const float* rd = red + (P.flagless ? (s & 1) * 1024 : 0);
             if (have_next)
@@ -990,10 +1000,16 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
             dh_run = dh;
             z_next = z;
         }
+        SA_TICK(3)
         if (P.flagless) continue;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#undef SA_TICK
+    if (timed) {
+        unsigned long long* o = P.timing + 5 * ((role_z * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
+        for (int k = 0; k < 5; ++k) atomicAdd(&o[k], tacc[k]);
     }
     if (live) J.dh_state[(long)b * H + u] = dh_run;
     if (stamper) P.stamp[1] = wall_clock64();
@@ -1929,7 +1945,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     for (int d = 0; d < 2; ++d)
                         if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg;
-                Q.stamp = nullptr; Q.n = 2;
+                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
                     const float* dho = (l == L - 1) ? dh_top : mid_of(l);
@@ -2002,7 +2018,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const bool side = wg && xcd && overlap_enabled(true) && g_side.init();
     const int wg_every = wgrad_every();
     if (xcd) {
-        if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+        if (hipMemsetAsync(sync, 0, getenv("SA_GRU_TIMING") ? kSyncBytes : 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
@@ -2036,6 +2052,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
+            Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
             Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
