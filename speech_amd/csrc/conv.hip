@@ -384,17 +384,26 @@ __global__ __launch_bounds__(256) void conv1_dw_direct_kernel(const float* __res
             dyp[(tl * g.Fo + fo) * 33 + c] = v;
         }
         __syncthreads();
-        for (int p0 = 2 * wave; p0 < npos; p0 += 8) {
-            const int p = p0 + h;
-            const bool pv = p < npos;
-            const int tl = pv ? p / g.Fo : 0, fo = pv ? p - tl * g.Fo : 0;
-            const float a = pv ? dyp[p * 33 + r] : 0.f;
-            const float* xb = xs + (g.s * tl) * g.F + g.s * fo;
+        for (int p0 = 2 * wave; p0 < npos; p0 += 16) {  // two position pairs per trip: their LDS reads go out together
+            float a[2], bv[2][NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float bvv = toff[n] >= 0 ? xb[toff[n]] : tone[n];
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pv ? bvv : 0.f, acc[n], 0, 0, 0);
+            for (int e = 0; e < 2; ++e) {
+                const int p = p0 + 8 * e + h;
+                const bool pv = p < npos;
+                const int tl = pv ? p / g.Fo : 0, fo = pv ? p - tl * g.Fo : 0;
+                a[e] = pv ? dyp[p * 33 + r] : 0.f;
+                const float* xb = xs + (g.s * tl) * g.F + g.s * fo;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float v = toff[n] >= 0 ? xb[toff[n]] : tone[n];
+                    bv[e][n] = pv ? v : 0.f;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e][n], acc[n], 0, 0, 0);
         }
     }
     // fold the 4 waves in wave order (fixed: deterministic) through one [32][32 NT] LDS tile, write the block's partial
@@ -418,18 +427,21 @@ __global__ __launch_bounds__(256) void conv1_dw_direct_kernel(const float* __res
 }
 
 // dw[c][k] (c < O, k < K) and dbias[c] = the fixed-order sum of the per-block partials [nb][32][NTK]
+// 8 lanes per output: lane j adds the partials j, j + 8, ... in order, then a fixed xor tree folds the 8 sums
 __global__ __launch_bounds__(256) void conv1_dw_fold_kernel(const float* __restrict__ part, int nb, int NTK, int O, int K,
                                                            float* __restrict__ dw, float* __restrict__ dbias) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= O * (K + 1)) return;
-    const int c = idx / (K + 1), k = idx - c * (K + 1);
+    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 3, j = threadIdx.x & 7;
+    const bool on = idx < O * (K + 1);
+    const int c = on ? idx / (K + 1) : 0, k = on ? idx - c * (K + 1) : 0;
     const float* p = part + (long)c * NTK + k;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 1 < nb; b += 2) { s0 += p[(long)b * 32 * NTK]; s1 += p[(long)(b + 1) * 32 * NTK]; }
-    if (b < nb) s0 += p[(long)b * 32 * NTK];
-    if (k < K) dw[(long)c * K + k] = s0 + s1;
-    else dbias[c] = s0 + s1;
+    float s0 = 0.f;
+    if (on)
+        for (int b = j; b < nb; b += 8) s0 += p[(long)b * 32 * NTK];
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+    if (!on || j != 0) return;
+    if (k < K) dw[(long)c * K + k] = s0;
+    else dbias[c] = s0;
 }
 
 constexpr int kDirDwBlocks = 512;
@@ -560,7 +572,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
             return CTC_STATUS_EXECUTION_FAILED;
         hipLaunchKernelGGL(fn, dim3(nb), dim3(256), lds, stream, x, y, dy, (float*)gws, dir_geom(g, ys_b, ys_c, ys_t),
                            nslab_t);
-        hipLaunchKernelGGL(conv1_dw_fold_kernel, dim3((g.O * (g.K + 1) + 255) / 256), dim3(256), 0, stream,
+        hipLaunchKernelGGL(conv1_dw_fold_kernel, dim3((g.O * (g.K + 1) * 8 + 255) / 256), dim3(256), 0, stream,
                            (const float*)gws, nb, 32 * NT, g.O, g.K, dw, dbias);
         SA_CHECK_LAUNCH();
         return CTC_STATUS_SUCCESS;
