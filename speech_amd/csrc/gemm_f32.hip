@@ -64,11 +64,14 @@ struct GemmArgs {
     // cs_partial [nprob][splits][M] and the reduce kernel folds them with the products.
     float* colsumg[kMaxGroup];
     float* cs_partial;
-    // XCD-filtered persistent mode (xcc_mask != 0): the launch is 512 blocks; a block that finds itself on an XCD outside
-    // the mask leaves at once, the others pull tiles off `tile_counter` (zeroed by the host) until none is left.  A
-    // side-stream GEMM can so be kept OFF the XCDs a persistent recurrence launch occupies (a bidirectional layer's
-    // groups sit on XCDs 0 .. u-1): no shared CUs, no interference -- hipExtStreamCreateWithCUMask cannot express this
-    // (measured: its bits select CUs inside every XCD alike, tools/ubench/cumask_probe.hip).
+    // XCD-filtered mode (xcc_mask != 0): the launch has (8 / allowed XCDs) x as many blocks as tiles (+ slack); a block
+    // that finds itself on an XCD outside the mask leaves at once, every other block draws ONE tile off `tile_counter`
+    // (zeroed by the host) and leaves when none is left.  A side-stream GEMM can so be kept OFF the XCDs a persistent
+    // recurrence launch occupies (a bidirectional layer's groups sit on XCDs 0 .. u-1): no shared CUs, no interference
+    // -- hipExtStreamCreateWithCUMask cannot express this (measured: its bits select CUs inside every XCD alike,
+    // tools/ubench/cumask_probe.hip).  One tile per block, not a persistent loop: the dispatcher hands out a grid in
+    // order, so resident long-lived blocks on the idle XCDs would keep the NEXT recurrence launch from starting (its
+    // own exit-at-once blocks for those XCDs find no room: profiles/r02_bidirectional_overlap_trace.txt).
     unsigned xcc_mask;
     unsigned* tile_counter;
     int grid_x, grid_y, grid_z;
@@ -229,6 +232,82 @@ __device__ __forceinline__ void gemm_ktile(const GemmArgs& g, const float* __res
     mma_quarter(fy, acc);
 }
 
+// The same k-tile with ONE register stage (the XCD-filtered kernel: 32 registers fewer, see gemm_f32_filtered_kernel): the
+// loads of tile it + 1 go out at the top of tile `it` and are stored between the MFMAs of quarter 2, half a tile later.
+template <bool TA, bool TB, bool FAST, bool MORE>
+__device__ __forceinline__ void gemm_ktile_d1(const GemmArgs& g, const float* __restrict__ gA,
+                                              const float* __restrict__ gB, float* smem, int m0, int n0, int k_next,
+                                              int kend, int tid, int cur, int fa, int fb, f32x16 (&acc)[2][2],
+                                              QFrag& fx, QFrag& fy, float4 (&sa)[NL], float4 (&sb)[NL], bool do_colsum,
+                                              float4& csum) {
+    constexpr bool AK = !TA, BKC = TB;
+    constexpr int qa = AK ? 4 : 4 * KPITCH, qb = BKC ? 4 : 4 * KPITCH;
+    float* Ac = smem + cur * (2 * TILE_F);
+    float* Bc = Ac + TILE_F;
+    float* An = smem + (cur ^ 1) * (2 * TILE_F);
+    float* Bn = An + TILE_F;
+    if (MORE) {
+        load_tile<!TA, FAST>(gA, g.lda, m0, g.M, k_next, kend, g.vecA, tid, sa);
+        load_tile<TB, FAST>(gB, g.ldb, n0, g.N, k_next, kend, g.vecB, tid, sb);
+    }
+    read_frag<AK>(Ac + fa + qa, fy.a);
+    read_frag<BKC>(Bc + fb + qb, fy.b);
+    mma_quarter(fx, acc);
+    read_frag<AK>(Ac + fa + 2 * qa, fx.a);
+    read_frag<BKC>(Bc + fb + 2 * qb, fx.b);
+    mma_quarter(fy, acc);
+    read_frag<AK>(Ac + fa + 3 * qa, fy.a);
+    read_frag<BKC>(Bc + fb + 3 * qb, fy.b);
+    if (MORE) {
+        if (TA && do_colsum) {
+#pragma unroll
+            for (int p = 0; p < NL; ++p) { csum.x += sa[p].x; csum.y += sa[p].y; csum.z += sa[p].z; csum.w += sa[p].w; }
+        }
+        store_tile<!TA>(An, tid, sa);
+        store_tile<TB>(Bn, tid, sb);
+    }
+    mma_quarter(fx, acc);
+    __syncthreads();
+    if (MORE) {
+        read_frag<AK>(An + fa, fx.a);
+        read_frag<BKC>(Bn + fb, fx.b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_quarter(fy, acc);
+}
+
+template <bool TA, bool TB, bool FAST>
+__device__ __forceinline__ void gemm_mainloop_d1(const GemmArgs& g, const float* __restrict__ gA,
+                                                 const float* __restrict__ gB, float* smem, int m0, int n0, int kbeg,
+                                                 int kend, int tid, f32x16 (&acc)[2][2], bool do_colsum, float4& csum) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    constexpr bool AK = !TA, BKC = TB;
+    const int fa = AK ? (wm * 64 + (lane & 31)) * PITCH + 16 * (lane >> 5) : 16 * (lane >> 5) * KPITCH + wm * 64 + (lane & 31);
+    const int fb = BKC ? (wn * 64 + (lane & 31)) * PITCH + 16 * (lane >> 5) : 16 * (lane >> 5) * KPITCH + wn * 64 + (lane & 31);
+    float4 ra[NL], rb[NL];
+    if (ntiles <= 0) return;
+    load_tile<!TA, FAST>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+    load_tile<TB, FAST>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+    if (TA && do_colsum) {
+#pragma unroll
+        for (int p = 0; p < NL; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+    }
+    store_tile<!TA>(smem, tid, ra);
+    store_tile<TB>(smem + TILE_F, tid, rb);
+    __syncthreads();
+    QFrag f0, f1;
+    read_frag<AK>(smem + fa, f0.a);
+    read_frag<BKC>(smem + TILE_F + fb, f0.b);
+    int it = 0;
+    for (; it + 1 < ntiles; ++it)
+        gemm_ktile_d1<TA, TB, FAST, true>(g, gA, gB, smem, m0, n0, kbeg + (it + 1) * BK, kend, tid, it & 1, fa, fb, acc, f0,
+                                          f1, ra, rb, do_colsum, csum);
+    gemm_ktile_d1<TA, TB, FAST, false>(g, gA, gB, smem, m0, n0, 0, kend, tid, it & 1, fa, fb, acc, f0, f1, ra, rb,
+                                       do_colsum, csum);
+}
+
 // The K loop (see the file header).  LDS: stage s holds the A tile at smem + s * 2 * TILE_F and the B tile behind it.
 // Global loads run TWO tiles ahead of the MFMAs (two register stages, the loop is unrolled by two so that they swap
 // roles without moves): a load has a whole k-tile (>= 4096 matrix-pipe cycles) to land before its LDS store.
@@ -290,7 +369,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
 
 // TA: A is stored (K, M) (m-contiguous);  !TA: A is stored (M, K) (k-contiguous)
 // TB: B is stored (N, K) (k-contiguous);  !TB: B is stored (K, N) (n-contiguous)
-template <bool TA, bool TB>
+template <bool TA, bool TB, int DEPTH = 2>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int bx, int by, int bz) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -314,8 +393,13 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
     const bool fast = g.vecA && g.vecB && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
     const bool do_colsum = TA && g.colsumg[prob] != nullptr && bx == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
-    else gemm_mainloop<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
+    if (DEPTH == 2) {
+        if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
+        else gemm_mainloop<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
+    } else {
+        if (fast) gemm_mainloop_d1<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
+        else gemm_mainloop_d1<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
+    }
     if (do_colsum) {  // fold the 8 k-rows of threads (tid >> 5) that share 4 columns; fixed order: deterministic
         float* cs = smem;  // the mainloop's last barrier has released the tiles
         *reinterpret_cast<float4*>(&cs[(tid >> 5) * BM + 4 * (tid & 31)]) = csum;
@@ -371,22 +455,26 @@ __device__ __forceinline__ int gemm_xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
-    if (g.xcc_mask == 0) {
-        gemm_block<TA, TB>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
-        return;
-    }
+    gemm_block<TA, TB>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The XCD-filtered launches (see GemmArgs::xcc_mask) run this copy with ONE register stage (<= 232 registers per lane):
+// a block that lands on an XCD where a persistent recurrence block (264 - 280 registers) holds every CU must still be
+// ADMITTED there in order to leave -- 264 + 256 does not fit a SIMD's 512, so the two-stage kernel's surplus blocks (and
+// with them the launch's completion, and everything queued behind it on the side stream) would wait for the recurrence
+// to end.  (clang's amdgpu_num_vgpr attribute does not cap the allocation: checked.)
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_filtered_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
     if (!((g.xcc_mask >> gemm_xcc_id()) & 1u)) return;
     __shared__ int s_tile;
     const int total = g.grid_x * g.grid_y * g.grid_z;
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = (int)atomicAdd(g.tile_counter, 1u);
-        __syncthreads();
-        const int tile = s_tile;
-        __syncthreads();  // s_tile may be rewritten; also separates this tile's LDS use from the previous one's
-        if (tile >= total) return;
-        const int bx = tile % g.grid_x, r = tile / g.grid_x;
-        gemm_block<TA, TB>(g, smem, bx, r % g.grid_y, r / g.grid_y);
-    }
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(g.tile_counter, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile >= total) return;
+    const int bx = tile % g.grid_x, r = tile / g.grid_x;
+    gemm_block<TA, TB, 1>(g, smem, bx, r % g.grid_y, r / g.grid_y);
 }
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int splits) {
@@ -490,7 +578,11 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.grid_x = (int)grid.x; g.grid_y = (int)grid.y; g.grid_z = (int)grid.z;
     if (opts && opts->xcc_mask && opts->tile_counter) {
         g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter;
-        grid = dim3(512, 1, 1);
+        int allowed = 0;
+        for (int x = 0; x < 8; ++x) allowed += (opts->xcc_mask >> x) & 1u;
+        const long tiles = (long)grid.x * grid.y * grid.z;
+        // block b lands on XCD b % 8: launch enough blocks that the allowed XCDs alone receive `tiles` of them
+        grid = dim3((unsigned)((tiles + allowed - 1) / allowed * 8 + 8), 1, 1);
     }
     // "polite" launches (opts->pad_lds): dynamic LDS on top of the kernel's 66 KB so that a CU admits ONE block of this
     // launch -- what a side-stream GEMM wants while a persistent recurrence kernel holds every CU (gru.hip): the
@@ -508,7 +600,15 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
             attr_set = true;
         }
     }
-    if (trans_a) {
+    if (g.xcc_mask) {
+        if (trans_a) {
+            if (trans_b) hipLaunchKernelGGL((gemm_f32_filtered_kernel<true, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_f32_filtered_kernel<true, false>), grid, dim3(256), 0, stream, g);
+        } else {
+            if (trans_b) hipLaunchKernelGGL((gemm_f32_filtered_kernel<false, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_f32_filtered_kernel<false, false>), grid, dim3(256), 0, stream, g);
+        }
+    } else if (trans_a) {
         if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), dyn, stream, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), dyn, stream, g);
     } else {

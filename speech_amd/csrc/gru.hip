@@ -1760,6 +1760,15 @@ struct SideStream {
 };
 SideStream g_side;
 
+// Holds the side stream back for ~`ticks` x 10 ns: enqueued in front of a batch of XCD-filtered GEMM launches so that the
+// persistent recurrence launch issued at the same moment on the caller's stream is DISPATCHED first -- its exit-at-once
+// workgroups for the idle XCDs need a free slot there, and once GEMM blocks (hundreds of us each) fill those CUs the
+// in-order dispatcher keeps the whole recurrence launch waiting (measured: 0.5 ms per layer).
+__global__ void side_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 int wgrad_every() {  // persistent launches between two hand-overs of weight-gradient work to the side stream
     const char* e = getenv("SA_GRU_WG_EVERY");
     const int v = e ? atoi(e) : 0;
@@ -1771,16 +1780,20 @@ int wgrad_every() {  // persistent launches between two hand-overs of weight-gra
 // block a recurrence launch takes 230-310 us instead of 169 (its MFMAs queue behind the GEMM's 64-cycle ones, its
 // exchange loads behind the GEMM's tile loads) and the GEMM runs at a third of its speed -- 15.4 ms per step against
 // 12.1 -- so the unidirectional default is OFF (SA_GRU_OVERLAP=1 switches it on).
-// Bidirectional layers leave XCDs idle, and XCD-FILTERED side GEMMs keep off the busy ones -- but the workgroup
-// dispatcher walks a grid in order: the next layer's persistent launch cannot place its (exit-at-once) workgroups on
-// XCDs whose CUs are full of resident GEMM blocks, and nothing behind them is dispatched until it can, so the
-// recurrence starts only when the GEMM launch before it has drained (profiles/r02_bidirectional_overlap_trace.txt:
-// 0.9 ms late per layer).  Net at bidirectional S-LIBRI 36.1 -> 35.5 ms, at the shipped TIMIT shapes 8.2 -> 8.3 ms:
-// OFF by default here too.
+// Bidirectional layers leave XCDs idle (a layer's groups sit on XCDs 0 .. u-1), and XCD-FILTERED side GEMMs keep off the
+// busy ones.  Three things had to hold before that paid (profiles/r02_bidirectional_overlap_trace.txt):
+//   * one tile per block, not a persistent tile loop: the dispatcher walks a grid in order, so long-lived GEMM blocks on
+//     the idle XCDs keep the NEXT recurrence launch from starting (its exit-at-once blocks for those XCDs find no room);
+//   * the recurrence launch must be dispatched BEFORE the GEMM blocks arrive (side_delay_kernel);
+//   * the filtered GEMM must fit BESIDE a recurrence block (<= 232 registers: the one-stage kernel), or its own surplus
+//     blocks on the busy XCDs -- and the launch's completion -- wait for the recurrence to end.
+// With all three: bidirectional S-LIBRI 36.3 -> 30.9 ms per step (backward stack 22.2 -> 17.7 ms: the 2.9 ms of weight-
+// gradient products of a layer run entirely inside the next layer's 2.96 ms recurrence).  ON by default for
+// bidirectional stacks, OFF for unidirectional ones (all 8 XCDs busy: see above); SA_GRU_OVERLAP=0 / 1 forces either.
 bool overlap_enabled(bool uni) {
-    (void)uni;
     const char* e = getenv("SA_GRU_OVERLAP");
-    return e && e[0] != '0';
+    if (e) return e[0] != '0';
+    return !uni;
 }
 
 // Issues the weight-gradient products of layer-direction k = l*D+d over the time steps [t0, t1) on `stream`.
@@ -1977,7 +1990,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                           d ? 1.f : 0.f, din, I, nullptr, nullptr, nullptr, 0, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
                 }
-            if (bi_xcd && wg && bi_side) {
+            if (bi_xcd && wg && bi_side && l > 0) {  // (layer 0's products have no recurrence left to hide behind: they
+                                                      // run unfiltered on the caller's stream, wgrad_rest below)
                 // this layer's weight gradients go to the side stream NOW, behind the input-gradient products above
                 // (those are on the critical path and need the whole chip: a persistent side GEMM started earlier
                 // would hold the idle XCDs' CUs and stall their share of the tiles): they run beside the NEXT layer's
@@ -1986,6 +2000,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 for (int k = 0; k < L * 2; ++k) { spans[k][0] = spans[k][1] = 0; }
                 for (int d = 0; d < 2; ++d) { spans[l * 2 + d][1] = T; wg_hi[l * 2 + d] = 0; }
                 if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
+                hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // ~40 us
                 issuer.polite = false; issuer.xcc_mask = bi_mask;
                 st = issuer.issue(spans, g_side.s, true);
                 issuer.xcc_mask = 0;
