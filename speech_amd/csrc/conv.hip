@@ -239,212 +239,409 @@ __global__ __launch_bounds__(256) void conv_dw_final_kernel(const float* __restr
     dw[idx] = s0 + s1;
 }
 
-// ------------------------------------------------------------------------------------------ direct first convolution
-// The first conv of every shipped config has ONE input channel (the spectrogram) and at most 32 output channels
-// ([32, 5, 32, 2]): its im2col matrix is 160 columns of re-arranged input -- 255 MB written and read back at S-LIBRI for
-// 10 MB of features -- and as a GEMM it fills a quarter of a 128-wide tile.  The direct kernels below never build it:
-// a block stages the input rows its output frames touch in LDS (a slab of (TT - 1) s + kh rows x F floats) and feeds
-// v_mfma_f32_32x32x2_f32 with operands gathered from that slab.
-//   forward : D[channel][position] += W[channel][tap] * x[window(position)][tap]      (M = 32 channels, N = positions)
-//             rows = channels so that a register of the accumulator tile holds 32 CONSECUTIVE positions of one channel:
-//             the epilogue (bias, ReLU, the caller's layout) writes contiguous segments.
-//   backward: dW[channel][tap] += dyp[position][channel] * x[window(position)][tap]   (reduction over positions),
-//             tap tiles of 32 plus one column of ones (-> the bias gradient); a block walks several slabs with its
-//             partial sums in registers, the per-block partials are folded in a fixed order (conv_dw_final_kernel).
+// ------------------------------------------------------------------------------------------------ direct convolutions
+// The convs of the shipped configs have 1 or 8 / 32 input channels and at most 32 output channels ([32, 5, 32, 2] on the
+// spectrogram, then [32, 5, 32, 1] or [32, 5, 8, 2] on 32 channels): as im2col + GEMM the first builds 255 MB of
+// re-arranged input for 10 MB of features at S-LIBRI, the stacked one 800 MB at the TIMIT shapes -- written, read back, and
+// in the backward pass written and read again as gradient columns -- and every one of their GEMMs fills a quarter of a
+// 128-wide tile.  The direct kernels below never build the matrix: a block stages the input (or gradient) rows its
+// positions touch in LDS and feeds v_mfma_f32_32x32x2_f32 with operands gathered from that slab.
+//   forward : D[out channel][position] += W[out][in, tap] * x[in][window(position)][tap]   (M = 32 channels, N = positions)
+//             rows = channels, so a register of the accumulator tile holds 32 CONSECUTIVE positions of one channel: the
+//             epilogue (bias, ReLU, the caller's layout) writes contiguous segments.                 conv_dirc_kernel<false>
+//   input   : dx[in][input position] += W[out][in, tap] * dyp[out][(position - tap) / s]   (M = 32 input channels,
+//             N = input positions): the transposed conv as the same gather over a zero-stuffed slab -- no
+//             gradient-column matrix, no col2im.                                                     conv_dirc_kernel<true>
+//   weights : dW[out][in, tap] += dyp[position][out] * x[in][window(position)][tap]        (reduction over positions);
+//             tap tiles of 32 plus one column of ones (-> the bias gradient); a block walks several slabs with its partial
+//             sums in registers, the per-block partials are folded in a fixed order.                 conv_dw2_kernel
+// Taken: <= 32 channels on either side, an even kernel width (a pair of taps -- the MFMA's k = 2 -- never straddles a tap
+// row), <= 224 taps per input channel; everything else runs as im2col + GEMM.
 typedef float f32x16c __attribute__((ext_vector_type(16)));
-constexpr int kDirMaxTT = 16;  // output frames per slab, at most
+constexpr int kDirMaxTT = 16;  // output frames per slab of the weight-gradient kernel, at most
 
-// frames per slab: the most (<= 16) whose LDS footprint stays <= 64 KB in both kernels (2+ blocks per CU)
+// frames per weight-gradient slab: the most (<= 16) whose one-channel LDS footprint stays <= 64 KB and whose positions
+// number <= 512
 __host__ __device__ inline int conv_direct_tt(int kh, int kw, int s, int F, int Fo) {
     for (int tt = kDirMaxTT; tt >= 1; tt >>= 1) {
         const long rows = (long)(tt - 1) * s + kh;
-        const long fwd = rows * F + (long)kh * kw * 32, bwd = rows * F + (long)tt * Fo * 33;
-        if ((fwd > bwd ? fwd : bwd) * 4 <= 64 * 1024) return tt;
+        if ((rows * F + (long)tt * Fo * 33) * 4 <= 64 * 1024 && (long)tt * Fo <= 512) return tt;
     }
     return 0;
 }
 __host__ __device__ inline bool conv_direct_ok(int C, int O, int kh, int kw, int s, int F, int Fo) {
-    const int K = kh * kw;
-    return C == 1 && O <= 32 && (K & 1) == 0 && K <= 224 && conv_direct_tt(kh, kw, s, F, Fo) > 0;
+    return C <= 32 && O <= 32 && (kw & 1) == 0 && kh * kw <= 224 && conv_direct_tt(kh, kw, s, F, Fo) > 0;
 }
 
 struct DirGeom {
-    int B, T, F, O, kh, kw, s, To, Fo, K, TT;
+    int B, C, T, F, O, kh, kw, s, To, Fo, K, TT;   // K = kh * kw: the taps of ONE input channel
     long ys_b, ys_c, ys_t;
 };
 
-// Stage the slab of input rows [s * t0, s * t0 + rows) of utterance b (zero beyond T) into xs[rows][F].
-__device__ __forceinline__ void dir_stage_x(const float* __restrict__ x, float* __restrict__ xs, const DirGeom& g, int b,
-                                            int t0, int rows) {
-    const float* src = x + ((long)b * g.T + (long)g.s * t0) * g.F;
-    const int n = rows * g.F;
-    const int valid = max(0, min(rows, g.T - g.s * t0)) * g.F;
-    for (int i = threadIdx.x; i < n; i += 256) xs[i] = i < valid ? src[i] : 0.f;
+// dw[o][c][k] (o < O, k < K) and dbias[o] = the fixed-order sum of the per-block partials [nb][C][32][NTK].
+// 8 lanes per output: lane j adds the partials j, j + 8, ... in order, then a fixed xor tree folds the 8 sums.
+__global__ __launch_bounds__(256) void conv_dw_fold_kernel(const float* __restrict__ part, int nb, int NTK, int O, int C,
+                                                          int K, float* __restrict__ dw, float* __restrict__ dbias) {
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    const bool on = idx < (long)O * C * (K + 1);
+    const int k = on ? (int)(idx % (K + 1)) : 0;
+    const int oc = on ? (int)(idx / (K + 1)) : 0;
+    const int o = oc / C, c = oc - o * C;
+    const float* p = part + ((long)c * 32 + o) * NTK + k;
+    float s0 = 0.f;
+    if (on)
+        for (int b = j; b < nb; b += 8) s0 += p[(long)b * C * 32 * NTK];
+#pragma unroll
+    for (int sh = 4; sh > 0; sh >>= 1) s0 += __shfl_xor(s0, sh, 64);
+    if (!on || j != 0) return;
+    if (k < K) dw[((long)o * C + c) * K + k] = s0;
+    else if (c == 0) dbias[o] = s0;
 }
 
-// grid (ceil(To / g.TT), B).  LDS: xs[rows][F] | ws[K][32] (tap-major weights, channels >= O zero).
-__global__ __launch_bounds__(256) void conv1_fwd_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ y,
-                                                              DirGeom g) {
+// ---- forward and input gradient ----
+// Forward and input gradient are one kernel: rows of the accumulator tile = the 32 "inner" channels (out channels for the
+// forward pass, input channels for the gradient), columns = positions, reduction over ("outer" channel, tap).
+//   A operand: a pre-transposed copy of the weights, wt[outer][tap][32], read straight from global memory -- 256
+//     consecutive bytes per wave and MFMA, the same for every wave and block (L1 / L2 hits), prefetched one group of 8 tap
+//     pairs ahead in registers.  No weight staging, no barrier per channel.
+//   B operand: gathered from an LDS slab of kOuterChunk outer channels at a time.
+//     forward : slab[cc][row][f] = x[b][c][s t0 + row][f]; position (tl, fo) reads + (s tl + i) P + s fo + j, P = F.
+//     gradient: slab[oo][a][bb] = the ZERO-STUFFED, zero-padded masked dy of output channel o: input row t0 - (kh-1) + a,
+//               input column bb - (kw-1) hold dyp[o][row / s][col / s] when both divide, else 0 -- so the transposed conv
+//               is the same predicate-free gather, with the tap offset subtracted: (tl + kh-1 - i) P + f + kw-1 - j,
+//               P = F + kw - 1.  (For s > 1 three quarters of the products multiply a stuffed zero; the stacked convs that
+//               matter are stride 1, and the strided ones have 40 taps.)
+constexpr int kOuterChunk = 8;
+constexpr int kDircWtPad = 2 * 8 * 64;  // floats: two groups of 8 tap pairs
+
+// wt[(outer K + k) 32 + inner]: forward: outer = c, inner = o; gradient: outer = o, inner = c.  Rows beyond the real
+// inner count are zero.
+__global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int O, int C,
+                                                     int K, int grad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n_outer = grad ? O : C, n_inner = grad ? C : O;
+    if (i >= (long)n_outer * K * 32 + kDircWtPad) return;
+    if (i >= (long)n_outer * K * 32) { wt[i] = 0.f; return; }  // the prefetch reads two groups past the end
+    const int inner = (int)(i & 31);
+    const int k = (int)((i >> 5) % K), outer = (int)((i >> 5) / K);
+    const int o = grad ? outer : inner, c = grad ? inner : outer;
+    wt[i] = inner < n_inner ? w[((long)o * C + c) * K + k] : 0.f;
+}
+
+struct DircArgs {
+    const float* src;     // forward: x; gradient: dy
+    const float* y;       // gradient: the forward output (ReLU mask); forward: unused
+    const float* wt;      // transposed weights (padded by two groups: the prefetch runs past the end)
+    const float* bias;    // forward only
+    float* dst;           // forward: y; gradient: dx
+    DirGeom g;
+};
+
+// One wave per SIMD has about 16 issue slots per v_mfma_f32_32x32x2_f32, and every scalar or vector instruction beside the
+// MFMAs takes one: the reduction is cut into GROUPS of GS tap pairs that lie in ONE tap row (GS divides kw / 2), so that
+//   * a group's B operands sit at compile-time offsets from one address per tile (ds_read_b32 ... offset:8u), the
+//     lane half h -- the second tap of a pair -- folded into that address once per block;
+//   * a group's A operands sit at compile-time offsets from a pointer that advances by the same 256 GS bytes every group
+//     (the weights are stored in reduction order), loaded TWO groups ahead -- an L2 round trip is longer than one
+//     group's products -- into three register sets in rotation (the loop is unrolled by three, no set is ever copied).
+struct DircCursor {
+    int outer, i, jg;     // the group being multiplied: outer channel, tap row, group within the row
+};
+
+// Stage the slabs of outer channels [c0, c0 + ncc) (see the layout above).
+template <bool GRAD>
+__device__ __forceinline__ void dirc_stage(const DircArgs& a, float* __restrict__ dsm, int b, int c0, int ncc, int row0,
+                                           int srows, int slab, int P, int tid) {
+    const DirGeom& g = a.g;
+    if (!GRAD) {
+        const int in0 = g.s * row0;
+        const int valid = max(0, min(srows, g.T - in0)) * g.F;
+        const float* src = a.src + (((long)b * g.C + c0) * g.T + in0) * g.F;
+#pragma unroll 4
+        for (int i = tid; i < ncc * slab; i += 256) {
+            const int cc = i / slab, o = i - cc * slab;
+            const float v = src[(long)cc * g.T * g.F + (o < valid ? o : 0)];
+            dsm[i] = o < valid ? v : 0.f;
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < ncc * slab; i += 256) {
+            const int oo = i / slab, o = i - oo * slab;
+            const int ar = o / P, bb = o - ar * P;
+            const int ti = row0 - (g.kh - 1) + ar, fj = bb - (g.kw - 1);
+            const int tq = ti / g.s, fq = fj / g.s;
+            const bool on = ti >= 0 && fj >= 0 && tq * g.s == ti && fq * g.s == fj && tq < g.To && fq < g.Fo;
+            const long off = on ? (long)b * g.ys_b + (long)(c0 + oo) * g.ys_c + (long)tq * g.ys_t + fq : 0;
+            const float yv = a.y[off], dv = a.src[off];
+            dsm[i] = on && yv > 0.f ? dv : 0.f;
+        }
+    }
+}
+
+template <int GS>
+__device__ __forceinline__ void dirc_load_a(const float* __restrict__& wp, float (&dst)[GS]) {
+#pragma unroll
+    for (int u = 0; u < GS; ++u) dst[u] = wp[64 * u];
+    wp += 64 * GS;
+}
+
+// One group: GS tap pairs x NQ tiles; at the first group of a chunk's first channel the block stages the chunk.
+template <bool GRAD, int NQ, int GS>
+__device__ __forceinline__ void dirc_group(const DircArgs& a, DircCursor& cu, float* __restrict__ dsm, int b, int row0,
+                                           int srows, int slab, int P, int n_outer, int GR, int tid,
+                                           const int (&xoffh)[NQ], const float (&av)[GS], f32x16c (&acc)[NQ]) {
+    const int cc = cu.outer % kOuterChunk;
+    if (cc == 0 && cu.i == 0 && cu.jg == 0) {
+        __syncthreads();  // the previous chunk's readers are done
+        dirc_stage<GRAD>(a, dsm, b, cu.outer, min(kOuterChunk, n_outer - cu.outer), row0, srows, slab, P, tid);
+        __syncthreads();
+    }
+    // tap pair u of the group = taps (i, 2 (jg GS + u) + h): forward + (i P + j), gradient - (i P + j)
+    const int j0 = 2 * GS * cu.jg;
+    const int soff = cc * slab + (GRAD ? -(cu.i * P + j0 + 2 * (GS - 1)) : cu.i * P + j0);
+    float bv[GS][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float* bp = dsm + (xoffh[q] + soff);
+#pragma unroll
+        for (int u = 0; u < GS; ++u) bv[u][q] = bp[GRAD ? 2 * (GS - 1 - u) : 2 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < GS; ++u)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][q], acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) asm volatile("" : "+a"(acc[q]));  // the tiles stay in accumulation registers between groups
+    if (++cu.jg == GR) {
+        cu.jg = 0;
+        if (++cu.i == a.g.kh) { cu.i = 0; ++cu.outer; }
+    }
+}
+
+// grid (ceil(rows * wpos / (128 NQ)), B): a block takes 128 NQ consecutive positions of one utterance in (row, column)
+// order -- every wave NQ full tiles, whatever the row width -- and stages the slab rows those positions touch.
+// GRAD = false: forward; true: input gradient.  kw is even and GS divides kw / 2.
+template <bool GRAD, int NQ, int GS>
+__global__ __launch_bounds__(256) void conv_dirc_kernel(DircArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int rows = (g.TT - 1) * g.s + g.kh;
-    float* xs = dsm;
-    float* ws = dsm + rows * g.F;
-    const int b = blockIdx.y, t0 = blockIdx.x * g.TT;
+    const DirGeom& g = a.g;
+    const int b = blockIdx.y, p_first = blockIdx.x * (128 * NQ);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    dir_stage_x(x, xs, g, b, t0, rows);
-    for (int i = tid; i < g.K * 32; i += 256) {
-        const int k = i >> 5, c = i & 31;
-        ws[i] = c < g.O ? w[(long)c * g.K + k] : 0.f;
-    }
-    __syncthreads();
-    const int nt = min(g.TT, g.To - t0);
-    const int npos = nt * g.Fo;
     const int h = lane >> 5, r = lane & 31;
-    for (int tile = wave; tile * 32 < npos; tile += 4) {
-        const int p = tile * 32 + r;
-        const bool pv = p < npos;
-        const int tl = pv ? p / g.Fo : 0, fo = pv ? p - tl * g.Fo : 0;
-        const float* xb = xs + (g.s * tl) * g.F + g.s * fo;       // + i * F + j for tap k = i * kw + j (k = 2 ks + h)
-        const float* wb = ws + h * 32 + r;                          // + 64 ks
-        f32x16c acc;
+    const int n_outer = GRAD ? g.O : g.C;
+    const int n_inner = GRAD ? g.C : g.O;
+    const int P = GRAD ? g.F + g.kw - 1 : g.F;                                  // slab pitch
+    const int wpos = GRAD ? g.F : g.Fo;                                         // positions per row
+    const int npos = (GRAD ? g.T : g.To) * wpos;                                // ... per utterance
+    const int p_end = min(p_first + 128 * NQ, npos);
+    const int row0 = p_first / wpos, nrow = (p_end - 1) / wpos - row0 + 1;
+    const int srows = GRAD ? nrow + g.kh - 1 : (nrow - 1) * g.s + g.kh;
+    const int slab = srows * P;
+    f32x16c acc[NQ];
+    int xoffh[NQ];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-        int j0 = 0, roff = 0;  // tap 2 ks = (roff / F, j0): kw is not assumed even, so a pair may straddle a row
-        for (int ks0 = 0; ks0 < g.K / 2; ks0 += 4) {
-            float av[4], bv[4];
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool on = ks0 + u < g.K / 2;
-                int jj = j0 + h, ro = roff;
-                if (jj >= g.kw) { jj -= g.kw; ro += g.F; }
-                av[u] = on ? wb[64 * (ks0 + u)] : 0.f;
-                bv[u] = on ? xb[ro + jj] : 0.f;
-                j0 += 2;
-                if (j0 >= g.kw) { j0 -= g.kw; roff += g.F; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+        const int p = min(p_first + (wave * NQ + q) * 32 + r, p_end - 1);  // beyond the end: recompute the last one
+        const int tl = p / wpos - row0, fo = p % wpos;
+        xoffh[q] = GRAD ? (tl + g.kh - 1) * P + fo + g.kw - 1 - h : (g.s * tl) * P + g.s * fo + h;
+    }
+    const int GR = g.kw / (2 * GS);
+    const int total = n_outer * g.kh * GR;
+    const float* wp = a.wt + h * 32 + r;
+    DircCursor cu;
+    cu.outer = 0; cu.i = 0; cu.jg = 0;
+    float a0[GS], a1[GS], a2[GS];
+    dirc_load_a<GS>(wp, a0);
+    dirc_load_a<GS>(wp, a1);
+    for (int fg = 0; fg < total; fg += 3) {
+        dirc_load_a<GS>(wp, a2);
+        dirc_group<GRAD, NQ, GS>(a, cu, dsm, b, row0, srows, slab, P, n_outer, GR, tid, xoffh, a0, acc);
+        if (fg + 1 < total) {
+            dirc_load_a<GS>(wp, a0);
+            dirc_group<GRAD, NQ, GS>(a, cu, dsm, b, row0, srows, slab, P, n_outer, GR, tid, xoffh, a1, acc);
         }
-        // C/D layout: column (position) = lane & 31, row (channel) = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
-        if (pv) {
-            float* yo = y + (long)b * g.ys_b + (long)(t0 + tl) * g.ys_t + fo;
+        if (fg + 2 < total) {
+            dirc_load_a<GS>(wp, a1);
+            dirc_group<GRAD, NQ, GS>(a, cu, dsm, b, row0, srows, slab, P, n_outer, GR, tid, xoffh, a2, acc);
+        }
+    }
+    // C/D layout: column (position) = lane & 31, row (inner channel) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5):
+    // a register holds 32 consecutive positions of one channel
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (c < g.O) yo[(long)c * g.ys_c] = fmaxf(acc[q] + bias[c], 0.f);
-            }
+    for (int q = 0; q < NQ; ++q) {
+        const int p = p_first + (wave * NQ + q) * 32 + r;
+        if (p >= p_end) continue;
+        const int t = p / wpos, fo = p - t * wpos;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ch = (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (ch >= n_inner) continue;
+            if (GRAD) a.dst[(((long)b * g.C + ch) * g.T + t) * g.F + fo] = acc[q][e];
+            else a.dst[(long)b * g.ys_b + (long)ch * g.ys_c + (long)t * g.ys_t + fo] = fmaxf(acc[q][e] + a.bias[ch], 0.f);
         }
     }
 }
 
-// Weight / bias gradient of the same conv.  grid = nblocks persistent blocks walking the (b, slab) list; LDS:
-// xs[rows][F] | dyp[g.TT * Fo][33] (dy masked by y > 0; pitch 33: the A fragment reads 32 channels of one position).
-// Each wave takes every 4th PAIR of positions of a slab (the MFMA's k = 2 lanes) and keeps NT tap tiles of 16 registers;
-// tile n covers taps 32 n .. 32 n + 31, column K of the last tile multiplies by 1 (the bias gradient).
+// Weight / bias gradient, any number of input channels <= 32.  512 threads: the 8 waves are CW channel slots x PW = 8 / CW
+// position ways (CW = 8 for the stacked convs: every wave one input channel and all positions; CW = 1 for the first
+// conv: the waves split the positions and are folded in a fixed order at the end).  grid (nb, ceil(C / CW)); a block
+// walks the (b, slab) list i, i + nb, ...; per slab it stages CW input slabs and the masked dy slab -- from the packed
+// copy ([position][O], one contiguous run) when several channel groups would each re-gather it from y / dy.
+// LDS: xs[CW][rows F] | {1, 0} | dyp[TT Fo + 40][33] | posoff[TT Fo + 40].
+// As in conv_dirc_kernel the instructions beside the MFMAs are what is scarce: a lane's B address is
+// posoff[p] * m01[n] + tabs[n] -- one v_mad -- where posoff is a per-block table (no division in the loop) and the
+// bias column (tap == K) and the padding columns point at the constants 1 and 0 stored behind the slabs.
 template <int NT>
-__global__ __launch_bounds__(256) void conv1_dw_direct_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                             const float* __restrict__ dy, float* __restrict__ part,
-                                                             DirGeom g, int nslab_t) {
+__device__ __forceinline__ void dw2_operands(const float* __restrict__ dsm, const float* __restrict__ dyp,
+                                             const int* __restrict__ posoff, int p0, int npos, int h, int r,
+                                             const int (&tabs)[NT], const int (&m01)[NT], float (&av)[2], float (&bv)[2][NT]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int p = p0 + 2 * e + h;
+        const int po = posoff[p];
+        const float a = dyp[p * 33 + r];
+        av[e] = p < npos ? a : 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[e][n] = dsm[po * m01[n] + tabs[n]];
+    }
+}
+
+template <int NT, int CW>
+__global__ __launch_bounds__(512) void conv_dw2_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ dy, const float* __restrict__ dypg,
+                                                      float* __restrict__ part, DirGeom g, int nslab_t) {
+    constexpr int PW = 8 / CW;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int rows = (g.TT - 1) * g.s + g.kh;
-    float* xs = dsm;
-    float* dyp = dsm + rows * g.F;                 // [g.TT * Fo][33]
+    const int slabsz = rows * g.F;
+    const int xs_end = CW * slabsz;                          // the constants 1, 0
+    const int maxpos = g.TT * g.Fo + 40;                     // the operand prefetch looks 4 PW + 3 positions past the last
+    float* dyp = dsm + ((xs_end + 2 + 3) & ~3);              // [maxpos][33]
+    int* posoff = reinterpret_cast<int*>(dyp + maxpos * 33); // [maxpos]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, r = lane & 31;
+    const int cs = wave % CW, pwy = wave / CW;
+    const int c = CW * blockIdx.y + cs;                      // wave-uniform; slots beyond C idle through the barriers
     f32x16c acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
-    // this lane's tap per tile: k = 32 n + r -> offset i * F + j in the slab; tap == K: the constant 1; beyond: 0
-    int toff[NT];
-    float tone[NT];
+    int tabs[NT], m01[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int k = 32 * n + r;
-        toff[n] = k < g.K ? (k / g.kw) * g.F + (k % g.kw) : -1;
-        tone[n] = k == g.K ? 1.f : 0.f;
+        m01[n] = k < g.K ? 1 : 0;
+        tabs[n] = k < g.K ? cs * slabsz + (k / g.kw) * g.F + (k % g.kw) : (k == g.K ? xs_end : xs_end + 1);
     }
+    for (int i = tid; i < maxpos; i += 512) {
+        const int tl = i / g.Fo, fo = i - tl * g.Fo;
+        posoff[i] = tl < g.TT ? (g.s * tl) * g.F + g.s * fo : 0;
+    }
+    for (int i = tid; i < maxpos * 33; i += 512) dyp[i] = 0.f;  // the columns >= O and the rows >= TT Fo stay zero
+    if (tid < 2) dsm[xs_end + tid] = tid == 0 ? 1.f : 0.f;
     const int nslabs = g.B * nslab_t;
     for (int slab = blockIdx.x; slab < nslabs; slab += gridDim.x) {
         const int b = slab / nslab_t, t0 = (slab - b * nslab_t) * g.TT;
         const int nt = min(g.TT, g.To - t0);
         const int npos = nt * g.Fo;
-        __syncthreads();  // the previous slab's readers are done
-        dir_stage_x(x, xs, g, b, t0, rows);
-        for (int i = tid; i < npos * 32; i += 256) {  // (channel, frame, f') with f' fastest: the caller's layout is f'-contiguous
-            const int fo = i % g.Fo, q = i / g.Fo;
-            const int tl = q % nt, c = q / nt;
-            float v = 0.f;
-            if (c < g.O) {
-                const long o = (long)b * g.ys_b + (long)c * g.ys_c + (long)(t0 + tl) * g.ys_t + fo;
-                v = y[o] > 0.f ? dy[o] : 0.f;
+        __syncthreads();  // the previous slab's readers are done (first trip: the fills above)
+        {
+            const int valid = max(0, min(rows, g.T - g.s * t0)) * g.F;
+            const float* src = x + (((long)b * g.C + CW * blockIdx.y) * g.T + (long)g.s * t0) * g.F;
+#pragma unroll 4
+            for (int i = tid; i < CW * slabsz; i += 512) {
+                const int cc = i / slabsz, o = i - cc * slabsz;
+                const bool on = o < valid && CW * (int)blockIdx.y + cc < g.C;
+                const float v = src[on ? (long)cc * g.T * g.F + o : 0];
+                dsm[i] = on ? v : 0.f;
             }
-            dyp[(tl * g.Fo + fo) * 33 + c] = v;
         }
-        __syncthreads();
-        for (int p0 = 2 * wave; p0 < npos; p0 += 16) {  // two position pairs per trip: their LDS reads go out together
-            float a[2], bv[2][NT];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int p = p0 + 8 * e + h;
-                const bool pv = p < npos;
-                const int tl = pv ? p / g.Fo : 0, fo = pv ? p - tl * g.Fo : 0;
-                a[e] = pv ? dyp[p * 33 + r] : 0.f;
-                const float* xb = xs + (g.s * tl) * g.F + g.s * fo;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float v = toff[n] >= 0 ? xb[toff[n]] : tone[n];
-                    bv[e][n] = pv ? v : 0.f;
+        if (dypg) {  // the slab of the packed masked gradient is contiguous: npos x O floats
+            const float* src = dypg + ((long)b * g.To + t0) * g.Fo * g.O;
+            if (g.O == 32) {
+                const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll 4
+                for (int i = tid; i < npos * 8; i += 512) {
+                    const float4 v = s4[i];
+                    float* d = dyp + (i >> 3) * 33 + (i & 7) * 4;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            } else {
+#pragma unroll 4
+                for (int i = tid; i < npos * g.O; i += 512) {
+                    const int pp = i / g.O;
+                    dyp[pp * 33 + (i - pp * g.O)] = src[i];
                 }
             }
+        } else {  // (channel, frame, f') with f' fastest: the caller's layout is f'-contiguous
+#pragma unroll 4
+            for (int i = tid; i < npos * g.O; i += 512) {
+                const int fo = i % g.Fo, q = i / g.Fo;
+                const int tl = q % nt, o = q / nt;
+                const long off = (long)b * g.ys_b + (long)o * g.ys_c + (long)(t0 + tl) * g.ys_t + fo;
+                const float yv = y[off], dv = dy[off];
+                dyp[(tl * g.Fo + fo) * 33 + o] = yv > 0.f ? dv : 0.f;
+            }
+        }
+        __syncthreads();
+        if (c < g.C) {
+            // operands of the next trip (two position pairs) are read before this trip's products are issued
+            float av[2], bv[2][NT], an[2], bn[2][NT];
+            dw2_operands<NT>(dsm, dyp, posoff, 4 * pwy, npos, h, r, tabs, m01, av, bv);
+            for (int p0 = 4 * pwy; p0 < npos; p0 += 4 * PW) {
+                dw2_operands<NT>(dsm, dyp, posoff, p0 + 4 * PW, npos, h, r, tabs, m01, an, bn);
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e][n], acc[n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e][n], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    av[e] = an[e];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bv[e][n] = bn[e][n];
+                }
+            }
         }
     }
-    // fold the 4 waves in wave order (fixed: deterministic) through one [32][32 NT] LDS tile, write the block's partial
-    float* red = dsm;  // 32 * 32 NT floats <= the LDS request (checked by the host)
-    for (int wv = 0; wv < 4; ++wv) {
+    if (PW == 1) {
+        if (c >= g.C) return;
+        float* out = part + ((long)blockIdx.x * g.C + c) * 32 * (32 * NT);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+                out[o * (32 * NT) + 32 * n + r] = acc[n][q];
+            }
+        return;
+    }
+    // fold the position ways in a fixed order (deterministic) through [CW][32][32 NT] floats of LDS
+    float* red = dsm + cs * (32 * 32 * NT);
+    for (int pw = 0; pw < PW; ++pw) {
         __syncthreads();
-        if (wave == wv) {
+        if (pwy == pw) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
-                    float* o = &red[c * (32 * NT) + 32 * n + r];
-                    *o = wv == 0 ? acc[n][q] : *o + acc[n][q];
+                    const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+                    float* dst = &red[o * (32 * NT) + 32 * n + r];
+                    *dst = pw == 0 ? acc[n][q] : *dst + acc[n][q];
                 }
         }
     }
     __syncthreads();
-    float* out = part + (long)blockIdx.x * 32 * (32 * NT);
-    for (int i = tid; i < 32 * 32 * NT; i += 256) out[i] = red[i];
+    for (int i = tid; i < CW * 32 * 32 * NT; i += 512) {
+        const int cc = i / (32 * 32 * NT);
+        if (CW * (int)blockIdx.y + cc < g.C)
+            part[((long)blockIdx.x * g.C + CW * blockIdx.y + cc) * 32 * (32 * NT) + (i - cc * (32 * 32 * NT))] = dsm[i];
+    }
 }
-
-// dw[c][k] (c < O, k < K) and dbias[c] = the fixed-order sum of the per-block partials [nb][32][NTK]
-// 8 lanes per output: lane j adds the partials j, j + 8, ... in order, then a fixed xor tree folds the 8 sums
-__global__ __launch_bounds__(256) void conv1_dw_fold_kernel(const float* __restrict__ part, int nb, int NTK, int O, int K,
-                                                           float* __restrict__ dw, float* __restrict__ dbias) {
-    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 3, j = threadIdx.x & 7;
-    const bool on = idx < O * (K + 1);
-    const int c = on ? idx / (K + 1) : 0, k = on ? idx - c * (K + 1) : 0;
-    const float* p = part + (long)c * NTK + k;
-    float s0 = 0.f;
-    if (on)
-        for (int b = j; b < nb; b += 8) s0 += p[(long)b * 32 * NTK];
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
-    if (!on || j != 0) return;
-    if (k < K) dw[(long)c * K + k] = s0;
-    else dbias[c] = s0;
-}
-
-constexpr int kDirDwBlocks = 512;
 
 constexpr int kDwBlocks = 512;
 
@@ -462,30 +659,123 @@ int grid_for(long total) {
 
 }  // namespace
 
-static DirGeom dir_geom(const ConvGeom& g, long ys_b, long ys_c, long ys_t) {
+static DirGeom dir_geom(const ConvGeom& g, long ys_b, long ys_c, long ys_t, int TT) {
     DirGeom d;
-    d.B = g.B; d.T = g.T; d.F = g.F; d.O = g.O; d.kh = g.kh; d.kw = g.kw; d.s = g.s; d.To = g.To; d.Fo = g.Fo; d.K = g.K;
+    d.B = g.B; d.C = g.C; d.T = g.T; d.F = g.F; d.O = g.O; d.kh = g.kh; d.kw = g.kw; d.s = g.s; d.To = g.To; d.Fo = g.Fo;
+    d.K = g.kh * g.kw;
     d.ys_b = ys_b; d.ys_c = ys_c; d.ys_t = ys_t;
-    d.TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
+    d.TT = TT;
     return d;
 }
+// conv_dirc_kernel: tiles per wave (a block takes 128 nq positions of an utterance).  The slab of the outer-channel chunk
+// must fit 64 KB; among those that do, the smallest estimated makespan (blocks / 256 CUs, rounded up, times nq), ties to
+// the larger nq (fewer weight loads per product).  0: no nq fits.
+static size_t dirc_lds(const ConvGeom& g, bool grad, int nq) {
+    const int wpos = grad ? g.F : g.Fo;
+    const int nrow = (128 * nq + wpos - 2) / wpos + 1;
+    const int srows = grad ? nrow + g.kh - 1 : (nrow - 1) * g.s + g.kh;
+    const int n_outer = grad ? g.O : g.C;
+    return (size_t)(n_outer < kOuterChunk ? n_outer : kOuterChunk) * srows * (grad ? g.F + g.kw - 1 : g.F) * sizeof(float);
+}
+static int dirc_nq(const ConvGeom& g, bool grad) {
+    const long npos = (long)(grad ? g.T : g.To) * (grad ? g.F : g.Fo);
+    if (g.kw & 1) return 0;  // a tap pair never straddles a tap row
+    int best = 0;
+    long best_cost = 0;
+    for (int nq = 1; nq <= 4; ++nq) {
+        if (dirc_lds(g, grad, nq) > 64 * 1024) break;
+        const long blocks = (npos + 128 * nq - 1) / (128 * nq) * g.B;
+        const long cost = (blocks + 255) / 256 * nq;
+        if (best == 0 || cost <= best_cost) { best = nq; best_cost = cost; }
+    }
+    return best;
+}
+static bool dir_dx_ok(const ConvGeom& g) { return dirc_nq(g, true) > 0; }
+static size_t dir_wt_bytes(const ConvGeom& g, bool grad) {  // the transposed weight copy of conv_dirc_kernel
+    return sa_align_up(((size_t)(grad ? g.O : g.C) * g.kh * g.kw * 32 + kDircWtPad) * sizeof(float), 256);
+}
 static int dir_nt(int K) { const int need = (K + 1 + 31) / 32; return need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 4 ? 4 : (need <= 6 ? 6 : 8))); }
-static size_t dir_dw_lds(const ConvGeom& g) {
+// conv_dw2_kernel: channel slots per block (the largest power of two <= min(C, 8) whose LDS footprint fits), LDS bytes
+static size_t dir_dw2_lds(const ConvGeom& g, int cw) {
     const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
-    const size_t stage = ((size_t)((TT - 1) * g.s + g.kh) * g.F + (size_t)TT * g.Fo * 33) * sizeof(float);
-    const size_t fold = (size_t)32 * 32 * dir_nt(g.K) * sizeof(float);
+    const size_t maxpos = (size_t)TT * g.Fo + 40;
+    const size_t stage = ((size_t)cw * ((TT - 1) * g.s + g.kh) * g.F + 8 + maxpos * 34) * sizeof(float);
+    const size_t fold = cw < 8 ? (size_t)cw * 32 * 32 * dir_nt(g.kh * g.kw) * sizeof(float) : 0;
     return stage > fold ? stage : fold;
+}
+static int dir_dw2_cw(const ConvGeom& g) {
+    int cw = g.C >= 8 ? 8 : g.C >= 4 ? 4 : g.C >= 2 ? 2 : 1;
+    while (cw > 1 && dir_dw2_lds(g, cw) > 150 * 1024) cw >>= 1;
+    return dir_dw2_lds(g, cw) <= 150 * 1024 ? cw : 0;
+}
+static bool dir_dw_packed(const ConvGeom& g) {  // several channel groups: gather the masked dy once, not once per group
+    return (g.C + dir_dw2_cw(g) - 1) / dir_dw2_cw(g) > 1;
+}
+// the three direct kernels take this geometry (the forward one alone decides sa_conv2d_is_direct)
+static bool dir_fwd_ok(const ConvGeom& g);
+static bool dir_bwd_ok(const ConvGeom& g) {
+    return conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo) && dir_dw2_cw(g) > 0;
+}
+static int dir_dw_blocks(const ConvGeom& g) {  // grid.x of the weight-gradient kernels
+    const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
+    const int slabs = g.B * ((g.To + TT - 1) / TT);
+    // one 512-thread block per CU (256 in all): two on some CUs and one on others would only stretch the makespan
+    const int cw = dir_dw2_cw(g);
+    int nb = 256 / ((g.C + cw - 1) / cw);
+    if (nb < 1) nb = 1;
+    if (nb > slabs) nb = slabs;
+    const int per = (slabs + nb - 1) / nb;  // even work: every block walks `per` slabs (the last ones maybe one fewer)
+    return (slabs + per - 1) / per;
+}
+
+typedef void (*Dw2FnT)(const float*, const float*, const float*, const float*, float*, DirGeom, int);
+template <int NT>
+static Dw2FnT dw2_fn_nt(int cw) {
+    return cw == 8 ? conv_dw2_kernel<NT, 8> : cw == 4 ? conv_dw2_kernel<NT, 4> : cw == 2 ? conv_dw2_kernel<NT, 2>
+                                                                                       : conv_dw2_kernel<NT, 1>;
+}
+static Dw2FnT dw2_fn(int NT, int cw) {
+    return NT == 2 ? dw2_fn_nt<2>(cw) : NT == 3 ? dw2_fn_nt<3>(cw) : NT == 4 ? dw2_fn_nt<4>(cw)
+           : NT == 6 ? dw2_fn_nt<6>(cw) : dw2_fn_nt<8>(cw);
+}
+typedef void (*DircFn)(DircArgs);
+template <bool GRAD, int GS>
+static DircFn dirc_fn(int nq) {
+    return nq == 1 ? conv_dirc_kernel<GRAD, 1, GS> : nq == 2 ? conv_dirc_kernel<GRAD, 2, GS>
+           : nq == 3 ? conv_dirc_kernel<GRAD, 3, GS> : conv_dirc_kernel<GRAD, 4, GS>;
+}
+template <bool GRAD>
+static DircFn dirc_fn(int nq, int gs) {
+    return gs == 8 ? dirc_fn<GRAD, 8>(nq) : gs == 4 ? dirc_fn<GRAD, 4>(nq) : gs == 2 ? dirc_fn<GRAD, 2>(nq) : dirc_fn<GRAD, 1>(nq);
+}
+static ctcStatus_t dirc_launch(const DircArgs& a, const ConvGeom& g, bool grad, hipStream_t stream) {
+    const int nq = dirc_nq(g, grad);
+    if (nq < 1) return CTC_STATUS_INVALID_VALUE;
+    const int kwh = g.kw / 2;
+    const int gs = kwh % 8 == 0 ? 8 : kwh % 4 == 0 ? 4 : kwh % 2 == 0 ? 2 : 1;  // tap pairs per group: divides kw / 2
+    const DircFn fn = grad ? dirc_fn<true>(nq, gs) : dirc_fn<false>(nq, gs);
+    const size_t lds = dirc_lds(g, grad, nq);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return CTC_STATUS_EXECUTION_FAILED;
+    const long npos = (long)(grad ? g.T : g.To) * (grad ? g.F : g.Fo);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((npos + 128 * nq - 1) / (128 * nq)), g.B), dim3(256), lds, stream, a);
+    return CTC_STATUS_SUCCESS;
+}
+
+static bool dir_fwd_ok(const ConvGeom& g) {
+    return conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo) && dirc_nq(g, false) > 0;
 }
 
 extern "C" int sa_conv2d_is_direct(int in_c, int F, int out_c, int kh, int kw, int s) {
-    const int Fo = conv_out(F, kw, s);
-    return Fo > 0 && conv_direct_ok(in_c, out_c, kh, kw, s, F, Fo) ? 1 : 0;
+    ConvGeom g;  // the forward kernel's footprint does not depend on B or T
+    return make_geom(&g, 1, in_c, kh + s, F, out_c, kh, kw, s) && dir_fwd_ok(g) ? 1 : 0;
 }
 
 extern "C" size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s) {
     ConvGeom g;
     if (!make_geom(&g, B, in_c, T, F, out_c, kh, kw, s)) return 0;
-    if (conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo)) return 256;  // the direct kernel needs none
+    if (dir_fwd_ok(g)) return 256 + dir_wt_bytes(g, false);  // no im2col matrix: only the transposed weight copy
     const long npos = (long)g.B * g.To * g.Fo;
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +
            sa_align_up(sa_gemm_workspace_bytes((int)npos, g.O, g.K), 256);
@@ -501,14 +791,15 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_conv2d_fwd_workspace_bytes(B, in_c, T, F, out_c, kh, kw, s)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
-    if (conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo)) {  // no im2col matrix at all (keep_cols is not filled)
-        const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
-        const size_t lds = ((size_t)((TT - 1) * g.s + g.kh) * g.F + (size_t)g.K * 32) * sizeof(float);
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)conv1_fwd_direct_kernel,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return CTC_STATUS_EXECUTION_FAILED;
-        hipLaunchKernelGGL(conv1_fwd_direct_kernel, dim3((g.To + TT - 1) / TT, g.B), dim3(256), lds, stream, x, w,
-                           bias, y, dir_geom(g, ys_b, ys_c, ys_t));
+    if (dir_fwd_ok(g)) {  // no im2col matrix at all (keep_cols is not filled)
+        const int Kc = g.kh * g.kw;
+        hipLaunchKernelGGL(conv_wt_kernel, dim3((unsigned)(((long)g.C * Kc * 32 + kDircWtPad + 255) / 256)), dim3(256), 0,
+                           stream, w, (float*)workspace, g.O, g.C, Kc, 0);
+        DircArgs a;
+        a.src = x; a.y = nullptr; a.wt = (const float*)workspace; a.bias = bias; a.dst = y;
+        a.g = dir_geom(g, ys_b, ys_c, ys_t, 0);
+        const ctcStatus_t st = dirc_launch(a, g, false, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
         SA_CHECK_LAUNCH();
         return CTC_STATUS_SUCCESS;
     }
@@ -534,8 +825,12 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
     if (gw3 > gw) gw = gw3;
     const size_t gw4 = (size_t)kDwBlocks * g.O * g.K * sizeof(float);  // conv_dw_partial_kernel
     if (conv_dw_fits(g.O, g.K) && gw4 > gw) gw = gw4;
-    const size_t gw5 = (size_t)kDirDwBlocks * 32 * 32 * 8 * sizeof(float);  // conv1_dw_direct_kernel partials
-    if (conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo) && gw5 > gw) gw = gw5;
+    if (dir_bwd_ok(g)) {  // conv_dw2_kernel partials
+        const size_t gw5 = (size_t)dir_dw_blocks(g) * g.C * 32 * 32 * dir_nt(g.kh * g.kw) * sizeof(float);
+        if (gw5 > gw) gw = gw5;
+        if (dir_dx_ok(g))  // no column matrices at all: partials | transposed weights | packed masked gradient
+            return sa_align_up(gw, 256) + dir_wt_bytes(g, true) + sa_align_up((size_t)npos * g.O * sizeof(float), 256) + 512;
+    }
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +   // cols, reused for dcols
            sa_align_up((size_t)npos * g.O * sizeof(float), 256) +   // dyp
            sa_align_up(gw, 256);
@@ -555,26 +850,54 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
     float* cols = (float*)workspace;
     float* dyp = (float*)((char*)cols + sa_align_up((size_t)npos * g.K * sizeof(float), 256));
     char* gws = (char*)dyp + sa_align_up((size_t)npos * g.O * sizeof(float), 256);
-    const size_t gws_bytes = workspace_bytes - (size_t)(gws - (char*)workspace);
-    if (!dx && conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo)) {  // direct weight / bias gradient
-        const int NT = dir_nt(g.K);
-        const size_t lds = dir_dw_lds(g);
+    size_t gws_bytes = workspace_bytes - (size_t)(gws - (char*)workspace);
+    const bool direct = dir_bwd_ok(g);
+    if (direct && dir_dx_ok(g)) {  // the workspace holds only the weight-gradient partials
+        gws = (char*)workspace;
+        gws_bytes = workspace_bytes;
+    }
+    if (direct && (!dx || dir_dx_ok(g))) {  // direct weight / bias (and input) gradient
+        const int Kc = g.kh * g.kw;
+        const int NT = dir_nt(Kc);
+        const int cw = dir_dw2_cw(g);
+        const size_t lds = dir_dw2_lds(g, cw);
         const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
         const int nslab_t = (g.To + TT - 1) / TT;
-        int nb = g.B * nslab_t;
-        if (nb > kDirDwBlocks) nb = kDirDwBlocks;
-        if (gws_bytes < (size_t)nb * 32 * 32 * NT * sizeof(float)) return CTC_STATUS_INVALID_VALUE;
-        void (*fn)(const float*, const float*, const float*, float*, DirGeom, int) =
-            NT == 2 ? conv1_dw_direct_kernel<2> : NT == 3 ? conv1_dw_direct_kernel<3> : NT == 4 ? conv1_dw_direct_kernel<4>
-            : NT == 6 ? conv1_dw_direct_kernel<6> : conv1_dw_direct_kernel<8>;
+        const int nb = dir_dw_blocks(g);
+        const size_t part_bytes = sa_align_up((size_t)nb * g.C * 32 * 32 * NT * sizeof(float), 256);
+        if (gws_bytes < part_bytes + (dx ? dir_wt_bytes(g, true) : 0)) return CTC_STATUS_INVALID_VALUE;
+        const float* dpk = nullptr;
+        if (dir_dw_packed(g)) {  // the masked gradient packed position-major ([position][O])
+            float* pk = dyp;
+            if (dir_dx_ok(g)) {
+                pk = (float*)(gws + part_bytes + dir_wt_bytes(g, true));
+                if (gws_bytes < part_bytes + dir_wt_bytes(g, true) + (size_t)npos * g.O * sizeof(float))
+                    return CTC_STATUS_INVALID_VALUE;
+            }
+            hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, pk, g, ys_b,
+                               ys_c, ys_t);
+            dpk = pk;
+        }
+        const Dw2FnT fn = dw2_fn(NT, cw);
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
-        hipLaunchKernelGGL(fn, dim3(nb), dim3(256), lds, stream, x, y, dy, (float*)gws, dir_geom(g, ys_b, ys_c, ys_t),
-                           nslab_t);
-        hipLaunchKernelGGL(conv1_dw_fold_kernel, dim3((g.O * (g.K + 1) * 8 + 255) / 256), dim3(256), 0, stream,
-                           (const float*)gws, nb, 32 * NT, g.O, g.K, dw, dbias);
+        hipLaunchKernelGGL(fn, dim3(nb, (g.C + cw - 1) / cw), dim3(512), lds, stream, x, y, dy, dpk, (float*)gws,
+                           dir_geom(g, ys_b, ys_c, ys_t, TT), nslab_t);
+        hipLaunchKernelGGL(conv_dw_fold_kernel, dim3((unsigned)(((long)g.O * g.C * (Kc + 1) * 8 + 255) / 256)), dim3(256),
+                           0, stream, (const float*)gws, nb, 32 * NT, g.O, g.C, Kc, dw, dbias);
         SA_CHECK_LAUNCH();
+        if (dx) {
+            float* wt = (float*)(gws + part_bytes);
+            hipLaunchKernelGGL(conv_wt_kernel, dim3((unsigned)(((long)g.O * Kc * 32 + kDircWtPad + 255) / 256)), dim3(256), 0,
+                               stream, w, wt, g.O, g.C, Kc, 1);
+            DircArgs a;
+            a.src = dy; a.y = y; a.wt = wt; a.bias = nullptr; a.dst = dx;
+            a.g = dir_geom(g, ys_b, ys_c, ys_t, TT);
+            const ctcStatus_t st = dirc_launch(a, g, true, stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+            SA_CHECK_LAUNCH();
+        }
         return CTC_STATUS_SUCCESS;
     }
     if (fwd_cols && !dx) {

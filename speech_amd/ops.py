@@ -110,7 +110,7 @@ def conv2d_relu_fwd(x, w, bias, s, layout="nchw", keep_cols=False):
     nbytes = L.sa_conv2d_fwd_workspace_bytes(B, C, T, F, O, kh, kw, s)
     ws = WORKSPACE.get(nbytes, x.device, "conv")
     if keep_cols and L.sa_conv2d_is_direct(C, F, O, kh, kw, s):
-        keep_cols = False  # the direct first-conv kernels build no im2col matrix: nothing to keep
+        keep_cols = False  # the direct conv kernels build no im2col matrix: nothing to keep
         direct = True
     else:
         direct = False

@@ -77,7 +77,13 @@ def test_gemm_split_k_alpha_beta_and_strided():
                                                # col2im: 8 channels per wave, several channel passes when C > 32)
                                                (2, 32, 30, 37, 32, 5, 8, 2), (1, 40, 13, 21, 8, 5, 8, 2),
                                                # kw > 32: the one-lane-per-tap col2im
-                                               (1, 2, 12, 40, 4, 3, 33, 2)])
+                                               (1, 2, 12, 40, 4, 3, 33, 2),
+                                               # direct kernels with several input channels (<= 32, even kh * kw): the
+                                               # stacked convs of the TIMIT / WSJ configs, stride 1 / 2 / other, a
+                                               # ragged last slab, more positions than one accumulator round
+                                               (2, 32, 20, 65, 32, 5, 32, 1), (2, 8, 24, 40, 32, 5, 32, 2),
+                                               (1, 32, 50, 33, 32, 5, 8, 2), (3, 5, 23, 31, 7, 4, 6, 3),
+                                               (1, 2, 70, 100, 3, 2, 2, 1)])
 @pytest.mark.parametrize("feature_layout", [False, True])
 def test_conv_relu_fwd_bwd(B, C, T, F, O, kh, kw, s, feature_layout):
     from speech_amd import ops
@@ -101,13 +107,15 @@ def test_conv_relu_fwd_bwd(B, C, T, F, O, kh, kw, s, feature_layout):
 
 @pytest.mark.parametrize("B,T,F,O,kh,kw,s", [(2, 70, 80, 32, 5, 32, 2),    # the first conv of every shipped config
                                              (1, 300, 161, 32, 5, 32, 2),  # ... at the TIMIT feature width
-                                             (3, 41, 40, 8, 5, 11, 2),     # kw odd, kh * kw odd -> generic path
-                                             (2, 37, 33, 16, 4, 7, 1),     # tap pairs straddle window rows
-                                             (2, 19, 50, 5, 2, 9, 3)])
+                                             (3, 41, 40, 8, 5, 11, 2),     # kw odd -> generic path (im2col + GEMM)
+                                             (2, 37, 33, 16, 4, 7, 1),     # kw odd, kh * kw even -> generic path
+                                             (2, 37, 33, 16, 3, 6, 1),     # kw / 2 odd: groups of one tap pair
+                                             (2, 19, 50, 5, 2, 12, 3),     # groups of two, stride 3
+                                             (2, 26, 44, 9, 5, 8, 2)])     # groups of four
 @pytest.mark.parametrize("layout", ["nchw", "btf", "tbf"])
 def test_first_conv_direct_kernels(B, T, F, O, kh, kw, s, layout):
     """One input channel: the direct MFMA kernels (no im2col matrix), forward and weight / bias gradient (need_dx=False,
-    as the encoder calls the first conv), every output layout; shapes they do not take fall back to the generic path."""
+    as the encoder calls the first conv), every output layout; an odd kernel width falls back to the generic path."""
     from speech_amd import ops, _lib
     rng = np.random.RandomState(T + F)
     x = rng.randn(B, 1, T, F)
@@ -115,7 +123,7 @@ def test_first_conv_direct_kernels(B, T, F, O, kh, kw, s, layout):
     b = rng.randn(O) * 0.1
     y_ref, cols = E.conv_relu_fwd(x, w, b, s)
     _, _, To, Fo = y_ref.shape
-    assert bool(_lib.lib().sa_conv2d_is_direct(1, F, O, kh, kw, s)) == ((kh * kw) % 2 == 0)
+    assert bool(_lib.lib().sa_conv2d_is_direct(1, F, O, kh, kw, s)) == (kw % 2 == 0)
     res = ops.conv2d_relu_fwd(dev(x), dev(w), dev(b), s, layout, keep_cols=True)
     y, ys = res[0], res[1]
     to_nchw = {"nchw": lambda t: t, "btf": lambda t: t.view(B, To, O, Fo).permute(0, 2, 1, 3),
