@@ -64,8 +64,16 @@ ctcStatus_t get_workspace_size(const int* label_lengths, const int* input_length
  *    (ctc_model.py:29-32,36); strides let both layouts run without a transpose copy:
  *        acts[b * stride_b + t * stride_t + k],  grads likewise.
  *    All pointers DEVICE.  d_costs[b] per-utterance cost.  No host synchronisation.
+ *    Below 512 utterances per call the alpha / beta chains run in the probability domain (no exp2 / log2 on the T-step
+ *    dependent chain), certified at run time -- range kept per batch of steps, flow conservation of every lattice row --
+ *    and an utterance that fails a check is recomputed by the log-domain kernels launched behind (csrc/ctc_loss.hip,
+ *    ctc_chain_p).  SA_CTC_PROB=0 selects the log-domain kernels alone.
  * ----------------------------------------------------------------------------------------------------------------*/
 size_t sa_ctc_workspace_bytes(int max_T, int max_L, int alphabet_size, int minibatch);
+
+/* Diagnostic: byte offset, inside that workspace, of int flags[minibatch] left by the last sa_ctc_loss call with gradients
+ * (0 = the probability-domain result stands, else the utterance came from the log-domain kernels). */
+size_t sa_ctc_flags_offset(int max_T, int max_L, int alphabet_size, int minibatch);
 
 ctcStatus_t sa_ctc_loss(const float* acts, float* grads /* or NULL */, long stride_t, long stride_b,
                         const int* d_flat_labels, const int* d_label_lengths, const int* d_input_lengths,

@@ -34,6 +34,7 @@ SIGNATURES = {
                                  ctcOptions]),
     "get_workspace_size": (c_int, [c_void_p, c_void_p, c_int, c_int, ctcOptions, ctypes.POINTER(c_size_t)]),
     "sa_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sa_ctc_flags_offset": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sa_ctc_loss": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                             c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sa_ctc_beam_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -124,6 +124,7 @@ struct AbShared {
     float fin[4];             // alpha-hat[T-1, 2L], its offset, alpha-hat[T-1, 2L-1], its offset
     int label_off;
     int timeout;
+    int suspect;              // probability-domain chain: a wave saw its states lose more range than the pass tolerates
 };
 constexpr int kAbSharedBytes = 256;
 
@@ -145,10 +146,13 @@ struct AbArgs {
     const int* in_lens;
     int K, T_max, blank, nchunks, Ppad, hand_stride, nbatch;
     long ly_sb;           // per-utterance stride of ly2 in floats (multiple of 4: 16-byte aligned rows block)
-    float* stash;         // [B][T_max][4][Ppad]
+    float* stash;         // [B][T_max][6][Ppad]
     float* goffs;         // [B][2][nchunks][nbatch]
     float* logp2_out;     // [B][2]: log2 p = hat + offset
     float* costs;         // [B]
+    int* flags;           // [B]: nonzero = the probability-domain pass may have lost mass for this utterance (see
+                          // ctc_chain_p): the log-domain kernels, launched behind it with gate = 1, redo exactly those
+    int gate;             // 1: process only the utterances whose flag is set
     unsigned long long* dbg;  // debug (SA_CTC_DBG): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
 };
 
@@ -180,7 +184,7 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
     // time moves forward for alpha, backward for beta
     const int t0 = DIR == 0 ? 0 : (T > 0 ? T - 1 : 0);
     const int dK = DIR == 0 ? K : -K;
-    const long dS = DIR == 0 ? 4L * Ppad : -4L * Ppad;
+    const long dS = DIR == 0 ? 6L * Ppad : -6L * Ppad;  // 6 planes per (b, t): the last two are the probability-domain chain's
     const float* em = LDS_EM ? em_lds : A.ly2 + (long)b * A.ly_sb;
     int e_l = t0 * K + own_lab;   // element index of the next step's label emission
     int e_b = t0 * K + A.blank;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
         // stash planes per (b, t): [alpha blank | alpha label | beta blank | beta label], Ppad floats each.
         // beta's label state belongs to pair j-1; lanes without a label state dump into a never-read slot
         // (label index Ppad-1 cannot exist because Ppad >= L+1).
-        float* base = A.stash + ((long)b * A.T_max + t0) * 4 * Ppad;
+        float* base = A.stash + ((long)b * A.T_max + t0) * 6 * Ppad;
         pB = base + (DIR == 0 ? 0 : 2) * Ppad + j;
         pL = base + (DIR == 0 ? 1 : 3) * Ppad + (own >= 0 ? own : Ppad - 1);
         goff = A.goffs + ((long)(b * 2 + DIR) * nchunks + chunk) * A.nbatch;
@@ -316,15 +320,207 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
     }
 }
 
-template <bool WITH_BETA, bool LDS_EM>
+// ---- the same chain in the PROBABILITY domain (the default; SA_CTC_PROB=0 keeps the log-domain chain above) ----
+// alpha_t(s) = (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) y_t(s): adds and multiplies, no exp2 / log2
+// on the 1000-step dependent chain (the log-domain step above is ~27 mostly dependent instructions, ~240 cycles).  The
+// emissions are converted once (exp2 while they are staged in LDS).
+// Range.  A lattice with T >> L spreads its states over hundreds of bits (alpha_t of "k labels emitted" goes like C(t, k):
+// C(500, 100) = 2^355), and the states that carry the posterior are NOT the largest ones, so one exponent per wave is not
+// enough (measured: with one, M-CTC loses mass from T ~ 750 on).  Every LANE therefore carries an integer exponent e for
+// its state pair (true value = hat * 2^e):
+//   * a step aligns the own pair and the value arriving from the neighbour lane to max(e, e_neighbour) -- three ldexp, the
+//     exponent travels beside the value on a second DPP; what is shifted out is below 2^-126 of the larger of two ADJACENT
+//     states, which differ by a few bits.  A pair no mass has reached yet carries the exponent "nothing" and adopts the
+//     neighbour's when the front arrives;
+//   * every kPRenorm steps a lane brings its pair's larger state back to 2^kPTarget (an exact power-of-two shift), so
+//     between two of them a pair may lose 2^-(126 + kPTarget) -- 56 bits per step -- before anything is flushed, and
+//     grows by at most 3^kPRenorm.
+// What can still go wrong is a pair decaying faster than that (every label in reach below 2^-56 for steps on end), or two
+// adjacent states more than 2^126 apart of which the smaller matters later -- emissions far beyond any model's.  The pass
+// is therefore CERTIFIED rather than trusted: ctc_grad_kernel checks flow conservation, sum_s alpha_t(s) beta_t(s) / y_t(s)
+// = p for every row t (a lost path shows up as rows that no longer sum to one; so does a NaN), and flags the utterance
+// otherwise; so does an utterance the pass finds infeasible.  Flagged utterances are recomputed by the log-domain kernels
+// launched right behind (they return at once when no flag is set).  test_gpu_ctc.py drives both paths and the hand-over.
+// Against the fp64 oracle the pass is the MORE accurate of the two: M-CTC max |gradient error| 7e-6 (log domain: 3e-4,
+// whose states sit at |log2 p| ~ 5000 where fp32 resolves 5e-4).
+constexpr int kPTarget = 100;
+constexpr int kPRenorm = 4;
+
+template <int DIR, bool WITH_BETA, bool LDS_EM, bool HAS_PROD, bool HAS_CONS>  // a chunk before / after this one in the pipeline
+__device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float* hand_all, float* hdummy,
+                                            const float* em_lds, int b, int chunk, int lane, int L, int T) {
+    const int nchunks = A.nchunks, K = A.K, Ppad = A.Ppad;
+    const int* lab = A.labels + sh->label_off;
+    const int j = chunk * 64 + lane;  // pair index: (blank_j, label_j) for alpha, (label_{j-1}, blank_j) for beta
+    const int own = DIR == 0 ? j : j - 1;
+    const bool own_ok = own >= 0 && own < L;
+    const int own_lab = own_ok ? lab[own] : A.blank;
+    const float skipf = (j >= 1 && j <= L - 1 && lab[j] != lab[j - 1]) ? 1.f : 0.f;
+
+    const int prod_chunk = DIR == 0 ? chunk - 1 : chunk + 1;
+    constexpr bool has_prod = HAS_PROD;  // = prod_chunk >= 0 && prod_chunk < nchunks
+    constexpr bool has_cons = HAS_CONS;  // = DIR == 0 ? (chunk + 1 < nchunks) : (chunk > 0), decided by the caller: a
+                                         // wave-uniform branch per step is still a taken branch per step
+    // hand-off arrays of {label hat, exponent} pairs: entry r holds the edge lane's state after step r - 1
+    float* hand_w = hand_all + (long)(DIR * nchunks + chunk) * 2 * A.hand_stride;
+    const float* hand_r = hand_all + (long)(DIR * nchunks + (has_prod ? prod_chunk : 0)) * 2 * A.hand_stride;
+    constexpr int edge_lane = DIR == 0 ? 63 : 0;
+    constexpr int kNoExp = -(1 << 28);  // exponent of "nothing": loses every max()
+
+    float Bst = (DIR == 0 ? (j == 0) : (j == L)) ? 1.0f : 0.f;
+    float Lst = 0.f;
+    int e = Bst > 0.f ? 0 : kNoExp;  // true states = (Bst, Lst) * 2^e; a pair no mass has reached yet yields to any neighbour
+
+    const int t0 = DIR == 0 ? 0 : (T > 0 ? T - 1 : 0);
+    const int dK = DIR == 0 ? K : -K;
+    const float* em = LDS_EM ? em_lds : A.ly2 + (long)b * A.ly_sb;
+    int e_l = t0 * K + own_lab;
+    int e_b = t0 * K + A.blank;
+    // The stash, per (b, t): alpha triples {blank_j, label_j, e_j}[Ppad], then beta triples {blank_j, label_{j-1}, e_j}[Ppad]
+    // -- ONE 12-byte buffer store per step and wave: per-lane byte offset in a VGPR that never changes, the step's offset
+    // in an SGPR (no 64-bit vector address arithmetic on the chain).
+    __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)(A.stash + (long)b * A.T_max * 6 * Ppad), 0,
+                                                                     0x7fffffff, 0x00020000);
+    const int s_lane = (DIR * Ppad + j) * 12;
+    int s_step = t0 * 6 * Ppad * 4;
+    const int s_dstep = (DIR == 0 ? 6 : -6) * Ppad * 4;
+    // The hand-off to the next chunk: the edge lane's (label hat, exponent) as ONE 8-byte LDS write per step; the other
+    // lanes write the same bytes into a scratch slot of their own (no divergent branch on the chain).
+    float* hand_lane = (lane == edge_lane) ? hand_w : hdummy + 2 * lane;
+    const int hand_dlane = (lane == edge_lane) ? 2 : 0;
+
+    // Emissions of a batch of kU steps (probabilities; a lane without a label state gets 0).  No branch: the rows past the
+    // utterance's end that the one-batch-ahead prefetch touches are slack rows of the LDS copy (never used), and the
+    // global path clamps its row.
+    float el[kU], eb[kU];
+    const int e_lo = 0, e_hi = (T > 0 ? T - 1 : 0) * K;
+    auto load_emissions = [&](float* pel, float* peb) {
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+            if (LDS_EM) {
+                peb[k] = em[e_b];
+                pel[k] = own_ok ? em[e_l] : 0.f;
+            } else {
+                const int rb = min(max(e_b - A.blank, e_lo), e_hi);  // row offset, clamped into the utterance
+                peb[k] = sa_exp2(em[rb + A.blank]);
+                pel[k] = own_ok ? sa_exp2(em[rb + own_lab]) : 0.f;
+            }
+            e_b += dK;
+            e_l += dK;
+        }
+    };
+    load_emissions(el, eb);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x3 __attribute__((ext_vector_type(3)));
+    const f32x2 skip2 = {1.0f, skipf};
+    auto do_step = [&](float yl, float yb, float h, int he, bool renorm) {
+        if (renorm) {  // every kPRenorm steps: the pair's larger state back to 2^kPTarget (exact: a power of two)
+            const float mx = fmaxf(Bst, Lst);
+            const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kPTarget : 0;
+            Bst = __builtin_amdgcn_ldexpf(Bst, -f);
+            Lst = __builtin_amdgcn_ldexpf(Lst, -f);
+            e += f;
+        }
+        const float n = DIR == 0 ? sa_wave_shr1(Lst, h) : sa_wave_shl1(Lst, h);
+        const int en = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, he))
+                                                       : sa_wave_shl1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, he)));
+        const int ec = max(e, en);
+        const float Bs = __builtin_amdgcn_ldexpf(Bst, e - ec), Ls = __builtin_amdgcn_ldexpf(Lst, e - ec);
+        const float ns = __builtin_amdgcn_ldexpf(n, en - ec);
+        const f32x2 nn = {ns, ns}, base = {Bs, Ls + Bs}, yy = {yb, yl};
+        const f32x2 sum = __builtin_elementwise_fma(nn, skip2, base);  // (blank_j + n, label_j + blank_j + [skip] n)
+        const f32x2 nxt = sum * yy;
+        Bst = nxt.x;
+        Lst = nxt.y;
+        // a pair that is still empty keeps "nothing": an exponent adopted ahead of the mass would run in front of it, never
+        // re-normalised (only a pair that holds something re-normalises), while the front behind it decays away from it
+        e = fmaxf(sum.x, sum.y) > 0.f ? ec : kNoExp;
+        if (WITH_BETA) {
+            const i32x3 tr = {__builtin_bit_cast(int, Bst), __builtin_bit_cast(int, Lst), e};
+            __builtin_amdgcn_raw_buffer_store_b96(tr, sres, s_lane, s_step, 0);
+            s_step += s_dstep;
+        }
+        if (has_cons) {  // wave-uniform
+            hand_lane += hand_dlane;
+            *reinterpret_cast<float2*>(hand_lane) = make_float2(Lst, __builtin_bit_cast(float, e));
+        }
+    };
+
+    int avail = 0;
+    const bool dbg_me = A.dbg != nullptr && b == 0 && DIR == 0 && chunk == 0 && lane == 0;
+    unsigned long long c0 = 0, w0 = 0;
+    if (dbg_me) { c0 = clock64(); w0 = wall_clock64(); }
+    // the neighbour chunk's edge values (hat, exponent) for the batch starting at r0
+    float hv[kU];
+    int hx[kU];
+    auto take_edges = [&](int r0) {
+        if (has_prod) {
+            const int need = min(r0 + kU, T);
+            if (avail < need) {
+                int spins = 0;
+                while ((avail = __hip_atomic_load(&sh->prog[DIR][prod_chunk], __ATOMIC_ACQUIRE,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24)) {  // bounded: never hang the GPU on a protocol bug
+                        sh->timeout = 1;
+                        break;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kU / 2; ++q) {  // {hat, exponent} x 2 per 16-byte read
+                const float4 hq = *reinterpret_cast<const float4*>(hand_r + 2 * r0 + 4 * q);
+                hv[2 * q] = hq.x; hx[2 * q] = __builtin_bit_cast(int, hq.y);
+                hv[2 * q + 1] = hq.z; hx[2 * q + 1] = __builtin_bit_cast(int, hq.w);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kU; ++k) { hv[k] = 0.f; hx[k] = kNoExp; }
+        }
+    };
+    const int nfull = T / kU;
+    for (int bi = 0; bi < nfull; ++bi) {  // whole batches: no condition inside (a taken branch costs ~40 cycles of the chain)
+        float nel[kU], neb[kU];
+        load_emissions(nel, neb);  // prefetch the next batch's emissions
+        take_edges(bi * kU);
+#pragma unroll
+        for (int k = 0; k < kU; ++k) do_step(el[k], eb[k], hv[k], hx[k], k % kPRenorm == 0);
+        if (has_cons && lane == 0)
+            __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 1) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
+    }
+    if (nfull * kU < T) {  // the last, partial batch
+        take_edges(nfull * kU);
+#pragma unroll
+        for (int k = 0; k < kU; ++k)
+            if (nfull * kU + k < T) do_step(el[k], eb[k], hv[k], hx[k], k % kPRenorm == 0);
+        if (has_cons && lane == 0)
+            __hip_atomic_store(&sh->prog[DIR][chunk], T, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+    if (dbg_me) { A.dbg[0] = clock64() - c0; A.dbg[1] = wall_clock64() - w0; A.dbg[2] = (unsigned long long)T; }
+    if (DIR == 0) {  // as (log2 hat, offset), the form the log-domain chain leaves
+        if (j == L) { sh->fin[0] = Bst > 0.f ? sa_log2(Bst) : SA_NEG; sh->fin[1] = (float)e; }
+        if (j == L - 1) { sh->fin[2] = Lst > 0.f ? sa_log2(Lst) : SA_NEG; sh->fin[3] = (float)e; }
+    }
+}
+
+template <bool WITH_BETA, bool LDS_EM, bool PROB>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AbShared* sh = reinterpret_cast<AbShared*>(smem_raw);
-    float* hand_all = reinterpret_cast<float*>(smem_raw + kAbSharedBytes);     // [2][nchunks][hand_stride]
-    float* hoff_all = hand_all + (long)2 * A.nchunks * A.hand_stride;           // [2][nchunks][nbatch]
-    float* em_lds = hoff_all + (long)2 * A.nchunks * A.nbatch;                  // [T][K] (LDS_EM only)
+    // hand-off arrays [2][nchunks][hand_stride]: floats in the log domain, {hat, exponent} pairs in the probability domain
+    // (the region holds 2 * hand_stride floats per (direction, chunk) either way)
+    float* hand_all = reinterpret_cast<float*>(smem_raw + kAbSharedBytes);
+    float* hoff_all = hand_all + (long)2 * A.nchunks * 2 * A.hand_stride;       // [2][nchunks][nbatch]
+    float* hdummy_all = hoff_all + (long)2 * A.nchunks * A.nbatch;              // [waves][64 x 2]: see ctc_chain_p
+    float* em_lds = hdummy_all + (long)2 * A.nchunks * 128 + kU * A.K;          // [kU slack rows][T][K][kU slack rows]
+                                                                                // (LDS_EM only; see ctc_chain_p)
 
     const int b = blockIdx.x;
+    if (A.gate && A.flags[b] == 0) return;  // the log-domain pass behind a probability-domain one: flagged utterances only
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dir = wave / A.nchunks;
@@ -340,12 +536,18 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         if (lane == 0) {
             sh->label_off = acc;
             sh->timeout = 0;
+            sh->suspect = 0;
             sh->fin[0] = SA_NEG; sh->fin[1] = 0.f; sh->fin[2] = SA_NEG; sh->fin[3] = 0.f;
         }
     }
     if (lane == 0) {
         sh->prog[dir][chunk] = 0;
-        hand_all[(long)(dir * A.nchunks + chunk) * A.hand_stride] = SA_NEG;
+        if (PROB) {
+            hand_all[(long)(dir * A.nchunks + chunk) * 2 * A.hand_stride] = 0.f;
+            hand_all[(long)(dir * A.nchunks + chunk) * 2 * A.hand_stride + 1] = __builtin_bit_cast(float, -(1 << 28));
+        } else {
+            hand_all[(long)(dir * A.nchunks + chunk) * A.hand_stride] = SA_NEG;
+        }
     }
     if (LDS_EM) {
         // Stage this utterance's emission rows once: contiguous T*K floats, 16-byte aligned at both ends, as
@@ -365,16 +567,34 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * nt;
+                if (PROB) {  // log2 softmax -> probabilities, once (exp2 of the SA_NEG floor is 0)
+                    v[u].x = sa_exp2(v[u].x); v[u].y = sa_exp2(v[u].y); v[u].z = sa_exp2(v[u].z); v[u].w = sa_exp2(v[u].w);
+                }
                 if (i < n4) dst[i] = v[u];
             }
         }
     }
     __syncthreads();
 
-    if (dir == 0)
-        ctc_chain<0, WITH_BETA, LDS_EM>(A, sh, hand_all, hoff_all, em_lds, b, chunk, lane, L, T);
-    else
-        ctc_chain<1, WITH_BETA, LDS_EM>(A, sh, hand_all, hoff_all, em_lds, b, chunk, lane, L, T);
+    if (PROB) {
+        float* hd = hdummy_all + wave * 128;
+        const bool first = dir == 0 ? chunk == 0 : chunk + 1 == A.nchunks;  // of the pipeline: takes no edge values
+        const bool last = dir == 0 ? chunk + 1 == A.nchunks : chunk == 0;   // hands none on
+#define SA_CHAIN_P(D_, P_, C_) ctc_chain_p<D_, WITH_BETA, LDS_EM, P_, C_>(A, sh, hand_all, hd, em_lds, b, chunk, lane, L, T)
+        if (dir == 0) {
+            if (first) { if (last) SA_CHAIN_P(0, false, false); else SA_CHAIN_P(0, false, true); }
+            else { if (last) SA_CHAIN_P(0, true, false); else SA_CHAIN_P(0, true, true); }
+        } else {
+            if (first) { if (last) SA_CHAIN_P(1, false, false); else SA_CHAIN_P(1, false, true); }
+            else { if (last) SA_CHAIN_P(1, true, false); else SA_CHAIN_P(1, true, true); }
+        }
+#undef SA_CHAIN_P
+    } else {
+        if (dir == 0)
+            ctc_chain<0, WITH_BETA, LDS_EM>(A, sh, hand_all, hoff_all, em_lds, b, chunk, lane, L, T);
+        else
+            ctc_chain<1, WITH_BETA, LDS_EM>(A, sh, hand_all, hoff_all, em_lds, b, chunk, lane, L, T);
+    }
 
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -384,21 +604,26 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         const float f1 = sh->fin[2] + (sh->fin[3] - o0);
         const float lp = lse2_1p(f0, f1);
         const bool dead = lp < SA_NEG_TEST;
-        A.logp2_out[2 * b] = dead ? SA_NEG : lp;
-        A.logp2_out[2 * b + 1] = dead ? 0.f : o0;
+        const float lpi = PROB && !dead ? __builtin_rintf(lp) : 0.f;  // PROB: the integer part joins the offset (exact)
+        A.logp2_out[2 * b] = dead ? SA_NEG : lp - lpi;
+        A.logp2_out[2 * b + 1] = dead ? 0.f : o0 + lpi;
         float c = dead ? __builtin_inff() : (float)(-((double)lp + (double)o0) * 0.6931471805599453);
         if (sh->timeout) c = __builtin_bit_cast(float, 0x7fc00000);  // NaN marks a hand-off timeout (never expected)
         A.costs[b] = c;
+        if (PROB) A.flags[b] = dead ? 1 : 0;  // every utterance writes its flag (no memset between calls); "infeasible" is
+                                              // the log-domain kernels' call
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------- K_C
 // grid (ceil(T_max / 4), B), 256 threads: one wave per lattice row.
+template <bool PROB>  // PROB: the stash holds hats of the probability-domain chain (log2 is taken here, off the chain)
 __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restrict__ grads, long st, long sb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* occ_all = reinterpret_cast<float*>(smem_raw);  // [4 waves][K]
     const int K = A.K, Ppad = A.Ppad, nchunks = A.nchunks;
     const int b = blockIdx.y;
+    if (A.gate && A.flags[b] == 0) return;  // see ctc_alphabeta_kernel
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 4 + wave;
@@ -421,7 +646,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restri
     for (int k = lane; k < K; k += 64) occ[k] = 0.f;
 
     const float* row = A.ly2 + (long)b * A.ly_sb + (long)t * K;
-    const float* sp = A.stash + ((long)b * A.T_max + t) * 4 * Ppad;
+    const float* sp = A.stash + ((long)b * A.T_max + t) * 6 * Ppad;
     const float* goA = A.goffs + (long)(b * 2 + 0) * nchunks * A.nbatch + t / kU;
     const float* goB = A.goffs + (long)(b * 2 + 1) * nchunks * A.nbatch + (T - 1 - t) / kU;
     const float lyblank = row[A.blank];
@@ -434,19 +659,51 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restri
         const float oBn = (c + 1 < nchunks) ? goB[(c + 1) * A.nbatch] : oB;
         const float io_b = oA + oB - lpo;                       // integers: exact
         const float io_l = oA + (lane == 63 ? oBn : oB) - lpo;
-        if (j <= L) accB += sa_exp2((sp[j] + sp[2 * Ppad + j] - lyblank - lp) + io_b);
-        if (j < L) {
-            const int k = lab[j];
-            const float gm = sa_exp2((sp[Ppad + j] + sp[3 * Ppad + j] - row[k] - lp) + io_l);
-            atomicAdd(&occ[k], gm);  // LDS float atomic (ds_add_f32); this wave owns the row
+        if (PROB) {
+            // log2 of a state = its integer exponents (the hat's own and the pair's: exact) + log2 of the hat's mantissa in
+            // [-1, 0): the float sum below only holds small numbers wherever the occupancy is not itself negligible
+            // stash of the probability-domain chain: alpha triples {blank_j, label_j, e_j}, then beta triples
+            // {blank_j, label_{j-1}, e_j} (ctc_chain_p)
+            const float* ta = sp + 3 * j;
+            const float* tb = sp + 3 * (Ppad + j);
+            if (j <= L) {
+                const float a = ta[0], bt = tb[0];
+                const float fr = sa_log2(__builtin_amdgcn_frexp_mantf(a)) + sa_log2(__builtin_amdgcn_frexp_mantf(bt));
+                const int in = __builtin_amdgcn_frexp_expf(a) + __builtin_amdgcn_frexp_expf(bt) +
+                               __builtin_bit_cast(int, ta[2]) + __builtin_bit_cast(int, tb[2]);
+                accB += sa_exp2((fr - lyblank - lp) + ((float)in - lpo));  // log2 0 = -inf: an empty state adds exp2(-inf) = 0
+            }
+            if (j < L) {
+                const int k = lab[j];
+                const float a = ta[1], bt = tb[4];  // beta's label state j belongs to beta pair j + 1
+                const float fr = sa_log2(__builtin_amdgcn_frexp_mantf(a)) + sa_log2(__builtin_amdgcn_frexp_mantf(bt));
+                const int in = __builtin_amdgcn_frexp_expf(a) + __builtin_amdgcn_frexp_expf(bt) +
+                               __builtin_bit_cast(int, ta[2]) + __builtin_bit_cast(int, tb[5]);
+                atomicAdd(&occ[k], sa_exp2((fr - row[k] - lp) + ((float)in - lpo)));
+            }
+        } else {
+            if (j <= L) accB += sa_exp2((sp[j] + sp[2 * Ppad + j] - lyblank - lp) + io_b);
+            if (j < L) {
+                const int k = lab[j];
+                const float gm = sa_exp2((sp[Ppad + j] + sp[3 * Ppad + j] - row[k] - lp) + io_l);
+                atomicAdd(&occ[k], gm);  // LDS float atomic (ds_add_f32); this wave owns the row
+            }
         }
     }
     accB = sa_wave_sum_dpp(accB);
     __threadfence_block();
+    float total = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float y = sa_exp2(row[k]);
         const float o = (k == A.blank) ? accB : occ[k];
         g[k] = y - o;
+        total += o;
+    }
+    if (PROB) {
+        // certification (2) of the probability-domain pass: the occupancies of a row sum to one -- the paths through the
+        // lattice at time t are all the paths -- unless mass was lost on the way (NaN compares false: flagged too)
+        total = sa_wave_sum_dpp(total);
+        if (!(fabsf(total - 1.0f) < 1e-4f) && lane == 0) atomicOr(&A.flags[b], 2);
     }
 }
 
@@ -847,31 +1104,50 @@ static inline int ctc_nchunks(int max_L) { return (max_L + 1 + 63) / 64; }
 static inline int ctc_nbatch(int max_T) { return (max_T + kU - 1) / kU + 1; }
 
 static size_t ctc_ws_layout(int max_T, int max_L, int K, int B, size_t* off_ly2, size_t* off_stash, size_t* off_lp,
-                            size_t* off_goffs) {
+                            size_t* off_goffs, size_t* off_flags) {
     const int nch = ctc_nchunks(max_L);
     size_t o = 0;
     *off_ly2 = o;   o += sa_align_up((size_t)B * sa_align_up((size_t)max_T * K, 4) * sizeof(float), 256);
-    *off_stash = o; o += sa_align_up((size_t)B * max_T * 4 * nch * 64 * sizeof(float), 256);
+    *off_stash = o; o += sa_align_up((size_t)B * max_T * 6 * nch * 64 * sizeof(float), 256);
     *off_lp = o;    o += sa_align_up((size_t)B * sizeof(float) * 2, 256);
     *off_goffs = o; o += sa_align_up((size_t)B * 2 * nch * ctc_nbatch(max_T) * sizeof(float), 256);
+    *off_flags = o; o += sa_align_up((size_t)B * sizeof(int), 256);
     return o;
 }
 
 extern "C" size_t sa_ctc_workspace_bytes(int max_T, int max_L, int alphabet_size, int minibatch) {
     if (max_T < 0 || max_L < 0 || alphabet_size <= 0 || minibatch <= 0) return 0;
-    size_t a, b, c, d;
-    return ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d);
+    size_t a, b, c, d, e;
+    return ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d, &e);
 }
 
-template <bool WITH_BETA, bool LDS_EM>
+// diagnostic (tests): byte offset, inside a workspace of sa_ctc_workspace_bytes(...) bytes, of the int[minibatch] flags the
+// probability-domain pass leaves (0 = its result stands; else the log-domain kernels redid the utterance)
+extern "C" size_t sa_ctc_flags_offset(int max_T, int max_L, int alphabet_size, int minibatch) {
+    size_t a, b, c, d, e = 0;
+    if (max_T < 0 || max_L < 0 || alphabet_size <= 0 || minibatch <= 0) return 0;
+    ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d, &e);
+    return e;
+}
+
+template <bool WITH_BETA, bool LDS_EM, bool PROB>
 static ctcStatus_t launch_alphabeta(const AbArgs& A, int B, int threads, size_t smem, hipStream_t stream) {
-    const void* fn = (const void*)ctc_alphabeta_kernel<WITH_BETA, LDS_EM>;
+    const void* fn = (const void*)ctc_alphabeta_kernel<WITH_BETA, LDS_EM, PROB>;
     if (smem > 48 * 1024 &&
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return CTC_STATUS_EXECUTION_FAILED;
-    hipLaunchKernelGGL((ctc_alphabeta_kernel<WITH_BETA, LDS_EM>), dim3(B), dim3(threads), smem, stream, A);
+    hipLaunchKernelGGL((ctc_alphabeta_kernel<WITH_BETA, LDS_EM, PROB>), dim3(B), dim3(threads), smem, stream, A);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
+}
+template <bool PROB>
+static ctcStatus_t launch_ab_any(const AbArgs& A, int B, int threads, size_t smem, bool with_beta, bool lds_em,
+                                 hipStream_t stream) {
+    if (with_beta)
+        return lds_em ? launch_alphabeta<true, true, PROB>(A, B, threads, smem, stream)
+                      : launch_alphabeta<true, false, PROB>(A, B, threads, smem, stream);
+    return lds_em ? launch_alphabeta<false, true, PROB>(A, B, threads, smem, stream)
+                  : launch_alphabeta<false, false, PROB>(A, B, threads, smem, stream);
 }
 
 extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_t, long stride_b,
@@ -891,8 +1167,8 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     const int K = alphabet_size, B = minibatch;
-    size_t o_ly2, o_stash, o_lp, o_goffs;
-    ctc_ws_layout(max_T, max_L, K, B, &o_ly2, &o_stash, &o_lp, &o_goffs);
+    size_t o_ly2, o_stash, o_lp, o_goffs, o_flags;
+    ctc_ws_layout(max_T, max_L, K, B, &o_ly2, &o_stash, &o_lp, &o_goffs, &o_flags);
     char* ws = (char*)workspace;
 
     AbArgs A;
@@ -908,6 +1184,8 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.goffs = (float*)(ws + o_goffs);
     A.logp2_out = (float*)(ws + o_lp);
     A.costs = d_costs;
+    A.flags = (int*)(ws + o_flags);
+    A.gate = 0;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
     if (K <= 64 && (long)B * max_T >= 256 * 1024) {  // K_A, one lane per row out of an LDS tile: the
@@ -972,26 +1250,36 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         }
     }
     {  // K_B
-        const size_t fixed = kAbSharedBytes + (size_t)2 * nch * (A.hand_stride + A.nbatch) * sizeof(float);
-        const size_t with_em = fixed + sa_align_up((size_t)max_T * K * sizeof(float), 16);
-        const bool lds_em = with_em <= 150 * 1024;  // stage the utterance's emissions in LDS when they fit
+        const size_t fixed = kAbSharedBytes + (size_t)2 * nch * (2 * A.hand_stride + A.nbatch + 128) * sizeof(float);
+        const size_t with_em = fixed + sa_align_up((size_t)(max_T + 2 * kU) * K * sizeof(float), 16);
+        const bool lds_em = with_em <= 156 * 1024;  // stage the utterance's emissions in LDS when they fit
         const size_t smem = lds_em ? with_em : fixed;
         if (smem > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
         const int threads = 64 * nch * (grads ? 2 : 1);
+        // probability-domain chain first (SA_CTC_PROB=0: log domain only; =2: flag every utterance, which exercises the
+        // hand-over in tests), then the log-domain kernels for whatever it flagged (see ctc_chain_p).  A score-only call
+        // has no rows to check: it stays in the log domain.
+        const char* pe = getenv("SA_CTC_PROB");
+        const int prob = !grads ? 0 : (pe ? atoi(pe) : 1);
         ctcStatus_t s;
-        if (grads)
-            s = lds_em ? launch_alphabeta<true, true>(A, B, threads, smem, stream)
-                       : launch_alphabeta<true, false>(A, B, threads, smem, stream);
-        else
-            s = lds_em ? launch_alphabeta<false, true>(A, B, threads, smem, stream)
-                       : launch_alphabeta<false, false>(A, B, threads, smem, stream);
+        const dim3 ggrid((max_T + 3) / 4, B);
+        const size_t gsmem = 4 * (size_t)K * sizeof(float);
+        if (prob) {
+            s = launch_ab_any<true>(A, B, threads, smem, true, lds_em, stream);
+            if (s != CTC_STATUS_SUCCESS) return s;
+            hipLaunchKernelGGL(ctc_grad_kernel<true>, ggrid, dim3(256), gsmem, stream, A, grads, stride_t, stride_b);
+            SA_CHECK_LAUNCH();
+            if (prob == 2 && hipMemsetAsync(A.flags, 1, (size_t)B * sizeof(int), stream) != hipSuccess)
+                return CTC_STATUS_MEMOPS_FAILED;
+            A.gate = 1;
+            if (prob == 3) return CTC_STATUS_SUCCESS;  // debug: the probability-domain pass alone, flags left for inspection
+        }
+        s = launch_ab_any<false>(A, B, threads, smem, grads != nullptr, lds_em, stream);
         if (s != CTC_STATUS_SUCCESS) return s;
-    }
-    if (grads) {  // K_C
-        dim3 grid((max_T + 3) / 4, B);
-        hipLaunchKernelGGL(ctc_grad_kernel, grid, dim3(256), 4 * (size_t)K * sizeof(float), stream, A, grads,
-                           stride_t, stride_b);
-        SA_CHECK_LAUNCH();
+        if (grads) {  // K_C
+            hipLaunchKernelGGL(ctc_grad_kernel<false>, ggrid, dim3(256), gsmem, stream, A, grads, stride_t, stride_b);
+            SA_CHECK_LAUNCH();
+        }
     }
     return CTC_STATUS_SUCCESS;
 }

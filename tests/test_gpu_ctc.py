@@ -18,6 +18,31 @@ pytestmark = pytest.mark.gpu
 COST_RTOL = 1e-5
 
 
+@pytest.fixture(autouse=True, params=["prob", "log", "handover"])
+def ctc_mode(request, monkeypatch):
+    """The latency-regime kernels run (prob) the probability-domain chain, certified at run time, with the log-domain
+    kernels behind it for whatever it flags -- the default; (log) the log-domain kernels alone, SA_CTC_PROB=0; (handover)
+    the probability-domain pass with EVERY utterance flagged, SA_CTC_PROB=2, so that the log-domain pass overwrites all
+    of its results.  Every test below holds in all three; the K_W tests (their own kernel) run once."""
+    if request.param != "prob" and "wide" in request.node.name:
+        pytest.skip("K_W does not depend on SA_CTC_PROB")
+    if request.param == "log":
+        monkeypatch.setenv("SA_CTC_PROB", "0")
+    elif request.param == "handover":
+        monkeypatch.setenv("SA_CTC_PROB", "2")
+    return request.param
+
+
+def flags_of(B, T, K, Lmax):
+    """The per-utterance flags the last sa_ctc_loss call left in the (cached) workspace: 0 = the probability-domain
+    result stands; 1 = a wave lost range; 2 = a lattice row did not conserve the flow."""
+    from speech_amd import _lib
+    off = _lib.lib().sa_ctc_flags_offset(T, Lmax, K, B)
+    ws = _lib.WORKSPACE.get(off + 4 * B, torch.device("cuda", torch.cuda.current_device()), "ctc")
+    torch.cuda.synchronize()
+    return ws.view(torch.uint8)[off:off + 4 * B].view(torch.int32).cpu().numpy()
+
+
 def grad_atol(costs):
     c = np.asarray(costs)
     c = c[np.isfinite(c)]
@@ -100,18 +125,48 @@ def test_peaky_logits():
     compare(acts, labs, al, ll)
 
 
-def test_full_size_m_ctc():
+def test_probability_pass_is_certified(ctc_mode):
+    """Ordinary emissions (random logits = an untrained model; the M-CTC inputs) stay on the probability-domain pass: no
+    flag.  Emissions whose best path loses hundreds of bits per batch of 8 steps are flagged by the pass itself and come
+    back from the log-domain kernels -- parity holds either way, far beyond any model's range (logit scale 30: softmax
+    probabilities down to e^-200, beyond fp32 itself)."""
+    if ctc_mode != "prob":
+        pytest.skip("checks the default path")
+    acts, labs, al, ll = make(29, 6, 160, 29, 10, 50)
+    compare(acts, labs, al, ll)
+    assert not flags_of(6, 160, 29, int(ll.max())).any()
+    for scale in (8.0, 30.0):
+        acts, labs, al, ll = make(31, 6, 160, 29, 10, 50, scale=scale)
+        compare(acts, labs, al, ll)
+    assert flags_of(6, 160, 29, int(ll.max())).any()   # scale 30: flagged (and still exact)
+    # a path that is nearly certain, then a stretch of frames where every label in reach is nearly impossible, then
+    # certain again: the mass that survives the stretch is what the probability domain could lose
+    rng = np.random.RandomState(37)
+    B, T, K, L = 3, 96, 12, 20
+    labs = np.concatenate([rng.permutation(K - 1)[:L % (K - 1)].tolist() + rng.randint(0, K - 1, L - L % (K - 1)).tolist()
+                           for _ in range(B)]).astype(np.int32)
+    acts = rng.randn(B, T, K).astype(np.float32)
+    acts[:, 40:56, :] *= 40.0
+    al, ll = np.full(B, T, np.int32), np.full(B, L, np.int32)
+    compare(acts, labs, al, ll)
+
+
+def test_full_size_m_ctc(ctc_mode):
     # BASELINE.json M-CTC: B=32, T=1000, V+1=29, L=100, seed 2017
     acts, labs, al, ll = make(2017, 32, 1000, 29, 100, 100)
     err = compare(acts, labs, al, ll)
     print("M-CTC max |grad err| vs fp64 oracle:", err)
+    if ctc_mode == "prob":
+        assert not flags_of(32, 1000, 29, 100).any()  # the headline shape runs the probability-domain pass alone
 
 
 def test_score_only_matches():
     acts, labs, al, ll = make(13, 4, 90, 29, 10, 30)
     c1, _ = run_hip(acts, labs, al, ll, want_grad=True)
     c2, g2 = run_hip(acts, labs, al, ll, want_grad=False)
-    assert g2 is None and np.array_equal(c1, c2)
+    # the score-only call runs the log-domain chain alone (no lattice rows to certify a probability-domain pass on)
+    assert g2 is None
+    np.testing.assert_allclose(c1, c2, rtol=2e-6)
 
 
 def test_autograd_module_reduction_and_backward():

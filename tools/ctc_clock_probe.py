@@ -18,7 +18,7 @@ for (B, L) in [(32, 100), (32, 60), (1, 60)]:
         # goffs region offset = sum of the aligned ly2, stash, lp regions (mirror of ctc_ws_layout)
         al256 = lambda x: (x + 255) // 256 * 256
         nch = (L + 1 + 63) // 64
-        off = al256(B * ((T * K + 3) // 4 * 4) * 4) + al256(B * T * 4 * nch * 64 * 4) + al256(B * 8)
+        off = al256(B * ((T * K + 3) // 4 * 4) * 4) + al256(B * T * 6 * nch * 64 * 4) + al256(B * 8)
         v = ws[off:off + 24].cpu().numpy().view(np.uint64)
         cyc, ticks, steps = int(v[0]), int(v[1]), int(v[2])
         print("B=%d L=%d grad=%s: %.1f cycles/step, %.1f ns/step, effective clock %.2f GHz" % (B, L, want_grad, cyc / steps, ticks * 10.0 / steps, cyc / (ticks * 10.0)))

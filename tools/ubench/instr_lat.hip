@@ -28,6 +28,10 @@ __global__ void probe(float* out, float seed) {
                 if (OP == 10) v[i] = __builtin_amdgcn_rcpf(v[i]);
                 if (OP == 11) v[i] = DPP(v[i], v[i], 0x130);   // wave_shl:1
                 if (OP == 12) v[i] = DPP(v[i], v[i], 0x142);   // row_bcast15
+                if (OP == 13) v[i] = __builtin_amdgcn_ldexpf(v[i], (int)threadIdx.x & 1);   // v_ldexp_f32
+                if (OP == 14) v[i] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[i]), (int)threadIdx.x) - 1);  // v_max_i32 + v_sub
+                if (OP == 15) v[i] = (float)__builtin_amdgcn_frexp_expf(v[i]) + 3.0f;   // frexp_exp + cvt + add
+                if (OP == 16) { out[(blockIdx.x * blockDim.x + threadIdx.x) + (it & 7) * 65536] = v[i]; v[i] += 1.0f; }   // store + add
             }
         }
     }
@@ -58,6 +62,7 @@ int main() {
     printf("clockRate %d kHz, CUs %d\n", p.clockRate, p.multiProcessorCount);
 #define ALL(OP, NAME) run<OP,1>(NAME, d, 256, 256); run<OP,4>(NAME, d, 256, 256); run<OP,4>(NAME, d, 256, 1024);
     ALL(0, "v_add") ALL(6, "v_fma") ALL(1, "v_exp") ALL(2, "v_log") ALL(10, "v_rcp") ALL(3, "dpp wave_shr") ALL(11, "dpp wave_shl") ALL(4, "dpp row_shr") ALL(12, "dpp row_bcast15")
+    ALL(13, "v_ldexp") ALL(14, "imax+sub") ALL(15, "frexp+cvt+add") ALL(16, "store+add")
     ALL(5, "v_max3") ALL(8, "v_med3") ALL(9, "cmp+cndmask+mul") ALL(7, "shfl_up")
     // warm clock check: same probe after everything
     run<0,1>("v_add (again)", d, 256, 256);
