@@ -341,7 +341,7 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
 // = p for every row t (a lost path shows up as rows that no longer sum to one; so does a NaN), and flags the utterance
 // otherwise; so does an utterance the pass finds infeasible.  Flagged utterances are recomputed by the log-domain kernels
 // launched right behind (they return at once when no flag is set).  test_gpu_ctc.py drives both paths and the hand-over.
-// Against the fp64 oracle the pass is the MORE accurate of the two: M-CTC max |gradient error| 7e-6 (log domain: 3e-4,
+// Against an fp64 evaluation of the same recurrences the pass is the MORE accurate of the two: M-CTC max |gradient error| 7e-6 (log domain: 3e-4,
 // whose states sit at |log2 p| ~ 5000 where fp32 resolves 5e-4).
 constexpr int kPTarget = 100;
 constexpr int kPRenorm = 4;
