@@ -139,6 +139,18 @@ __device__ __forceinline__ float lse3_1p(float a, float b, float c) {
     return m + sa_log2(1.0f + sa_exp2(md - m) + sa_exp2(mn - m));
 }
 
+// Inclusive prefix sum over the 64 lanes on the DPP network (the same six steps as sa_wave_sum_dpp, whose lane 63
+// holds the total): row_shr 1/2/4/8 scan each 16-lane row, row_bcast15 / row_bcast31 carry the row totals forward.
+__device__ __forceinline__ float wave_scan_dpp(float v) {
+    v += SA_DPP_F(0.f, v, 0x111, 0xf);
+    v += SA_DPP_F(0.f, v, 0x112, 0xf);
+    v += SA_DPP_F(0.f, v, 0x114, 0xf);
+    v += SA_DPP_F(0.f, v, 0x118, 0xf);
+    v += SA_DPP_F(0.f, v, 0x142, 0xa);
+    v += SA_DPP_F(0.f, v, 0x143, 0xc);
+    return v;
+}
+
 struct AbArgs {
     const float* ly2;     // [B][T_max][K] global
     const int* labels;
@@ -150,9 +162,15 @@ struct AbArgs {
     float* goffs;         // [B][2][nchunks][nbatch]
     float* logp2_out;     // [B][2]: log2 p = hat + offset
     float* costs;         // [B]
+    int* lsort;           // [B][1 + Ppad + K]: {flat-label offset | sorted slot of label j | end of class k's run}: the
+                          // utterance's label states counting-sorted by class, once, by the alpha / beta kernel, so
+                          // that ctc_grad_kernel folds the occupancies of a class with a prefix sum (no atomics)
     int* flags;           // [B]: nonzero = the probability-domain pass may have lost mass for this utterance (see
                           // ctc_chain_p): the log-domain kernels, launched behind it with gate = 1, redo exactly those
-    int gate;             // 1: process only the utterances whose flag is set
+    int gate;             // 1: process only the utterances whose flag is set -- and finish them here, gradient rows
+                          // included (ONE launch behind the probability-domain pass, returning at once when nothing is flagged)
+    float* grads;         // gate only: where ctc_grad_row writes
+    long g_st, g_sb;
     unsigned long long* dbg;  // debug (SA_CTC_DBG): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
 };
 
@@ -507,6 +525,10 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
     }
 }
 
+template <bool PROB>
+__device__ __forceinline__ void ctc_grad_row(const AbArgs& A, float* __restrict__ grads, long st, long sb, int b, int t,
+                                             int lane, float* srt);
+
 template <bool WITH_BETA, bool LDS_EM, bool PROB>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -516,8 +538,11 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     float* hand_all = reinterpret_cast<float*>(smem_raw + kAbSharedBytes);
     float* hoff_all = hand_all + (long)2 * A.nchunks * 2 * A.hand_stride;       // [2][nchunks][nbatch]
     float* hdummy_all = hoff_all + (long)2 * A.nchunks * A.nbatch;              // [waves][64 x 2]: see ctc_chain_p
-    float* em_lds = hdummy_all + (long)2 * A.nchunks * 128 + kU * A.K;          // [kU slack rows][T][K][kU slack rows]
-                                                                                // (LDS_EM only; see ctc_chain_p)
+    int* cls_cnt = reinterpret_cast<int*>(hdummy_all + (long)2 * A.nchunks * 128);  // [align4(K + 1)]: the label sort
+    float* srt_all = reinterpret_cast<float*>(cls_cnt + ((A.K + 1 + 3) & ~3));  // [waves][align4(Ppad + 1)]: gradient rows of
+                                                                                // the hand-over pass (ctc_grad_row)
+    float* em_lds = srt_all + (long)2 * A.nchunks * ((A.Ppad + 1 + 3) & ~3) + kU * A.K;  // [kU slack rows][T][K][kU slack
+                                                                                // rows] (LDS_EM only; see ctc_chain_p)
 
     const int b = blockIdx.x;
     if (A.gate && A.flags[b] == 0) return;  // the log-domain pass behind a probability-domain one: flagged utterances only
@@ -538,6 +563,38 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
             sh->timeout = 0;
             sh->suspect = 0;
             sh->fin[0] = SA_NEG; sh->fin[1] = 0.f; sh->fin[2] = SA_NEG; sh->fin[3] = 0.f;
+        }
+        if (WITH_BETA) {
+            // Counting sort of the label states by class (this wave alone, before the chains start): slot[j] = position of
+            // label j among the labels ordered by class (ties in label order: the LDS atomic serves its lanes in order),
+            // cend[k] = one past the last slot of class k.
+            int* ls = A.lsort + (long)b * (1 + A.Ppad + A.K);
+            const int* lab = A.labels + acc;
+            for (int k = lane; k <= A.K; k += 64) cls_cnt[k] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            int rank[kMaxChunks];
+#pragma unroll
+            for (int c = 0; c < kMaxChunks; ++c) {
+                const int j = c * 64 + lane;
+                rank[c] = (c < A.nchunks && j < L) ? atomicAdd(&cls_cnt[lab[j]], 1) : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            int carry = 0;  // exclusive scan of the class counts, 64 classes at a time
+            for (int k0 = 0; k0 < A.K; k0 += 64) {
+                const int k = k0 + lane;
+                const int cnt = k < A.K ? cls_cnt[k] : 0;
+                const int incl = (int)wave_scan_dpp((float)cnt) + carry;  // counts <= 511: exact in fp32
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (k < A.K) { cls_cnt[k] = incl - cnt; ls[1 + A.Ppad + k] = incl; }
+                carry = __builtin_amdgcn_readlane(incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int c = 0; c < kMaxChunks; ++c) {
+                const int j = c * 64 + lane;
+                if (c < A.nchunks && j < L) ls[1 + j] = cls_cnt[lab[j]] + rank[c];
+            }
+            if (lane == 0) ls[0] = acc;
         }
     }
     if (lane == 0) {
@@ -613,21 +670,21 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         if (PROB) A.flags[b] = dead ? 1 : 0;  // every utterance writes its flag (no memset between calls); "infeasible" is
                                               // the log-domain kernels' call
     }
+    if (!PROB && WITH_BETA && A.gate) {  // the hand-over pass: this block also writes the utterance's gradient rows
+        __threadfence();                 // the stash, costs and log2 p written above are read back through memory
+        __syncthreads();
+        float* srt = srt_all + (long)wave * ((A.Ppad + 1 + 3) & ~3);
+        const int nw = blockDim.x >> 6;
+        for (int t = wave; t < A.T_max; t += nw) ctc_grad_row<false>(A, A.grads, A.g_st, A.g_sb, b, t, lane, srt);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------- K_C
-// grid (ceil(T_max / 4), B), 256 threads: one wave per lattice row.
+// One wave, one lattice row t of utterance b; srt: Ppad + 1 floats of LDS owned by the wave.
 template <bool PROB>  // PROB: the stash holds hats of the probability-domain chain (log2 is taken here, off the chain)
-__global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restrict__ grads, long st, long sb) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* occ_all = reinterpret_cast<float*>(smem_raw);  // [4 waves][K]
+__device__ __forceinline__ void ctc_grad_row(const AbArgs& A, float* __restrict__ grads, long st, long sb, int b, int t,
+                                             int lane, float* srt) {
     const int K = A.K, Ppad = A.Ppad, nchunks = A.nchunks;
-    const int b = blockIdx.y;
-    if (A.gate && A.flags[b] == 0) return;  // see ctc_alphabeta_kernel
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= A.T_max) return;
     const int L = A.label_lens[b];
     const int T = A.in_lens[b];
     float* g = grads + (long)b * sb + (long)t * st;
@@ -637,13 +694,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restri
         for (int k = lane; k < K; k += 64) g[k] = 0.f;
         return;
     }
-    int loff = 0;
-    for (int i = lane; i < b; i += 64) loff += A.label_lens[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) loff += __shfl_xor(loff, o, 64);
-    const int* lab = A.labels + loff;
-    float* occ = occ_all + wave * K;
-    for (int k = lane; k < K; k += 64) occ[k] = 0.f;
+    const int* ls = A.lsort + (long)b * (1 + Ppad + K);  // see AbArgs
+    const int* lab = A.labels + ls[0];
 
     const float* row = A.ly2 + (long)b * A.ly_sb + (long)t * K;
     const float* sp = A.stash + ((long)b * A.T_max + t) * 6 * Ppad;
@@ -679,32 +731,57 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restri
                 const float fr = sa_log2(__builtin_amdgcn_frexp_mantf(a)) + sa_log2(__builtin_amdgcn_frexp_mantf(bt));
                 const int in = __builtin_amdgcn_frexp_expf(a) + __builtin_amdgcn_frexp_expf(bt) +
                                __builtin_bit_cast(int, ta[2]) + __builtin_bit_cast(int, tb[5]);
-                atomicAdd(&occ[k], sa_exp2((fr - row[k] - lp) + ((float)in - lpo)));
+                srt[ls[1 + j]] = sa_exp2((fr - row[k] - lp) + ((float)in - lpo));
             }
         } else {
             if (j <= L) accB += sa_exp2((sp[j] + sp[2 * Ppad + j] - lyblank - lp) + io_b);
             if (j < L) {
                 const int k = lab[j];
                 const float gm = sa_exp2((sp[Ppad + j] + sp[3 * Ppad + j] - row[k] - lp) + io_l);
-                atomicAdd(&occ[k], gm);  // LDS float atomic (ds_add_f32); this wave owns the row
+                srt[ls[1 + j]] = gm;
             }
         }
     }
     accB = sa_wave_sum_dpp(accB);
-    __threadfence_block();
-    float total = 0.f;
+    // Occupancy of class k = the sum over its run of sorted slots = a difference of two prefix sums.  (LDS float atomics, the
+    // obvious way, cost ~4 cycles per lane on the CU's one LDS pipe: 100 label states x 32000 rows bounded this kernel.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float carry = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int i = c * 64 + lane;
+        const float v = i < L ? srt[i] : 0.f;
+        const float incl = wave_scan_dpp(v) + carry;
+        srt[i] = incl;   // in place: the sum of slots 0 .. i
+        carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float total = accB + carry;
     for (int k = lane; k < K; k += 64) {
         const float y = sa_exp2(row[k]);
-        const float o = (k == A.blank) ? accB : occ[k];
+        const int hi = ls[1 + Ppad + k], lo = k > 0 ? ls[Ppad + k] : 0;
+        const float run = hi > lo ? srt[hi - 1] - (lo > 0 ? srt[lo - 1] : 0.f) : 0.f;
+        const float o = (k == A.blank) ? accB : run;
         g[k] = y - o;
-        total += o;
     }
     if (PROB) {
         // certification (2) of the probability-domain pass: the occupancies of a row sum to one -- the paths through the
         // lattice at time t are all the paths -- unless mass was lost on the way (NaN compares false: flagged too)
-        total = sa_wave_sum_dpp(total);
         if (!(fabsf(total - 1.0f) < 1e-4f) && lane == 0) atomicOr(&A.flags[b], 2);
     }
+}
+
+// grid (ceil(T_max / 4), B), 256 threads: one wave per lattice row.
+template <bool PROB>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restrict__ grads, long st, long sb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* srt_all = reinterpret_cast<float*>(smem_raw);  // [4 waves][Ppad + 1]
+    const int b = blockIdx.y;
+    if (A.gate && A.flags[b] == 0) return;  // see ctc_alphabeta_kernel
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= A.T_max) return;
+    ctc_grad_row<PROB>(A, grads, st, sb, b, t, lane, srt_all + wave * (A.Ppad + 1));
 }
 
 // ---------------------------------------------------------------------------------------------------------- K_W
@@ -809,18 +886,6 @@ __device__ __forceinline__ float wave_renorm(float (&Bst)[R], float (&Lst)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) { Bst[r] -= d; Lst[r] -= d; }
     return d;
-}
-
-// Inclusive prefix sum over the 64 lanes on the DPP network (the same six steps as sa_wave_sum_dpp, whose lane 63
-// holds the total): row_shr 1/2/4/8 scan each 16-lane row, row_bcast15 / row_bcast31 carry the row totals forward.
-__device__ __forceinline__ float wave_scan_dpp(float v) {
-    v += SA_DPP_F(0.f, v, 0x111, 0xf);
-    v += SA_DPP_F(0.f, v, 0x112, 0xf);
-    v += SA_DPP_F(0.f, v, 0x114, 0xf);
-    v += SA_DPP_F(0.f, v, 0x118, 0xf);
-    v += SA_DPP_F(0.f, v, 0x142, 0xa);
-    v += SA_DPP_F(0.f, v, 0x143, 0xc);
-    return v;
 }
 
 template <int R, bool WITH_GRAD, bool SMALLK>
@@ -1104,7 +1169,7 @@ static inline int ctc_nchunks(int max_L) { return (max_L + 1 + 63) / 64; }
 static inline int ctc_nbatch(int max_T) { return (max_T + kU - 1) / kU + 1; }
 
 static size_t ctc_ws_layout(int max_T, int max_L, int K, int B, size_t* off_ly2, size_t* off_stash, size_t* off_lp,
-                            size_t* off_goffs, size_t* off_flags) {
+                            size_t* off_goffs, size_t* off_flags, size_t* off_lsort) {
     const int nch = ctc_nchunks(max_L);
     size_t o = 0;
     *off_ly2 = o;   o += sa_align_up((size_t)B * sa_align_up((size_t)max_T * K, 4) * sizeof(float), 256);
@@ -1112,21 +1177,22 @@ static size_t ctc_ws_layout(int max_T, int max_L, int K, int B, size_t* off_ly2,
     *off_lp = o;    o += sa_align_up((size_t)B * sizeof(float) * 2, 256);
     *off_goffs = o; o += sa_align_up((size_t)B * 2 * nch * ctc_nbatch(max_T) * sizeof(float), 256);
     *off_flags = o; o += sa_align_up((size_t)B * sizeof(int), 256);
+    *off_lsort = o; o += sa_align_up((size_t)B * (1 + nch * 64 + K) * sizeof(int), 256);
     return o;
 }
 
 extern "C" size_t sa_ctc_workspace_bytes(int max_T, int max_L, int alphabet_size, int minibatch) {
     if (max_T < 0 || max_L < 0 || alphabet_size <= 0 || minibatch <= 0) return 0;
-    size_t a, b, c, d, e;
-    return ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d, &e);
+    size_t a, b, c, d, e, f;
+    return ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d, &e, &f);
 }
 
 // diagnostic (tests): byte offset, inside a workspace of sa_ctc_workspace_bytes(...) bytes, of the int[minibatch] flags the
 // probability-domain pass leaves (0 = its result stands; else the log-domain kernels redid the utterance)
 extern "C" size_t sa_ctc_flags_offset(int max_T, int max_L, int alphabet_size, int minibatch) {
-    size_t a, b, c, d, e = 0;
+    size_t a, b, c, d, e = 0, f;
     if (max_T < 0 || max_L < 0 || alphabet_size <= 0 || minibatch <= 0) return 0;
-    ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d, &e);
+    ctc_ws_layout(max_T > 0 ? max_T : 1, max_L, alphabet_size, minibatch, &a, &b, &c, &d, &e, &f);
     return e;
 }
 
@@ -1167,8 +1233,8 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     const int K = alphabet_size, B = minibatch;
-    size_t o_ly2, o_stash, o_lp, o_goffs, o_flags;
-    ctc_ws_layout(max_T, max_L, K, B, &o_ly2, &o_stash, &o_lp, &o_goffs, &o_flags);
+    size_t o_ly2, o_stash, o_lp, o_goffs, o_flags, o_lsort;
+    ctc_ws_layout(max_T, max_L, K, B, &o_ly2, &o_stash, &o_lp, &o_goffs, &o_flags, &o_lsort);
     char* ws = (char*)workspace;
 
     AbArgs A;
@@ -1185,7 +1251,9 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.logp2_out = (float*)(ws + o_lp);
     A.costs = d_costs;
     A.flags = (int*)(ws + o_flags);
+    A.lsort = (int*)(ws + o_lsort);
     A.gate = 0;
+    A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
     if (K <= 64 && (long)B * max_T >= 256 * 1024) {  // K_A, one lane per row out of an LDS tile: the
@@ -1250,7 +1318,8 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         }
     }
     {  // K_B
-        const size_t fixed = kAbSharedBytes + (size_t)2 * nch * (2 * A.hand_stride + A.nbatch + 128) * sizeof(float);
+        const size_t fixed = kAbSharedBytes + ((size_t)2 * nch * (2 * A.hand_stride + A.nbatch + 128 + ((A.Ppad + 1 + 3) & ~3)) +
+                                               ((K + 1 + 3) & ~3)) * sizeof(float);
         const size_t with_em = fixed + sa_align_up((size_t)(max_T + 2 * kU) * K * sizeof(float), 16);
         const bool lds_em = with_em <= 156 * 1024;  // stage the utterance's emissions in LDS when they fit
         const size_t smem = lds_em ? with_em : fixed;
@@ -1263,7 +1332,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         const int prob = !grads ? 0 : (pe ? atoi(pe) : 1);
         ctcStatus_t s;
         const dim3 ggrid((max_T + 3) / 4, B);
-        const size_t gsmem = 4 * (size_t)K * sizeof(float);
+        const size_t gsmem = 4 * (size_t)(A.Ppad + 1) * sizeof(float);
         if (prob) {
             s = launch_ab_any<true>(A, B, threads, smem, true, lds_em, stream);
             if (s != CTC_STATUS_SUCCESS) return s;
@@ -1276,7 +1345,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         }
         s = launch_ab_any<false>(A, B, threads, smem, grads != nullptr, lds_em, stream);
         if (s != CTC_STATUS_SUCCESS) return s;
-        if (grads) {  // K_C
+        if (grads && !A.gate) {  // K_C (the hand-over pass writes its rows itself)
             hipLaunchKernelGGL(ctc_grad_kernel<false>, ggrid, dim3(256), gsmem, stream, A, grads, stride_t, stride_b);
             SA_CHECK_LAUNCH();
         }
