@@ -167,6 +167,7 @@ struct AbArgs {
                           // that ctc_grad_kernel folds the occupancies of a class with a prefix sum (no atomics)
     int* flags;           // [B]: nonzero = the probability-domain pass may have lost mass for this utterance (see
                           // ctc_chain_p): the log-domain kernels, launched behind it with gate = 1, redo exactly those
+    int no_fast;          // debug / tests (SA_CTC_PROB_FAST=0): keep ctc_chain_p in its per-step alignment (phase 1) throughout
     int gate;             // 1: process only the utterances whose flag is set -- and finish them here, gradient rows
                           // included (ONE launch behind the probability-domain pass, returning at once when nothing is flagged)
     float* grads;         // gate only: where ctc_grad_row writes
@@ -363,6 +364,8 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
 // whose states sit at |log2 p| ~ 5000 where fp32 resolves 5e-4).
 constexpr int kPTarget = 100;
 constexpr int kPRenorm = 4;
+constexpr int kFTarget = 10;    // phase 2: a pair is re-normalised to 2^kFTarget at every batch ...
+constexpr int kFMaxShift = 90;  // ... and may sit up to 2^kFMaxShift below its neighbour (2^(10 + 13 + 90) < 2^127)
 
 template <int DIR, bool WITH_BETA, bool LDS_EM, bool HAS_PROD, bool HAS_CONS>  // a chunk before / after this one in the pipeline
 __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float* hand_all, float* hdummy,
@@ -497,13 +500,72 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
             for (int k = 0; k < kU; ++k) { hv[k] = 0.f; hx[k] = kNoExp; }
         }
     };
+    // Phase 2, once the front has passed every pair of this chunk (all its pairs carry an exponent): the exponents are
+    // FROZEN for a batch of kU steps.  At the start of the batch a lane re-normalises its pair to 2^kFTarget, reads the
+    // neighbour's exponent once and keeps pd = 2^(e_neighbour - e) as a float; a step is then
+    //     (blank, label) <- ((blank, label + blank) + n * (pd, [skip] pd)) * (y_blank, y_label)
+    // -- one DPP, one add, one packed fma, one packed multiply.  The values arriving from the neighbour chunk each carry
+    // their own exponent and are brought to the edge lane's scale when the batch is loaded (uniform work, off the chain).
+    // A neighbour more than 2^kFMaxShift above the own pair would overflow the frozen product: it flags the utterance.
+    float pdx = 0.f, pdy = 0.f;
+    float hs[kU];
+    auto refresh = [&]() {
+        const float mx = fmaxf(Bst, Lst);
+        const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kFTarget : 0;
+        Bst = __builtin_amdgcn_ldexpf(Bst, -f);
+        Lst = __builtin_amdgcn_ldexpf(Lst, -f);
+        e += f;
+        const int e_edge = __builtin_amdgcn_readlane(e, DIR == 0 ? 0 : 63);
+#pragma unroll
+        for (int k = 0; k < kU; ++k)
+            hs[k] = (has_prod && e_edge != kNoExp) ? __builtin_amdgcn_ldexpf(hv[k], max(hx[k], kNoExp) - e_edge) : 0.f;
+        const int en = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, e))
+                                                       : sa_wave_shl1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, e)));
+        const bool valid = e != kNoExp && en != kNoExp;
+        const int d = valid ? en - e : 0;
+        if (d > kFMaxShift) atomicOr(&sh->suspect, 1);
+        const float pd = valid ? __builtin_amdgcn_ldexpf(1.0f, min(d, kFMaxShift)) : 0.f;
+        pdx = pd;
+        pdy = pd * skipf;
+    };
+    auto fast_step = [&](float yl, float yb, float h) {
+        const float n = DIR == 0 ? sa_wave_shr1(Lst, h) : sa_wave_shl1(Lst, h);
+        const f32x2 nn = {n, n}, pp = {pdx, pdy}, base = {Bst, Lst + Bst}, yy = {yb, yl};
+        const f32x2 nxt = __builtin_elementwise_fma(nn, pp, base) * yy;
+        Bst = nxt.x;
+        Lst = nxt.y;
+        if (WITH_BETA) {
+            const i32x3 tr = {__builtin_bit_cast(int, Bst), __builtin_bit_cast(int, Lst), e};
+            __builtin_amdgcn_raw_buffer_store_b96(tr, sres, s_lane, s_step, 0);
+            s_step += s_dstep;
+        }
+        if (has_cons) {
+            hand_lane += hand_dlane;
+            *reinterpret_cast<float2*>(hand_lane) = make_float2(Lst, __builtin_bit_cast(float, e));
+        }
+    };
     const int nfull = T / kU;
-    for (int bi = 0; bi < nfull; ++bi) {  // whole batches: no condition inside (a taken branch costs ~40 cycles of the chain)
+    // batches of phase 1: until the front, one pair per step from the lattice's start, has crossed this chunk
+    const int front = DIR == 0 ? 64 * (chunk + 1) : max(L - 64 * chunk, 0);
+    const int nslow = A.no_fast ? nfull : min(nfull, (front + 2 * kU) / kU);
+    for (int bi = 0; bi < nslow; ++bi) {  // whole batches: no condition inside (a taken branch costs ~40 cycles of the chain)
         float nel[kU], neb[kU];
         load_emissions(nel, neb);  // prefetch the next batch's emissions
         take_edges(bi * kU);
 #pragma unroll
         for (int k = 0; k < kU; ++k) do_step(el[k], eb[k], hv[k], hx[k], k % kPRenorm == 0);
+        if (has_cons && lane == 0)
+            __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 1) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
+    }
+    for (int bi = nslow; bi < nfull; ++bi) {
+        float nel[kU], neb[kU];
+        load_emissions(nel, neb);
+        take_edges(bi * kU);
+        refresh();
+#pragma unroll
+        for (int k = 0; k < kU; ++k) fast_step(el[k], eb[k], hs[k]);
         if (has_cons && lane == 0)
             __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 1) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
@@ -667,7 +729,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         float c = dead ? __builtin_inff() : (float)(-((double)lp + (double)o0) * 0.6931471805599453);
         if (sh->timeout) c = __builtin_bit_cast(float, 0x7fc00000);  // NaN marks a hand-off timeout (never expected)
         A.costs[b] = c;
-        if (PROB) A.flags[b] = dead ? 1 : 0;  // every utterance writes its flag (no memset between calls); "infeasible" is
+        if (PROB) A.flags[b] = (dead || sh->suspect) ? 1 : 0;  // every utterance writes its flag (no memset between calls); "infeasible" is
                                               // the log-domain kernels' call
     }
     if (!PROB && WITH_BETA && A.gate) {  // the hand-over pass: this block also writes the utterance's gradient rows
@@ -1253,6 +1315,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.flags = (int*)(ws + o_flags);
     A.lsort = (int*)(ws + o_lsort);
     A.gate = 0;
+    { const char* fe = getenv("SA_CTC_PROB_FAST"); A.no_fast = fe && fe[0] == '0'; }
     A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
