@@ -597,14 +597,18 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     AbShared* sh = reinterpret_cast<AbShared*>(smem_raw);
     // hand-off arrays [2][nchunks][hand_stride]: floats in the log domain, {hat, exponent} pairs in the probability domain
     // (the region holds 2 * hand_stride floats per (direction, chunk) either way)
+    // The layout differs by domain (the host sizes it the same way, ab_fixed_lds): what does not fit costs the emissions'
+    // place in LDS.
+    //   PROB: hand {hat, exponent}[2][nchunks][hand_stride] | scratch slots [waves][64 x 2] | class counts | emissions
+    //   log : hand [2][nchunks][hand_stride] | offsets [2][nchunks][nbatch] | class counts | gradient-row scratch
+    //         [waves][align4(Ppad + 1)] (the hand-over pass, ctc_grad_row) | emissions
     float* hand_all = reinterpret_cast<float*>(smem_raw + kAbSharedBytes);
-    float* hoff_all = hand_all + (long)2 * A.nchunks * 2 * A.hand_stride;       // [2][nchunks][nbatch]
-    float* hdummy_all = hoff_all + (long)2 * A.nchunks * A.nbatch;              // [waves][64 x 2]: see ctc_chain_p
-    int* cls_cnt = reinterpret_cast<int*>(hdummy_all + (long)2 * A.nchunks * 128);  // [align4(K + 1)]: the label sort
-    float* srt_all = reinterpret_cast<float*>(cls_cnt + ((A.K + 1 + 3) & ~3));  // [waves][align4(Ppad + 1)]: gradient rows of
-                                                                                // the hand-over pass (ctc_grad_row)
-    float* em_lds = srt_all + (long)2 * A.nchunks * ((A.Ppad + 1 + 3) & ~3) + kU * A.K;  // [kU slack rows][T][K][kU slack
-                                                                                // rows] (LDS_EM only; see ctc_chain_p)
+    float* hoff_all = hand_all + (long)2 * A.nchunks * (PROB ? 2 : 1) * A.hand_stride;  // log only
+    float* hdummy_all = hoff_all;                                                          // PROB only
+    int* cls_cnt = reinterpret_cast<int*>(hoff_all + (long)2 * A.nchunks * (PROB ? 128 : A.nbatch));
+    float* srt_all = reinterpret_cast<float*>(cls_cnt + ((A.K + 1 + 3) & ~3));           // log only
+    float* em_lds = srt_all + (PROB ? 0L : (long)2 * A.nchunks * ((A.Ppad + 1 + 3) & ~3)) +
+                    kU * A.K;  // [kU slack rows][T][K][kU slack rows] (LDS_EM only; see ctc_chain_p)
 
     const int b = blockIdx.x;
     if (A.gate && A.flags[b] == 0) return;  // the log-domain pass behind a probability-domain one: flagged utterances only
@@ -1381,23 +1385,31 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
         }
     }
     {  // K_B
-        const size_t fixed = kAbSharedBytes + ((size_t)2 * nch * (2 * A.hand_stride + A.nbatch + 128 + ((A.Ppad + 1 + 3) & ~3)) +
-                                               ((K + 1 + 3) & ~3)) * sizeof(float);
-        const size_t with_em = fixed + sa_align_up((size_t)(max_T + 2 * kU) * K * sizeof(float), 16);
-        const bool lds_em = with_em <= 156 * 1024;  // stage the utterance's emissions in LDS when they fit
-        const size_t smem = lds_em ? with_em : fixed;
-        if (smem > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
+        // LDS of ctc_alphabeta_kernel by domain (see its layout); the emission copy joins when it fits
+        auto ab_fixed_lds = [&](bool prob) {
+            const size_t per_dc = prob ? (size_t)2 * A.hand_stride + 128
+                                       : (size_t)A.hand_stride + A.nbatch + ((A.Ppad + 1 + 3) & ~3);
+            return kAbSharedBytes + ((size_t)2 * nch * per_dc + ((K + 1 + 3) & ~3)) * sizeof(float);
+        };
+        const size_t em_bytes = sa_align_up((size_t)(max_T + 2 * kU) * K * sizeof(float), 16);
+        auto ab_lds_em = [&](bool prob) { return ab_fixed_lds(prob) + em_bytes <= 156 * 1024; };
+        auto ab_smem = [&](bool prob) { return ab_fixed_lds(prob) + (ab_lds_em(prob) ? em_bytes : 0); };
+        if (ab_smem(false) > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
         const int threads = 64 * nch * (grads ? 2 : 1);
         // probability-domain chain first (SA_CTC_PROB=0: log domain only; =2: flag every utterance, which exercises the
         // hand-over in tests), then the log-domain kernels for whatever it flagged (see ctc_chain_p).  A score-only call
         // has no rows to check: it stays in the log domain.
         const char* pe = getenv("SA_CTC_PROB");
-        const int prob = !grads ? 0 : (pe ? atoi(pe) : 1);
+        int prob = !grads ? 0 : (pe ? atoi(pe) : 1);
+        // the probability-domain chain needs its emissions in LDS to pay (its hand-off arrays are twice the log domain's:
+        // from three chunks at T = 1000 they do not fit beside them) -- then the log-domain kernels run alone
+        if (prob && (!ab_lds_em(true) || ab_smem(true) > 160 * 1024) && !(pe && atoi(pe) >= 2)) prob = 0;
         ctcStatus_t s;
         const dim3 ggrid((max_T + 3) / 4, B);
         const size_t gsmem = 4 * (size_t)(A.Ppad + 1) * sizeof(float);
         if (prob) {
-            s = launch_ab_any<true>(A, B, threads, smem, true, lds_em, stream);
+            if (ab_smem(true) > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
+            s = launch_ab_any<true>(A, B, threads, ab_smem(true), true, ab_lds_em(true), stream);
             if (s != CTC_STATUS_SUCCESS) return s;
             hipLaunchKernelGGL(ctc_grad_kernel<true>, ggrid, dim3(256), gsmem, stream, A, grads, stride_t, stride_b);
             SA_CHECK_LAUNCH();
@@ -1406,7 +1418,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
             A.gate = 1;
             if (prob == 3) return CTC_STATUS_SUCCESS;  // debug: the probability-domain pass alone, flags left for inspection
         }
-        s = launch_ab_any<false>(A, B, threads, smem, grads != nullptr, lds_em, stream);
+        s = launch_ab_any<false>(A, B, threads, ab_smem(false), grads != nullptr, ab_lds_em(false), stream);
         if (s != CTC_STATUS_SUCCESS) return s;
         if (grads && !A.gate) {  // K_C (the hand-over pass writes its rows itself)
             hipLaunchKernelGGL(ctc_grad_kernel<false>, ggrid, dim3(256), gsmem, stream, A, grads, stride_t, stride_b);
