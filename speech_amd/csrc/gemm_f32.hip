@@ -64,10 +64,6 @@ struct GemmArgs {
     // cs_partial [nprob][splits][M] and the reduce kernel folds them with the products.
     float* colsumg[kMaxGroup];
     float* cs_partial;
-    // split-K without a second launch: every block of a tile bumps tile_done[tile] after its partial is visible; the one that
-    // arrives LAST folds the partials (in split order: deterministic, the same sum the reduce kernel forms), applies the
-    // epilogue and puts the counter back to zero.  Null: gemm_splitk_reduce_kernel does it in a launch of its own.
-    unsigned* tile_done;
     // XCD-filtered mode (xcc_mask != 0): the launch has (8 / allowed XCDs) x as many blocks as tiles (+ slack); a block
     // that finds itself on an XCD outside the mask leaves at once, every other block draws ONE tile off `tile_counter`
     // (zeroed by the host) and leaves when none is left.  A side-stream GEMM can so be kept OFF the XCDs a persistent
@@ -413,7 +409,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += cs[r * BM + tid];
             if (g.partial) {
-                __hip_atomic_store(&g.cs_partial[(long)bz * g.M + m0 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g.cs_partial[(long)bz * g.M + m0 + tid] = t;
             } else {
                 float* o = g.colsumg[prob] + m0 + tid;
                 *o = g.beta != 0.f ? g.beta * *o + t : t;
@@ -438,9 +434,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= g.M) continue;
                 if (splitk) {
-                    float* pp = &g.partial[((long)bz * g.M + row) * g.N + col];
-                    if (g.tile_done) __hip_atomic_store(pp, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
-                    else *pp = acc[i][j][r];
+                    g.partial[((long)bz * g.M + row) * g.N + col] = acc[i][j][r];
                 } else {
                     float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride
                                              : gC + (long)row * g.ldc + col;
@@ -451,46 +445,6 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
                 }
             }
         }
-    }
-    if (!splitk || !g.tile_done) return;
-    // in-kernel fold (see GemmArgs::tile_done)
-    // No cache-wide fence (an agent-scope fence writes back and invalidates the whole L2: measured 29 -> 170 us on the
-    // per-chunk products): the partials are written THROUGH (sc1 stores, acknowledged by memory once vmcnt drains) and
-    // read back with sc1 loads, as the persistent recurrence kernels exchange their rows.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-        unsigned* cnt = g.tile_done + ((long)prob * g.grid_y + by) * g.grid_x + bx;
-        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = old + 1 == (unsigned)g.splits;
-        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        *flag = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    if (do_colsum && tid < BM && m0 + tid < g.M) {
-        float t = 0.f;
-        for (int z = 0; z < g.splits; ++z)
-            t += __hip_atomic_load(&g.cs_partial[((long)prob * g.splits + z) * g.M + m0 + tid], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        float* o = g.colsumg[prob] + m0 + tid;
-        *o = g.beta != 0.f ? g.beta * *o + t : t;
-    }
-    const long zstride = (long)g.M * g.N;
-    const float* p0 = g.partial + (long)prob * g.splits * zstride;
-    for (int e = tid; e < BM * BN; e += 256) {  // a thread takes column e % 128 of rows e / 128, e / 128 + 2, ...: coalesced
-        const int row = m0 + e / BN, col = n0 + e % BN;
-        if (row >= g.M || col >= g.N) continue;
-        const float* pp = p0 + (long)row * g.N + col;
-        float a = 0.f;
-        for (int z = 0; z < g.splits; ++z)  // split order: deterministic
-            a += __hip_atomic_load(pp + z * zstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride : gC + (long)row * g.ldc + col;
-        float v = g.alpha * a + (gbias ? gbias[col] : 0.f);
-        if (g.beta != 0.f) v += g.beta * *c;
-        if (g.relu) v = fmaxf(v, 0.f);
-        *c = v;
     }
 }
 
@@ -548,30 +502,6 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
     if (g.beta != 0.f) v += g.beta * *c;
     if (g.relu) v = fmaxf(v, 0.f);
     *c = v;
-}
-
-// Tile counters of the in-kernel split-K fold: a library-owned, zero-initialised ring (every launch draws a fresh run of
-// slots and leaves them zero again, so launches on different streams never share one).
-constexpr size_t kDoneSlots = (size_t)1 << 20;
-unsigned* g_done = nullptr;
-size_t g_done_next = 0;
-bool g_done_off = false;
-unsigned* done_slots(size_t n) {
-    if (g_done_off || n > kDoneSlots / 4) return nullptr;
-    if (!g_done) {
-        const char* e = getenv("SA_GEMM_FOLD");
-        if (e && e[0] == '0') { g_done_off = true; return nullptr; }
-        if (hipMalloc((void**)&g_done, kDoneSlots * sizeof(unsigned)) != hipSuccess ||
-            hipMemset(g_done, 0, kDoneSlots * sizeof(unsigned)) != hipSuccess) {
-            g_done = nullptr; g_done_off = true;
-            (void)hipGetLastError();
-            return nullptr;
-        }
-    }
-    if (g_done_next + n > kDoneSlots) g_done_next = 0;
-    unsigned* p = g_done + g_done_next;
-    g_done_next += n;
-    return p;
 }
 
 int choose_splits(int M, int N, int K, int nprob = 1) {
@@ -646,7 +576,6 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
     g.xcc_mask = 0; g.tile_counter = nullptr;
     g.grid_x = (int)grid.x; g.grid_y = (int)grid.y; g.grid_z = (int)grid.z;
-    g.tile_done = splits > 1 ? done_slots((size_t)nprob * grid.x * grid.y) : nullptr;
     if (opts && opts->xcc_mask && opts->tile_counter) {
         g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter;
         int allowed = 0;
@@ -687,7 +616,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), dyn, stream, g);
     }
     SA_CHECK_LAUNCH();
-    if (splits > 1 && !g.tile_done) {
+    if (splits > 1) {
         const long total = (long)M * N + M;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), nprob), dim3(256), 0,
                            stream, g, splits);
