@@ -1143,6 +1143,67 @@ extern "C" ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, con
     return CTC_STATUS_SUCCESS;
 }
 
+// ---- side stream and overlap switches (used by both stack passes) ----
+struct SideStream {
+    static constexpr int kEvents = 64;
+    hipStream_t s = nullptr;
+    hipEvent_t ev[kEvents];
+    int next = 0;
+    bool ready = false;
+    bool init() {
+        if (ready) return true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < kEvents; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        ready = true;
+        return true;
+    }
+    // `waiter` will not start work queued after this call before everything queued on `signaller` so far is done
+    bool order(hipStream_t signaller, hipStream_t waiter) {
+        hipEvent_t e = ev[next];
+        next = (next + 1) % kEvents;
+        return hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
+    }
+};
+SideStream g_side;
+
+// Holds the side stream back for ~`ticks` x 10 ns: enqueued in front of a batch of XCD-filtered GEMM launches so that the
+// persistent recurrence launch issued at the same moment on the caller's stream is DISPATCHED first -- its exit-at-once
+// workgroups for the idle XCDs need a free slot there, and once GEMM blocks (hundreds of us each) fill those CUs the
+// in-order dispatcher keeps the whole recurrence launch waiting (measured: 0.5 ms per layer).
+__global__ void side_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+int wgrad_every() {  // persistent launches between two hand-overs of weight-gradient work to the side stream
+    const char* e = getenv("SA_GRU_WG_EVERY");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4;
+}
+
+// uni = the layer wavefront of a unidirectional stack (all 8 XCDs busy: the GEMM blocks share CUs with recurrence
+// blocks); bidirectional layers keep half the chip idle.  Measured at S-LIBRI (profiles/r02_overlap_*): beside a GEMM
+// block a recurrence launch takes 230-310 us instead of 169 (its MFMAs queue behind the GEMM's 64-cycle ones, its
+// exchange loads behind the GEMM's tile loads) and the GEMM runs at a third of its speed -- 15.4 ms per step against
+// 12.1 -- so the unidirectional default is OFF (SA_GRU_OVERLAP=1 switches it on).
+// Bidirectional layers leave XCDs idle (a layer's groups sit on XCDs 0 .. u-1), and XCD-FILTERED side GEMMs keep off the
+// busy ones.  Three things had to hold before that paid (profiles/r02_bidirectional_overlap_trace.txt):
+//   * one tile per block, not a persistent tile loop: the dispatcher walks a grid in order, so long-lived GEMM blocks on
+//     the idle XCDs keep the NEXT recurrence launch from starting (its exit-at-once blocks for those XCDs find no room);
+//   * the recurrence launch must be dispatched BEFORE the GEMM blocks arrive (side_delay_kernel);
+//   * the filtered GEMM must fit BESIDE a recurrence block (<= 232 registers: the one-stage kernel), or its own surplus
+//     blocks on the busy XCDs -- and the launch's completion -- wait for the recurrence to end.
+// With all three: bidirectional S-LIBRI 36.3 -> 30.9 ms per step (backward stack 22.2 -> 17.7 ms: the 2.9 ms of weight-
+// gradient products of a layer run entirely inside the next layer's 2.96 ms recurrence).  ON by default for
+// bidirectional stacks, OFF for unidirectional ones (all 8 XCDs busy: see above); SA_GRU_OVERLAP=0 / 1 forces either.
+bool overlap_enabled(bool uni) {
+    const char* e = getenv("SA_GRU_OVERLAP");
+    if (e) return e[0] != '0';
+    return !uni;
+}
+
+
 // ------------------------------------------------------------------------------------------------- the layer stack
 // A step launch is a dependent-latency chain that leaves the chip mostly idle (profiles/r01_pmc_gru_step_kernels.txt:
 // >60 % of wave cycles in s_waitcnt), so the batch is cut into independent groups of rows ("chains"), each advanced on
@@ -1417,6 +1478,13 @@ static BwdPersistFn bwd_persist_fn() {  // SA_GRU_POLL = 0 / 1 (light trips), SA
     if (poll == 0) return sl >= 1 ? gru_bwd_persist_kernel<0, 1> : gru_bwd_persist_kernel<0, 0>;
     return sl >= 2 ? gru_bwd_persist_kernel<1, 2> : (sl == 1 ? gru_bwd_persist_kernel<1, 1> : gru_bwd_persist_kernel<1, 0>);
 }
+static int fwd_chunks(int T) {  // bidirectional forward: time chunks per layer for the projection / recurrence overlap
+    const char* e = getenv("SA_GRU_FWD_CHUNKS");
+    const int v = e ? atoi(e) : 0;
+    // measured (S-LIBRI T' = 498 / TIMIT T' = 144, ms per step): 1 chunk 30.9 / 6.26, 2: 29.5 / 6.15, 4: 29.5 / 6.27,
+    // 6: 29.7 / 6.55, 8: 32.0 / 6.78 -- a chunk launch costs a ramp and an event
+    return v > 0 ? (v > 15 ? 15 : v) : (T >= 256 ? 4 : 2);
+}
 static int persist_prio() {
     const char* e = getenv("SA_GRU_PRIO");
     return e ? atoi(e) : 1;
@@ -1506,33 +1574,80 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                                     (int)bi_lds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
         }
+        // Overlap (default on, SA_GRU_OVERLAP=0 off): a layer's two directions x batch tiles hold bi_used of the 8 XCDs.  The
+        // layer's input projections are cut into kFwdChunks time chunks per direction in the order the recurrences consume
+        // them (first steps of the forward direction, last steps of the reverse one); chunk 0 runs on the whole chip, the
+        // others on the side stream, XCD-filtered to the idle XCDs, BESIDE the recurrence launches of the earlier chunks
+        // (the same mechanism as the backward pass's weight gradients: one tile per block, the <= 170-register kernel, a
+        // delay kernel so that the recurrence launch is dispatched first).
+        const int per_xcd = 32 / (H / 16);
+        const int bi_used = (2 * min(bi_tpp, bi_nbt) + per_xcd - 1) / per_xcd;
+        const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
+        const int nck = fwd_chunks(T);
+        const bool fside = bi_xcd && bi_mask && nck > 1 && T >= 16 * nck && bi_nbt <= bi_tpp && overlap_enabled(false) &&
+                           L * (nck - 1) <= kSyncTileWords && g_side.init();
+        const int S = (T + nck - 1) / nck;
+        int side_launch = 0;
         for (int l = 0; l < L; ++l) {
             const float* in = l == 0 ? x : h_out[l - 1];
             const int I = l == 0 ? I0 : 2 * H;
-            for (int d = 0; d < 2; ++d) {
-                st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I, 1.f, in, I, w_ih[l * 2 + d], I, 0.f, ai_of(l, d), 3 * H,
-                                      b_ih[l * 2 + d], nullptr, nullptr, 0, stream);
+            auto project = [&](int c, hipStream_t on, unsigned mask) {  // both directions' rows of time chunk c
+                const int n = min(S, T - c * S);
+                const float* gA[2]; const float* gB[2]; float* gC[2]; const float* gbias[2];
+                for (int d = 0; d < 2; ++d) {
+                    const long r0 = (long)(d ? T - c * S - n : c * S) * B;
+                    gA[d] = in + r0 * I; gB[d] = w_ih[l * 2 + d]; gC[d] = ai_of(l, d) + r0 * 3 * H; gbias[d] = b_ih[l * 2 + d];
+                }
+                SaGemmOpts o;
+                o.no_split = 1; o.pad_lds = 0; o.colsum = nullptr; o.xcc_mask = mask;
+                o.tile_counter = mask ? sync + kSyncTiles + side_launch++ : nullptr;
+                return sa_gemm_f32_group_impl(2, 0, 1, n * B, 3 * H, I, 1.f, gA, I, gB, I, 0.f, gC, 3 * H, gbias, nullptr,
+                                              nullptr, 0, on, &o);
+            };
+            hipEvent_t ready[16];
+            if (fside) {
+                st = project(0, stream, 0u);
                 if (st != CTC_STATUS_SUCCESS) return st;
+                if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;  // the layer's input is complete
+                hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);
+                for (int c = 1; c < nck && c * S < T; ++c) {
+                    st = project(c, g_side.s, bi_mask);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                    ready[c] = g_side.ev[g_side.next];
+                    g_side.next = (g_side.next + 1) % SideStream::kEvents;
+                    if (hipEventRecord(ready[c], g_side.s) != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
+                }
+            } else {
+                for (int d = 0; d < 2; ++d) {
+                    st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I, 1.f, in, I, w_ih[l * 2 + d], I, 0.f, ai_of(l, d), 3 * H,
+                                          b_ih[l * 2 + d], nullptr, nullptr, 0, stream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
             }
-            if (bi_xcd) {  // ONE persistent launch runs both directions of the layer over all T steps
+            if (bi_xcd) {  // persistent launches run both directions of the layer: all T steps, or chunk by chunk
                 PFwdJobs Q;
                 Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.timing = nullptr;
                 Q.xcd_mode = 1; Q.nbt_all = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
                 Q.flagless = flagless_mode() ? 1 : 0;
                 if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
                 Q.stamp = nullptr; Q.n = 2;
-                for (int d = 0; d < 2; ++d) {
-                    PFwdJob& J = Q.j[d];
-                    J.ai = ai_of(l, d); J.w_hh = w_hh[l * 2 + d]; J.b_hh = b_hh[l * 2 + d];
-                    J.h_out = h_out[l] + (long)d * H; J.stash = stash ? stash[l * 2 + d] : nullptr;
-                    J.counters = sync + (l * 2 + d) * bi_nbt;
-                    J.hs_b = DH; J.hs_t = (long)B * DH; J.nsteps = T; J.base = 0;
-                    J.dt = d ? -1 : 1; J.t0 = J.t_first = d ? T - 1 : 0;
-                }
-                for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
-                    Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
-                    Q.reg_base = bi_launches++ * 32u;
-                    hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
+                const int nlaunch = fside ? (T + S - 1) / S : 1;
+                for (int c = 0; c < nlaunch; ++c) {
+                    const int s0 = fside ? c * S : 0, n = fside ? min(S, T - c * S) : T;
+                    if (c > 0 && hipStreamWaitEvent(stream, ready[c], 0) != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
+                    for (int d = 0; d < 2; ++d) {
+                        PFwdJob& J = Q.j[d];
+                        J.ai = ai_of(l, d); J.w_hh = w_hh[l * 2 + d]; J.b_hh = b_hh[l * 2 + d];
+                        J.h_out = h_out[l] + (long)d * H; J.stash = stash ? stash[l * 2 + d] : nullptr;
+                        J.counters = sync + (l * 2 + d) * bi_nbt;
+                        J.hs_b = DH; J.hs_t = (long)B * DH; J.nsteps = n; J.base = (unsigned)(H / 16) * (unsigned)s0;
+                        J.dt = d ? -1 : 1; J.t_first = d ? T - 1 : 0; J.t0 = d ? T - 1 - s0 : s0;
+                    }
+                    for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
+                        Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
+                        Q.reg_base = bi_launches++ * 32u;
+                        hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
+                    }
                 }
                 continue;
             }
@@ -1736,65 +1851,6 @@ struct WGrad {
     float* const* db_ih;          // [L*D] (3H)
     float* const* db_hh;          // [L*D] (3H)
 };
-
-struct SideStream {
-    static constexpr int kEvents = 64;
-    hipStream_t s = nullptr;
-    hipEvent_t ev[kEvents];
-    int next = 0;
-    bool ready = false;
-    bool init() {
-        if (ready) return true;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
-        for (int i = 0; i < kEvents; ++i)
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
-        ready = true;
-        return true;
-    }
-    // `waiter` will not start work queued after this call before everything queued on `signaller` so far is done
-    bool order(hipStream_t signaller, hipStream_t waiter) {
-        hipEvent_t e = ev[next];
-        next = (next + 1) % kEvents;
-        return hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
-    }
-};
-SideStream g_side;
-
-// Holds the side stream back for ~`ticks` x 10 ns: enqueued in front of a batch of XCD-filtered GEMM launches so that the
-// persistent recurrence launch issued at the same moment on the caller's stream is DISPATCHED first -- its exit-at-once
-// workgroups for the idle XCDs need a free slot there, and once GEMM blocks (hundreds of us each) fill those CUs the
-// in-order dispatcher keeps the whole recurrence launch waiting (measured: 0.5 ms per layer).
-__global__ void side_delay_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-int wgrad_every() {  // persistent launches between two hand-overs of weight-gradient work to the side stream
-    const char* e = getenv("SA_GRU_WG_EVERY");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 4;
-}
-
-// uni = the layer wavefront of a unidirectional stack (all 8 XCDs busy: the GEMM blocks share CUs with recurrence
-// blocks); bidirectional layers keep half the chip idle.  Measured at S-LIBRI (profiles/r02_overlap_*): beside a GEMM
-// block a recurrence launch takes 230-310 us instead of 169 (its MFMAs queue behind the GEMM's 64-cycle ones, its
-// exchange loads behind the GEMM's tile loads) and the GEMM runs at a third of its speed -- 15.4 ms per step against
-// 12.1 -- so the unidirectional default is OFF (SA_GRU_OVERLAP=1 switches it on).
-// Bidirectional layers leave XCDs idle (a layer's groups sit on XCDs 0 .. u-1), and XCD-FILTERED side GEMMs keep off the
-// busy ones.  Three things had to hold before that paid (profiles/r02_bidirectional_overlap_trace.txt):
-//   * one tile per block, not a persistent tile loop: the dispatcher walks a grid in order, so long-lived GEMM blocks on
-//     the idle XCDs keep the NEXT recurrence launch from starting (its exit-at-once blocks for those XCDs find no room);
-//   * the recurrence launch must be dispatched BEFORE the GEMM blocks arrive (side_delay_kernel);
-//   * the filtered GEMM must fit BESIDE a recurrence block (<= 232 registers: the one-stage kernel), or its own surplus
-//     blocks on the busy XCDs -- and the launch's completion -- wait for the recurrence to end.
-// With all three: bidirectional S-LIBRI 36.3 -> 30.9 ms per step (backward stack 22.2 -> 17.7 ms: the 2.9 ms of weight-
-// gradient products of a layer run entirely inside the next layer's 2.96 ms recurrence).  ON by default for
-// bidirectional stacks, OFF for unidirectional ones (all 8 XCDs busy: see above); SA_GRU_OVERLAP=0 / 1 forces either.
-bool overlap_enabled(bool uni) {
-    const char* e = getenv("SA_GRU_OVERLAP");
-    if (e) return e[0] != '0';
-    return !uni;
-}
 
 // Issues the weight-gradient products of layer-direction k = l*D+d over the time steps [t0, t1) on `stream`.
 // `first[k]` tracks whether the slot has been written yet (beta = 0 the first time, 1 afterwards).
