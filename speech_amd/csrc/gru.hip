@@ -1674,11 +1674,12 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
     size_t plds = ((size_t)48 * (H + 4) + 2 * 4 * 3 * 256) * sizeof(float);
-    bool persist = persist_mode() != 0 && g_health.init() && ch.n == 1 && (H % 64) == 0 && plds <= 160 * 1024 &&
-                   (long)L * ntile_u * nbt <= device_cus() && L * nbt <= kSyncErr &&
-                   (long)T * B * H * 4 < 0x7fffffffL;
-    // XCD-local groups: 8 XCDs x 32 CUs, 32 / ntile_u (layer, batch tile) groups per XCD
-    const bool xcd = persist && xcd_shape_ok(L, B, H);
+    const bool persist_common = persist_mode() != 0 && g_health.init() && ch.n == 1 && (H % 64) == 0 &&
+                                L * nbt <= kSyncErr && (long)T * B * H * 4 < 0x7fffffffL;
+    // XCD-local groups: 8 XCDs x 32 CUs, 32 / ntile_u (layer, batch tile) groups per XCD; larger batches run in passes over
+    // their batch tiles (tiles_per_pass), so the chip-wide "every block co-resident" bound does not apply to them
+    const bool xcd = persist_common && xcd_shape_ok(L, B, H);
+    bool persist = xcd || (persist_common && plds <= 160 * 1024 && (long)L * ntile_u * nbt <= device_cus());
     if (persist_mode() == 2 && !xcd) persist = false;
     if (xcd) plds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
     unsigned persist_launches = 0;
