@@ -414,6 +414,44 @@ def test_xcd_local_persistent_kernels_bidirectional():
             assert len(res[0]) == len(other) and all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
 
 
+def test_bidirectional_forward_projection_overlap():
+    """Bidirectional forward with a layer's input projections cut into time chunks that run XCD-filtered on the side stream
+    beside the chunked recurrence launches (the default from T >= 32; SA_GRU_FWD_CHUNKS=1 is the one-launch path): same
+    hidden states and stash up to the summation order of the projection GEMMs, healthy, and the backward pass accepts
+    the stash."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\nfrom speech_amd import ops, _lib\n"
+            "L, B, T, I0, H = [int(v) for v in sys.argv[2:7]]\n"
+            "torch.manual_seed(0)\nk = 1.0 / H ** 0.5\n"
+            "x = torch.randn(T, B, I0, device='cuda')\n"
+            "mk = lambda *s: torch.empty(*s, device='cuda').uniform_(-k, k)\n"
+            "w_ih = [mk(3 * H, I0 if l == 0 else 2 * H) for l in range(L) for d in range(2)]\n"
+            "w_hh = [mk(3 * H, H) for l in range(L) for d in range(2)]\n"
+            "b_ih = [mk(3 * H) for l in range(L) for d in range(2)]\n"
+            "b_hh = [mk(3 * H) for l in range(L) for d in range(2)]\n"
+            "dtop = torch.randn(T, B, 2 * H, device='cuda')\n"
+            "for _ in range(2):\n"
+            "    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 2, H, want_stash=True)\n"
+            "    dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 2, H, I0)\n"
+            "torch.cuda.synchronize()\n"
+            "assert _lib.lib().sa_gru_persist_status() == 0\n"
+            "torch.save([t.cpu() for t in h + st + [dx]], sys.argv[1])\n") % (root,)
+    for shape in ((2, 32, 96, 64, 256), (3, 20, 131, 40, 128)):
+        res = []
+        for chunks in ("1", "4", "7"):
+            out = "/tmp/sa_bi_fwd_chunks_%s.pt" % chunks
+            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
+                           env=dict(os.environ, SA_GRU_FWD_CHUNKS=chunks), check=True, timeout=180)
+            res.append(torch.load(out))
+        for other in res[1:]:
+            assert len(res[0]) == len(other)
+            for a, b in zip(res[0], other):
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max())), shape
+
+
 def test_fused_forward_wavefront_matches_oracle_and_default():
     """gru_fwd_fused_kernel (the default forward of eligible unidirectional stacks: one launch, in-kernel input
     projections, weights resident in registers) against the NumPy oracle and against the chunked path; its stash feeds
