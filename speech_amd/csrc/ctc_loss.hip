@@ -559,17 +559,36 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
 #pragma unroll
         for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
     }
-    for (int bi = nslow; bi < nfull; ++bi) {
+    {
         float nel[kU], neb[kU];
-        load_emissions(nel, neb);
-        take_edges(bi * kU);
-        refresh();
+        int bi = nslow;
+        for (; bi + 1 < nfull; bi += 2) {  // two batches per trip: the emission registers alternate instead of being copied
+            load_emissions(nel, neb);
+            take_edges(bi * kU);
+            refresh();
 #pragma unroll
-        for (int k = 0; k < kU; ++k) fast_step(el[k], eb[k], hs[k]);
-        if (has_cons && lane == 0)
-            __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 1) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int k = 0; k < kU; ++k) fast_step(el[k], eb[k], hs[k]);
+            if (has_cons && lane == 0)
+                __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 1) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            load_emissions(el, eb);
+            take_edges((bi + 1) * kU);
+            refresh();
 #pragma unroll
-        for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
+            for (int k = 0; k < kU; ++k) fast_step(nel[k], neb[k], hs[k]);
+            if (has_cons && lane == 0)
+                __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 2) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (bi < nfull) {
+            load_emissions(nel, neb);
+            take_edges(bi * kU);
+            refresh();
+#pragma unroll
+            for (int k = 0; k < kU; ++k) fast_step(el[k], eb[k], hs[k]);
+            if (has_cons && lane == 0)
+                __hip_atomic_store(&sh->prog[DIR][chunk], (bi + 1) * kU, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int k = 0; k < kU; ++k) { el[k] = nel[k]; eb[k] = neb[k]; }
+        }
     }
     if (nfull * kU < T) {  // the last, partial batch
         take_edges(nfull * kU);
