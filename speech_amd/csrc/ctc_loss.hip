@@ -125,6 +125,7 @@ struct AbShared {
     int label_off;
     int timeout;
     int suspect;              // probability-domain chain: a wave saw its states lose more range than the pass tolerates
+    int nrep;                 // labels equal to their predecessor: each costs the lattice's front one more step
 };
 constexpr int kAbSharedBytes = 256;
 
@@ -460,6 +461,11 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
         if (WITH_BETA) {
             const i32x3 tr = {__builtin_bit_cast(int, Bst), __builtin_bit_cast(int, Lst), e};
             __builtin_amdgcn_raw_buffer_store_b96(tr, sres, s_lane, s_step, 0);
+            // A 12-byte store reads its data registers over several cycles AFTER it has issued, and hipcc's hazard recogniser
+            // only guards stores without an SGPR offset: the next step's first VALU result (the alignment shift, allocated
+            // to the register that held e) landed in the third dword of the LAST lanes' triples -- found by the row check
+            // of ctc_grad_kernel on runs of repeated labels.  Two idle issue cycles close the window.
+            asm volatile("s_nop 1" ::: "memory");
             s_step += s_dstep;
         }
         if (has_cons) {  // wave-uniform
@@ -537,6 +543,11 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
         if (WITH_BETA) {
             const i32x3 tr = {__builtin_bit_cast(int, Bst), __builtin_bit_cast(int, Lst), e};
             __builtin_amdgcn_raw_buffer_store_b96(tr, sres, s_lane, s_step, 0);
+            // A 12-byte store reads its data registers over several cycles AFTER it has issued, and hipcc's hazard recogniser
+            // only guards stores without an SGPR offset: the next step's first VALU result (the alignment shift, allocated
+            // to the register that held e) landed in the third dword of the LAST lanes' triples -- found by the row check
+            // of ctc_grad_kernel on runs of repeated labels.  Two idle issue cycles close the window.
+            asm volatile("s_nop 1" ::: "memory");
             s_step += s_dstep;
         }
         if (has_cons) {
@@ -545,8 +556,9 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
         }
     };
     const int nfull = T / kU;
-    // batches of phase 1: until the front, one pair per step from the lattice's start, has crossed this chunk
-    const int front = DIR == 0 ? 64 * (chunk + 1) : max(L - 64 * chunk, 0);
+    // batches of phase 1: until the front -- one pair per step from the lattice's start, one more step per repeated label
+    // (label_j reaches label_{j+1} of the same class only through the blank between them) -- has crossed this chunk
+    const int front = (DIR == 0 ? 64 * (chunk + 1) : max(L - 64 * chunk, 0)) + sh->nrep;
     const int nslow = A.no_fast ? nfull : min(nfull, (front + 2 * kU) / kU);
     for (int bi = 0; bi < nslow; ++bi) {  // whole batches: no condition inside (a taken branch costs ~40 cycles of the chain)
         float nel[kU], neb[kU];
@@ -643,6 +655,13 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         for (int i = lane; i < b; i += 64) acc += A.label_lens[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        {
+            const int* labp = A.labels + acc;
+            float nr = 0.f;
+            for (int j = 1 + lane; j < L; j += 64) nr += labp[j] == labp[j - 1] ? 1.f : 0.f;
+            nr = sa_wave_sum_dpp(nr);
+            if (lane == 0) sh->nrep = (int)nr;
+        }
         if (lane == 0) {
             sh->label_off = acc;
             sh->timeout = 0;
@@ -896,6 +915,7 @@ struct WaveArgs {
     float* costs;
     float* grads;
     long st, sb;
+    const int* only;  // non-null: redo only the utterances whose flag is set (the pass behind ctc_wave_p_kernel)
 };
 
 template <int R>
@@ -1210,6 +1230,375 @@ __device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane
     }
 }
 
+// ---- K_W in the PROBABILITY domain (gradient calls, K <= 64, up to 255 labels; certified like ctc_chain_p) ----
+// The same per-pair exponents and two phases as ctc_chain_p, for R pairs per lane: until the front has crossed the lattice
+// (L + 1 steps) a step aligns every pair with its predecessor's exponent; afterwards the exponents are frozen for a batch
+// of KU steps and a step is one add, one packed fma and one packed multiply per pair.  Hats are re-normalised to
+// 2^kFTarget in BOTH phases here (they stay below 2^23, so that a product of an alpha and a beta hat cannot overflow).
+// alpha keeps a checkpoint {blank, label, exponent} of every pair at the START of each batch; the beta pass replays the
+// batch from it -- the same instructions in the same order, so the recomputed states are bit-identical -- and forms the
+// occupancies from alpha_t(s) and beta's PRE-emission sums (gamma = alpha_t(s) * sum_beta_t(s) / p: no division by y).
+// The emission rows are converted to probabilities once, when they are committed to the LDS ring.
+// Certification: the beta pass checks that every row's occupancies sum to one and flags the utterance otherwise (as does
+// an "infeasible" verdict or a frozen shift beyond 2^kFMaxShift); flagged utterances are redone by the log-domain kernel
+// (ctc_wave_kernel with `only` = the flags), launched right behind.
+template <int R, int DIR>
+__device__ __forceinline__ void wavep_slow_step(float (&Bst)[R], float (&Lst)[R], int (&e)[R], const float (&yl)[R], float yb,
+                                                const float (&skipf)[R], float (&sB)[R], float (&sL)[R], bool renorm) {
+    constexpr int kNoExp = -(1 << 28);
+    if (renorm) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float mx = fmaxf(Bst[r], Lst[r]);
+            const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kFTarget : 0;
+            Bst[r] = __builtin_amdgcn_ldexpf(Bst[r], -f);
+            Lst[r] = __builtin_amdgcn_ldexpf(Lst[r], -f);
+            e[r] += f;
+        }
+    }
+    const float nedge = DIR == 0 ? sa_wave_shr1(Lst[R - 1], 0.f) : sa_wave_shl1(Lst[0], 0.f);
+    const int eedge = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e[R - 1]), __builtin_bit_cast(float, kNoExp))
+                                                       : sa_wave_shl1(__builtin_bit_cast(float, e[0]), __builtin_bit_cast(float, kNoExp)));
+    float nB[R], nL[R];
+    int ne[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float n = DIR == 0 ? (r == 0 ? nedge : Lst[r - 1]) : (r == R - 1 ? nedge : Lst[r + 1]);
+        const int en = DIR == 0 ? (r == 0 ? eedge : e[r - 1]) : (r == R - 1 ? eedge : e[r + 1]);
+        const int ec = max(e[r], en);
+        const float Bs = __builtin_amdgcn_ldexpf(Bst[r], e[r] - ec), Ls = __builtin_amdgcn_ldexpf(Lst[r], e[r] - ec);
+        const float ns = __builtin_amdgcn_ldexpf(n, en - ec);
+        sB[r] = Bs + ns;
+        sL[r] = __builtin_fmaf(ns, skipf[r], Ls + Bs);
+        nB[r] = sB[r] * yb;
+        nL[r] = sL[r] * yl[r];
+        ne[r] = fmaxf(sB[r], sL[r]) > 0.f ? ec : kNoExp;  // a pair that is still empty keeps "nothing" (see ctc_chain_p)
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Bst[r] = nB[r]; Lst[r] = nL[r]; e[r] = ne[r]; }
+}
+
+// start of a frozen batch: re-normalise, read the predecessors' exponents once, keep pd = 2^(e_pred - e); returns true when
+// a shift beyond 2^kFMaxShift had to be clamped (the caller flags the utterance)
+template <int R, int DIR>
+__device__ __forceinline__ bool wavep_refresh(float (&Bst)[R], float (&Lst)[R], int (&e)[R], const float (&skipf)[R],
+                                              float (&pdx)[R], float (&pdy)[R]) {
+    constexpr int kNoExp = -(1 << 28);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float mx = fmaxf(Bst[r], Lst[r]);
+        const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kFTarget : 0;
+        Bst[r] = __builtin_amdgcn_ldexpf(Bst[r], -f);
+        Lst[r] = __builtin_amdgcn_ldexpf(Lst[r], -f);
+        e[r] += f;
+    }
+    const int eedge = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e[R - 1]), __builtin_bit_cast(float, kNoExp))
+                                                       : sa_wave_shl1(__builtin_bit_cast(float, e[0]), __builtin_bit_cast(float, kNoExp)));
+    bool clamped = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int en = DIR == 0 ? (r == 0 ? eedge : e[r - 1]) : (r == R - 1 ? eedge : e[r + 1]);
+        const bool valid = e[r] != kNoExp && en != kNoExp;
+        const int d = valid ? en - e[r] : 0;
+        clamped = clamped || d > kFMaxShift;
+        const float pd = valid ? __builtin_amdgcn_ldexpf(1.0f, min(d, kFMaxShift)) : 0.f;
+        pdx[r] = pd;
+        pdy[r] = pd * skipf[r];
+    }
+    return clamped;
+}
+
+template <int R, int DIR>
+__device__ __forceinline__ void wavep_fast_step(float (&Bst)[R], float (&Lst)[R], const float (&yl)[R], float yb,
+                                                const float (&pdx)[R], const float (&pdy)[R], float (&sB)[R],
+                                                float (&sL)[R]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float nedge = DIR == 0 ? sa_wave_shr1(Lst[R - 1], 0.f) : sa_wave_shl1(Lst[0], 0.f);
+    float nB[R], nL[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float n = DIR == 0 ? (r == 0 ? nedge : Lst[r - 1]) : (r == R - 1 ? nedge : Lst[r + 1]);
+        const f32x2 nn = {n, n}, pp = {pdx[r], pdy[r]}, base = {Bst[r], Lst[r] + Bst[r]}, yy = {yb, yl[r]};
+        const f32x2 sum = __builtin_elementwise_fma(nn, pp, base);
+        const f32x2 nxt = sum * yy;
+        sB[r] = sum.x; sL[r] = sum.y;
+        nB[r] = nxt.x; nL[r] = nxt.y;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { Bst[r] = nB[r]; Lst[r] = nL[r]; }
+}
+
+// Emission rows -> registers -> the LDS ring AS PROBABILITIES (SMALLK staging of RowStager, with the exp2 at the commit).
+template <int R>
+struct RowStagerP {
+    static constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
+    const float* ly;
+    int K, lane;
+    float pv[NU];
+    __device__ __forceinline__ void issue(int tlo, int nrows) {
+        const int n = nrows * K;
+        const float* src = ly + (long)tlo * K;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) pv[u] = src[min(lane + 64 * u, n - 1)];
+    }
+    __device__ __forceinline__ void commit(float* dst) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) dst[lane + 64 * u] = sa_exp2(pv[u]);
+    }
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU, P = 64 * R;
+    constexpr int kNoExp = -(1 << 28);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= A.B) return;  // waves are independent: no workgroup barrier anywhere in this kernel
+    float* base = reinterpret_cast<float*>(smem_raw) + (long)wave * A.wave_lds_floats;
+    float* ring = base;                 // [2][64 * NU]
+    float* occ = ring + 2 * 64 * NU;    // sorted occupancies [64 R + 1]
+    const int K = A.K, L = A.label_lens[b], T = A.in_lens[b];
+    int loff = 0;
+    for (int i = lane; i < b; i += 64) loff += A.label_lens[i];
+    loff = (int)sa_wave_sum_dpp((float)loff);  // label counts: exact in fp32 below 2^24
+    const int* lab = A.labels + loff;
+    float* ckb = A.stash + (long)b * A.nq * 3 * P + lane * R;  // checkpoints [nq][3][P]
+
+    // ------------------------------------------------------------------------------------------------ alpha
+    int a_lab[R];
+    bool a_ok[R];
+    float skipf[R];
+    float aB[R], aL[R];
+    int ae[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * R + r;
+        a_ok[r] = j < L;
+        a_lab[r] = a_ok[r] ? lab[j] : A.blank;
+        skipf[r] = (j >= 1 && j <= L - 1 && lab[j] != lab[j - 1]) ? 1.f : 0.f;
+        aB[r] = j == 0 ? 1.0f : 0.f;
+        aL[r] = 0.f;
+        ae[r] = j == 0 ? 0 : kNoExp;
+    }
+    // batches of phase 1: the front moves one pair per step, and a repeated label costs it one more (label_j can reach
+    // label_{j+1} = the same class only through the blank between them) -- L + 1 + repeats steps to cross the lattice
+    float nrep_f = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * R + r;
+        nrep_f += (j >= 1 && j <= L - 1 && skipf[r] == 0.f) ? 1.f : 0.f;
+    }
+    const int nslow = (L + 1 + (int)sa_wave_sum_dpp(nrep_f) + 2 * KU) / KU;
+    RowStagerP<R> stage;
+    stage.ly = A.ly2 + (long)b * A.ly_sb; stage.K = K; stage.lane = lane;
+    if (T > 0) { stage.issue(0, min(KU, T)); stage.commit(ring); }
+    __builtin_amdgcn_s_waitcnt(0);
+    bool suspect = false;
+    // one batch of alpha steps from the state in (aB, aL, ae); optionally records the states after every step
+    auto alpha_batch = [&](int q, int nrows, const float* cur, float (*recB)[R], float (*recL)[R], int (*recE)[R]) {
+        float pdx[R], pdy[R], sB[R], sL[R];
+        const bool fast = q >= nslow;
+        if (fast) suspect = wavep_refresh<R, 0>(aB, aL, ae, skipf, pdx, pdy) || suspect;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            if (k < nrows) {
+                const float* rowp = cur + k * K;
+                const float yb = rowp[A.blank];
+                float yl[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float v = rowp[a_lab[r]];
+                    yl[r] = a_ok[r] ? v : 0.f;
+                }
+                if (fast) wavep_fast_step<R, 0>(aB, aL, yl, yb, pdx, pdy, sB, sL);
+                else wavep_slow_step<R, 0>(aB, aL, ae, yl, yb, skipf, sB, sL, (k & 3) == 0);
+            }
+            if (recB) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) { recB[k][r] = aB[r]; recL[k][r] = aL[r]; recE[k][r] = ae[r]; }
+            }
+        }
+    };
+    {
+        int q = 0;
+        for (int r0 = 0; r0 < T; r0 += KU, ++q) {
+            const float* cur = ring + (q & 1) * 64 * NU;
+            float* nxt = ring + ((q + 1) & 1) * 64 * NU;
+            float* ck = ckb + (long)q * 3 * P;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { ck[r] = aB[r]; ck[P + r] = aL[r]; ck[2 * P + r] = __builtin_bit_cast(float, ae[r]); }
+            const bool more = r0 + KU < T;
+            if (more) stage.issue(r0 + KU, min(KU, T - r0 - KU));
+            alpha_batch(q, min(KU, T - r0), cur, nullptr, nullptr, nullptr);
+            if (more) stage.commit(nxt);
+        }
+    }
+    // p = alpha_T(blank_L) + alpha_T(label_{L-1}) as p_hat * 2^pe with p_hat in [0.5, 1)
+    float f0 = 0.f, f1 = 0.f;
+    int e0 = kNoExp, e1 = kNoExp;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * R + r;
+        if (j == L) { f0 = aB[r]; e0 = ae[r]; }
+        if (j == L - 1) { f1 = aL[r]; e1 = ae[r]; }
+    }
+    f0 = sa_wave_max_dpp(f0); f1 = sa_wave_max_dpp(f1);   // one lane holds each; hats are >= 0
+    e0 = (int)sa_wave_max_dpp((float)e0); e1 = (int)sa_wave_max_dpp((float)e1);  // |exponents| < 2^24 ... kNoExp is exact too
+    const int em = max(f0 > 0.f ? e0 : kNoExp, f1 > 0.f ? e1 : kNoExp);
+    const float psum = (f0 > 0.f ? __builtin_amdgcn_ldexpf(f0, e0 - em) : 0.f) + (f1 > 0.f ? __builtin_amdgcn_ldexpf(f1, e1 - em) : 0.f);
+    const bool dead = !(psum > 0.f);
+    const int pe = dead ? 0 : em + __builtin_amdgcn_frexp_expf(psum);
+    const float ph = dead ? 1.f : __builtin_amdgcn_frexp_mantf(psum);
+    if (lane == 0) {
+        A.costs[b] = dead ? __builtin_inff() : (float)(-((double)sa_log2(ph) + (double)pe) * 0.6931471805599453);
+        flags[b] = dead ? 1 : 0;  // every utterance writes its flag; "infeasible" is the log-domain kernel's call
+    }
+    const int T_live = (dead || T <= 0) ? 0 : T;
+    if (T_live > 0) {
+        // ------------------------------------------------------------------------------------------------- beta
+        const float rcp = 1.0f / ph;
+        int b_lab[R];
+        bool b_ok[R];
+        float bB[R], bL[R];
+        int be[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = lane * R + r;
+            b_ok[r] = j >= 1 && j - 1 < L;
+            b_lab[r] = b_ok[r] ? lab[j - 1] : A.blank;
+            bB[r] = j == L ? 1.0f : 0.f;
+            bL[r] = 0.f;
+            be[r] = j == L ? 0 : kNoExp;
+        }
+        // label states counting-sorted by class (see ctc_wave_beta)
+        int pos[R], seg_hi = P, seg_lo = P;
+        {
+            int cnt = 0, rank[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) rank[r] = 0;
+            for (int i = 0; i < L; ++i) {
+                const int li = lab[i];
+                cnt += li == lane ? 1 : 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) rank[r] += (i < lane * R + r - 1 && li == b_lab[r]) ? 1 : 0;
+            }
+            const int incl = (int)wave_scan_dpp((float)cnt);
+            const int start = incl - cnt;
+            occ[lane] = (float)start;
+            if (lane == 0) occ[P] = 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int j = lane * R + r;
+                pos[r] = b_ok[r] ? (int)occ[b_lab[r]] + rank[r] : (j == 0 ? P - 1 : j - 1);
+            }
+            seg_lo = start > 0 ? start - 1 : P;
+            seg_hi = cnt > 0 ? start + cnt - 1 : seg_lo;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const int q_last = (T - 1) / KU;
+        float cB[R], cL[R];
+        int cE[R];
+        {
+            const int tlo = q_last * KU;
+            stage.issue(tlo, T - tlo);
+            stage.commit(ring);
+            const float* ck = ckb + (long)q_last * 3 * P;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { cB[r] = ck[r]; cL[r] = ck[P + r]; cE[r] = __builtin_bit_cast(int, ck[2 * P + r]); }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        bool bad_row = false;
+        int bi = 0;
+        for (int q = q_last; q >= 0; --q, ++bi) {
+            const int tlo = q * KU;
+            const int nrows = min(KU, T - tlo);
+            const float* cur = ring + (bi & 1) * 64 * NU;
+            float* nxt = ring + ((bi + 1) & 1) * 64 * NU;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { aB[r] = cB[r]; aL[r] = cL[r]; ae[r] = cE[r]; }
+            if (q > 0) {  // the previous batch in time: rows and checkpoint, a batch ahead of their use
+                stage.issue(tlo - KU, KU);
+                const float* ck = ckb + (long)(q - 1) * 3 * P;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { cB[r] = ck[r]; cL[r] = ck[P + r]; cE[r] = __builtin_bit_cast(int, ck[2 * P + r]); }
+            }
+            // (1) replay this batch's alpha states from its checkpoint
+            float rB[KU][R], rL[KU][R];
+            int rE[KU][R];
+            alpha_batch(q, nrows, cur, rB, rL, rE);
+            // (2) beta steps, backwards in time, with the occupancies and the gradient row of each step
+            float pdx[R], pdy[R];
+            const bool fast = bi >= nslow;
+            if (fast) suspect = wavep_refresh<R, 1>(bB, bL, be, skipf, pdx, pdy) || suspect;
+#pragma unroll
+            for (int k = KU - 1; k >= 0; --k) {
+                if (k < nrows) {
+                    const int t = tlo + k;
+                    const float* rowp = cur + k * K;
+                    const float yb = rowp[A.blank];
+                    float yl[R], sB[R], sL[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float v = rowp[b_lab[r]];
+                        yl[r] = b_ok[r] ? v : 0.f;
+                    }
+                    int es[R];  // the exponent the pre-emission sums sB, sL are expressed in
+                    if (fast) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) es[r] = be[r];
+                        wavep_fast_step<R, 1>(bB, bL, yl, yb, pdx, pdy, sB, sL);
+                    } else {
+                        wavep_slow_step<R, 1>(bB, bL, be, yl, yb, skipf, sB, sL, ((KU - 1 - k) & 3) == 0);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) es[r] = be[r];  // = the aligned exponent of the step (kNoExp: sums are 0)
+                    }
+                    // occupancy = alpha_t(s) * sum_beta_t(s) / p; alpha's label state of pair j-1 comes across the lane edge
+                    const float aedge = sa_wave_shr1(rL[k][R - 1], 0.f);
+                    const int aeedge = __builtin_bit_cast(int, sa_wave_shr1(__builtin_bit_cast(float, rE[k][R - 1]), __builtin_bit_cast(float, kNoExp)));
+                    float gb = 0.f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int eb_ = es[r] == kNoExp ? 0 : es[r];
+                        const int ea_b = rE[k][r] == kNoExp ? 0 : rE[k][r];
+                        gb += __builtin_amdgcn_ldexpf(rB[k][r] * sB[r] * rcp, ea_b + eb_ - pe);
+                        const float al = r == 0 ? aedge : rL[k][r - 1];
+                        const int eal = r == 0 ? aeedge : rE[k][r - 1];
+                        // (a pair without a label state drops a zero into its slot past the sorted labels)
+                        occ[pos[r]] = b_ok[r] ? __builtin_amdgcn_ldexpf(al * sL[r] * rcp, (eal == kNoExp ? 0 : eal) + eb_ - pe) : 0.f;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    float sv[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) sv[r] = occ[lane * R + r];
+#pragma unroll
+                    for (int r = 1; r < R; ++r) sv[r] += sv[r - 1];
+                    const float incl = wave_scan_dpp(sv[R - 1]);
+                    const float excl = incl - sv[R - 1];
+                    gb = sa_wave_sum_dpp(gb);
+                    const float total = gb + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+                    bad_row = bad_row || !(fabsf(total - 1.0f) < 1e-4f);  // flow conservation (NaN compares false)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) occ[lane * R + r] = sv[r] + excl;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int c = min(lane, K - 1);  // K <= 64: lanes past K repeat lane K-1's store
+                    const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
+                    float* g = A.grads + (long)b * A.sb + (long)t * A.st;
+                    g[c] = rowp[c] - o;
+                }
+            }
+            if (q > 0) stage.commit(nxt);
+        }
+        if ((bad_row || suspect) && lane == 0) flags[b] = 2;
+    }
+    for (int t = T_live; t < A.T_max; ++t) {  // padding rows / infeasible alignment: zero gradient
+        float* g = A.grads + (long)b * A.sb + (long)t * A.st;
+        for (int c = lane; c < K; c += 64) g[c] = 0.f;
+    }
+}
+
 template <int R, bool WITH_GRAD, bool SMALLK>
 __global__ __launch_bounds__(256) void ctc_wave_kernel(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1217,6 +1606,7 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(WaveArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;
     if (b >= A.B) return;  // waves are independent: no workgroup barrier anywhere in this kernel
+    if (A.only && A.only[b] == 0) return;
     constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
     float* base = reinterpret_cast<float*>(smem_raw) + (long)wave * A.wave_lds_floats;
     float* ring = base;                                       // [2][KU][K]  (SMALLK: [2][64 * NU])
@@ -1382,9 +1772,25 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
             W.K = K; W.T_max = max_T; W.blank = blank_label; W.B = B; W.nren = nren; W.nq = (max_T + KU - 1) / KU;
             W.wave_lds_floats = (int)wave_floats;
             W.ly_sb = A.ly_sb; W.stash = A.stash; W.costs = d_costs; W.grads = grads;
-            W.st = stride_t; W.sb = stride_b;
+            W.st = stride_t; W.sb = stride_b; W.only = nullptr;
             const size_t smem = waves * wave_bytes;
             const dim3 grid((B + waves - 1) / waves), block(64 * waves);
+            // probability-domain pass first (gradient calls, K <= 64, R <= 4), the log-domain kernel behind it for flagged
+            // utterances; SA_CTC_PROB=0: log domain only, =2: everything flagged (tests), =3: probability pass alone
+            const char* pe = getenv("SA_CTC_PROB");
+            const int prob = (grads && smallk && R <= 4) ? (pe ? atoi(pe) : 1) : 0;
+            if (prob) {
+                void (*pf)(WaveArgs, int*) = R == 1 ? ctc_wave_p_kernel<1> : R == 2 ? ctc_wave_p_kernel<2> : ctc_wave_p_kernel<4>;
+                if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)pf, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            (int)smem) != hipSuccess)
+                    return CTC_STATUS_EXECUTION_FAILED;
+                hipLaunchKernelGGL(pf, grid, block, smem, stream, W, A.flags);
+                SA_CHECK_LAUNCH();
+                if (prob == 2 && hipMemsetAsync(A.flags, 1, (size_t)B * sizeof(int), stream) != hipSuccess)
+                    return CTC_STATUS_MEMOPS_FAILED;
+                if (prob == 3) return CTC_STATUS_SUCCESS;
+                W.only = A.flags;
+            }
 #define SA_WIDE_LAUNCH(R_)                                                                                        \
     do {                                                                                                          \
         void (*fn)(WaveArgs) = grads ? (smallk ? ctc_wave_kernel<R_, true, true> : ctc_wave_kernel<R_, true, false>)    \

@@ -23,9 +23,8 @@ def ctc_mode(request, monkeypatch):
     """The latency-regime kernels run (prob) the probability-domain chain, certified at run time, with the log-domain
     kernels behind it for whatever it flags -- the default; (log) the log-domain kernels alone, SA_CTC_PROB=0; (handover)
     the probability-domain pass with EVERY utterance flagged, SA_CTC_PROB=2, so that the log-domain pass overwrites all
-    of its results.  Every test below holds in all three; the K_W tests (their own kernel) run once."""
-    if request.param != "prob" and "wide" in request.node.name:
-        pytest.skip("K_W does not depend on SA_CTC_PROB")
+    of its results.  Every test below holds in all three, the K_W tests (one wave per utterance; their probability-domain
+    kernel and the log-domain kernel behind it follow the same switch) included."""
     if request.param == "log":
         monkeypatch.setenv("SA_CTC_PROB", "0")
     elif request.param == "handover":
@@ -117,6 +116,24 @@ def test_infeasible_and_repeats():
     assert np.isinf(c[0]) and c[0] > 0 and np.all(g[0] == 0)
     np.testing.assert_allclose(c[1:], co[1:], rtol=COST_RTOL)
     assert np.abs(g - go).max() < grad_atol(co[1:])
+
+
+def test_repeated_labels(ctc_mode, monkeypatch):
+    """Runs of one class: every repeat costs the lattice one more frame (label_j reaches label_{j+1} only through the blank
+    between them) -- the probability-domain chains' front phase is sized by it.  Latency and one-wave kernels, with no
+    flag raised on the default path."""
+    rng = np.random.RandomState(41)
+    B, T, K = 4, 400, 11
+    ll = np.array([70, 130, 64, 100], dtype=np.int32)
+    labs = np.concatenate([np.full(70, 3), np.repeat(rng.randint(0, K - 1, 26), 5), np.repeat([1, 2], 32),
+                           rng.randint(0, 2, 100)]).astype(np.int32)
+    acts = rng.randn(B, T, K).astype(np.float32)
+    al = np.full(B, T, np.int32)
+    for wide in ("0", "1"):
+        monkeypatch.setenv("SA_CTC_WIDE", wide)
+        compare(acts, labs, al, ll)
+        if ctc_mode == "prob":
+            assert not flags_of(B, T, K, int(ll.max())).any(), wide
 
 
 def test_peaky_logits():
@@ -263,8 +280,9 @@ def test_wide_infeasible_and_score_only(wide):
     assert np.isinf(c[0]) and c[0] > 0 and np.all(g[0] == 0)
     np.testing.assert_allclose(c[1:], co[1:], rtol=COST_RTOL)
     assert np.abs(g - go).max() < grad_atol(co[1:])
-    c2, g2 = run_hip(acts, labs, al, ll, want_grad=False)
-    assert g2 is None and np.array_equal(c, c2)
+    c2, g2 = run_hip(acts, labs, al, ll, want_grad=False)  # score only: the log-domain kernel
+    assert g2 is None and np.isinf(c2[0])
+    np.testing.assert_allclose(c[1:], c2[1:], rtol=2e-6)
 
 
 def test_wide_full_size_rows_and_default_switch(monkeypatch):
