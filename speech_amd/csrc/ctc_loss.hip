@@ -27,6 +27,7 @@
 // HIPCC_FLAGS: -fno-honor-nans
 // (no NaN is ever an operand here -- log(0) is the finite SA_NEG -- so fmaxf/fminf need no canonicalising v_max.)
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -1397,13 +1398,17 @@ __global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __rest
     __builtin_amdgcn_s_waitcnt(0);
     bool suspect = false;
     // one batch of alpha steps from the state in (aB, aL, ae); optionally records the states after every step
-    auto alpha_batch = [&](int q, int nrows, const float* cur, float (*recB)[R], float (*recL)[R], int (*recE)[R]) {
+    // (FAST: frozen exponents; FULL: all KU rows exist; REC: record the state after every step -- compile-time, so that a
+    // whole batch is one branch-free block: a taken branch costs ~40 cycles of a dependent chain)
+    float rB[KU][R], rL[KU][R];  // the replayed alpha states of a batch (beta pass; indexed at compile time only: a pointer
+    int rE[KU][R];               // to these arrays would send them to scratch memory)
+    auto alpha_batch_t = [&](auto fast_c, auto full_c, auto rec_c, int nrows, const float* cur) {
+        constexpr bool FAST = decltype(fast_c)::value, FULL = decltype(full_c)::value, REC = decltype(rec_c)::value;
         float pdx[R], pdy[R], sB[R], sL[R];
-        const bool fast = q >= nslow;
-        if (fast) suspect = wavep_refresh<R, 0>(aB, aL, ae, skipf, pdx, pdy) || suspect;
+        if (FAST) suspect = wavep_refresh<R, 0>(aB, aL, ae, skipf, pdx, pdy) || suspect;
 #pragma unroll
         for (int k = 0; k < KU; ++k) {
-            if (k < nrows) {
+            if (FULL || k < nrows) {
                 const float* rowp = cur + k * K;
                 const float yb = rowp[A.blank];
                 float yl[R];
@@ -1412,14 +1417,22 @@ __global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __rest
                     const float v = rowp[a_lab[r]];
                     yl[r] = a_ok[r] ? v : 0.f;
                 }
-                if (fast) wavep_fast_step<R, 0>(aB, aL, yl, yb, pdx, pdy, sB, sL);
+                if (FAST) wavep_fast_step<R, 0>(aB, aL, yl, yb, pdx, pdy, sB, sL);
                 else wavep_slow_step<R, 0>(aB, aL, ae, yl, yb, skipf, sB, sL, (k & 3) == 0);
             }
-            if (recB) {
+            if (REC) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) { recB[k][r] = aB[r]; recL[k][r] = aL[r]; recE[k][r] = ae[r]; }
+                for (int r = 0; r < R; ++r) { rB[k][r] = aB[r]; rL[k][r] = aL[r]; rE[k][r] = ae[r]; }
             }
         }
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+    auto alpha_batch = [&](auto rec_c, int q, int nrows, const float* cur) {
+        const bool fast = q >= nslow, full = nrows == KU;
+        if (fast && full) alpha_batch_t(Yes(), Yes(), rec_c, nrows, cur);
+        else if (fast) alpha_batch_t(Yes(), No(), rec_c, nrows, cur);
+        else alpha_batch_t(No(), No(), rec_c, nrows, cur);
     };
     {
         int q = 0;
@@ -1431,7 +1444,7 @@ __global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __rest
             for (int r = 0; r < R; ++r) { ck[r] = aB[r]; ck[P + r] = aL[r]; ck[2 * P + r] = __builtin_bit_cast(float, ae[r]); }
             const bool more = r0 + KU < T;
             if (more) stage.issue(r0 + KU, min(KU, T - r0 - KU));
-            alpha_batch(q, min(KU, T - r0), cur, nullptr, nullptr, nullptr);
+            alpha_batch(No(), q, min(KU, T - r0), cur);
             if (more) stage.commit(nxt);
         }
     }
@@ -1526,68 +1539,74 @@ __global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __rest
                 for (int r = 0; r < R; ++r) { cB[r] = ck[r]; cL[r] = ck[P + r]; cE[r] = __builtin_bit_cast(int, ck[2 * P + r]); }
             }
             // (1) replay this batch's alpha states from its checkpoint
-            float rB[KU][R], rL[KU][R];
-            int rE[KU][R];
-            alpha_batch(q, nrows, cur, rB, rL, rE);
+            alpha_batch(Yes(), q, nrows, cur);
             // (2) beta steps, backwards in time, with the occupancies and the gradient row of each step
-            float pdx[R], pdy[R];
-            const bool fast = bi >= nslow;
-            if (fast) suspect = wavep_refresh<R, 1>(bB, bL, be, skipf, pdx, pdy) || suspect;
+            auto beta_batch_t = [&](auto fast_c, auto full_c) {
+                constexpr bool FAST = decltype(fast_c)::value, FULL = decltype(full_c)::value;
+                float pdx[R], pdy[R];
+                if (FAST) suspect = wavep_refresh<R, 1>(bB, bL, be, skipf, pdx, pdy) || suspect;
 #pragma unroll
-            for (int k = KU - 1; k >= 0; --k) {
-                if (k < nrows) {
-                    const int t = tlo + k;
-                    const float* rowp = cur + k * K;
-                    const float yb = rowp[A.blank];
-                    float yl[R], sB[R], sL[R];
+                for (int k = KU - 1; k >= 0; --k) {
+                    if (FULL || k < nrows) {
+                        const int t = tlo + k;
+                        const float* rowp = cur + k * K;
+                        const float yb = rowp[A.blank];
+                        float yl[R], sB[R], sL[R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float v = rowp[b_lab[r]];
-                        yl[r] = b_ok[r] ? v : 0.f;
+                        for (int r = 0; r < R; ++r) {
+                            const float v = rowp[b_lab[r]];
+                            yl[r] = b_ok[r] ? v : 0.f;
+                        }
+                        int es[R];  // the exponent the pre-emission sums sB, sL are expressed in
+                        if (FAST) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) es[r] = be[r];
+                            wavep_fast_step<R, 1>(bB, bL, yl, yb, pdx, pdy, sB, sL);
+                        } else {
+                            wavep_slow_step<R, 1>(bB, bL, be, yl, yb, skipf, sB, sL, ((KU - 1 - k) & 3) == 0);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) es[r] = be[r];  // the aligned exponent of the step (kNoExp: sums are 0)
+                        }
+                        // occupancy = alpha_t(s) * sum_beta_t(s) / p; alpha's label state of pair j-1 comes across the lane edge
+                        const float aedge = sa_wave_shr1(rL[k][R - 1], 0.f);
+                        const int aeedge = __builtin_bit_cast(int, sa_wave_shr1(__builtin_bit_cast(float, rE[k][R - 1]), __builtin_bit_cast(float, kNoExp)));
+                        float gb = 0.f;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int eb_ = es[r] == kNoExp ? 0 : es[r];
+                            const int ea_b = rE[k][r] == kNoExp ? 0 : rE[k][r];
+                            gb += __builtin_amdgcn_ldexpf(rB[k][r] * sB[r] * rcp, ea_b + eb_ - pe);
+                            const float al = r == 0 ? aedge : rL[k][r - 1];
+                            const int eal = r == 0 ? aeedge : rE[k][r - 1];
+                            // (a pair without a label state drops a zero into its slot past the sorted labels)
+                            occ[pos[r]] = b_ok[r] ? __builtin_amdgcn_ldexpf(al * sL[r] * rcp, (eal == kNoExp ? 0 : eal) + eb_ - pe) : 0.f;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        float sv[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) sv[r] = occ[lane * R + r];
+#pragma unroll
+                        for (int r = 1; r < R; ++r) sv[r] += sv[r - 1];
+                        const float incl = wave_scan_dpp(sv[R - 1]);
+                        const float excl = incl - sv[R - 1];
+                        gb = sa_wave_sum_dpp(gb);
+                        const float total = gb + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+                        bad_row = bad_row || !(fabsf(total - 1.0f) < 1e-4f);  // flow conservation (NaN compares false)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) occ[lane * R + r] = sv[r] + excl;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        const int c = min(lane, K - 1);  // K <= 64: lanes past K repeat lane K-1's store
+                        const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
+                        float* g = A.grads + (long)b * A.sb + (long)t * A.st;
+                        g[c] = rowp[c] - o;
                     }
-                    int es[R];  // the exponent the pre-emission sums sB, sL are expressed in
-                    if (fast) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) es[r] = be[r];
-                        wavep_fast_step<R, 1>(bB, bL, yl, yb, pdx, pdy, sB, sL);
-                    } else {
-                        wavep_slow_step<R, 1>(bB, bL, be, yl, yb, skipf, sB, sL, ((KU - 1 - k) & 3) == 0);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) es[r] = be[r];  // = the aligned exponent of the step (kNoExp: sums are 0)
-                    }
-                    // occupancy = alpha_t(s) * sum_beta_t(s) / p; alpha's label state of pair j-1 comes across the lane edge
-                    const float aedge = sa_wave_shr1(rL[k][R - 1], 0.f);
-                    const int aeedge = __builtin_bit_cast(int, sa_wave_shr1(__builtin_bit_cast(float, rE[k][R - 1]), __builtin_bit_cast(float, kNoExp)));
-                    float gb = 0.f;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int eb_ = es[r] == kNoExp ? 0 : es[r];
-                        const int ea_b = rE[k][r] == kNoExp ? 0 : rE[k][r];
-                        gb += __builtin_amdgcn_ldexpf(rB[k][r] * sB[r] * rcp, ea_b + eb_ - pe);
-                        const float al = r == 0 ? aedge : rL[k][r - 1];
-                        const int eal = r == 0 ? aeedge : rE[k][r - 1];
-                        // (a pair without a label state drops a zero into its slot past the sorted labels)
-                        occ[pos[r]] = b_ok[r] ? __builtin_amdgcn_ldexpf(al * sL[r] * rcp, (eal == kNoExp ? 0 : eal) + eb_ - pe) : 0.f;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    float sv[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) sv[r] = occ[lane * R + r];
-#pragma unroll
-                    for (int r = 1; r < R; ++r) sv[r] += sv[r - 1];
-                    const float incl = wave_scan_dpp(sv[R - 1]);
-                    const float excl = incl - sv[R - 1];
-                    gb = sa_wave_sum_dpp(gb);
-                    const float total = gb + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
-                    bad_row = bad_row || !(fabsf(total - 1.0f) < 1e-4f);  // flow conservation (NaN compares false)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) occ[lane * R + r] = sv[r] + excl;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const int c = min(lane, K - 1);  // K <= 64: lanes past K repeat lane K-1's store
-                    const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
-                    float* g = A.grads + (long)b * A.sb + (long)t * A.st;
-                    g[c] = rowp[c] - o;
                 }
+            };
+            {
+                const bool fast = bi >= nslow, full = nrows == KU;
+                if (fast && full) beta_batch_t(Yes(), Yes());
+                else if (fast) beta_batch_t(Yes(), No());
+                else beta_batch_t(No(), No());
             }
             if (q > 0) stage.commit(nxt);
         }
