@@ -1349,7 +1349,7 @@ struct RowStagerP {
 };
 
 template <int R>
-__global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __restrict__ flags) {
+__device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU, P = 64 * R;
     constexpr int kNoExp = -(1 << 28);
@@ -1618,6 +1618,16 @@ __global__ __launch_bounds__(256) void ctc_wave_p_kernel(WaveArgs A, int* __rest
     }
 }
 
+// R <= 2: four waves per SIMD (<= 128 registers) -- the kernel lives off the latency hiding of its neighbours
+template <int R>
+__global__ __launch_bounds__(256, 4) void ctc_wave_p_kernel(WaveArgs A, int* __restrict__ flags) {
+    ctc_wave_p_body<R>(A, flags);
+}
+template <int R>
+__global__ __launch_bounds__(256) void ctc_wave_p_wide_kernel(WaveArgs A, int* __restrict__ flags) {
+    ctc_wave_p_body<R>(A, flags);
+}
+
 template <int R, bool WITH_GRAD, bool SMALLK>
 __global__ __launch_bounds__(256) void ctc_wave_kernel(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1799,7 +1809,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
             const char* pe = getenv("SA_CTC_PROB");
             const int prob = (grads && smallk && R <= 4) ? (pe ? atoi(pe) : 1) : 0;
             if (prob) {
-                void (*pf)(WaveArgs, int*) = R == 1 ? ctc_wave_p_kernel<1> : R == 2 ? ctc_wave_p_kernel<2> : ctc_wave_p_kernel<4>;
+                void (*pf)(WaveArgs, int*) = R == 1 ? ctc_wave_p_kernel<1> : R == 2 ? ctc_wave_p_kernel<2> : ctc_wave_p_wide_kernel<4>;
                 if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)pf, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)smem) != hipSuccess)
                     return CTC_STATUS_EXECUTION_FAILED;
