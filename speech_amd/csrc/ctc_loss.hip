@@ -153,6 +153,12 @@ __device__ __forceinline__ float wave_scan_dpp(float v) {
     return v;
 }
 
+// Hand-off arrays exist only for the chunks that HAVE a consumer: alpha chunks 0 .. n-2, beta chunks 1 .. n-1 -- n - 1 per
+// direction (none for a one-chunk lattice): with all 2n of them the emission copy stopped fitting LDS from three chunks.
+__device__ __forceinline__ int ctc_hand_slot(int dir, int chunk, int nchunks) {
+    return dir * (nchunks - 1) + (dir == 0 ? chunk : chunk - 1);
+}
+
 struct AbArgs {
     const float* ly2;     // [B][T_max][K] global
     const int* labels;
@@ -192,10 +198,13 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
     const int prod_chunk = DIR == 0 ? chunk - 1 : chunk + 1;
     const bool has_prod = prod_chunk >= 0 && prod_chunk < nchunks;
     const bool has_cons = DIR == 0 ? (chunk + 1 < nchunks) : (chunk > 0);
-    float* hand_w = hand_all + (long)(DIR * nchunks + chunk) * A.hand_stride;
-    float* hoff_w = hoff_all + (long)(DIR * nchunks + chunk) * A.nbatch;
-    const float* hand_r = hand_all + (long)(DIR * nchunks + (has_prod ? prod_chunk : 0)) * A.hand_stride;
-    const float* hoff_r = hoff_all + (long)(DIR * nchunks + (has_prod ? prod_chunk : 0)) * A.nbatch;
+    // (a chunk without a consumer never writes, one without a producer never reads: their slot index is clamped, unused)
+    const int slot_w = has_cons ? ctc_hand_slot(DIR, chunk, nchunks) : 0;
+    const int slot_r = has_prod ? ctc_hand_slot(DIR, prod_chunk, nchunks) : 0;
+    float* hand_w = hand_all + (long)slot_w * A.hand_stride;
+    float* hoff_w = hoff_all + (long)slot_w * A.nbatch;
+    const float* hand_r = hand_all + (long)slot_r * A.hand_stride;
+    const float* hoff_r = hoff_all + (long)slot_r * A.nbatch;
     constexpr int edge_lane = DIR == 0 ? 63 : 0;
 
     float Bst = (DIR == 0 ? (j == 0) : (j == L)) ? 0.0f : SA_NEG;
@@ -385,8 +394,8 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
     constexpr bool has_cons = HAS_CONS;  // = DIR == 0 ? (chunk + 1 < nchunks) : (chunk > 0), decided by the caller: a
                                          // wave-uniform branch per step is still a taken branch per step
     // hand-off arrays of {label hat, exponent} pairs: entry r holds the edge lane's state after step r - 1
-    float* hand_w = hand_all + (long)(DIR * nchunks + chunk) * 2 * A.hand_stride;
-    const float* hand_r = hand_all + (long)(DIR * nchunks + (has_prod ? prod_chunk : 0)) * 2 * A.hand_stride;
+    float* hand_w = hand_all + (long)(has_cons ? ctc_hand_slot(DIR, chunk, nchunks) : 0) * 2 * A.hand_stride;
+    const float* hand_r = hand_all + (long)(has_prod ? ctc_hand_slot(DIR, prod_chunk, nchunks) : 0) * 2 * A.hand_stride;
     constexpr int edge_lane = DIR == 0 ? 63 : 0;
     constexpr int kNoExp = -(1 << 28);  // exponent of "nothing": loses every max()
 
@@ -635,9 +644,11 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     //   log : hand [2][nchunks][hand_stride] | offsets [2][nchunks][nbatch] | class counts | gradient-row scratch
     //         [waves][align4(Ppad + 1)] (the hand-over pass, ctc_grad_row) | emissions
     float* hand_all = reinterpret_cast<float*>(smem_raw + kAbSharedBytes);
-    float* hoff_all = hand_all + (long)2 * A.nchunks * (PROB ? 2 : 1) * A.hand_stride;  // log only
+    const int nslots = 2 * (A.nchunks - 1);                                              // see ctc_hand_slot
+    float* hoff_all = hand_all + (long)nslots * (PROB ? 2 : 1) * A.hand_stride;         // log only
     float* hdummy_all = hoff_all;                                                          // PROB only
-    int* cls_cnt = reinterpret_cast<int*>(hoff_all + (long)2 * A.nchunks * (PROB ? 128 : A.nbatch));
+    int* cls_cnt = reinterpret_cast<int*>(hoff_all + (PROB ? (long)2 * A.nchunks * 128
+                                                            : (((long)nslots * A.nbatch + 3) & ~3L)));  // 16-byte steps
     float* srt_all = reinterpret_cast<float*>(cls_cnt + ((A.K + 1 + 3) & ~3));           // log only
     float* em_lds = srt_all + (PROB ? 0L : (long)2 * A.nchunks * ((A.Ppad + 1 + 3) & ~3)) +
                     kU * A.K;  // [kU slack rows][T][K][kU slack rows] (LDS_EM only; see ctc_chain_p)
@@ -704,11 +715,15 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     }
     if (lane == 0) {
         sh->prog[dir][chunk] = 0;
-        if (PROB) {
-            hand_all[(long)(dir * A.nchunks + chunk) * 2 * A.hand_stride] = 0.f;
-            hand_all[(long)(dir * A.nchunks + chunk) * 2 * A.hand_stride + 1] = __builtin_bit_cast(float, -(1 << 28));
-        } else {
-            hand_all[(long)(dir * A.nchunks + chunk) * A.hand_stride] = SA_NEG;
+        const bool cons = dir == 0 ? (chunk + 1 < A.nchunks) : (chunk > 0);
+        if (cons) {  // entry 0 of this chunk's hand-off array: "nothing yet"
+            const long slot = ctc_hand_slot(dir, chunk, A.nchunks);
+            if (PROB) {
+                hand_all[slot * 2 * A.hand_stride] = 0.f;
+                hand_all[slot * 2 * A.hand_stride + 1] = __builtin_bit_cast(float, -(1 << 28));
+            } else {
+                hand_all[slot * A.hand_stride] = SA_NEG;
+            }
         }
     }
     if (LDS_EM) {
@@ -1841,9 +1856,11 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     {  // K_B
         // LDS of ctc_alphabeta_kernel by domain (see its layout); the emission copy joins when it fits
         auto ab_fixed_lds = [&](bool prob) {
-            const size_t per_dc = prob ? (size_t)2 * A.hand_stride + 128
-                                       : (size_t)A.hand_stride + A.nbatch + ((A.Ppad + 1 + 3) & ~3);
-            return kAbSharedBytes + ((size_t)2 * nch * per_dc + ((K + 1 + 3) & ~3)) * sizeof(float);
+            const size_t slots = (size_t)2 * (nch - 1);  // hand-off arrays: chunks with a consumer only (ctc_hand_slot)
+            const size_t floats = prob ? slots * 2 * A.hand_stride + (size_t)2 * nch * 128
+                                       : slots * A.hand_stride + ((slots * A.nbatch + 3) & ~(size_t)3) +
+                                             (size_t)2 * nch * ((A.Ppad + 1 + 3) & ~3);
+            return kAbSharedBytes + (floats + ((K + 1 + 3) & ~3)) * sizeof(float);
         };
         const size_t em_bytes = sa_align_up((size_t)(max_T + 2 * kU) * K * sizeof(float), 16);
         auto ab_lds_em = [&](bool prob) { return ab_fixed_lds(prob) + em_bytes <= 156 * 1024; };
