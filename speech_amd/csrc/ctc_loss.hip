@@ -134,12 +134,6 @@ __device__ __forceinline__ float lse2_1p(float a, float b) {  // log2(2^a + 2^b)
     const float m = fmaxf(a, b);
     return m + sa_log2(1.0f + sa_exp2(fminf(a, b) - m));
 }
-__device__ __forceinline__ float lse3_1p(float a, float b, float c) {
-    const float m = fmaxf(fmaxf(a, b), c);
-    const float md = __builtin_amdgcn_fmed3f(a, b, c);
-    const float mn = fminf(fminf(a, b), c);
-    return m + sa_log2(1.0f + sa_exp2(md - m) + sa_exp2(mn - m));
-}
 
 // Inclusive prefix sum over the 64 lanes on the DPP network (the same six steps as sa_wave_sum_dpp, whose lane 63
 // holds the total): row_shr 1/2/4/8 scan each 16-lane row, row_bcast15 / row_bcast31 carry the row totals forward.
