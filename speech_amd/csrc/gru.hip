@@ -825,6 +825,10 @@ struct PBwdJob {
     float* dh_state;       // (B, H): running dh carried across launches
     unsigned* counters;    // one per batch tile; monotonic over the whole stack call
     long ds_b, ds_t;
+    const float* w_ih_t;   // gru_bwd_fused_kernel: (H, 3H) = this layer's W_ih transposed, or null (bottom layer)
+    float* dx_out;         // gru_bwd_fused_kernel: d h_out of the layer below, [b * xs_b + t * xs_t + j], or null
+    float* xch;            // gru_bwd_fused_kernel: the exchange buffer, dai tiled [t][batch tile][k / 16][b % 16][k % 16]
+    long xs_b, xs_t;
     int t0, nsteps;        // first time index this launch unwinds, number of steps
     int dt, t_first;       // -1 for a forward-in-time chain (unwinds from T-1), +1 for a reverse chain; the very first index
     unsigned base;
@@ -838,6 +842,8 @@ struct PBwdJobs {
     unsigned long long* stamp;
     unsigned* err;
     int spin_limit, fault, prio;  // see PFwdJobs
+    int packed;                   // gru_bwd_fused_kernel: 1 = publish with plain stores (default), 0 = write-through
+    int dbg_hot;                  // SA_GRU_DBG_HOT=1 (timing experiment, wrong results): stash / dh_out reads stay on one row
     unsigned long long* timing;   // debug (SA_GRU_TIMING=1): per block {poll+load, mfma, reduce+barrier, gates+publish} in
                                   // 10 ns ticks and the number of polling trips; else null
     PBwdJob j[kMaxJobs];
@@ -912,8 +918,9 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
         float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
         if (live) {
-            dh = J.dh_out[(long)b * J.ds_b + (long)t * J.ds_t + u];
-            const float* st = J.stash + row * 5 * H;
+            const int tl_ = P.dbg_hot ? J.t0 : t;  // timing experiment only: every step reads the same (cache-hot) rows
+            dh = J.dh_out[(long)b * J.ds_b + (long)tl_ * J.ds_t + u];
+            const float* st = J.stash + ((long)b * P.rb + (long)tl_ * P.rt) * 5 * H;
             r = st[u]; z = st[H + u]; n = st[2 * H + u]; q = st[3 * H + u]; hp = st[4 * H + u];
         }
         if (s > 0 && !P.flagless) {  // every unit tile of this (job, batch tile) must have published dah[t + 1]
@@ -1010,6 +1017,233 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     if (timed) {
         unsigned long long* o = P.timing + 5 * ((role_z * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
         for (int k = 0; k < 5; ++k) atomicAdd(&o[k], tacc[k]);
+    }
+    if (live) J.dh_state[(long)b * H + u] = dh_run;
+    if (stamper) P.stamp[1] = wall_clock64();
+}
+
+// --------------------------------------------------------------- persistent backward chunk with the input gradient fused
+// gru_bwd_persist_kernel plus the product the layer wavefront used to pay one grouped GEMM launch (and its split-K
+// reduce) per wave for:   d h_out[l-1][t] = dai[l][t] W_ih[l]   -- the gradient the layer below starts its step t from.
+// The block that owns units u0 .. u0+15 of layer l has, every step, the WHOLE gate-gradient row block of its batch tile
+// in registers (that is the exchange), so it can also form columns u0 .. u0+15 of that product: 16 more rows of weights
+// (W_ih^T) resident in the register file, 24 more MFMAs per wave and step -- issued right after the step's own values
+// have been published, i.e. while they travel to the other blocks, where the matrix pipe has nothing else to do.
+// Two things change against gru_bwd_persist_kernel to make one gathered row serve both products:
+//  * what is exchanged is dai = {dpr, dpz, dpn} (what W_ih multiplies); the recurrent product needs dqn = dpn * r, so a
+//    wave multiplies its n-gate fragments by r_{t+1} out of the forward stash (the producer's own dqn, bit for bit);
+//    dah is still written -- with plain stores -- for the W_hh weight gradient;
+//  * the k-space is dealt out by gate: wave w takes columns w H/4 .. (w+1) H/4 of EACH gate (instead of a contiguous
+//    quarter of 3H), so every wave needs the same H/4 r-values per batch row.
+// The second product's partial sums cross the waves through their own double-buffered LDS slab and ride on the next
+// step's barrier; the chunk's last row is gathered once more after the loop.  H = 64 IPG; flag-less hand-off only.
+template <int IPG>
+__global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
+    constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE(P.prio);
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {
+        if (threadIdx.x == 0) atomicOr(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
+    if (role_z >= P.n) return;
+    if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+    const PBwdJob& J = P.j[role_z];
+    const int B = P.B;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    float* red = psm;          // [2][4][256]: the four waves' partial sums of the recurrent product, per step parity
+    float* red2 = psm + 2048;  // [2][4][256]: the same for the input-gradient product
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    const bool fuse = J.dx_out != nullptr;
+    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
+    const int brow = min(b0 + i, B - 1);
+    const int kw = wave * (H / 4) + 4 * g;  // the lane's column offset inside a gate; fragment `it` adds 16 (it % IPG)
+    __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
+    // Resident in the register file for the whole launch: the lane's fragments of rows u0 + i of W_hh^T and W_ih^T.
+    float4 wr[NIT], wx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = (it / IPG) * H + kw + 16 * (it % IPG);
+        wr[it] = *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + i) * H3 + k);
+        wx[it] = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // Every address inside the loop is a per-thread base (formed here, once) plus t times a scalar stride.  The job's
+    // fields are read out of the kernel-argument segment HERE: left alone, hipcc re-loads them inside the loop (an
+    // s_load and a wait each -- about 1 us per step, measured) rather than keep them live; SA_KEEP makes a value
+    // opaque, so the worst the register allocator can do is park it in a VGPR lane.
+#define SA_KEEP(v) asm volatile("" : "+s"(v))
+    const int bl = live ? b : 0;
+    int t0 = J.t0, dt = J.dt, t_first = J.t_first, nsteps = J.nsteps, packed = P.packed, hot = P.dbg_hot;
+    long s_dh = J.ds_t, s_st = (long)P.rt * 5 * H, s_d = (long)P.rt * H3, s_dx = J.xs_t;
+    long s_x = (long)P.nbt_all * (H3 / 16) * 256;  // floats of the exchange buffer per time step
+    unsigned* errp = P.err;
+    SA_KEEP(t0); SA_KEEP(dt); SA_KEEP(t_first); SA_KEEP(nsteps); SA_KEEP(packed); SA_KEEP(hot);
+    SA_KEEP(s_dh); SA_KEEP(s_st); SA_KEEP(s_d); SA_KEEP(s_dx); SA_KEEP(s_x); SA_KEEP(errp);
+#undef SA_KEEP
+    const float* p_dh = J.dh_out + (long)bl * J.ds_b + u;
+    const float* p_st = J.stash + (long)bl * P.rb * 5 * H + u;
+    const float* p_rn = J.stash + (long)brow * P.rb * 5 * H + kw;
+    float* p_xs = J.xch + ((long)role_y * (H3 / 16) + role_x) * 256 + tid;
+    float* p_di = J.dai + (long)bl * P.rb * H3 + u;
+    float* p_dhh = J.dah + (long)bl * P.rb * H3 + u;
+    float* p_dx = fuse ? J.dx_out + (long)b * J.xs_b + u : nullptr;
+    // tile (gate, wave, j) = 16 batch rows x 16 columns, 1 KB contiguous: one load instruction of a wave covers it
+    const int a0 = (int)((((long)role_y * (H3 / 16) + wave * IPG) * 256 + i * 16 + 4 * g) * 4);
+    __syncthreads();
+
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;  // SA_GRU_TIMING=1: {gather, mfma, barrier .. fetch, second, trips}
+    const bool timed = P.timing != nullptr && tid == 0;
+    if (timed) tprev = wall_clock64();
+#define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
+    f32x4v a[NIT];  // the gathered row block: rows = the batch tile, this wave's fragments of dai[trow]
+    auto gather = [&](int trow) {  // returns once no fragment holds the sentinel (or the call is lost)
+        const int abase = a0 + trow * (int)(s_x * 4);
+        for (int spins = 0;; ++spins) {
+            asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
+            bool stale = false;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) stale |= has_sentinel(a[it]);
+            if (timed) ++tacc[4];
+            if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+            if (spins > budget) { if (lane == 0) atomicOr(errp, 1u); budget = 0; break; }
+        }
+    };
+    auto second = [&](int par) {  // a[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15)
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const float4 w = wx[it];
+            f32x4& d = (it & 1) ? c1 : c0;
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, d, 0, 0, 0);
+        }
+        float* rd = red2 + par * 1024;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = c0[rr] + c1[rr];
+    };
+    auto flush2 = [&](int par, int trow) {  // after a barrier: add the four waves' parts, store the row's 16 x 16 tile
+        if (!live) return;
+        const float* rd = red2 + par * 1024;
+        p_dx[(long)trow * s_dx] = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
+    };
+
+    // A step's operands out of memory -- its stashed gates, its d h_out, and r of the row the gather brings -- are
+    // fetched during the PREVIOUS step, right after that step's values went out: the vector-memory queue returns in
+    // order, so a load still on its way to HBM when the gather is issued would hold the gather's data back.
+    // Unconditional loads on clamped indices (a branch around a load costs a vmcnt(0) at the join).
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
+    f32x4v rn[IPG];
+    auto fetch = [&](int tt) {
+        const int tr = hot == 1 ? t0 : (tt != t_first ? tt - dt : tt);  // the first step of the sequence gathers nothing
+        const int to = hot == 1 ? t0 : tt;  // hot: timing experiment only, always the same (cache-hot) rows
+        dh = p_dh[(long)to * s_dh];
+        const float* st = p_st + (long)to * s_st;
+        r = st[0]; z = st[H]; n = st[2 * H]; q = st[3 * H]; hp = st[4 * H];
+        const float* rrow = p_rn + (long)tr * s_st;
+#pragma unroll
+        for (int j = 0; j < IPG; ++j) rn[j] = *reinterpret_cast<const f32x4v*>(rrow + 16 * j);
+    };
+    float dh_run = 0.f, z_next = 0.f;
+    if (live && t0 != t_first) {
+        dh_run = J.dh_state[(long)b * H + u];
+        z_next = p_st[(long)(t0 - dt) * s_st + H];
+    }
+    fetch(t0);
+    int pend_t = -1;  // time index of the input-gradient row whose partial sums wait in red2[(s - 1) & 1]
+    for (int s = 0; s < nsteps; ++s) {
+        const int t = t0 + s * dt;
+        const bool have_next = t != t_first;
+        if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
+            gather(t - dt);
+            SA_TICK(0)
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // even / odd fragments
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                f32x4v f = a[it];
+                if (it >= 2 * IPG) f = f * rn[it - 2 * IPG];  // dqn = dpn * r
+                const float4 w = wr[it];
+                f32x4& d = (it & 1) ? acc1 : acc;  // two chains: the 40-cycle dependent latency is hidden
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w.x, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w.y, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w.z, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, w.w, d, 0, 0, 0);
+            }
+            float* rd = red + (s & 1) * 1024;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = acc[rr] + acc1[rr];
+            SA_TICK(1)
+        }
+        __syncthreads();
+        if (hot == 2) { SA_TICK(3) }  // experiment: slot 3 = barrier wait, slot 2 = everything after it
+        if (pend_t >= 0) { flush2((s - 1) & 1, pend_t); pend_t = -1; }
+        {
+            float dpr = 0.f, dpz = 0.f, dpn = 0.f, dqn = 0.f;
+            if (live) {
+                const float* rd = red + (s & 1) * 1024;
+                if (have_next)
+                    dh = gru_bwd_total_dh(dh, rd[tid], rd[256 + tid], rd[512 + tid], rd[768 + tid], dh_run, z_next);
+                gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
+            }
+            // The exchange: this block's three 16 x 16 tiles (rows beyond the batch publish zeros -- a tile has no
+            // holes a reader could wait on).  Consecutive threads, consecutive addresses: 1 KB per store instruction.
+            float* xp = p_xs + (long)t * s_x;
+            if (packed) {  // plain stores: the XCD's own L2 is where the group meets, nothing needs to reach memory
+                xp[0] = dpr; xp[(H / 16) * 256] = dpz; xp[2 * (H / 16) * 256] = dpn;
+            } else {
+                __hip_atomic_store(xp, dpr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+                __hip_atomic_store(xp + (H / 16) * 256, dpz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xp + 2 * (H / 16) * 256, dpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (live) {  // the row-major copies the weight-gradient products read
+                float* di = p_di + (long)t * s_d;
+                float* dhh = p_dhh + (long)t * s_d;
+                di[0] = dpr; di[H] = dpz; di[2 * H] = dpn;
+                dhh[0] = dpr; dhh[H] = dpz; dhh[2 * H] = dqn;
+                dh_run = dh;
+                z_next = z;
+            }
+        }
+        fetch(s + 1 < nsteps ? t + dt : t);  // the next step's operands (the last step re-reads its own: unused)
+        SA_TICK(2)
+        // the row gathered at the top of this step, through W_ih, while this step's values travel (s = 0: that row
+        // belongs to the previous launch, whose last act was this product)
+        if (fuse && have_next && s > 0) { second(s & 1); pend_t = t - dt; }
+        if (hot == 2) { SA_TICK(2) } else { SA_TICK(3) }
+    }
+#undef SA_TICK
+    if (timed) {
+        unsigned long long* o = P.timing + 5 * ((role_z * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
+        for (int k = 0; k < 5; ++k) atomicAdd(&o[k], tacc[k]);
+    }
+    if (fuse) {  // the chunk's last row, published by the step that just ended
+        const int tl = t0 + (nsteps - 1) * dt;
+        gather(tl);
+        second(nsteps & 1);
+        __syncthreads();
+        if (pend_t >= 0) flush2((nsteps - 1) & 1, pend_t);
+        flush2(nsteps & 1, tl);
     }
     if (live) J.dh_state[(long)b * H + u] = dh_run;
     if (stamper) P.stamp[1] = wall_clock64();
@@ -1485,6 +1719,13 @@ static int fwd_chunks(int T) {  // bidirectional forward: time chunks per layer 
     // 6: 29.7 / 6.55, 8: 32.0 / 6.78 -- a chunk launch costs a ramp and an event
     return v > 0 ? (v > 15 ? 15 : v) : (T >= 256 ? 4 : 2);
 }
+static bool fuse_dx_enabled() {  // SA_GRU_FUSE_DX=0: the per-wave grouped GEMM computes d h_out of the lower layers
+    const char* e = getenv("SA_GRU_FUSE_DX");
+    return !(e && e[0] == '0');
+}
+static BwdPersistFn bwd_fused_fn(int H) {
+    return H == 512 ? gru_bwd_fused_kernel<8> : (H == 256 ? gru_bwd_fused_kernel<4> : nullptr);
+}
 static int persist_prio() {
     const char* e = getenv("SA_GRU_PRIO");
     return e ? atoi(e) : 1;
@@ -1828,8 +2069,12 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
-    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + gw + wgrad_ws_bytes(L, D, B, T, H, I0) +
-           kSyncBytes;
+    // the fused backward kernel: W_ih^T of the upper layers, and a tiled exchange copy of dai per layer
+    const size_t wih_t = D == 1 && L > 1 ? (size_t)(L - 1) * sa_align_up((size_t)3 * H * H * sizeof(float), 256) +
+                                               (size_t)L * sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256)
+                                         : 0;
+    return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + wih_t + gw +
+           wgrad_ws_bytes(L, D, B, T, H, I0) + kSyncBytes;
 }
 
 // dh_top (T, B, D*H): gradient wrt the top layer's output.  Fills dai / dah [l*D+d] (T, B, 3H) for every layer and
@@ -1943,7 +2188,11 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
     const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
     char* ws = (char*)workspace;
-    const size_t fixed_bytes = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
+    const size_t wih_t_each = sa_align_up((size_t)3 * H * H * sizeof(float), 256);
+    const size_t wih_t_off = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
+    const size_t xch_each = sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256);
+    const size_t xch_off = wih_t_off + (D == 1 && L > 1 ? (size_t)(L - 1) * wih_t_each : 0);
+    const size_t fixed_bytes = xch_off + (D == 1 && L > 1 ? (size_t)L * xch_each : 0);
     char* gws = ws + fixed_bytes;
     const size_t wws_bytes = wgrad_ws_bytes(L, D, B, T, H, I0);
     const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes - wws_bytes;
@@ -2014,7 +2263,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 if (Q.flagless)
                     for (int d = 0; d < 2; ++d)
                         if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = getenv("SA_GRU_DBG_HOT") ? atoi(getenv("SA_GRU_DBG_HOT")) : 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
@@ -2082,9 +2331,25 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                      (long)T * B * 3 * H * 4 < 0x7fffffffL;
     unsigned persist_launches = 0;
     const bool flagless = xcd && flagless_mode();
+    // the lower layers' d h_out inside the recurrence kernel (gru_bwd_fused_kernel): no GEMM between the launches
+    const bool fused = flagless && L > 1 && fuse_dx_enabled() && bwd_fused_fn(H) != nullptr &&
+                       (long)T * nbt * 16 * 3 * H * 4 < 0x7fffffffL;
+    const size_t flds = xcd_lds((size_t)4 * 4 * 256 * sizeof(float));
+    auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
+    auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
     if (flagless)
-        for (int l = 0; l < L; ++l)
-            if (!sentinel_fill(dah[l], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+        for (int l = 0; l < L; ++l)  // the exchanged values are their own flags
+            if (!sentinel_fill(fused ? xch_of(l) : dah[l], fused ? (size_t)T * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
+                               stream))
+                return CTC_STATUS_MEMOPS_FAILED;
+    if (fused) {
+        for (int l = 1; l < L; ++l)
+            hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream, w_ih[l],
+                               wih_t_of(l), 3 * H, H);
+        if (hipFuncSetAttribute((const void*)bwd_fused_fn(H), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds) !=
+            hipSuccess)
+            return CTC_STATUS_EXECUTION_FAILED;
+    }
     // weight gradients ride beside the persistent launches: every kWgEvery launches, the time steps that have become
     // final since the last hand-over go to the side stream
     const bool side = wg && xcd && overlap_enabled(true) && g_side.init();
@@ -2097,7 +2362,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     }
     for (int w = 0; w < nch + L - 1; ++w) {
         // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
-        {
+        if (!fused) {
             const float* gA[kMaxJobs]; const float* gB[kMaxJobs]; float* gC[kMaxJobs];
             int ng = 0;
             for (int l = L - 2; l >= 0; --l) {
@@ -2125,7 +2390,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.reg = sync + kSyncReg;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = getenv("SA_GRU_DBG_HOT") ? atoi(getenv("SA_GRU_DBG_HOT")) : 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
@@ -2135,6 +2400,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
                 J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
+                J.w_ih_t = fused && l > 0 ? wih_t_of(l) : nullptr; J.dx_out = fused && l > 0 ? mid_of(l - 1) : nullptr;
+                J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = fused ? xch_of(l) : nullptr;
                 J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
                 J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);
             }
@@ -2146,7 +2413,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
                     Q.reg_base = persist_launches++ * 32u;
                     if (bt0 > 0) Q.stamp = nullptr;
-                    hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
+                    if (fused) hipLaunchKernelGGL(bwd_fused_fn(H), dim3(256), dim3(256), flds, stream, Q);
+                    else hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
                 }
             }
             if (side && ((w + 1) % wg_every == 0 || w == nch + L - 2)) {

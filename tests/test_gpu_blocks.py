@@ -359,7 +359,7 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     res = []
     for mode in ("0", "2", "3"):   # step kernels; XCD-local groups with arrival counters; flag-less hand-off (default)
         out = "/tmp/sa_xcd_%s.pt" % mode
-        env = dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0")  # the fused forward sums in another order
+        env = dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0", SA_GRU_FUSE_DX="0")  # the fused kernels sum in another order
         subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=180)
         res.append(torch.load(out))
     for other in res[1:]:
@@ -374,10 +374,47 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd2_%s.pt" % mode
             subprocess.run([sys.executable, "-c", code2, out],
-                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0"), check=True, timeout=180)
+                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0", SA_GRU_FUSE_DX="0"), check=True,
+                           timeout=180)
             res.append(torch.load(out))
         for other in res[1:]:
             assert all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
+
+
+def test_fused_backward_input_gradient():
+    """gru_bwd_fused_kernel (the default backward of eligible unidirectional stacks with H = 512 / 256: the lower layers'
+    d h_out formed inside the recurrence kernel instead of by a grouped GEMM per wave of the layer wavefront) against
+    the GEMM path (SA_GRU_FUSE_DX=0): every gradient equal up to the summation order (the k-space is dealt out by gate
+    and the product runs on 16x16x4 MFMAs), ragged chunks, several batch tiles and passes, one-step chunks.  (The
+    oracle comparisons of the whole stack -- test_gru_stack_*, tests/test_gpu_baseline_configs.py -- run the default,
+    i.e. this kernel, wherever it is eligible.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_blocks import _stack_case\nfrom speech_amd import ops, _lib\n"
+            "L, B, T, I0, H, CH = [int(v) for v in sys.argv[2:8]]\n"
+            "x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)\n"
+            "dtop = torch.randn(T, B, H, device='cuda')\n"
+            "for _ in range(2):\n"
+            "    h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True)\n"
+            "    dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0, chunk=CH)\n"
+            "torch.cuda.synchronize()\nassert _lib.lib().sa_gru_persist_status() == 0\n"
+            "torch.save([t.cpu() for t in dai + dah + [dx]], sys.argv[1])\n") % (root, root)
+    for shape in ((4, 32, 70, 48, 512, 16), (4, 32, 90, 48, 512, 0), (2, 20, 33, 48, 512, 16), (2, 32, 45, 40, 256, 16),
+                  (4, 64, 21, 24, 256, 16), (4, 48, 37, 40, 512, 16), (4, 80, 19, 24, 256, 16), (3, 5, 9, 16, 512, 1),
+                  (2, 32, 7, 16, 256, 64)):
+        res = []
+        for fuse in ("0", "1"):
+            out = "/tmp/sa_fuse_dx_%s.pt" % fuse
+            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
+                           env=dict(os.environ, SA_GRU_FUSE_DX=fuse), check=True, timeout=180)
+            res.append(torch.load(out))
+        assert len(res[0]) == len(res[1])
+        for a, b in zip(*res):
+            assert torch.isfinite(b).all(), shape
+            assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max())), shape
 
 
 def test_xcd_local_persistent_kernels_bidirectional():

@@ -22,6 +22,8 @@ sync = ws[ws.numel() - 16384: ws.numel()].cpu().numpy().view(np.uint64)
 tim = sync[256:256 + 5 * 256].reshape(-1, 5).astype(np.float64)   # sync + 512 uints = 256 u64
 steps = T
 us = tim[:, :4] * 0.01 / steps
+if os.environ.get("SA_GRU_FUSE_DX", "1") != "0":
+    print("(fused kernel: the four phases are gather | mfma | barrier .. publish | second product)")
 print("per-step us (mean over blocks): poll+load %.2f  mfma %.2f  reduce+barrier %.2f  gates+publish %.2f | total %.2f | polling trips per step %.2f"
       % (us[:, 0].mean(), us[:, 1].mean(), us[:, 2].mean(), us[:, 3].mean(), us.sum(1).mean(), tim[:, 4].mean() / steps))
 print("min/max over blocks of poll+load: %.2f / %.2f ; trips %.2f / %.2f" % (us[:, 0].min(), us[:, 0].max(), tim[:, 4].min() / steps, tim[:, 4].max() / steps))

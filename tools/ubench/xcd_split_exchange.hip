@@ -21,7 +21,7 @@ __device__ __forceinline__ bool sent(f4 v) {
 
 // buf layout per step: A: [xcd][16 rows][1536]            (block r writes columns 48 r .. 48 r + 47 of every row)
 //                      B: [xcd][32 producers][16 rows][512] (consumer c reads columns 16 c .. 16 c + 15 of every producer row)
-template <int MODE, int WT>
+template <int MODE, int WT, int LD>
 __global__ __launch_bounds__(256) void k(int* reg, float* buf, int steps, long long* out) {
     __shared__ float pad[24 * 1024];  // one block per CU
     __shared__ int s_x, s_r;
@@ -68,12 +68,15 @@ __global__ __launch_bounds__(256) void k(int* reg, float* buf, int steps, long l
         __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
         if (MODE == 0) {  // 16 x 1536 floats = 6144 float4: 24 per thread
             f4 a[24];
-            for (int spins = 0; spins < (1 << 16); ++spins) {
+            for (int spins = 0; spins < (1 << 12); ++spins) {
                 bool st = false;
                 asm volatile("" ::: "memory");  // the loads must be re-issued every trip
+                if (LD == 2) asm volatile("buffer_inv sc1" ::: "memory");       // drop the CU's L1 copies, then plain loads
 #pragma unroll
                 for (int u = 0; u < 24; ++u)
-                    a[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(res, (tid + 256 * u) * 16, 0, 16));
+                    a[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                     res, (tid + 256 * (LD >= 4 ? (u + (LD == 5 ? 3 * r : r)) % 24 : u)) * 16, 0,
+                                     LD == 0 || LD >= 4 ? 16 : LD == 1 ? 1 : LD == 3 ? 2 : 0));  // LD 4 / 5: start rotated by the block's rank
 #pragma unroll
                 for (int u = 0; u < 24; ++u) st |= sent(a[u]);
                 if (__builtin_amdgcn_ballot_w64(st) == 0) break;
@@ -109,13 +112,13 @@ __global__ __launch_bounds__(256) void k(int* reg, float* buf, int steps, long l
     if (tid == 0) { out[blockIdx.x] = (t1 - t0); out[256 + blockIdx.x] = (long long)s_err; }
 }
 
-template <int MODE, int WT>
+template <int MODE, int WT, int LD = 0>
 int run(const char* name, int steps, int* reg, float* buf, long long* out, size_t bytes) {
     CHECK(hipMemset(reg, 0, 64));
     CHECK(hipMemset(out, 0, 512 * 8));
     CHECK(hipMemsetD32((hipDeviceptr_t)buf, 0x7fc00001, bytes / 4));
     CHECK(hipDeviceSynchronize());
-    hipLaunchKernelGGL((k<MODE, WT>), dim3(256), dim3(256), 0, 0, reg, buf, steps, out);
+    hipLaunchKernelGGL((k<MODE, WT, LD>), dim3(256), dim3(256), 0, 0, reg, buf, steps, out);
     CHECK(hipDeviceSynchronize());
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) printf("launch error: %s\n", hipGetErrorString(le));
@@ -133,12 +136,14 @@ int main(int argc, char** argv) {
     const size_t bytes = (size_t)steps * kXcds * 32 * 16 * 512 * 4;
     CHECK(hipMalloc(&reg, 64)); CHECK(hipMalloc(&buf, bytes)); CHECK(hipMalloc(&out, 512 * 8));
     for (int rep = 0; rep < 2; ++rep) {
+        run<0, 0, 4>("A, plain 16-byte stores, sc1 loads, order rotated by rank", steps, reg, buf, out, bytes);
+        run<0, 0, 5>("A, plain 16-byte stores, sc1 loads, order rotated by 3 rank", steps, reg, buf, out, bytes);
+        run<0, 1, 4>("A, 4-byte write-through stores, sc1 loads, rotated by rank", steps, reg, buf, out, bytes);
+        run<0, 0, 1>("A, plain 16-byte stores, sc0 loads", steps, reg, buf, out, bytes);
+        run<0, 0, 3>("A, plain 16-byte stores, nt loads", steps, reg, buf, out, bytes);
+        run<0, 1, 1>("A, 4-byte write-through stores, sc0 loads", steps, reg, buf, out, bytes);
         run<0, 1>("A gather 98 KB / block, write-through", steps, reg, buf, out, bytes);
         run<0, 0>("A gather 98 KB / block, plain 16-byte stores", steps, reg, buf, out, bytes);
-        run<0, 2>("A gather 98 KB / block, plain 4-byte stores", steps, reg, buf, out, bytes);
-        run<0, 3>("A gather 98 KB / block, 16-byte stores sc1", steps, reg, buf, out, bytes);
-        run<0, 4>("A gather 98 KB / block, 16-byte stores sc0 sc1", steps, reg, buf, out, bytes);
-        run<1, 1>("B partials 32 KB out + 32 KB in, write-through", steps, reg, buf, out, bytes);
         run<1, 0>("B partials 32 KB out + 32 KB in, plain stores", steps, reg, buf, out, bytes);
     }
     return 0;
