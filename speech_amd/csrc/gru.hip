@@ -828,6 +828,7 @@ struct PBwdJob {
     const float* w_ih_t;   // gru_bwd_fused_kernel: (H, 3H) = this layer's W_ih transposed, or null (bottom layer)
     float* dx_out;         // gru_bwd_fused_kernel: d h_out of the layer below, [b * xs_b + t * xs_t + j], or null
     float* xch;            // gru_bwd_fused_kernel: the exchange buffer, dai tiled [t][batch tile][k / 16][b % 16][k % 16]
+    float* dump;           // gru_bwd_fused_kernel: 256 x 256 floats nobody reads (where predicated-off stores go)
     long xs_b, xs_t;
     int t0, nsteps;        // first time index this launch unwinds, number of steps
     int dt, t_first;       // -1 for a forward-in-time chain (unwinds from T-1), +1 for a reverse chain; the very first index
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const int a0 = (int)((((long)role_y * (H3 / 16) + wave * IPG) * 256 + i * 16 + 4 * g) * 4);
     __syncthreads();
 
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;  // SA_GRU_TIMING=1: {gather, mfma, barrier .. fetch, second, trips}
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;  // SA_GRU_TIMING=1: {gather, mfma, barrier .. publish, tail, trips}
     const bool timed = P.timing != nullptr && tid == 0;
     if (timed) tprev = wall_clock64();
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
@@ -1129,24 +1130,29 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         }
     };
     auto second = [&](int par) {  // a[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15)
-        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // four chains (one per k within a fragment): wherever the scheduler cuts the sequence to slip a memory
+        // instruction in, neighbouring MFMAs stay independent
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const float4 w = wx[it];
-            f32x4& d = (it & 1) ? c1 : c0;
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, d, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, c3, 0, 0, 0);
         }
         float* rd = red2 + par * 1024;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = c0[rr] + c1[rr];
+        for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = (c0[rr] + c1[rr]) + (c2[rr] + c3[rr]);
     };
-    auto flush2 = [&](int par, int trow) {  // after a barrier: add the four waves' parts, store the row's 16 x 16 tile
-        if (!live) return;
+    // Stores that do not apply (a row beyond the batch, no product pending) still execute, aimed at a per-thread dump
+    // slot: a BRANCH around a vector-memory instruction makes hipcc wait vmcnt(0) at the join, i.e. here for the
+    // store's own acknowledgement -- 1.2 us per step when the d h_out store sat under `if (pending && live)`.
+    float* p_dump = J.dump + blockIdx.x * 256 + tid;
+    auto flush2 = [&](int par, bool on, int trow) {  // after a barrier: add the four waves' parts, store the row's tile
         const float* rd = red2 + par * 1024;
-        p_dx[(long)trow * s_dx] = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
+        float* dst = on && live ? p_dx + (long)trow * s_dx : p_dump;
+        *dst = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
     };
 
     // A step's operands out of memory -- its stashed gates, its d h_out, and r of the row the gather brings -- are
@@ -1196,16 +1202,14 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             SA_TICK(1)
         }
         __syncthreads();
-        if (hot == 2) { SA_TICK(3) }  // experiment: slot 3 = barrier wait, slot 2 = everything after it
-        if (pend_t >= 0) { flush2((s - 1) & 1, pend_t); pend_t = -1; }
+        float dpr = 0.f, dpz = 0.f, dpn = 0.f, dqn = 0.f;
+        if (live) {
+            const float* rd = red + (s & 1) * 1024;
+            if (have_next)
+                dh = gru_bwd_total_dh(dh, rd[tid], rd[256 + tid], rd[512 + tid], rd[768 + tid], dh_run, z_next);
+            gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
+        }
         {
-            float dpr = 0.f, dpz = 0.f, dpn = 0.f, dqn = 0.f;
-            if (live) {
-                const float* rd = red + (s & 1) * 1024;
-                if (have_next)
-                    dh = gru_bwd_total_dh(dh, rd[tid], rd[256 + tid], rd[512 + tid], rd[768 + tid], dh_run, z_next);
-                gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
-            }
             // The exchange: this block's three 16 x 16 tiles (rows beyond the batch publish zeros -- a tile has no
             // holes a reader could wait on).  Consecutive threads, consecutive addresses: 1 KB per store instruction.
             float* xp = p_xs + (long)t * s_x;
@@ -1216,21 +1220,32 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                 __hip_atomic_store(xp + (H / 16) * 256, dpz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(xp + 2 * (H / 16) * 256, dpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (live) {  // the row-major copies the weight-gradient products read
-                float* di = p_di + (long)t * s_d;
-                float* dhh = p_dhh + (long)t * s_d;
-                di[0] = dpr; di[H] = dpz; di[2 * H] = dpn;
-                dhh[0] = dpr; dhh[H] = dpz; dhh[2 * H] = dqn;
-                dh_run = dh;
-                z_next = z;
-            }
+        }
+        SA_TICK(2)
+        // ---- everything the other blocks wait for is out.  The rest of the step is one branch-free scheduling region:
+        // the previous row's input gradient leaves, the row-major copies leave, the next step's operands are
+        // requested -- 21 vector-memory instructions per wave whose address processing (~0.8 us per step when issued
+        // back to back, measured) is dealt out between the 96 MFMAs of the second product instead.  The product runs
+        // unconditionally (bottom layer: zero weights; first step: no row -- the result goes to the dump slot).
+        flush2((s - 1) & 1, pend_t >= 0, pend_t);
+        {  // the row-major copies the weight-gradient products read
+            float* di = live ? p_di + (long)t * s_d : p_dump;
+            float* dhh = live ? p_dhh + (long)t * s_d : p_dump;
+            const int g1 = live ? H : 0, g2 = live ? 2 * H : 0;
+            di[0] = dpr; di[g1] = dpz; di[g2] = dpn;
+            dhh[0] = dpr; dhh[g1] = dpz; dhh[g2] = dqn;
+            dh_run = dh;
+            z_next = z;
         }
         fetch(s + 1 < nsteps ? t + dt : t);  // the next step's operands (the last step re-reads its own: unused)
-        SA_TICK(2)
-        // the row gathered at the top of this step, through W_ih, while this step's values travel (s = 0: that row
-        // belongs to the previous launch, whose last act was this product)
-        if (fuse && have_next && s > 0) { second(s & 1); pend_t = t - dt; }
-        if (hot == 2) { SA_TICK(2) } else { SA_TICK(3) }
+        second(s & 1);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 vector-memory instruction
+        }
+        pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
+        SA_TICK(3)
     }
 #undef SA_TICK
     if (timed) {
@@ -1242,8 +1257,8 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         gather(tl);
         second(nsteps & 1);
         __syncthreads();
-        if (pend_t >= 0) flush2((nsteps - 1) & 1, pend_t);
-        flush2(nsteps & 1, tl);
+        flush2((nsteps - 1) & 1, pend_t >= 0, pend_t);
+        flush2(nsteps & 1, true, tl);
     }
     if (live) J.dh_state[(long)b * H + u] = dh_run;
     if (stamper) P.stamp[1] = wall_clock64();
@@ -2071,7 +2086,8 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
     // the fused backward kernel: W_ih^T of the upper layers, and a tiled exchange copy of dai per layer
     const size_t wih_t = D == 1 && L > 1 ? (size_t)(L - 1) * sa_align_up((size_t)3 * H * H * sizeof(float), 256) +
-                                               (size_t)L * sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256)
+                                               (size_t)L * sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256) +
+                                               (size_t)256 * 256 * sizeof(float)
                                          : 0;
     return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + wih_t + gw +
            wgrad_ws_bytes(L, D, B, T, H, I0) + kSyncBytes;
@@ -2192,7 +2208,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const size_t wih_t_off = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
     const size_t xch_each = sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256);
     const size_t xch_off = wih_t_off + (D == 1 && L > 1 ? (size_t)(L - 1) * wih_t_each : 0);
-    const size_t fixed_bytes = xch_off + (D == 1 && L > 1 ? (size_t)L * xch_each : 0);
+    const size_t dump_off = xch_off + (D == 1 && L > 1 ? (size_t)L * xch_each : 0);
+    const size_t fixed_bytes = dump_off + (D == 1 && L > 1 ? (size_t)256 * 256 * sizeof(float) : 0);
     char* gws = ws + fixed_bytes;
     const size_t wws_bytes = wgrad_ws_bytes(L, D, B, T, H, I0);
     const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes - wws_bytes;
@@ -2401,7 +2418,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
                 J.w_ih_t = fused && l > 0 ? wih_t_of(l) : nullptr; J.dx_out = fused && l > 0 ? mid_of(l - 1) : nullptr;
-                J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = fused ? xch_of(l) : nullptr;
+                J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = fused ? xch_of(l) : nullptr; J.dump = (float*)(ws + dump_off);
                 J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
                 J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);
             }

@@ -26,4 +26,7 @@ if os.environ.get("SA_GRU_FUSE_DX", "1") != "0":
     print("(fused kernel: the four phases are gather | mfma | barrier .. publish | second product)")
 print("per-step us (mean over blocks): poll+load %.2f  mfma %.2f  reduce+barrier %.2f  gates+publish %.2f | total %.2f | polling trips per step %.2f"
       % (us[:, 0].mean(), us[:, 1].mean(), us[:, 2].mean(), us[:, 3].mean(), us.sum(1).mean(), tim[:, 4].mean() / steps))
+if os.environ.get("SA_GRU_DBG_HOT") == "3":  # hot3: slots = flush | reduce + gates | exchange stores | row-major stores | fetch
+    print("hot3 per-step us: flush %.2f  reduce+gates %.2f  exchange stores %.2f  row-major stores %.2f  fetch %.2f"
+          % (us[:, 0].mean(), us[:, 1].mean(), us[:, 2].mean(), us[:, 3].mean(), tim[:, 4].mean() * 0.01 / steps))
 print("min/max over blocks of poll+load: %.2f / %.2f ; trips %.2f / %.2f" % (us[:, 0].min(), us[:, 0].max(), tim[:, 4].min() / steps, tim[:, 4].max() / steps))
