@@ -1038,7 +1038,9 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 //    quarter of 3H), so every wave needs the same H/4 r-values per batch row.
 // The second product's partial sums cross the waves through their own double-buffered LDS slab and ride on the next
 // step's barrier; the chunk's last row is gathered once more after the loop.  H = 64 IPG; flag-less hand-off only.
-template <int IPG>
+// FUSE = false: the same kernel without the second product (bidirectional layers, one-layer stacks, SA_GRU_FUSE_DX=0):
+// tiled exchange, operands a step ahead, d h_out of the layer below left to a GEMM.
+template <int IPG, bool FUSE>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     extern __shared__ __attribute__((aligned(16))) float psm[];
@@ -1070,19 +1072,20 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const int bi = tid >> 4, uj = tid & 15;
     const int b = b0 + bi, u = u0 + uj;
     const bool live = b < B;
-    const bool fuse = J.dx_out != nullptr;
+    const bool fuse = FUSE && J.dx_out != nullptr;
     int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
     const int brow = min(b0 + i, B - 1);
     const int kw = wave * (H / 4) + 4 * g;  // the lane's column offset inside a gate; fragment `it` adds 16 (it % IPG)
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
     // Resident in the register file for the whole launch: the lane's fragments of rows u0 + i of W_hh^T and W_ih^T.
-    float4 wr[NIT], wx[NIT];
+    float4 wr[NIT], wx[FUSE ? NIT : 1];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int k = (it / IPG) * H + kw + 16 * (it % IPG);
         wr[it] = *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + i) * H3 + k);
-        wx[it] = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FUSE)
+            wx[it] = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // Every address inside the loop is a per-thread base (formed here, once) plus t times a scalar stride.  The job's
     // fields are read out of the kernel-argument segment HERE: left alone, hipcc re-loads them inside the loop (an
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const float4 w = wx[it];
+            const float4 w = wx[FUSE ? it : 0];
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, c1, 0, 0, 0);
             c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, c2, 0, 0, 0);
@@ -1227,7 +1230,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         // requested -- 21 vector-memory instructions per wave whose address processing (~0.8 us per step when issued
         // back to back, measured) is dealt out between the 96 MFMAs of the second product instead.  The product runs
         // unconditionally (bottom layer: zero weights; first step: no row -- the result goes to the dump slot).
-        flush2((s - 1) & 1, pend_t >= 0, pend_t);
+        if constexpr (FUSE) flush2((s - 1) & 1, pend_t >= 0, pend_t);
         {  // the row-major copies the weight-gradient products read
             float* di = live ? p_di + (long)t * s_d : p_dump;
             float* dhh = live ? p_dhh + (long)t * s_d : p_dump;
@@ -1238,13 +1241,15 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             z_next = z;
         }
         fetch(s + 1 < nsteps ? t + dt : t);  // the next step's operands (the last step re-reads its own: unused)
-        second(s & 1);
+        if constexpr (FUSE) {
+            second(s & 1);
 #pragma unroll
-        for (int k = 0; k < 21; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 vector-memory instruction
+            for (int k = 0; k < 21; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 vector-memory instruction
+            }
+            pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
         }
-        pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
         SA_TICK(3)
     }
 #undef SA_TICK
@@ -1252,7 +1257,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         unsigned long long* o = P.timing + 5 * ((role_z * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
         for (int k = 0; k < 5; ++k) atomicAdd(&o[k], tacc[k]);
     }
-    if (fuse) {  // the chunk's last row, published by the step that just ended
+    if (FUSE && fuse) {  // the chunk's last row, published by the step that just ended
         const int tl = t0 + (nsteps - 1) * dt;
         gather(tl);
         second(nsteps & 1);
@@ -1738,8 +1743,15 @@ static bool fuse_dx_enabled() {  // SA_GRU_FUSE_DX=0: the per-wave grouped GEMM 
     const char* e = getenv("SA_GRU_FUSE_DX");
     return !(e && e[0] == '0');
 }
-static BwdPersistFn bwd_fused_fn(int H) {
-    return H == 512 ? gru_bwd_fused_kernel<8> : (H == 256 ? gru_bwd_fused_kernel<4> : nullptr);
+static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels (row-major exchange; bit-identical to the step kernels)
+    const char* e = getenv("SA_GRU_TILED");
+    return !(e && e[0] == '0');
+}
+static BwdPersistFn bwd_fused_fn(int H, bool fuse) {
+    if (!tiled_enabled()) return nullptr;
+    if (H == 512) return fuse ? gru_bwd_fused_kernel<8, true> : gru_bwd_fused_kernel<8, false>;
+    if (H == 256) return fuse ? gru_bwd_fused_kernel<4, true> : gru_bwd_fused_kernel<4, false>;
+    return nullptr;
 }
 static int persist_prio() {
     const char* e = getenv("SA_GRU_PRIO");
@@ -2085,10 +2097,9 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
     // the fused backward kernel: W_ih^T of the upper layers, and a tiled exchange copy of dai per layer
-    const size_t wih_t = D == 1 && L > 1 ? (size_t)(L - 1) * sa_align_up((size_t)3 * H * H * sizeof(float), 256) +
-                                               (size_t)L * sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256) +
-                                               (size_t)256 * 256 * sizeof(float)
-                                         : 0;
+    const size_t wih_t = (D == 1 && L > 1 ? (size_t)(L - 1) * sa_align_up((size_t)3 * H * H * sizeof(float), 256) : 0) +
+                         (size_t)L * D * sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256) +
+                         (size_t)256 * 256 * sizeof(float);
     return (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid + wih_t + gw +
            wgrad_ws_bytes(L, D, B, T, H, I0) + kSyncBytes;
 }
@@ -2208,8 +2219,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const size_t wih_t_off = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
     const size_t xch_each = sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256);
     const size_t xch_off = wih_t_off + (D == 1 && L > 1 ? (size_t)(L - 1) * wih_t_each : 0);
-    const size_t dump_off = xch_off + (D == 1 && L > 1 ? (size_t)L * xch_each : 0);
-    const size_t fixed_bytes = dump_off + (D == 1 && L > 1 ? (size_t)256 * 256 * sizeof(float) : 0);
+    const size_t dump_off = xch_off + (size_t)L * D * xch_each;
+    const size_t fixed_bytes = dump_off + (size_t)256 * 256 * sizeof(float);
     char* gws = ws + fixed_bytes;
     const size_t wws_bytes = wgrad_ws_bytes(L, D, B, T, H, I0);
     const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes - wws_bytes;
@@ -2266,10 +2277,13 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
         const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled(false) && g_side.init();
         issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords;
+        // tiled exchange, operands a step ahead (gru_bwd_fused_kernel without the second product): H = 512 / 256
+        const BwdPersistFn bi_tiled_fn = bi_xcd && flagless_mode() && (long)T * bi_nbt * 16 * 3 * H * 4 < 0x7fffffffL
+                                             ? bwd_fused_fn(H, false) : nullptr;
         if (bi_xcd) {
             if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
-            if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bi_lds) != hipSuccess)
+            if (hipFuncSetAttribute(bi_tiled_fn ? (const void*)bi_tiled_fn : (const void*)bwd_persist_fn(),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bi_lds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
         }
         for (int l = L - 1; l >= 0; --l) {
@@ -2279,7 +2293,9 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 Q.flagless = flagless_mode() ? 1 : 0;
                 if (Q.flagless)
                     for (int d = 0; d < 2; ++d)
-                        if (!sentinel_fill(dah[l * 2 + d], (size_t)T * B * 3 * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+                        if (!sentinel_fill(bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : dah[l * 2 + d],
+                                           bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
+                            return CTC_STATUS_MEMOPS_FAILED;
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = getenv("SA_GRU_DBG_HOT") ? atoi(getenv("SA_GRU_DBG_HOT")) : 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr;
                 for (int d = 0; d < 2; ++d) {
@@ -2289,12 +2305,15 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     J.stash = stash[l * 2 + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * 2 + d]; J.dah = dah[l * 2 + d];
                     J.dh_state = dh_buf(l, d, 0); J.counters = sync + (l * 2 + d) * bi_nbt;
                     J.nsteps = T; J.base = 0;
+                    J.w_ih_t = nullptr; J.dx_out = nullptr; J.xs_b = J.xs_t = 0;
+                    J.xch = bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : nullptr;
+                    J.dump = (float*)(ws + dump_off);
                     J.dt = d ? 1 : -1; J.t0 = J.t_first = d ? 0 : T - 1;   // the reverse chain unwinds forward in time
                 }
                 for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
                     Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
                     Q.reg_base = bi_launches++ * 32u;
-                    hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
+                    hipLaunchKernelGGL(bi_tiled_fn ? bi_tiled_fn : bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
                 }
             } else {
             P.n = 2; grid.z = 2;
@@ -2349,24 +2368,24 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     unsigned persist_launches = 0;
     const bool flagless = xcd && flagless_mode();
     // the lower layers' d h_out inside the recurrence kernel (gru_bwd_fused_kernel): no GEMM between the launches
-    const bool fused = flagless && L > 1 && fuse_dx_enabled() && bwd_fused_fn(H) != nullptr &&
-                       (long)T * nbt * 16 * 3 * H * 4 < 0x7fffffffL;
+    const bool tiled = flagless && bwd_fused_fn(H, false) != nullptr && (long)T * nbt * 16 * 3 * H * 4 < 0x7fffffffL;
+    const bool fused = tiled && L > 1 && fuse_dx_enabled();
+    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused) : nullptr;
     const size_t flds = xcd_lds((size_t)4 * 4 * 256 * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
     if (flagless)
         for (int l = 0; l < L; ++l)  // the exchanged values are their own flags
-            if (!sentinel_fill(fused ? xch_of(l) : dah[l], fused ? (size_t)T * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
+            if (!sentinel_fill(tiled ? xch_of(l) : dah[l], tiled ? (size_t)T * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
                                stream))
                 return CTC_STATUS_MEMOPS_FAILED;
     if (fused) {
         for (int l = 1; l < L; ++l)
             hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream, w_ih[l],
                                wih_t_of(l), 3 * H, H);
-        if (hipFuncSetAttribute((const void*)bwd_fused_fn(H), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds) !=
-            hipSuccess)
-            return CTC_STATUS_EXECUTION_FAILED;
     }
+    if (tiled && hipFuncSetAttribute((const void*)tiled_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds) != hipSuccess)
+        return CTC_STATUS_EXECUTION_FAILED;
     // weight gradients ride beside the persistent launches: every kWgEvery launches, the time steps that have become
     // final since the last hand-over go to the side stream
     const bool side = wg && xcd && overlap_enabled(true) && g_side.init();
@@ -2418,7 +2437,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
                 J.w_ih_t = fused && l > 0 ? wih_t_of(l) : nullptr; J.dx_out = fused && l > 0 ? mid_of(l - 1) : nullptr;
-                J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = fused ? xch_of(l) : nullptr; J.dump = (float*)(ws + dump_off);
+                J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = tiled ? xch_of(l) : nullptr; J.dump = (float*)(ws + dump_off);
                 J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
                 J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);
             }
@@ -2430,7 +2449,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
                     Q.reg_base = persist_launches++ * 32u;
                     if (bt0 > 0) Q.stamp = nullptr;
-                    if (fused) hipLaunchKernelGGL(bwd_fused_fn(H), dim3(256), dim3(256), flds, stream, Q);
+                    if (tiled) hipLaunchKernelGGL(tiled_fn, dim3(256), dim3(256), flds, stream, Q);
                     else hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
                 }
             }

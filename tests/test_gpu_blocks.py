@@ -359,7 +359,7 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     res = []
     for mode in ("0", "2", "3"):   # step kernels; XCD-local groups with arrival counters; flag-less hand-off (default)
         out = "/tmp/sa_xcd_%s.pt" % mode
-        env = dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0", SA_GRU_FUSE_DX="0")  # the fused kernels sum in another order
+        env = dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0", SA_GRU_TILED="0")  # the fused / tiled kernels sum in another order
         subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=180)
         res.append(torch.load(out))
     for other in res[1:]:
@@ -374,7 +374,7 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd2_%s.pt" % mode
             subprocess.run([sys.executable, "-c", code2, out],
-                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0", SA_GRU_FUSE_DX="0"), check=True,
+                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_FUSED="0", SA_GRU_TILED="0"), check=True,
                            timeout=180)
             res.append(torch.load(out))
         for other in res[1:]:
@@ -384,7 +384,7 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
 def test_fused_backward_input_gradient():
     """gru_bwd_fused_kernel (the default backward of eligible unidirectional stacks with H = 512 / 256: the lower layers'
     d h_out formed inside the recurrence kernel instead of by a grouped GEMM per wave of the layer wavefront) against
-    the GEMM path (SA_GRU_FUSE_DX=0): every gradient equal up to the summation order (the k-space is dealt out by gate
+    the GEMM path (SA_GRU_FUSE_DX=0) and the round-1 kernels (SA_GRU_TILED=0): every gradient equal up to the summation order (the k-space is dealt out by gate
     and the product runs on 16x16x4 MFMAs), ragged chunks, several batch tiles and passes, one-step chunks.  (The
     oracle comparisons of the whole stack -- test_gru_stack_*, tests/test_gpu_baseline_configs.py -- run the default,
     i.e. this kernel, wherever it is eligible.)"""
@@ -406,15 +406,17 @@ def test_fused_backward_input_gradient():
                   (4, 64, 21, 24, 256, 16), (4, 48, 37, 40, 512, 16), (4, 80, 19, 24, 256, 16), (3, 5, 9, 16, 512, 1),
                   (2, 32, 7, 16, 256, 64)):
         res = []
-        for fuse in ("0", "1"):
-            out = "/tmp/sa_fuse_dx_%s.pt" % fuse
+        # the round-1 kernels (row-major exchange); the tiled kernel with the GEMM; the tiled kernel with the product fused
+        for env in ({"SA_GRU_TILED": "0"}, {"SA_GRU_FUSE_DX": "0"}, {}):
+            out = "/tmp/sa_fuse_dx_%d.pt" % len(res)
             subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
-                           env=dict(os.environ, SA_GRU_FUSE_DX=fuse), check=True, timeout=180)
+                           env=dict(os.environ, **env), check=True, timeout=180)
             res.append(torch.load(out))
-        assert len(res[0]) == len(res[1])
-        for a, b in zip(*res):
-            assert torch.isfinite(b).all(), shape
-            assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max())), shape
+        for other in res[1:]:
+            assert len(res[0]) == len(other)
+            for a, b in zip(res[0], other):
+                assert torch.isfinite(b).all(), shape
+                assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max())), shape
 
 
 def test_xcd_local_persistent_kernels_bidirectional():
@@ -445,10 +447,18 @@ def test_xcd_local_persistent_kernels_bidirectional():
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd_bi_%s.pt" % mode
             subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
-                           env=dict(os.environ, SA_GRU_PERSIST=mode), check=True, timeout=180)
+                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_TILED="0"), check=True, timeout=180)
             res.append(torch.load(out))
         for other in res[1:]:
             assert len(res[0]) == len(other) and all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
+        # the default backward of H = 512 / 256 layers (tiled exchange, the k-space dealt out by gate: another summation
+        # order) against the same
+        out = "/tmp/sa_xcd_bi_tiled.pt"
+        subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape], env=dict(os.environ), check=True,
+                       timeout=180)
+        for a, b in zip(res[0], torch.load(out)):
+            assert torch.isfinite(b).all(), shape
+            assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max())), shape
 
 
 def test_bidirectional_forward_projection_overlap():
