@@ -229,7 +229,8 @@ def roofline(prof, step_us, steps):
         if nsteps > 1:
             # the recurrence ran as persistent chunk kernels (one launch = `nsteps` time steps x 4 layer-jobs, launches
             # separated by the chunk's GEMMs): duration = the kernel's own entry-to-exit clock
-            name, us = name.replace("_step_", "_fused_" if (nsteps > 64 and "fwd" in name) else "_persist_"), kern_us
+            # (more than 64 steps in one launch: the fused kernels that run the whole stack's recurrence in one launch)
+            name, us = name.replace("_step_", "_fused_" if nsteps > 64 else "_persist_"), kern_us
         if us <= 0:
             continue
         nbytes = 4.0 * B * 512 * per_job * 4 * nsteps  # 4 layer-jobs x nsteps steps per launch, B x H fp32 each

@@ -1155,7 +1155,9 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     auto flush2 = [&](int par, bool on, int trow) {  // after a barrier: add the four waves' parts, store the row's tile
         const float* rd = red2 + par * 1024;
         float* dst = on && live ? p_dx + (long)trow * s_dx : p_dump;
-        *dst = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
+        // write-through: in one-launch mode the layer below (another XCD) is waiting for exactly this value
+        __hip_atomic_store(dst, ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // A step's operands out of memory -- its stashed gates, its d h_out, and r of the row the gather brings -- are
@@ -1167,7 +1169,8 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     auto fetch = [&](int tt) {
         const int tr = hot == 1 ? t0 : (tt != t_first ? tt - dt : tt);  // the first step of the sequence gathers nothing
         const int to = hot == 1 ? t0 : tt;  // hot: timing experiment only, always the same (cache-hot) rows
-        dh = p_dh[(long)to * s_dh];
+        // d h_out may be a row the layer ABOVE forms in this very launch (one-launch mode, another XCD): agent scope
+        dh = __hip_atomic_load(p_dh + (long)to * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float* st = p_st + (long)to * s_st;
         r = st[0]; z = st[H]; n = st[2 * H]; q = st[3 * H]; hp = st[4 * H];
         const float* rrow = p_rn + (long)tr * s_st;
@@ -1205,6 +1208,16 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             SA_TICK(1)
         }
         __syncthreads();
+        if constexpr (FUSE) {
+            // one-launch mode: the row of d h_out fetched a step ago may not have been there yet (the host pre-fills
+            // the lower layers' d h_out with the sentinel; the layer above stores it two steps after it ran the same
+            // time index, so a lower layer settles a few steps behind the one above and this loop seldom turns)
+            for (int spins = 0; __builtin_amdgcn_ballot_w64(live && __builtin_bit_cast(unsigned, dh) == kSentinel) != 0; ++spins) {
+                if (__builtin_bit_cast(unsigned, dh) == kSentinel)
+                    dh = __hip_atomic_load(p_dh + (long)(hot == 1 ? t0 : t) * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (spins > budget) { if (lane == 0) atomicOr(errp, 1u); budget = 0; break; }
+            }
+        }
         float dpr = 0.f, dpz = 0.f, dpn = 0.f, dqn = 0.f;
         if (live) {
             const float* rd = red + (s & 1) * 1024;
@@ -2396,7 +2409,38 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                 (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
     }
-    for (int w = 0; w < nch + L - 1; ++w) {
+    // ONE launch for the whole backward recurrence of the stack (fused kernel only): every layer runs all T steps, a
+    // lower layer picks each row of its d h_out up as the layer above stores it (sentinel pre-fill, see the kernel) --
+    // T + a few steps per layer of lag instead of (T / chunk + L - 1) chunks, and no launch ramps in between.
+    const char* one_e = getenv("SA_GRU_BWD_ONE");
+    const bool one_launch = fused && !(one_e && one_e[0] == '0') && !getenv("SA_GRU_TIMING");
+    if (one_launch) {
+        for (int l = 0; l + 1 < L; ++l)
+            if (!sentinel_fill(mid_of(l), (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+        PBwdJobs Q;
+        Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
+        Q.timing = nullptr;
+        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+        for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
+            PBwdJob& J = Q.j[n];
+            J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
+            J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
+            J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
+            J.w_ih_t = l > 0 ? wih_t_of(l) : nullptr; J.dx_out = l > 0 ? mid_of(l - 1) : nullptr;
+            J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = xch_of(l); J.dump = (float*)(ws + dump_off);
+            J.t0 = T - 1; J.nsteps = T; J.dt = -1; J.t_first = T - 1; J.base = 0;
+        }
+        Q.n = L;
+        Q.stamp = g_prof.slot(1, true, false, T);
+        const int tpp = tiles_per_pass(L, H);
+        for (int bt0 = 0; bt0 < nbt; bt0 += tpp) {  // passes over the batch tiles
+            Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
+            Q.reg_base = persist_launches++ * 32u;
+            if (bt0 > 0) Q.stamp = nullptr;
+            hipLaunchKernelGGL(tiled_fn, dim3(256), dim3(256), flds, stream, Q);
+        }
+    }
+    for (int w = 0; !one_launch && w < nch + L - 1; ++w) {
         // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
         if (!fused) {
             const float* gA[kMaxJobs]; const float* gB[kMaxJobs]; float* gC[kMaxJobs];

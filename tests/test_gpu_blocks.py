@@ -407,7 +407,8 @@ def test_fused_backward_input_gradient():
                   (2, 32, 7, 16, 256, 64)):
         res = []
         # the round-1 kernels (row-major exchange); the tiled kernel with the GEMM; the tiled kernel with the product fused
-        for env in ({"SA_GRU_TILED": "0"}, {"SA_GRU_FUSE_DX": "0"}, {}):
+        # ... launched chunk by chunk; the same as ONE launch for the whole recurrence (the default)
+        for env in ({"SA_GRU_TILED": "0"}, {"SA_GRU_FUSE_DX": "0"}, {"SA_GRU_BWD_ONE": "0"}, {}):
             out = "/tmp/sa_fuse_dx_%d.pt" % len(res)
             subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
                            env=dict(os.environ, **env), check=True, timeout=180)
