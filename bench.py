@@ -178,13 +178,12 @@ def cpu_baseline(steps=4, state0=None):
 def stack_gemm_rates(dev, Tp):
     """The GEMM families INSIDE the GRU stack calls (the bulk of the step's 443 GEMM-shaped GFLOP; the per-op profile cannot
     see them: a stack call is one library entry point): each shape timed as standalone launches right after the timed
-    region (HIP events over 10 launches), weighted by how often the step runs it.  The per-chunk dX product is timed as a
-    single problem here; in the step three of them share a grouped launch."""
+    region (HIP events over 10 launches), weighted by how often the step runs it."""
     from speech_amd import ops
     H, rows = 512, Tp * B
     fams = [  # name, M, N, K, trans_a, trans_b, launches per step
         ("i2h layer 0", rows, 3 * H, 800, False, True, 1),
-        ("dX per 28-step chunk", 28 * B, H, 3 * H, False, False, 3 * 18),
+        ("dX layer 0", rows, 800, 3 * H, False, False, 1),  # (the upper layers' dX runs inside the recurrence kernel)
         ("dW_hh / dW_ih (H)", 3 * H, H, rows, True, False, 7),
         ("dW_ih layer 0", 3 * H, 800, rows, True, False, 1),
     ]

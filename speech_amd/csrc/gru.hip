@@ -844,7 +844,6 @@ struct PBwdJobs {
     unsigned* err;
     int spin_limit, fault, prio;  // see PFwdJobs
     int packed;                   // gru_bwd_fused_kernel: 1 = publish with plain stores (default), 0 = write-through
-    int dbg_hot;                  // SA_GRU_DBG_HOT=1 (timing experiment, wrong results): stash / dh_out reads stay on one row
     unsigned long long* timing;   // debug (SA_GRU_TIMING=1): per block {poll+load, mfma, reduce+barrier, gates+publish} in
                                   // 10 ns ticks and the number of polling trips; else null
     PBwdJob j[kMaxJobs];
@@ -919,9 +918,8 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
         float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
         if (live) {
-            const int tl_ = P.dbg_hot ? J.t0 : t;  // timing experiment only: every step reads the same (cache-hot) rows
-            dh = J.dh_out[(long)b * J.ds_b + (long)tl_ * J.ds_t + u];
-            const float* st = J.stash + ((long)b * P.rb + (long)tl_ * P.rt) * 5 * H;
+            dh = J.dh_out[(long)b * J.ds_b + (long)t * J.ds_t + u];
+            const float* st = J.stash + row * 5 * H;
             r = st[u]; z = st[H + u]; n = st[2 * H + u]; q = st[3 * H + u]; hp = st[4 * H + u];
         }
         if (s > 0 && !P.flagless) {  // every unit tile of this (job, batch tile) must have published dah[t + 1]
@@ -1093,11 +1091,11 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     // opaque, so the worst the register allocator can do is park it in a VGPR lane.
 #define SA_KEEP(v) asm volatile("" : "+s"(v))
     const int bl = live ? b : 0;
-    int t0 = J.t0, dt = J.dt, t_first = J.t_first, nsteps = J.nsteps, packed = P.packed, hot = P.dbg_hot;
+    int t0 = J.t0, dt = J.dt, t_first = J.t_first, nsteps = J.nsteps, packed = P.packed;
     long s_dh = J.ds_t, s_st = (long)P.rt * 5 * H, s_d = (long)P.rt * H3, s_dx = J.xs_t;
     long s_x = (long)P.nbt_all * (H3 / 16) * 256;  // floats of the exchange buffer per time step
     unsigned* errp = P.err;
-    SA_KEEP(t0); SA_KEEP(dt); SA_KEEP(t_first); SA_KEEP(nsteps); SA_KEEP(packed); SA_KEEP(hot);
+    SA_KEEP(t0); SA_KEEP(dt); SA_KEEP(t_first); SA_KEEP(nsteps); SA_KEEP(packed);
     SA_KEEP(s_dh); SA_KEEP(s_st); SA_KEEP(s_d); SA_KEEP(s_dx); SA_KEEP(s_x); SA_KEEP(errp);
 #undef SA_KEEP
     const float* p_dh = J.dh_out + (long)bl * J.ds_b + u;
@@ -1167,8 +1165,8 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
     f32x4v rn[IPG];
     auto fetch = [&](int tt) {
-        const int tr = hot == 1 ? t0 : (tt != t_first ? tt - dt : tt);  // the first step of the sequence gathers nothing
-        const int to = hot == 1 ? t0 : tt;  // hot: timing experiment only, always the same (cache-hot) rows
+        const int tr = tt != t_first ? tt - dt : tt;  // the first step of the sequence gathers nothing
+        const int to = tt;
         // d h_out may be a row the layer ABOVE forms in this very launch (one-launch mode, another XCD): agent scope
         dh = __hip_atomic_load(p_dh + (long)to * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float* st = p_st + (long)to * s_st;
@@ -1214,7 +1212,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             // time index, so a lower layer settles a few steps behind the one above and this loop seldom turns)
             for (int spins = 0; __builtin_amdgcn_ballot_w64(live && __builtin_bit_cast(unsigned, dh) == kSentinel) != 0; ++spins) {
                 if (__builtin_bit_cast(unsigned, dh) == kSentinel)
-                    dh = __hip_atomic_load(p_dh + (long)(hot == 1 ? t0 : t) * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dh = __hip_atomic_load(p_dh + (long)t * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (spins > budget) { if (lane == 0) atomicOr(errp, 1u); budget = 0; break; }
             }
         }
@@ -2309,7 +2307,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                         if (!sentinel_fill(bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : dah[l * 2 + d],
                                            bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = getenv("SA_GRU_DBG_HOT") ? atoi(getenv("SA_GRU_DBG_HOT")) : 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
@@ -2420,7 +2418,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr;
-        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
             PBwdJob& J = Q.j[n];
             J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
@@ -2470,7 +2468,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.dbg_hot = getenv("SA_GRU_DBG_HOT") ? atoi(getenv("SA_GRU_DBG_HOT")) : 0; Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
