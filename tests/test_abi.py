@@ -43,6 +43,25 @@ def test_host_side_argument_checks_need_no_gpu():
                                 ctypes.byref(n)) == 3
 
 
+def test_gru_stack_workspaces_hold_what_the_kernels_lay_out():
+    """The backward workspace must have room for the tiled exchange copy of the gate gradients per (layer, direction)
+    (T * ceil(B / 16) * 16 * 3H floats: what gru_bwd_fused_kernel's blocks read from each other), the transposed
+    weights and the d h_out of the lower layers; sizes grow with every dimension; bad arguments give 0."""
+    L = _lib.lib()
+    f = L.sa_gru_stack_bwd_workspace_bytes
+    Ls, D, B, T, H, I0 = 4, 1, 32, 498, 512, 800
+    w = f(Ls, D, B, T, H, I0)
+    exchange = Ls * D * T * ((B + 15) // 16) * 16 * 3 * H * 4
+    mid = (Ls - 1) * T * B * D * H * 4
+    weights_t = Ls * D * 3 * H * H * 4 + (Ls - 1) * 3 * H * H * 4
+    assert w >= exchange + mid + weights_t
+    assert f(Ls, D, 33, T, H, I0) - w >= Ls * T * 16 * 3 * H * 4      # a ragged batch tile is padded to 16 rows
+    assert f(Ls, 2, B, T, H, I0) > w and f(Ls, D, B, 2 * T, H, I0) > w and f(Ls + 1, D, B, T, H, I0) > w
+    for bad in ((0, 1, 32, 498, 512, 800), (4, 1, 0, 498, 512, 800), (4, 1, 32, 0, 512, 800), (4, 1, 32, 498, 0, 800)):
+        assert f(*bad) == 0
+    assert L.sa_gru_stack_fwd_workspace_bytes(Ls, D, B, T, H, I0) >= Ls * D * T * B * 3 * H * 4
+
+
 def test_shape_gates_of_the_fused_operators_need_no_gpu():
     """The host-side shape gates that choose between the fused and the general operators."""
     L = _lib.lib()
