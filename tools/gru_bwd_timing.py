@@ -1,4 +1,6 @@
-"""Phase clocks of the persistent backward recurrence (SA_GRU_TIMING=1): per time step, mean over the 256 blocks."""
+"""Phase clocks of the persistent backward recurrence (SA_GRU_TIMING=1): per time step, mean over the 256 blocks.
+With the clocks on, the library runs the recurrence chunk by chunk (the one-launch mode of gru_bwd_fused_kernel is off:
+the accumulators are sized for one launch per chunk); the per-step phases are the same."""
 import os, sys
 os.environ["SA_GRU_TIMING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +25,7 @@ tim = sync[256:256 + 5 * 256].reshape(-1, 5).astype(np.float64)   # sync + 512 u
 steps = T
 us = tim[:, :4] * 0.01 / steps
 if os.environ.get("SA_GRU_FUSE_DX", "1") != "0":
-    print("(fused kernel: the four phases are gather | mfma | barrier .. publish | second product)")
+    print("(fused kernel: the four phases are gather | recurrent mfma | barrier .. publish | tail = copies, next operands, second product)")
 print("per-step us (mean over blocks): poll+load %.2f  mfma %.2f  reduce+barrier %.2f  gates+publish %.2f | total %.2f | polling trips per step %.2f"
       % (us[:, 0].mean(), us[:, 1].mean(), us[:, 2].mean(), us[:, 3].mean(), us.sum(1).mean(), tim[:, 4].mean() / steps))
 if os.environ.get("SA_GRU_DBG_HOT") == "3":  # hot3: slots = flush | reduce + gates | exchange stores | row-major stores | fetch
