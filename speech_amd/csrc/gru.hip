@@ -1047,6 +1047,14 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 template <int IPG, bool FUSE>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
+    // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
+    // multiplies.  With it they are {dpr, dpz, dpn} (what W_ih multiplies) and a wave forms dqn = dpn * r itself from
+    // r_{t+1} of the forward stash (RN): exchanging dqn as a FOURTH tile instead was measured 0.1 ms slower per step
+    // (9.04 -> 9.12 ms: eight more loads in the gather, which is on the critical path, against eight row-major loads in the
+    // tail, which is not), while dropping the r loads from the kernel without the product gained 0.5 ms on the
+    // bidirectional step.
+    constexpr bool RN = FUSE;
+    constexpr int NG = 3, NITG = NG * IPG, XT = NG * (H / 16);
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
     SA_PERSIST_EXCLUSIVE(P.prio);
@@ -1078,7 +1086,6 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const bool live = b < B;
     const bool fuse = FUSE && J.dx_out != nullptr;
     int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
-    const int brow = min(b0 + i, B - 1);
     const int kw = wave * (H / 4) + 4 * g;  // the lane's column offset inside a gate; fragment `it` adds 16 (it % IPG)
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
     // Resident in the register file for the whole launch: the lane's fragments of rows u0 + i of W_hh^T and W_ih^T.
@@ -1099,38 +1106,38 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const int bl = live ? b : 0;
     int t0 = J.t0, dt = J.dt, t_first = J.t_first, nsteps = J.nsteps, packed = P.packed;
     long s_dh = J.ds_t, s_st = (long)P.rt * 5 * H, s_d = (long)P.rt * H3, s_dx = J.xs_t;
-    long s_x = (long)P.nbt_all * (H3 / 16) * 256;  // floats of the exchange buffer per time step
+    long s_x = (long)P.nbt_all * XT * 256;  // floats of the exchange buffer per time step
     unsigned* errp = P.err;
     SA_KEEP(t0); SA_KEEP(dt); SA_KEEP(t_first); SA_KEEP(nsteps); SA_KEEP(packed);
     SA_KEEP(s_dh); SA_KEEP(s_st); SA_KEEP(s_d); SA_KEEP(s_dx); SA_KEEP(s_x); SA_KEEP(errp);
 #undef SA_KEEP
     const float* p_dh = J.dh_out + (long)bl * J.ds_b + u;
     const float* p_st = J.stash + (long)bl * P.rb * 5 * H + u;
-    const float* p_rn = J.stash + (long)brow * P.rb * 5 * H + kw;
-    float* p_xs = J.xch + ((long)role_y * (H3 / 16) + role_x) * 256 + tid;
+    const float* p_rn = J.stash + (long)min(b0 + i, B - 1) * P.rb * 5 * H + kw;  // RN: r of row i, this wave's columns
+    float* p_xs = J.xch + ((long)role_y * XT + role_x) * 256 + tid;
     float* p_di = J.dai + (long)bl * P.rb * H3 + u;
     float* p_dhh = J.dah + (long)bl * P.rb * H3 + u;
     float* p_dx = fuse ? J.dx_out + (long)b * J.xs_b + u : nullptr;
     // tile (gate, wave, j) = 16 batch rows x 16 columns, 1 KB contiguous: one load instruction of a wave covers it
-    const int a0 = (int)((((long)role_y * (H3 / 16) + wave * IPG) * 256 + i * 16 + 4 * g) * 4);
+    const int a0 = (int)((((long)role_y * XT + wave * IPG) * 256 + i * 16 + 4 * g) * 4);
     __syncthreads();
 
     unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;  // SA_GRU_TIMING=1: {gather, mfma, barrier .. publish, tail, trips}
     const bool timed = P.timing != nullptr && tid == 0;
     if (timed) tprev = wall_clock64();
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
-    f32x4v a[NIT];  // the gathered row block: rows = the batch tile, this wave's fragments of dai[trow]
+    f32x4v a[NITG];  // the gathered row block: rows = the batch tile, this wave's fragments of every exchanged gate
     auto gather = [&](int trow) {  // returns once no fragment holds the sentinel (or the call is lost)
         const int abase = a0 + trow * (int)(s_x * 4);
         for (int spins = 0;; ++spins) {
             asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
+            for (int it = 0; it < NITG; ++it)
                 a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
                                                        dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
             bool stale = false;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) stale |= has_sentinel(a[it]);
+            for (int it = 0; it < NITG; ++it) stale |= has_sentinel(a[it]);
             if (timed) ++tacc[4];
             if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
             if (spins > budget) { if (lane == 0) atomicOr(errp, 1u); budget = 0; break; }
@@ -1169,17 +1176,19 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     // order, so a load still on its way to HBM when the gather is issued would hold the gather's data back.
     // Unconditional loads on clamped indices (a branch around a load costs a vmcnt(0) at the join).
     float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
-    f32x4v rn[IPG];
+    f32x4v rn[RN ? IPG : 1];
     auto fetch = [&](int tt) {
-        const int tr = tt != t_first ? tt - dt : tt;  // the first step of the sequence gathers nothing
         const int to = tt;
         // d h_out may be a row the layer ABOVE forms in this very launch (one-launch mode, another XCD): agent scope
         dh = __hip_atomic_load(p_dh + (long)to * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float* st = p_st + (long)to * s_st;
         r = st[0]; z = st[H]; n = st[2 * H]; q = st[3 * H]; hp = st[4 * H];
-        const float* rrow = p_rn + (long)tr * s_st;
+        if constexpr (RN) {
+            const int tr = tt != t_first ? tt - dt : tt;  // the first step of the sequence gathers nothing
+            const float* rrow = p_rn + (long)tr * s_st;
 #pragma unroll
-        for (int j = 0; j < IPG; ++j) rn[j] = *reinterpret_cast<const f32x4v*>(rrow + 16 * j);
+            for (int j = 0; j < IPG; ++j) rn[j] = *reinterpret_cast<const f32x4v*>(rrow + 16 * j);
+        }
     };
     float dh_run = 0.f, z_next = 0.f;
     if (live && t0 != t_first) {
@@ -1198,7 +1207,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 f32x4v f = a[it];
-                if (it >= 2 * IPG) f = f * rn[it - 2 * IPG];  // dqn = dpn * r
+                if (RN && it >= 2 * IPG) f = f * rn[RN ? it - 2 * IPG : 0];  // dqn = dpn * r
                 const float4 w = wr[it];
                 f32x4& d = (it & 1) ? acc1 : acc;  // two chains: the 40-cycle dependent latency is hidden
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w.x, d, 0, 0, 0);
@@ -1233,12 +1242,13 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             // The exchange: this block's three 16 x 16 tiles (rows beyond the batch publish zeros -- a tile has no
             // holes a reader could wait on).  Consecutive threads, consecutive addresses: 1 KB per store instruction.
             float* xp = p_xs + (long)t * s_x;
+            const float third = FUSE ? dpn : dqn;
             if (packed) {  // plain stores: the XCD's own L2 is where the group meets, nothing needs to reach memory
-                xp[0] = dpr; xp[(H / 16) * 256] = dpz; xp[2 * (H / 16) * 256] = dpn;
+                xp[0] = dpr; xp[(H / 16) * 256] = dpz; xp[2 * (H / 16) * 256] = third;
             } else {
                 __hip_atomic_store(xp, dpr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
                 __hip_atomic_store(xp + (H / 16) * 256, dpz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(xp + 2 * (H / 16) * 256, dpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xp + 2 * (H / 16) * 256, third, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         SA_TICK(2)
