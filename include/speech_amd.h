@@ -138,6 +138,31 @@ ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, c
                                long ys_b, long ys_c, long ys_t, const float* fwd_cols /* or NULL */, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Dropout (config["dropout"] != 0, training mode): nn.Dropout(p) behind every conv ReLU (model.py:25-27) and
+ * nn.GRU(dropout=p) between the layers of the stack (model.py:35-39); every shipped config trains with p = 0.2 .. 0.5
+ * (examples/timit/ctc_config.json:20).  The masks are generated INSIDE the kernels that write / route the masked
+ * elements: element `idx` of masked tensor `mask_stream` of a pass keyed by `seed` is kept iff word (idx & 3) of
+ * Philox4x32-10(counter = {idx >> 2 (64 bit), mask_stream, 0}, key = seed) >= floor(p * 2^32), kept elements are
+ * scaled by 1 / (1 - p).  0 <= p < 1; p == 0 is exactly the entry point without dropout.
+ *   conv:  idx = the element's NCHW offset ((b O + c) T' + t') F' + f' (whatever strides y is written with);
+ *   GRU :  layer l < L-1, mask_stream0 + l, idx = the element's offset in the (T, B, D*H) output.
+ * sa_dropout_mask_f32 writes the factors (0 or 1 / (1 - p)) of elements idx0 .. idx0 + n - 1 (tests hand the oracle the
+ * SAME mask); sa_dropout_apply_f32: out[i] = in[i] * factor(idx0 + i), in == out allowed. */
+ctcStatus_t sa_dropout_mask_f32(float* d_out, size_t n, size_t idx0, float p, unsigned long long seed,
+                                unsigned int mask_stream, void* stream);
+ctcStatus_t sa_dropout_apply_f32(const float* d_in, float* d_out, size_t n, size_t idx0, float p,
+                                 unsigned long long seed, unsigned int mask_stream, void* stream);
+/* sa_conv2d_relu_fwd with the mask applied in the epilogue (y = the DROPPED output), and its backward pass: y must
+ * be that dropped output -- [y > 0] is then "ReLU passed and kept", so the backward needs p only for the scale. */
+ctcStatus_t sa_conv2d_relu_dropout_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in_c,
+                                       int T, int F, int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t,
+                                       float* keep_cols /* or NULL */, void* workspace, size_t workspace_bytes, float p,
+                                       unsigned long long seed, unsigned int mask_stream, void* stream);
+ctcStatus_t sa_conv2d_relu_dropout_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                                       float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh, int kw,
+                                       int s, long ys_b, long ys_c, long ys_t, const float* fwd_cols /* or NULL */,
+                                       void* workspace, size_t workspace_bytes, float p, void* stream);
+
 /* One direction of one nn.GRU layer (model.py:35-39,73; equations SURVEY.md App. B; gate order [r; z; n]).
  *   ai   (B, T, 3H): input pre-activations x W_ih^T + b_ih (from sa_gemm_f32), batch-first.
  *   w_hh (3H, H), b_hh (3H).   h_out[b * hs_b + t * hs_t + j], j < H  (strides allow writing one half of a
@@ -196,6 +221,25 @@ ctcStatus_t sa_gru_stack_bwd_wgrad(const float* dh_top, const float* const* stas
                                    float* const* db_ih, float* const* db_hh, void* workspace, size_t workspace_bytes,
                                    void* stream);
 
+/* The stack with nn.GRU's inter-layer dropout (model.py:38; see "Dropout" above).  h_drop[l], l < L-1: caller-owned
+ * (T, B, D*H) buffers that receive h_out[l] * mask -- what layer l+1 reads, and what its dW_ih product reads in the
+ * backward pass (h_out[l] itself, undropped, stays the layer's own recurrence state).  The one-launch fused kernels of
+ * eligible unidirectional stacks write / apply the mask themselves (the stack stays ONE launch per direction of time);
+ * other paths add one element-wise launch per layer (bidirectional) or per wavefront chunk.  The backward entry point
+ * takes the same p / seed / mask_stream0 and the h_drop buffers the forward call filled. */
+ctcStatus_t sa_gru_stack_fwd_dropout(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
+                                     const float* const* w_hh, const float* const* b_hh, float* const* h_out,
+                                     float* const* h_drop, float* const* stash, int L, int D, int B, int T, int H,
+                                     int chunk, void* workspace, size_t workspace_bytes, float p,
+                                     unsigned long long seed, unsigned int mask_stream0, void* stream);
+ctcStatus_t sa_gru_stack_bwd_wgrad_dropout(const float* dh_top, const float* const* stash, const float* const* w_ih,
+                                           const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
+                                           int I0, int L, int D, int B, int T, int H, int chunk, const float* x,
+                                           const float* const* h_out, float* const* h_drop, float* const* dw_ih,
+                                           float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                                           void* workspace, size_t workspace_bytes, float p, unsigned long long seed,
+                                           unsigned int mask_stream0, void* stream);
+
 /* Opt-in launch profiler for the stack entry points (bench.py): after sa_gru_profile_configure(1), block 0 of every
  * step launch stamps the 100 MHz wall clock at entry and exit into a device ring (16 K launches).
  * sa_gru_profile_read(kind, &interval_us, &kernel_us) (kind 0 = forward, 1 = backward step kernel; SYNC) returns the
@@ -221,7 +265,10 @@ int sa_gru_profile_steps_per_launch(int kind);
  *     copy the persistent path is off for the process (every stack call from then on runs the step kernels).  The
  *     calls themselves keep returning success -- data-parallel ranks must stay in lock-step, so the failure travels
  *     through the gate above, not through one rank's return code; forward-only users call sa_gru_persist_status();
- *   - sa_gru_persist_status() waits for every outstanding copy and returns the OR of the codes seen (0 = fine);
+ *   - sa_gru_persist_status() waits for every outstanding copy and returns the OR of the codes seen (0 = fine;
+ *     1 = a hand-off timed out, 2 = more than 32 workgroups landed on one XCD, 4 = an XCD-filtered side-stream GEMM
+ *     launch -- the weight gradients / input projections that run beside a bidirectional layer's recurrence on the XCDs
+ *     it leaves idle -- did not draw all of its tiles because the dispatcher placed too few of its blocks there);
  *     sa_gru_persist_reset() does the same, then clears the device word and the host state (the path stays off: the
  *     caller re-runs the lost step on the step kernels).
  * Tests: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave before its first step,

@@ -38,18 +38,45 @@ class TorchRefCTC(nn.Module):
         self.fc.fc = nn.Linear(rnn["dim"], output_dim + 1)
         self.blank = output_dim
 
-    def encode(self, x):
-        x = self.conv(x.unsqueeze(1))
+    def encode(self, x, masks=None):
+        """masks = None: the modules as the reference builds them (their own dropout in training mode).
+        masks = {"conv": [m_i (B, O, T', F')], "gru": [m_l (B, T', D*H), l < layers - 1]}: the SAME computation with the
+        Bernoulli factors given instead of drawn -- nn.Dropout(x) = x * m behind each ReLU (model.py:25-27), and
+        nn.GRU(dropout=p) = layer l+1 reads (layer l output) * m_l (model.py:38) -- so that a HIP pass whose masks are
+        known (oracle/philox_ref.py) can be checked value by value."""
+        if masks is None:
+            x = self.conv(x.unsqueeze(1))
+        else:
+            x, i = x.unsqueeze(1), 0
+            for m in self.conv.children():
+                if isinstance(m, nn.Dropout):
+                    continue
+                x = m(x)
+                if isinstance(m, nn.ReLU):
+                    x = x * torch.as_tensor(masks["conv"][i])
+                    i += 1
         x = torch.transpose(x, 1, 2).contiguous()
         b, t, f, c = x.size()
-        x, _ = self.rnn(x.view((b, t, f * c)))
+        x = x.view((b, t, f * c))
+        if masks is None:
+            x, _ = self.rnn(x)
+        else:
+            r = self.rnn
+            D = 2 if r.bidirectional else 1
+            for l in range(r.num_layers):
+                flat = [getattr(r, "%s_l%d%s" % (n, l, sfx)) for sfx in (("", "_reverse") if D == 2 else ("",))
+                        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                h0 = torch.zeros(D, b, r.hidden_size, dtype=x.dtype)
+                x, _ = torch._VF.gru(x, h0, flat, True, 1, 0.0, False, r.bidirectional, True)
+                if l + 1 < r.num_layers:
+                    x = x * torch.as_tensor(masks["gru"][l])
         if self.rnn.bidirectional:
             half = x.size()[-1] // 2
             x = x[:, :, :half] + x[:, :, half:]
         return x
 
-    def forward(self, x):
-        return self.fc.fc(self.encode(x))
+    def forward(self, x, masks=None):
+        return self.fc.fc(self.encode(x, masks))
 
 
 class _CTCRef(torch.autograd.Function):

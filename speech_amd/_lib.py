@@ -16,6 +16,7 @@ STATUS_NAMES = {0: "CTC_STATUS_SUCCESS", 1: "CTC_STATUS_MEMOPS_FAILED", 2: "CTC_
                 3: "CTC_STATUS_EXECUTION_FAILED", 4: "CTC_STATUS_UNKNOWN_ERROR"}
 
 c_int, c_long, c_size_t, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p
+c_uint, c_ulonglong = ctypes.c_uint, ctypes.c_ulonglong
 
 
 class ctcOptions(ctypes.Structure):
@@ -52,6 +53,17 @@ SIGNATURES = {
     "sa_conv2d_bwd_workspace_bytes": (c_size_t, [c_int] * 8),
     "sa_conv2d_relu_bwd": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_long] * 3 + [c_void_p, c_void_p, c_size_t,
                                                                                 c_void_p]),
+    "sa_dropout_mask_f32": (c_int, [c_void_p, c_size_t, c_size_t, c_float, c_ulonglong, c_uint, c_void_p]),
+    "sa_dropout_apply_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_ulonglong, c_uint, c_void_p]),
+    "sa_conv2d_relu_dropout_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_size_t,
+                                           c_float, c_ulonglong, c_uint, c_void_p]),
+    "sa_conv2d_relu_dropout_bwd": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_long] * 3 + [c_void_p, c_void_p, c_size_t,
+                                                                                        c_float, c_void_p]),
+    "sa_gru_stack_fwd_dropout": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int] * 6 +
+                                 [c_void_p, c_size_t, c_float, c_ulonglong, c_uint, c_void_p]),
+    "sa_gru_stack_bwd_wgrad_dropout": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 7 +
+                                       [c_void_p, c_size_t, c_float, c_ulonglong, c_uint, c_void_p]),
     "sa_gru_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int,
                            c_int, c_void_p]),
     "sa_gru_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -7,6 +7,7 @@
 // channel-major feature layout directly (no transpose pass).  Backward: mask + repack dy, dW = dyp^T cols (split-K
 // GEMM over ~4e5 positions), db = column sums, dx = col2im gather of dyp W (only for stacked convs).
 #include "common.h"
+#include "dropout.h"
 #include "internal.h"
 
 namespace {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 // dyp[pos][o] = dy[b, o, t', f'] * (y > 0), reading dy / y through the caller's strides
 __global__ __launch_bounds__(256) void relu_mask_pack_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              float* __restrict__ dyp, ConvGeom g, long ys_b, long ys_c,
-                                                             long ys_t) {
+                                                             long ys_t, float dscale) {
     const long total = (long)g.B * g.To * g.Fo * g.O;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         // thread order: f' fastest (coalesced reads), then o, then (b, t')
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void relu_mask_pack_kernel(const float* __rest
         const int to = (int)(bt % g.To);
         const int b = (int)(bt / g.To);
         const long off = (long)b * ys_b + (long)o * ys_c + (long)to * ys_t + fo;
-        const float v = y[off] > 0.f ? dy[off] : 0.f;
+        const float v = y[off] > 0.f ? dy[off] * dscale : 0.f;
         dyp[((bt * g.Fo) + fo) * g.O + o] = v;
     }
 }
@@ -276,6 +277,12 @@ __host__ __device__ inline bool conv_direct_ok(int C, int O, int kh, int kw, int
 struct DirGeom {
     int B, C, T, F, O, kh, kw, s, To, Fo, K, TT;   // K = kh * kw: the taps of ONE input channel
     long ys_b, ys_c, ys_t;
+    // nn.Dropout behind the ReLU (model.py:25-27).  Forward: the epilogue multiplies element (b, c, t', f') by the factor
+    // of mask index ((b O + c) T' + t') F' + f' (dropout.h).  Backward: y is the DROPPED output, so [y > 0] is already
+    // "ReLU passed AND kept" and the gradient only needs the 1 / (1 - p) of the kept elements: dscale.
+    SaDrop drop;
+    unsigned drop_stream;
+    float dscale;
 };
 
 // dw[o][c][k] (o < O, k < K) and dbias[o] = the fixed-order sum of the per-block partials [nb][C][32][NTK].
@@ -374,7 +381,7 @@ __device__ __forceinline__ void dirc_stage(const DircArgs& a, float* __restrict_
             const bool on = ti >= 0 && fj >= 0 && tq * g.s == ti && fq * g.s == fj && tq < g.To && fq < g.Fo;
             const long off = on ? (long)b * g.ys_b + (long)(c0 + oo) * g.ys_c + (long)tq * g.ys_t + fq : 0;
             const float yv = a.y[off], dv = a.src[off];
-            dsm[i] = on && yv > 0.f ? dv : 0.f;
+            dsm[i] = on && yv > 0.f ? dv * g.dscale : 0.f;
         }
     }
 }
@@ -479,8 +486,15 @@ __global__ __launch_bounds__(256) void conv_dirc_kernel(DircArgs a) {
         for (int e = 0; e < 16; ++e) {
             const int ch = (e & 3) + 8 * (e >> 2) + 4 * h;
             if (ch >= n_inner) continue;
-            if (GRAD) a.dst[(((long)b * g.C + ch) * g.T + t) * g.F + fo] = acc[q][e];
-            else a.dst[(long)b * g.ys_b + (long)ch * g.ys_c + (long)t * g.ys_t + fo] = fmaxf(acc[q][e] + a.bias[ch], 0.f);
+            if (GRAD) {
+                a.dst[(((long)b * g.C + ch) * g.T + t) * g.F + fo] = acc[q][e];
+            } else {
+                float v = fmaxf(acc[q][e] + a.bias[ch], 0.f);
+                // wave-uniform branch (a kernel argument); the mask index is the element's NCHW position, whatever
+                // layout the strides describe
+                if (g.drop.on()) v *= sa_drop_factor(g.drop, g.drop_stream, (uint64_t)(((long)b * g.O + ch) * g.To + t) * g.Fo + fo);
+                a.dst[(long)b * g.ys_b + (long)ch * g.ys_c + (long)t * g.ys_t + fo] = v;
+            }
         }
     }
 }
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(512) void conv_dw2_kernel(const float* __restrict__
                 const int tl = q % nt, o = q / nt;
                 const long off = (long)b * g.ys_b + (long)o * g.ys_c + (long)(t0 + tl) * g.ys_t + fo;
                 const float yv = y[off], dv = dy[off];
-                dyp[(tl * g.Fo + fo) * 33 + o] = yv > 0.f ? dv : 0.f;
+                dyp[(tl * g.Fo + fo) * 33 + o] = yv > 0.f ? dv * g.dscale : 0.f;
             }
         }
         __syncthreads();
@@ -665,6 +679,7 @@ static DirGeom dir_geom(const ConvGeom& g, long ys_b, long ys_c, long ys_t, int 
     d.K = g.kh * g.kw;
     d.ys_b = ys_b; d.ys_c = ys_c; d.ys_t = ys_t;
     d.TT = TT;
+    d.drop = sa_drop_make(0.f, 0ull); d.drop_stream = 0u; d.dscale = 1.f;
     return d;
 }
 // conv_dirc_kernel: tiles per wave (a block takes 128 nq positions of an utterance).  The slab of the outer-channel chunk
@@ -781,10 +796,10 @@ extern "C" size_t sa_conv2d_fwd_workspace_bytes(int B, int in_c, int T, int F, i
            sa_align_up(sa_gemm_workspace_bytes((int)npos, g.O, g.K), 256);
 }
 
-extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B,
-                                          int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
-                                          long ys_c, long ys_t, float* keep_cols, void* workspace,
-                                          size_t workspace_bytes, void* stream_) {
+static ctcStatus_t conv2d_relu_fwd_impl(const float* x, const float* w, const float* bias, float* y, int B,
+                                        int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
+                                        long ys_c, long ys_t, float* keep_cols, void* workspace,
+                                        size_t workspace_bytes, void* stream_, const SaDrop& drop, unsigned mask_stream) {
     SA_CLEAR_ERR();
     ConvGeom g;
     if (!x || !w || !bias || !y || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
@@ -798,6 +813,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
         DircArgs a;
         a.src = x; a.y = nullptr; a.wt = (const float*)workspace; a.bias = bias; a.dst = y;
         a.g = dir_geom(g, ys_b, ys_c, ys_t, 0);
+        a.g.drop = drop; a.g.drop_stream = mask_stream;
         const ctcStatus_t st = dirc_launch(a, g, false, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
         SA_CHECK_LAUNCH();
@@ -810,8 +826,29 @@ extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const 
     SA_CHECK_LAUNCH();
     SaGemmEpilogue ep;
     ep.m_inner = g.Fo; ep.m_mid = g.To; ep.s_outer = ys_b; ep.s_mid = ys_t; ep.col_stride = ys_c; ep.relu = 1;
-    return sa_gemm_f32_impl(0, 1, (int)npos, g.O, g.K, 1.0f, cols, g.K, w, g.K, 0.f, y, 0, bias, &ep, gws,
-                            workspace_bytes - (size_t)(gws - (char*)workspace), stream);
+    const ctcStatus_t st = sa_gemm_f32_impl(0, 1, (int)npos, g.O, g.K, 1.0f, cols, g.K, w, g.K, 0.f, y, 0, bias, &ep, gws,
+                                            workspace_bytes - (size_t)(gws - (char*)workspace), stream);
+    if (st != CTC_STATUS_SUCCESS) return st;
+    // the generic path has no fused mask: one in-place pass over y (no shipped config takes this path)
+    return sa_dropout_nchw_strided_impl(y, g.B, g.O, g.To, g.Fo, ys_b, ys_c, ys_t, drop, mask_stream, stream);
+}
+
+extern "C" ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B,
+                                          int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
+                                          long ys_c, long ys_t, float* keep_cols, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    return conv2d_relu_fwd_impl(x, w, bias, y, B, in_c, T, F, out_c, kh, kw, s, ys_b, ys_c, ys_t, keep_cols, workspace,
+                                workspace_bytes, stream_, sa_drop_make(0.f, 0ull), 0u);
+}
+
+extern "C" ctcStatus_t sa_conv2d_relu_dropout_fwd(const float* x, const float* w, const float* bias, float* y, int B,
+                                                  int in_c, int T, int F, int out_c, int kh, int kw, int s, long ys_b,
+                                                  long ys_c, long ys_t, float* keep_cols, void* workspace,
+                                                  size_t workspace_bytes, float p, unsigned long long seed,
+                                                  unsigned int mask_stream, void* stream_) {
+    if (!sa_drop_valid(p)) return CTC_STATUS_INVALID_VALUE;
+    return conv2d_relu_fwd_impl(x, w, bias, y, B, in_c, T, F, out_c, kh, kw, s, ys_b, ys_c, ys_t, keep_cols, workspace,
+                                workspace_bytes, stream_, sa_drop_make(p, seed), mask_stream);
 }
 
 extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s) {
@@ -836,10 +873,10 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
            sa_align_up(gw, 256);
 }
 
-extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
-                                          float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh,
-                                          int kw, int s, long ys_b, long ys_c, long ys_t, const float* fwd_cols,
-                                          void* workspace, size_t workspace_bytes, void* stream_) {
+static ctcStatus_t conv2d_relu_bwd_impl(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                                        float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh,
+                                        int kw, int s, long ys_b, long ys_c, long ys_t, const float* fwd_cols,
+                                        void* workspace, size_t workspace_bytes, void* stream_, float dscale) {
     SA_CLEAR_ERR();
     ConvGeom g;
     if (!x || !w || !y || !dy || !dw || !dbias || !workspace || !make_geom(&g, B, in_c, T, F, out_c, kh, kw, s))
@@ -875,15 +912,16 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
                     return CTC_STATUS_INVALID_VALUE;
             }
             hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, pk, g, ys_b,
-                               ys_c, ys_t);
+                               ys_c, ys_t, dscale);
             dpk = pk;
         }
         const Dw2FnT fn = dw2_fn(NT, cw);
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
-        hipLaunchKernelGGL(fn, dim3(nb, (g.C + cw - 1) / cw), dim3(512), lds, stream, x, y, dy, dpk, (float*)gws,
-                           dir_geom(g, ys_b, ys_c, ys_t, TT), nslab_t);
+        DirGeom dg = dir_geom(g, ys_b, ys_c, ys_t, TT);
+        dg.dscale = dscale;
+        hipLaunchKernelGGL(fn, dim3(nb, (g.C + cw - 1) / cw), dim3(512), lds, stream, x, y, dy, dpk, (float*)gws, dg, nslab_t);
         hipLaunchKernelGGL(conv_dw_fold_kernel, dim3((unsigned)(((long)g.O * g.C * (Kc + 1) * 8 + 255) / 256)), dim3(256),
                            0, stream, (const float*)gws, nb, 32 * NT, g.O, g.C, Kc, dw, dbias);
         SA_CHECK_LAUNCH();
@@ -893,7 +931,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
                                stream, w, wt, g.O, g.C, Kc, 1);
             DircArgs a;
             a.src = dy; a.y = y; a.wt = wt; a.bias = nullptr; a.dst = dx;
-            a.g = dir_geom(g, ys_b, ys_c, ys_t, TT);
+            a.g = dg;
             const ctcStatus_t st = dirc_launch(a, g, true, stream);
             if (st != CTC_STATUS_SUCCESS) return st;
             SA_CHECK_LAUNCH();
@@ -906,7 +944,7 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
         hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((npos + 15) / 16)), dim3(256), 0, stream, x, cols, g);
     }
     hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, dyp, g, ys_b,
-                       ys_c, ys_t);
+                       ys_c, ys_t, dscale);
     SA_CHECK_LAUNCH();
     // dW[o, k] = sum_pos dyp[pos, o] * cols[pos, k]
     ctcStatus_t st;
@@ -944,4 +982,23 @@ extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const 
         SA_CHECK_LAUNCH();
     }
     return CTC_STATUS_SUCCESS;
+}
+
+extern "C" ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx,
+                                          float* dw, float* dbias, int B, int in_c, int T, int F, int out_c, int kh,
+                                          int kw, int s, long ys_b, long ys_c, long ys_t, const float* fwd_cols,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+    return conv2d_relu_bwd_impl(x, w, y, dy, dx, dw, dbias, B, in_c, T, F, out_c, kh, kw, s, ys_b, ys_c, ys_t, fwd_cols,
+                                workspace, workspace_bytes, stream_, 1.f);
+}
+
+// y = the DROPPED forward output (sa_conv2d_relu_dropout_fwd with the same p): [y > 0] is "ReLU passed and kept"
+extern "C" ctcStatus_t sa_conv2d_relu_dropout_bwd(const float* x, const float* w, const float* y, const float* dy,
+                                                  float* dx, float* dw, float* dbias, int B, int in_c, int T, int F,
+                                                  int out_c, int kh, int kw, int s, long ys_b, long ys_c, long ys_t,
+                                                  const float* fwd_cols, void* workspace, size_t workspace_bytes,
+                                                  float p, void* stream_) {
+    if (!sa_drop_valid(p)) return CTC_STATUS_INVALID_VALUE;
+    return conv2d_relu_bwd_impl(x, w, y, dy, dx, dw, dbias, B, in_c, T, F, out_c, kh, kw, s, ys_b, ys_c, ys_t, fwd_cols,
+                                workspace, workspace_bytes, stream_, sa_drop_make(p, 0ull).scale);
 }

@@ -477,6 +477,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_filtered_kernel(GemmArgs g) {
     gemm_block<TA, TB, 1>(g, smem, bx, r % g.grid_y, r / g.grid_y);
 }
 
+// Queued behind every XCD-filtered launch: all `total` tiles were drawn iff the counter reached `total` (draws are
+// sequential; blocks that drew a tile have finished it by the time this kernel runs on the same stream).
+__global__ void gemm_filtered_check_kernel(const unsigned* __restrict__ tile_counter, unsigned total,
+                                           unsigned* __restrict__ err_word) {
+    if (__hip_atomic_load(tile_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) atomicOr(err_word, 4u);
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int splits) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)g.M * g.N;
@@ -608,6 +615,9 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
             if (trans_b) hipLaunchKernelGGL((gemm_f32_filtered_kernel<false, true>), grid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((gemm_f32_filtered_kernel<false, false>), grid, dim3(256), 0, stream, g);
         }
+        if (opts->err_word)
+            hipLaunchKernelGGL(gemm_filtered_check_kernel, dim3(1), dim3(1), 0, stream, (const unsigned*)g.tile_counter,
+                               (unsigned)(g.grid_x * g.grid_y * g.grid_z), opts->err_word);
     } else if (trans_a) {
         if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), dyn, stream, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), dyn, stream, g);

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "dropout.h"
 #include "internal.h"
 
 namespace {
@@ -460,6 +461,10 @@ struct PFusedFwd {
     const float* w_hh[kMaxJobs];
     const float* b_hh[kMaxJobs];
     float* h_out[kMaxJobs];      // (T, B, H), pre-filled with the sentinel
+    float* h_drop[kMaxJobs];     // inter-layer dropout (nn.GRU(dropout=p), model.py:38): layer l < L-1 also writes
+                                 // h_out[l] * mask here and layer l+1 reads THAT; null without dropout
+    SaDrop drop;                 // mask of layer l's output: stream drop_stream0 + l, index (t B + b) H + u (dropout.h)
+    unsigned drop_stream0;
     float* stash[kMaxJobs];      // rows x 5H or null
     unsigned* prog;              // [L][nbt] arrival counters, zeroed by the host
     unsigned* reg;
@@ -509,8 +514,12 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     const int kslice = H / 4, kbeg = wave * kslice;
     const int brow = min(b0 + i, B - 1);
     __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)h_out, 0, 0x7fffffff, 0x00020000);
-    __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)(l > 0 ? P.h_out[l - 1] : h_out), 0, 0x7fffffff,
-                                                                    0x00020000);
+    // the layer below as THIS layer sees it: its dropped copy when inter-layer dropout is on
+    const float* lower = l > 0 ? (P.h_drop[l - 1] ? P.h_drop[l - 1] : P.h_out[l - 1]) : h_out;
+    __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)lower, 0, 0x7fffffff, 0x00020000);
+    float* h_drop = P.h_drop[l];  // null: the top layer, or no dropout
+    const SaDrop drop = P.drop;
+    const unsigned drop_stream = P.drop_stream0 + (unsigned)l;
     unsigned* my_prog = P.prog + l * P.nbt_all + role_y;
     const unsigned* lower_prog = P.prog + (l > 0 ? l - 1 : 0) * P.nbt_all + role_y;
     const float* w_ih = l > 0 ? P.w_ih[l] : nullptr;
@@ -698,6 +707,12 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
             const float n = tanhf(e_ai_n + sin_ + r * q);
             const float h = (1.0f - z) * n + z * hp;
             __hip_atomic_store(h_out + (long)t * hs_t + (long)b * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // what the layer above reads: written through like h (another XCD picks it up once `prog` says so), AFTER
+            // h -- the own layer's next step waits for h, the layer above trails a step behind anyway
+            if (h_drop)
+                __hip_atomic_store(h_drop + (long)t * hs_t + (long)b * H + u,
+                                   h * sa_drop_factor(drop, drop_stream, (uint64_t)((long)t * hs_t + (long)b * H + u)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (stash) {  // streaming stores: the stash must not push the W_ih rows out of the XCD's L2
                 float* st = stash + row * 5 * H;
                 __builtin_nontemporal_store(r, st + u);
@@ -836,6 +851,7 @@ struct PBwdJob {
     float* xch;            // gru_bwd_fused_kernel: the exchange buffer, dai tiled [t][batch tile][k / 16][b % 16][k % 16]
     float* dump;           // gru_bwd_fused_kernel: 256 x 256 floats nobody reads (where predicated-off stores go)
     long xs_b, xs_t;
+    unsigned dx_drop_stream;  // gru_bwd_fused_kernel: mask stream of dx_out (= the dropped output of the layer below)
     int t0, nsteps;        // first time index this launch unwinds, number of steps
     int dt, t_first;       // -1 for a forward-in-time chain (unwinds from T-1), +1 for a reverse chain; the very first index
     unsigned base;
@@ -850,6 +866,7 @@ struct PBwdJobs {
     unsigned* err;
     int spin_limit, fault, prio;  // see PFwdJobs
     int packed;                   // gru_bwd_fused_kernel: 1 = publish with plain stores (default), 0 = write-through
+    SaDrop drop;                  // gru_bwd_fused_kernel: inter-layer dropout -- d h_out[l-1] = mask * (dai[l] W_ih[l])
     unsigned long long* timing;   // debug (SA_GRU_TIMING=1): per block {poll+load, mfma, reduce+barrier, gates+publish} in
                                   // 10 ns ticks and the number of polling trips; else null
     PBwdJob j[kMaxJobs];
@@ -1044,7 +1061,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // step's barrier; the chunk's last row is gathered once more after the loop.  H = 64 IPG; flag-less hand-off only.
 // FUSE = false: the same kernel without the second product (bidirectional layers, one-layer stacks, SA_GRU_FUSE_DX=0):
 // tiled exchange, operands a step ahead, d h_out of the layer below left to a GEMM.
-template <int IPG, bool FUSE>
+// DROP (with FUSE): inter-layer dropout -- the row of d h_out[l-1] is multiplied by the mask the forward pass applied to
+// h_out[l-1] (recomputed from (seed, stream, index), dropout.h) before it is stored.  A template parameter, so that the
+// kernel without dropout keeps its branch-free tail.
+template <int IPG, bool FUSE, bool DROP = false>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
@@ -1163,12 +1183,18 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     // slot: a BRANCH around a vector-memory instruction makes hipcc wait vmcnt(0) at the join, i.e. here for the
     // store's own acknowledgement -- 1.2 us per step when the d h_out store sat under `if (pending && live)`.
     float* p_dump = J.dump + blockIdx.x * 256 + tid;
+    const SaDrop drop = P.drop;
+    const unsigned dx_stream = J.dx_drop_stream;
+    const long dx_idx0 = (long)bl * H + u;  // mask index of element (trow, b, u) of the layer below: (trow B + b) H + u
     auto flush2 = [&](int par, bool on, int trow) {  // after a barrier: add the four waves' parts, store the row's tile
         const float* rd = red2 + par * 1024;
         float* dst = on && live ? p_dx + (long)trow * s_dx : p_dump;
+        float v = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
+        // the layer below fed this layer its DROPPED output (nn.GRU(dropout=p)): the same mask routes the gradient.
+        // Off the critical path (the layer below trails by a few steps).
+        if constexpr (DROP) v *= sa_drop_factor(drop, dx_stream, (uint64_t)((long)(trow < 0 ? 0 : trow) * B * H + dx_idx0));
         // write-through: in one-launch mode the layer below (another XCD) is waiting for exactly this value
-        __hip_atomic_store(dst, ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // A step's operands out of memory -- its stashed gates, its d h_out, and r of the row the gather brings -- are
@@ -1774,10 +1800,10 @@ static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels
     const char* e = getenv("SA_GRU_TILED");
     return !(e && e[0] == '0');
 }
-static BwdPersistFn bwd_fused_fn(int H, bool fuse) {
+static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false) {
     if (!tiled_enabled()) return nullptr;
-    if (H == 512) return fuse ? gru_bwd_fused_kernel<8, true> : gru_bwd_fused_kernel<8, false>;
-    if (H == 256) return fuse ? gru_bwd_fused_kernel<4, true> : gru_bwd_fused_kernel<4, false>;
+    if (H == 512) return fuse ? (drop ? gru_bwd_fused_kernel<8, true, true> : gru_bwd_fused_kernel<8, true>) : gru_bwd_fused_kernel<8, false>;
+    if (H == 256) return fuse ? (drop ? gru_bwd_fused_kernel<4, true, true> : gru_bwd_fused_kernel<4, true>) : gru_bwd_fused_kernel<4, false>;
     return nullptr;
 }
 static int persist_prio() {
@@ -1824,13 +1850,33 @@ extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, i
     return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + kSyncBytes;
 }
 
-extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
-                                        const float* const* w_hh, const float* const* b_hh, float* const* h_out,
-                                        float* const* stash, int L, int D, int B, int T, int H, int chunk,
-                                        void* workspace, size_t workspace_bytes, void* stream_,
-                                        void* const* aux_streams, int n_aux) {
+namespace {
+// Inter-layer dropout of the stack (nn.GRU(dropout=p), /root/reference/speech/models/model.py:38): layer l < L-1 hands
+// h_out[l] * mask to layer l+1; mask stream stream0 + l, index = the element's offset in the (T, B, D*H) array.
+// h_drop[l] (l < L-1) are caller-owned (T, B, D*H) buffers for the dropped copies: the next layer's input projection,
+// and its dW_ih product in the backward pass, read them.  The one-launch fused kernels apply the mask themselves;
+// every other path applies it with an element-wise launch per layer (bidirectional) or per wavefront chunk.
+struct DropCtx {
+    SaDrop drop;
+    unsigned stream0;
+    float* const* h_drop;
+    bool on() const { return drop.on(); }
+};
+
+ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
+                           const float* const* w_hh, const float* const* b_hh, float* const* h_out,
+                           float* const* stash, int L, int D, int B, int T, int H, int chunk,
+                           void* workspace, size_t workspace_bytes, void* stream_,
+                           void* const* aux_streams, int n_aux, const DropCtx& dc) {
     SA_CLEAR_ERR();
     if (!x || !w_ih || !b_ih || !w_hh || !b_hh || !h_out || !workspace) return CTC_STATUS_INVALID_VALUE;
+    const bool drop_on = dc.on() && L > 1;
+    if (drop_on) {
+        if (!dc.h_drop) return CTC_STATUS_INVALID_VALUE;
+        for (int l = 0; l + 1 < L; ++l) if (!dc.h_drop[l]) return CTC_STATUS_INVALID_VALUE;
+    }
+    // layer l's input as layer l sees it (l >= 1)
+    auto lower_of = [&](int l) -> const float* { return drop_on ? dc.h_drop[l - 1] : h_out[l - 1]; };
     if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
@@ -1884,8 +1930,12 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
         const int S = (T + nck - 1) / nck;
         int side_launch = 0;
         for (int l = 0; l < L; ++l) {
-            const float* in = l == 0 ? x : h_out[l - 1];
+            const float* in = l == 0 ? x : lower_of(l);
             const int I = l == 0 ? I0 : 2 * H;
+            auto finish_layer = [&]() -> ctcStatus_t {  // the layer is complete on `stream`: its dropped copy for layer l+1
+                if (!drop_on || l + 1 >= L) return CTC_STATUS_SUCCESS;
+                return sa_dropout_apply_impl(h_out[l], dc.h_drop[l], (size_t)T * B * DH, 0, dc.drop, dc.stream0 + l, stream);
+            };
             auto project = [&](int c, hipStream_t on, unsigned mask) {  // both directions' rows of time chunk c
                 const int n = min(S, T - c * S);
                 const float* gA[2]; const float* gB[2]; float* gC[2]; const float* gbias[2];
@@ -1896,6 +1946,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 SaGemmOpts o;
                 o.no_split = 1; o.pad_lds = 0; o.colsum = nullptr; o.xcc_mask = mask;
                 o.tile_counter = mask ? sync + kSyncTiles + side_launch++ : nullptr;
+                o.err_word = g_health.dev;  // a filtered launch that did not cover its tiles stops the step's update
                 return sa_gemm_f32_group_impl(2, 0, 1, n * B, 3 * H, I, 1.f, gA, I, gB, I, 0.f, gC, 3 * H, gbias, nullptr,
                                               nullptr, 0, on, &o);
             };
@@ -1944,6 +1995,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                         hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
                     }
                 }
+                st = finish_layer();
+                if (st != CTC_STATUS_SUCCESS) return st;
                 continue;
             }
             P.n = 2; grid.z = 2;
@@ -1952,6 +2005,8 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 P.j[1] = make_job(l, 1, T - 1 - s, s == 0 ? -1 : T - s);
                 hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, stream, P);
             }
+            st = finish_layer();
+            if (st != CTC_STATUS_SUCCESS) return st;
         }
         SA_CHECK_LAUNCH();
         if (bi_xcd) g_health.submit(stream);
@@ -1996,9 +2051,12 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
             Q.stamp = g_prof.slot(0, true, false, T);
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            Q.drop = dc.drop; Q.drop_stream0 = dc.stream0;
+            for (int l = 0; l < kMaxJobs; ++l) Q.h_drop[l] = nullptr;
             for (int l = 0; l < L; ++l) {
                 Q.w_ih[l] = w_ih[l]; Q.b_ih[l] = b_ih[l]; Q.w_hh[l] = w_hh[l]; Q.b_hh[l] = b_hh[l];
                 Q.h_out[l] = h_out[l]; Q.stash[l] = stash ? stash[l] : nullptr;
+                Q.h_drop[l] = drop_on && l + 1 < L ? dc.h_drop[l] : nullptr;
             }
             const int tpp = tiles_per_pass(L, H);
             unsigned launches = 0;
@@ -2029,7 +2087,12 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
                 const int c = w - l;
                 if (c < 0 || c >= nch) continue;
                 const int t0 = c * chunk, t1 = min(T, t0 + chunk);
-                const float* Ap = h_out[l - 1] + (long)t0 * B * H;
+                if (drop_on) {  // the chunk's rows of the layer below, dropped (it finished them last wave)
+                    st = sa_dropout_apply_impl(h_out[l - 1] + (long)t0 * B * H, dc.h_drop[l - 1] + (long)t0 * B * H,
+                                               (size_t)(t1 - t0) * B * H, (size_t)t0 * B * H, dc.drop, dc.stream0 + l - 1, stream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
+                const float* Ap = lower_of(l) + (long)t0 * B * H;
                 float* Cp = ai_of(l, 0) + (long)t0 * B * 3 * H;
                 if (t1 - t0 == chunk) {
                     gA[ng] = Ap; gB[ng] = w_ih[l]; gC[ng] = Cp; gb[ng] = b_ih[l]; ++ng;
@@ -2102,6 +2165,29 @@ extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* con
     if (xcd) g_health.submit(stream);
     return CTC_STATUS_SUCCESS;
 }
+}  // namespace
+
+extern "C" ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
+                                        const float* const* w_hh, const float* const* b_hh, float* const* h_out,
+                                        float* const* stash, int L, int D, int B, int T, int H, int chunk,
+                                        void* workspace, size_t workspace_bytes, void* stream_,
+                                        void* const* aux_streams, int n_aux) {
+    const DropCtx dc{sa_drop_make(0.f, 0ull), 0u, nullptr};
+    return stack_fwd_impl(x, I0, w_ih, b_ih, w_hh, b_hh, h_out, stash, L, D, B, T, H, chunk, workspace, workspace_bytes,
+                          stream_, aux_streams, n_aux, dc);
+}
+
+extern "C" ctcStatus_t sa_gru_stack_fwd_dropout(const float* x, int I0, const float* const* w_ih,
+                                                const float* const* b_ih, const float* const* w_hh,
+                                                const float* const* b_hh, float* const* h_out, float* const* h_drop,
+                                                float* const* stash, int L, int D, int B, int T, int H, int chunk,
+                                                void* workspace, size_t workspace_bytes, float p,
+                                                unsigned long long seed, unsigned int mask_stream0, void* stream_) {
+    if (!sa_drop_valid(p)) return CTC_STATUS_INVALID_VALUE;
+    const DropCtx dc{sa_drop_make(p, seed), mask_stream0, h_drop};
+    return stack_fwd_impl(x, I0, w_ih, b_ih, w_hh, b_hh, h_out, stash, L, D, B, T, H, chunk, workspace, workspace_bytes,
+                          stream_, nullptr, 0, dc);
+}
 
 // split-K workspace of the weight-gradient products (one region: the products of a call run on ONE stream, in order)
 static size_t wgrad_ws_bytes(int L, int D, int B, int T, int H, int I0) {
@@ -2161,8 +2247,10 @@ struct WGradIssuer {
     float* const* dah;
     int L, D, B, T, H, I0;
     bool polite;
+    const float* lower[kMaxJobs]; // layer l's input as the forward pass fed it (l >= 1): h_out[l-1], or its dropped copy
     unsigned xcc_mask = 0;        // != 0: the launches keep to these XCDs (the ones the recurrence leaves idle)
     unsigned* counters = nullptr; // zeroed device words, one per filtered launch
+    unsigned* err_word = nullptr; // the sticky health word: a filtered launch that missed tiles reports there
     int next_counter = 0, max_counters = 0;
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -2171,6 +2259,7 @@ struct WGradIssuer {
                 int T_, int H_, int I0_, bool pol)
         : wg(w), stash(st), dai(da), dah(dh), L(L_), D(D_), B(B_), T(T_), H(H_), I0(I0_), polite(pol) {
         for (int i = 0; i < 2 * kMaxJobs; ++i) first_ih[i] = first_hh[i] = true;
+        for (int l = 0; l < kMaxJobs; ++l) lower[l] = l >= 1 && l < L && wg.h_out ? wg.h_out[l - 1] : nullptr;
     }
     // spans[k] = {t0, t1} (t1 <= t0: nothing).  Same-shaped problems share a grouped launch.
     ctcStatus_t issue(const int (*spans)[2], hipStream_t stream, bool allow_split) {
@@ -2199,7 +2288,7 @@ struct WGradIssuer {
                         gA[ng] = dah[k] + r0 * 3 * H; gB[ng] = stash[k] + r0 * 5 * H + 4 * H;
                         gC[ng] = wg.dw_hh[k]; gS[ng] = wg.db_hh[k];
                     } else {
-                        gA[ng] = dai[k] + r0 * 3 * H; gB[ng] = (l == 0 ? wg.x : wg.h_out[l - 1]) + r0 * N0;
+                        gA[ng] = dai[k] + r0 * 3 * H; gB[ng] = (l == 0 ? wg.x : lower[l]) + r0 * N0;
                         gC[ng] = wg.dw_ih[k]; gS[ng] = wg.db_ih[k];
                     }
                     done[k] = true;
@@ -2208,6 +2297,7 @@ struct WGradIssuer {
                 o.colsum = gS;
                 if (xcc_mask && counters && next_counter < max_counters) {
                     o.xcc_mask = xcc_mask; o.tile_counter = counters + next_counter++; o.pad_lds = 0;
+                    o.err_word = err_word;
                 } else {
                     o.xcc_mask = 0; o.tile_counter = nullptr;
                 }
@@ -2228,9 +2318,14 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                            const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
                            int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
                            size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux,
-                           const WGrad* wg) {
+                           const WGrad* wg, const DropCtx& dc) {
     SA_CLEAR_ERR();
     if (!dh_top || !stash || !w_ih || !w_hh || !dai || !dah || !workspace) return CTC_STATUS_INVALID_VALUE;
+    const bool drop_on = dc.on() && L > 1;
+    if (drop_on) {
+        if (!dc.h_drop) return CTC_STATUS_INVALID_VALUE;
+        for (int l = 0; l + 1 < L; ++l) if (!dc.h_drop[l]) return CTC_STATUS_INVALID_VALUE;
+    }
     if (L <= 0 || L > kMaxJobs || (D != 1 && D != 2) || B <= 0 || T <= 0 || H <= 0 || (H & 3) || I0 <= 0)
         return CTC_STATUS_INVALID_VALUE;
     if (workspace_bytes < sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)) return CTC_STATUS_INVALID_VALUE;
@@ -2254,6 +2349,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     char* wws = gws + gws_bytes;
     WGradIssuer issuer(wg ? *wg : WGrad{}, stash, dai, dah, L, D, B, T, H, I0, false);
     issuer.ws = wws; issuer.ws_bytes = wws_bytes;
+    if (drop_on) for (int l = 1; l < L; ++l) issuer.lower[l] = dc.h_drop[l - 1];
     // everything that is still owed when the recurrence is done goes out on the caller's stream (the fallback path)
     int wg_hi[2 * kMaxJobs];
     for (int k = 0; k < L * D; ++k) wg_hi[k] = T;
@@ -2303,7 +2399,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         const int bi_used = (2 * min(bi_tpp, bi_nbt) + (32 / (H / 16)) - 1) / (32 / (H / 16));
         const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
         const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled(false) && g_side.init();
-        issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords;
+        issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords; issuer.err_word = g_health.dev;
         // tiled exchange, operands a step ahead (gru_bwd_fused_kernel without the second product): H = 512 / 256
         const BwdPersistFn bi_tiled_fn = bi_xcd && flagless_mode() && (long)T * bi_nbt * 16 * 3 * H * 4 < 0x7fffffffL
                                              ? bwd_fused_fn(H, false) : nullptr;
@@ -2324,9 +2420,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                            bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
-                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr;
+                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
+                    J.dx_drop_stream = 0u;
                     const float* dho = (l == L - 1) ? dh_top : mid_of(l);
                     J.dh_out = dho + (long)d * H; J.ds_b = DH; J.ds_t = (long)B * DH;
                     J.stash = stash[l * 2 + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * 2 + d]; J.dah = dah[l * 2 + d];
@@ -2359,6 +2456,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                           d ? 1.f : 0.f, din, I, nullptr, nullptr, nullptr, 0, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
                 }
+            if (drop_on && l > 0) {  // the layer below fed this one its dropped output: the same mask routes the gradient
+                st = sa_dropout_apply_impl(din, din, (size_t)T * B * DH, 0, dc.drop, dc.stream0 + l - 1, stream);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
             if (bi_xcd && wg && bi_side && l > 0) {  // (layer 0's products have no recurrence left to hide behind: they
                                                       // run unfiltered on the caller's stream, wgrad_rest below)
                 // this layer's weight gradients go to the side stream NOW, behind the input-gradient products above
@@ -2397,7 +2498,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // the lower layers' d h_out inside the recurrence kernel (gru_bwd_fused_kernel): no GEMM between the launches
     const bool tiled = flagless && bwd_fused_fn(H, false) != nullptr && (long)T * nbt * 16 * 3 * H * 4 < 0x7fffffffL;
     const bool fused = tiled && L > 1 && fuse_dx_enabled();
-    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused) : nullptr;
+    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on) : nullptr;
     const size_t flds = xcd_lds((size_t)4 * 4 * 256 * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
@@ -2433,7 +2534,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             if (!sentinel_fill(mid_of(l), (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
-        Q.timing = nullptr;
+        Q.timing = nullptr; Q.drop = dc.drop;
         Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
             PBwdJob& J = Q.j[n];
@@ -2442,6 +2543,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
             J.w_ih_t = l > 0 ? wih_t_of(l) : nullptr; J.dx_out = l > 0 ? mid_of(l - 1) : nullptr;
             J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = xch_of(l); J.dump = (float*)(ws + dump_off);
+            J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
             J.t0 = T - 1; J.nsteps = T; J.dt = -1; J.t_first = T - 1; J.base = 0;
         }
         Q.n = L;
@@ -2458,6 +2560,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         // d h_out of each lower layer's next chunk = dai of the layer above (finished last wave) times its W_ih
         if (!fused) {
             const float* gA[kMaxJobs]; const float* gB[kMaxJobs]; float* gC[kMaxJobs];
+            int gL[kMaxJobs], gT[kMaxJobs];
             int ng = 0;
             for (int l = L - 2; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
@@ -2467,23 +2570,32 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 const float* Ap = dai[l + 1] + (long)t0 * B * 3 * H;
                 float* Cp = mid_of(l) + (long)t0 * B * H;
                 if (t1 - t0 == chunk) {
-                    gA[ng] = Ap; gB[ng] = w_ih[l + 1]; gC[ng] = Cp; ++ng;
+                    gA[ng] = Ap; gB[ng] = w_ih[l + 1]; gC[ng] = Cp; gL[ng] = l; gT[ng] = t0; ++ng;
                 } else {
                     st = sa_gemm_f32_impl(0, 0, (t1 - t0) * B, H, 3 * H, 1.f, Ap, 3 * H, w_ih[l + 1], H, 0.f, Cp, H,
                                           nullptr, nullptr, gws, gws_bytes, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
+                    if (drop_on) {  // layer l+1 read layer l's DROPPED output: the same mask routes the gradient
+                        st = sa_dropout_apply_impl(Cp, Cp, (size_t)(t1 - t0) * B * H, (size_t)t0 * B * H, dc.drop, dc.stream0 + l, stream);
+                        if (st != CTC_STATUS_SUCCESS) return st;
+                    }
                 }
             }
             if (ng > 0) {
                 st = sa_gemm_f32_group_impl(ng, 0, 0, chunk * B, H, 3 * H, 1.f, gA, 3 * H, gB, H, 0.f, gC, H, nullptr,
                                             nullptr, gws, gws_bytes, stream);
                 if (st != CTC_STATUS_SUCCESS) return st;
+                for (int k = 0; drop_on && k < ng; ++k) {
+                    st = sa_dropout_apply_impl(gC[k], gC[k], (size_t)chunk * B * H, (size_t)gT[k] * B * H, dc.drop, dc.stream0 + gL[k], stream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
             }
         }
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
+            Q.drop = dc.drop;
             Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
@@ -2496,6 +2608,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
                 J.w_ih_t = fused && l > 0 ? wih_t_of(l) : nullptr; J.dx_out = fused && l > 0 ? mid_of(l - 1) : nullptr;
                 J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = tiled ? xch_of(l) : nullptr; J.dump = (float*)(ws + dump_off);
+                J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
                 J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
                 J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);
             }
@@ -2568,8 +2681,9 @@ extern "C" ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const*
                                         const float* const* w_hh, float* const* dai, float* const* dah, float* dx,
                                         int I0, int L, int D, int B, int T, int H, int chunk, void* workspace,
                                         size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux) {
+    const DropCtx dc{sa_drop_make(0.f, 0ull), 0u, nullptr};
     return stack_bwd_impl(dh_top, stash, w_ih, w_hh, dai, dah, dx, I0, L, D, B, T, H, chunk, workspace,
-                          workspace_bytes, stream_, aux_streams, n_aux, nullptr);
+                          workspace_bytes, stream_, aux_streams, n_aux, nullptr, dc);
 }
 
 extern "C" ctcStatus_t sa_gru_stack_bwd_wgrad(const float* dh_top, const float* const* stash,
@@ -2583,8 +2697,28 @@ extern "C" ctcStatus_t sa_gru_stack_bwd_wgrad(const float* dh_top, const float* 
     for (int k = 0; k < L * D && k < 2 * kMaxJobs; ++k)
         if (!dw_ih[k] || !dw_hh[k] || !db_ih[k] || !db_hh[k]) return CTC_STATUS_INVALID_VALUE;
     WGrad wg{x, h_out, dw_ih, dw_hh, db_ih, db_hh};
+    const DropCtx dc{sa_drop_make(0.f, 0ull), 0u, nullptr};
     return stack_bwd_impl(dh_top, stash, w_ih, w_hh, dai, dah, dx, I0, L, D, B, T, H, chunk, workspace,
-                          workspace_bytes, stream_, nullptr, 0, &wg);
+                          workspace_bytes, stream_, nullptr, 0, &wg, dc);
+}
+
+// The backward pass of sa_gru_stack_fwd_dropout (same p, seed, mask_stream0, and the h_drop buffers it filled).
+extern "C" ctcStatus_t sa_gru_stack_bwd_wgrad_dropout(const float* dh_top, const float* const* stash,
+                                                      const float* const* w_ih, const float* const* w_hh,
+                                                      float* const* dai, float* const* dah, float* dx, int I0, int L,
+                                                      int D, int B, int T, int H, int chunk, const float* x,
+                                                      const float* const* h_out, float* const* h_drop,
+                                                      float* const* dw_ih, float* const* dw_hh, float* const* db_ih,
+                                                      float* const* db_hh, void* workspace, size_t workspace_bytes,
+                                                      float p, unsigned long long seed, unsigned int mask_stream0,
+                                                      void* stream_) {
+    if (!x || !h_out || !dw_ih || !dw_hh || !db_ih || !db_hh || !sa_drop_valid(p)) return CTC_STATUS_INVALID_VALUE;
+    for (int k = 0; k < L * D && k < 2 * kMaxJobs; ++k)
+        if (!dw_ih[k] || !dw_hh[k] || !db_ih[k] || !db_hh[k]) return CTC_STATUS_INVALID_VALUE;
+    WGrad wg{x, h_out, dw_ih, dw_hh, db_ih, db_hh};
+    const DropCtx dc{sa_drop_make(p, seed), mask_stream0, h_drop};
+    return stack_bwd_impl(dh_top, stash, w_ih, w_hh, dai, dah, dx, I0, L, D, B, T, H, chunk, workspace,
+                          workspace_bytes, stream_, nullptr, 0, &wg, dc);
 }
 
 extern "C" size_t sa_colsum_workspace_bytes(int M, int N) {

@@ -1,6 +1,7 @@
 // internal.h -- C++-side interfaces shared between translation units of libspeech_amd (not part of the C ABI).
 #pragma once
 #include "common.h"
+#include "dropout.h"
 
 struct SaGemmEpilogue {
     // addr(m, n) = (m / (m_inner * m_mid)) * s_outer + ((m / m_inner) % m_mid) * s_mid + (m % m_inner) + n * col_stride
@@ -20,6 +21,12 @@ struct SaGemmOpts {
     float* const* colsum;   // trans_a products: per problem, also write the column sums of A (K x M) -> [M]; or null
     unsigned xcc_mask;      // != 0: run only on the XCDs in the mask (persistent tile loop); needs tile_counter
     unsigned* tile_counter; // device word, zero before the launch
+    // XCD-filtered launches assume the dispatcher spreads their blocks over the XCDs (block b -> XCD b % 8) closely enough
+    // that the allowed XCDs receive one block per tile.  That is an observation, not a contract: behind every filtered
+    // launch a one-thread kernel on the same stream ORs code 4 into this word (the library's sticky health word, see
+    // sa_gru_health_flag) when fewer than all tiles were drawn -- the step's optimiser update is then skipped and the
+    // caller replays it without the filtered path, exactly as for a failed persistent-kernel hand-off.
+    unsigned* err_word = nullptr;
 };
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
                                    const float* const* A, long lda, const float* const* B, long ldb, float beta,
@@ -28,3 +35,10 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
                                    const SaGemmOpts* opts = nullptr);
 size_t sa_gemm_group_workspace_bytes(int nprob, int M, int N, int K);
 extern "C" size_t sa_colsum_workspace_bytes(int M, int N);
+
+// dropout.hip: the stand-alone forms of the mask (dropout.h)
+ctcStatus_t sa_dropout_nchw_strided_impl(float* y, int B, int O, int To, int Fo, long ys_b, long ys_c, long ys_t,
+                                         const SaDrop& d, unsigned stream_id, hipStream_t stream);
+// out[i] = (in ? in[i] : 1) * factor(idx0 + i); in == out allowed
+ctcStatus_t sa_dropout_apply_impl(const float* in, float* out, size_t n, size_t idx0, const SaDrop& d,
+                                  unsigned stream_id, hipStream_t stream);

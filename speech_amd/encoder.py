@@ -10,8 +10,10 @@ that layout, a time chunk of any layer is then a contiguous row range (what the 
 logits come out as (T', B, V+1) -- warp-ctc's native layout -- and are handed to the caller as a (B, T', V+1) view.
 
 Every tensor op below is a libspeech_amd.so call through speech_amd.ops; torch only allocates.
-Dropout (config["dropout"] != 0, training mode) multiplies by a torch-generated Bernoulli mask between kernels; the
-GRU stack is then run one layer per call so the mask can sit between layers (nn.GRU's inter-layer dropout).
+Dropout (config["dropout"] != 0, training mode; model.py:25-27 behind every conv ReLU, model.py:38 between the GRU
+layers) happens INSIDE those kernels: each forward pass draws one 64-bit Philox key, the conv epilogue and the fused
+recurrence kernels evaluate the mask of the element they write (or whose gradient they route) from (key, tensor, index)
+-- no mask tensor, no extra pass, and the GRU stack stays one launch per direction of time (csrc/dropout.h).
 """
 import os
 
@@ -39,14 +41,13 @@ class EncoderPlan:
         self.input_dim = input_dim
         self.chunk = int(os.environ.get("SA_GRU_CHUNK", "0"))  # time steps per wavefront chunk (0: library default)
 
+        # tests pin the masks: a fixed key instead of a fresh one per forward pass (None: draw from torch's CPU generator)
+        self.fixed_seed = None
+
     def time_out(self, t):
         for out_c, h, w, s in self.conv_cfg:
             t = ops.conv_out_size(t, h, s)
         return t
-
-
-def _drop_mask(t, p):
-    return (torch.rand_like(t) >= p).to(t.dtype) / (1.0 - p)
 
 
 class EncoderFunction(torch.autograd.Function):
@@ -68,6 +69,9 @@ class EncoderFunction(torch.autograd.Function):
         # fine-tuning / gradient checks with dropout off); `training` only selects dropout
         need_grad = any(ctx.needs_input_grad[3:])
         p_drop = plan.dropout if training else 0.0
+        seed = 0
+        if p_drop:
+            seed = plan.fixed_seed if plan.fixed_seed is not None else ops.new_dropout_seed()
         B, T, F = x.shape
 
         # conv stack; the last conv writes time-major channel-major features (T', B, C*F') (model.py:66-71)
@@ -76,35 +80,20 @@ class EncoderFunction(torch.autograd.Function):
         for i, ((w, b), (out_c, kh, kw, s)) in enumerate(zip(conv_p, plan.conv_cfg)):
             # the first conv keeps its im2col matrix for the backward pass (no dx there, so it is read-only)
             keep = need_grad and i == 0
-            res = ops.conv2d_relu_fwd(a, w, b, s, "tbf" if i == nconv - 1 else "nchw", keep_cols=keep)
-            y, ys = res[0], res[1]
+            res = ops.conv2d_relu_fwd(a, w, b, s, "tbf" if i == nconv - 1 else "nchw", keep_cols=keep,
+                                      drop=(p_drop, seed, ops.DROP_STREAM_CONV + i) if p_drop else None)
+            y, ys = res[0], res[1]  # with dropout: the dropped output (what the next layer reads, what backward masks by)
             cols = res[2] if keep else None
-            mask = None
-            if p_drop:
-                mask = _drop_mask(y, p_drop)
-                y = y * mask
-            conv_saved.append((a, y, ys, mask, cols))
+            conv_saved.append((a, y, ys, cols))
             a = y
         feat = a  # (T', B, conv_out)
         Tp = feat.shape[0]
 
-        # GRU stack: one wavefront call for all layers, or one call per layer when dropout masks sit in between
-        groups = [list(range(L))] if not p_drop else [[l] for l in range(L)]
-        inp = feat
-        gru_saved = []
-        for grp in groups:
-            sel = [l * D + d for l in grp for d in range(D)]
-            h_out, stash = ops.gru_stack_fwd(inp, [w_ih[k] for k in sel], [b_ih[k] for k in sel],
-                                             [w_hh[k] for k in sel], [b_hh[k] for k in sel], len(grp), D, H,
-                                             want_stash=need_grad, chunk=plan.chunk)
-            top = h_out[-1]
-            mask = None
-            if p_drop and grp[-1] + 1 < L:  # nn.GRU: dropout on every layer's output except the last
-                mask = _drop_mask(top, p_drop)
-                top = top * mask
-            gru_saved.append((grp, inp, h_out, stash, mask))
-            inp = top
-        top2 = inp.view(Tp * B, D * H)
+        # GRU stack: ONE call for all layers, nn.GRU's inter-layer dropout (every layer's output but the last) inside it
+        gdrop = (p_drop, seed, ops.DROP_STREAM_GRU)
+        h_out, stash, h_drop = ops.gru_stack_fwd(feat, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash=need_grad,
+                                                 chunk=plan.chunk, drop=gdrop)
+        top2 = h_out[-1].view(Tp * B, D * H)
         enc = ops.add_rows(top2[:, :H], top2[:, H:]) if D == 2 else top2  # model.py:75-77
         logits_tm = ops.gemm(enc, fc_w, trans_b=True, bias=fc_b).view(Tp, B, fc_w.shape[0])
 
@@ -115,7 +104,9 @@ class EncoderFunction(torch.autograd.Function):
             ctx.param_refs = params
             ctx.plan = plan
             ctx.conv_p, ctx.w_ih, ctx.w_hh, ctx.fc_w = conv_p, w_ih, w_hh, fc_w
-            ctx.conv_saved, ctx.gru_saved, ctx.enc = conv_saved, gru_saved, enc
+            ctx.conv_saved, ctx.enc = conv_saved, enc
+            ctx.gru_saved = (feat, h_out, stash, h_drop, gdrop)
+            ctx.p_drop = p_drop
             ctx.dims = (B, Tp)
         return logits_tm.transpose(0, 1)  # (B, T', V+1) view of the time-major buffer
 
@@ -134,40 +125,33 @@ class EncoderFunction(torch.autograd.Function):
         denc = ops.gemm(dl, ctx.fc_w)  # (T'*B, H)
         # both directions of the top layer receive denc (model.py:75-77)
         dtop = torch.cat([denc, denc], dim=1).view(Tp, B, 2 * H) if D == 2 else denc.view(Tp, B, H)
-        for grp, inp, h_out, stash, mask in reversed(ctx.gru_saved):
-            if mask is not None:
-                dtop = dtop * mask
-            sel = [l * D + d for l in grp for d in range(D)]
-            I0 = inp.shape[2]
-            # the library computes the stack's parameter gradients itself (and overlaps them with the recurrence):
-            # hand it the slots of the flat gradient buffer, or fresh tensors for parameters that have none
-            outs = []
-            for j, l in enumerate(grp):
-                for d in range(D):
-                    gi = 2 * nconv + 4 * (l * D + d)
-                    for q in range(4):
-                        slot = slots[gi + q]
-                        if slot is None:
-                            ref = (ctx.w_ih, ctx.w_hh)[q][l * D + d] if q < 2 else None
-                            slot = torch.empty_like(ref) if ref is not None else \
-                                torch.empty(3 * H, dtype=torch.float32, device=dtop.device)
-                        grads[gi + q] = slot
-                    outs.append(gi)
-            wg = (inp, h_out, [grads[g] for g in outs], [grads[g + 1] for g in outs], [grads[g + 2] for g in outs],
-                  [grads[g + 3] for g in outs])
-            dai, dah, dx = ops.gru_stack_bwd(dtop.contiguous(), stash, [ctx.w_ih[k] for k in sel],
-                                             [ctx.w_hh[k] for k in sel], len(grp), D, H, I0, want_dx=True,
-                                             chunk=plan.chunk, wgrad=wg)
-            dtop = dx
+        feat, h_out, stash, h_drop, gdrop = ctx.gru_saved
+        I0 = feat.shape[2]
+        # the library computes the stack's parameter gradients itself (and overlaps them with the recurrence):
+        # hand it the slots of the flat gradient buffer, or fresh tensors for parameters that have none
+        outs = []
+        for l in range(L):
+            for d in range(D):
+                gi = 2 * nconv + 4 * (l * D + d)
+                for q in range(4):
+                    slot = slots[gi + q]
+                    if slot is None:
+                        ref = (ctx.w_ih, ctx.w_hh)[q][l * D + d] if q < 2 else None
+                        slot = torch.empty_like(ref) if ref is not None else \
+                            torch.empty(3 * H, dtype=torch.float32, device=dtop.device)
+                    grads[gi + q] = slot
+                outs.append(gi)
+        wg = (feat, h_out, [grads[g] for g in outs], [grads[g + 1] for g in outs], [grads[g + 2] for g in outs],
+              [grads[g + 3] for g in outs])
+        dai, dah, dtop = ops.gru_stack_bwd(dtop.contiguous(), stash, ctx.w_ih, ctx.w_hh, L, D, H, I0, want_dx=True,
+                                           chunk=plan.chunk, wgrad=wg, drop=gdrop, h_drop=h_drop)
         # conv stack
         dy = dtop
         for i in range(nconv - 1, -1, -1):
-            a, y, ys, mask, cols = ctx.conv_saved[i]
-            if mask is not None:
-                dy = dy * mask
+            a, y, ys, cols = ctx.conv_saved[i]
             s = plan.conv_cfg[i][3]
             dx, dw, db = ops.conv2d_relu_bwd(a, ctx.conv_p[i][0], y, dy.contiguous(), ys, s, need_dx=(i > 0),
-                                             dw=slots[2 * i], db=slots[2 * i + 1], cols=cols)
+                                             dw=slots[2 * i], db=slots[2 * i + 1], cols=cols, p_drop=ctx.p_drop)
             grads[2 * i], grads[2 * i + 1] = dw, db
             dy = dx
         # A gradient that sits in its slot of the flat buffer is handed over by reference: autograd's accumulator would

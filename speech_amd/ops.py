@@ -82,13 +82,43 @@ def conv_out_size(n, k, s):
     return int(math.ceil((n - k + 1) / s))
 
 
-def conv2d_relu_fwd(x, w, bias, s, layout="nchw", keep_cols=False):
+# Mask streams of one forward pass (csrc/dropout.h): conv layer i -> DROP_STREAM_CONV + i, GRU layer l -> DROP_STREAM_GRU + l
+DROP_STREAM_CONV, DROP_STREAM_GRU, DROP_STREAM_PRED = 0, 64, 128
+
+
+def new_dropout_seed():
+    """A fresh 64-bit Philox key for one forward pass, drawn from torch's CPU generator (so torch.manual_seed makes a
+    run reproducible); no device work, no sync."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def dropout_mask(n, p, seed, stream_id, device, idx0=0):
+    """The factors (0 or 1/(1-p)) the kernels apply to elements idx0 .. idx0+n-1 of mask stream `stream_id`."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.lib().sa_dropout_mask_f32(ptr(out), n, idx0, p, seed, stream_id, cur_stream()), "sa_dropout_mask_f32")
+    return out
+
+
+def dropout_apply(x, p, seed, stream_id, out=None):
+    """out = x * mask (element i of the contiguous tensor <-> mask index i)."""
+    _f32(x, "x")
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().sa_dropout_apply_f32(ptr(x), ptr(out), x.numel(), 0, p, seed, stream_id, cur_stream()),
+          "sa_dropout_apply_f32")
+    return out
+
+
+def conv2d_relu_fwd(x, w, bias, s, layout="nchw", keep_cols=False, drop=None):
     """x (B,C,T,F) contiguous -> relu(conv(x)) in one of three output layouts:
       "nchw": (B, O, T', F')              (input of a following conv)
       "btf" : (B, T', O*F') channel-major features, batch-major   (model.py:66-71)
       "tbf" : (T', B, O*F') the same features time-major          (what the GRU stack consumes)
     Returns (y, (ys_b, ys_c, ys_t)) with y[b*ys_b + c*ys_c + t*ys_t + f]; with keep_cols also the im2col matrix
-    (a tensor the caller passes to conv2d_relu_bwd(cols=...) so that backward does not rebuild it)."""
+    (a tensor the caller passes to conv2d_relu_bwd(cols=...) so that backward does not rebuild it).
+    drop = (p, seed, stream_id): nn.Dropout(p) behind the ReLU (model.py:25-27), applied in the kernel's epilogue; y is
+    then the DROPPED output and conv2d_relu_bwd must be given the same p."""
     _f32(x, "x"), _f32(w, "w"), _f32(bias, "bias")
     assert x.is_contiguous() and w.is_contiguous()
     B, C, T, F = x.shape
@@ -116,15 +146,21 @@ def conv2d_relu_fwd(x, w, bias, s, layout="nchw", keep_cols=False):
         direct = False
     cols = torch.empty(B * To * Fo, C * kh * kw, dtype=torch.float32, device=x.device) if keep_cols else None
     with _span("conv_fwd", 2, 2.0 * B * To * Fo * O * C * kh * kw):
-        check(L.sa_conv2d_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1], ys[2],
-                                   ptr(cols), ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
+        if drop is not None and drop[0] > 0.0:
+            check(L.sa_conv2d_relu_dropout_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1],
+                                               ys[2], ptr(cols), ptr(ws), ws.numel(), float(drop[0]), int(drop[1]),
+                                               int(drop[2]), cur_stream()), "sa_conv2d_relu_dropout_fwd")
+        else:
+            check(L.sa_conv2d_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, C, T, F, O, kh, kw, s, ys[0], ys[1], ys[2],
+                                       ptr(cols), ptr(ws), ws.numel(), cur_stream()), "sa_conv2d_relu_fwd")
     if keep_cols or direct:
         return y, ys, cols
     return y, ys
 
 
-def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None, cols=None):
-    """Gradients of relu(conv(x)): returns (dx or None, dw, dbias).  y / dy share the strides `ys`."""
+def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None, cols=None, p_drop=0.0):
+    """Gradients of relu(conv(x)) (p_drop: of dropout(relu(conv(x))), y being the dropped output): returns
+    (dx or None, dw, dbias).  y / dy share the strides `ys`."""
     B, C, T, F = x.shape
     O, _, kh, kw = w.shape
     if dw is None:
@@ -137,9 +173,14 @@ def conv2d_relu_bwd(x, w, y, dy, ys, s, need_dx, dw=None, db=None, cols=None):
     nbytes = L.sa_conv2d_bwd_workspace_bytes(B, C, T, F, O, kh, kw, s)
     ws = WORKSPACE.get(nbytes, x.device, "conv")
     with _span("conv_bwd", 5, 0.0):
-        check(L.sa_conv2d_relu_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), B, C, T, F, O, kh, kw,
-                                   s, ys[0], ys[1], ys[2], ptr(cols), ptr(ws), ws.numel(), cur_stream()),
-              "sa_conv2d_relu_bwd")
+        if p_drop > 0.0:
+            check(L.sa_conv2d_relu_dropout_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), B, C, T, F, O,
+                                               kh, kw, s, ys[0], ys[1], ys[2], ptr(cols), ptr(ws), ws.numel(),
+                                               float(p_drop), cur_stream()), "sa_conv2d_relu_dropout_bwd")
+        else:
+            check(L.sa_conv2d_relu_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), B, C, T, F, O, kh,
+                                       kw, s, ys[0], ys[1], ys[2], ptr(cols), ptr(ws), ws.numel(), cur_stream()),
+                  "sa_conv2d_relu_bwd")
     return dx, dw, db
 
 
@@ -208,9 +249,11 @@ def _ptr_array(tensors):
     return arr
 
 
-def gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash, chunk=0):
+def gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash, chunk=0, drop=None):
     """x (T, B, I0) time-major.  Parameter lists hold L*D tensors (index l*D + d).  Returns (h_out list of L
-    (T, B, D*H) tensors, stash list of L*D (T, B, 5H) tensors or None)."""
+    (T, B, D*H) tensors, stash list of L*D (T, B, 5H) tensors or None).
+    drop = (p, seed, stream0): nn.GRU's inter-layer dropout (model.py:38) inside the library; a third value is then
+    returned, the list of L-1 dropped layer outputs (what gru_stack_bwd(drop=..., h_drop=...) needs back)."""
     _f32(x, "x")
     assert x.is_contiguous()
     T, B, I0 = x.shape
@@ -221,15 +264,26 @@ def gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, D, H, want_stash, chunk=0):
     ws = WORKSPACE.get(lib.sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0), dev, "gru_stack")
     launches = (T + L - 1 if D == 1 else L * T)
     nbytes = 4.0 * B * H * (5 + (5 if want_stash else 0)) * T * L * D
+    dropping = drop is not None and drop[0] > 0.0 and L > 1
     with _span("gru_fwd_stack", launches, nbytes):
-        check(lib.sa_gru_stack_fwd(ptr(x), I0, _ptr_array(w_ih), _ptr_array(b_ih), _ptr_array(w_hh),
-                                   _ptr_array(b_hh), _ptr_array(h_out), _ptr_array(stash) if stash else None, L, D, B,
-                                   T, H, chunk, ptr(ws), ws.numel(), cur_stream(), _aux_streams(dev, N_CHAINS - 1),
-                                   N_CHAINS - 1), "sa_gru_stack_fwd")
+        if dropping:
+            h_drop = [torch.empty(T, B, D * H, dtype=torch.float32, device=dev) for _ in range(L - 1)]
+            check(lib.sa_gru_stack_fwd_dropout(ptr(x), I0, _ptr_array(w_ih), _ptr_array(b_ih), _ptr_array(w_hh),
+                                               _ptr_array(b_hh), _ptr_array(h_out), _ptr_array(h_drop + [None]),
+                                               _ptr_array(stash) if stash else None, L, D, B, T, H, chunk, ptr(ws),
+                                               ws.numel(), float(drop[0]), int(drop[1]), int(drop[2]), cur_stream()),
+                  "sa_gru_stack_fwd_dropout")
+        else:
+            check(lib.sa_gru_stack_fwd(ptr(x), I0, _ptr_array(w_ih), _ptr_array(b_ih), _ptr_array(w_hh),
+                                       _ptr_array(b_hh), _ptr_array(h_out), _ptr_array(stash) if stash else None, L, D,
+                                       B, T, H, chunk, ptr(ws), ws.numel(), cur_stream(),
+                                       _aux_streams(dev, N_CHAINS - 1), N_CHAINS - 1), "sa_gru_stack_fwd")
+    if drop is not None:
+        return h_out, stash, (h_drop if dropping else None)
     return h_out, stash
 
 
-def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0, wgrad=None):
+def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0, wgrad=None, drop=None, h_drop=None):
     """dh_top (T, B, D*H).  Returns (dai list, dah list of L*D (T, B, 3H) tensors, dx (T, B, I0) or None).
     wgrad = (x, h_out, dw_ih, dw_hh, db_ih, db_hh): the stack input (T, B, I0), the L layer outputs of the forward
     pass, and L*D output tensors each for the weight / bias gradients -- the library then computes them itself and
@@ -245,6 +299,7 @@ def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0,
     launches = (T + L - 1 if D == 1 else L * T)
     with _span("gru_bwd_stack", launches, 4.0 * B * H * 17 * T * L * D):
         if wgrad is None:
+            assert drop is None or not drop[0], "inter-layer dropout needs the wgrad form of the backward pass"
             check(lib.sa_gru_stack_bwd(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
                                        _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk, ptr(ws),
                                        ws.numel(), cur_stream(), _aux_streams(dev, N_CHAINS - 1), N_CHAINS - 1),
@@ -256,11 +311,20 @@ def gru_stack_bwd(dh_top, stash, w_ih, w_hh, L, D, H, I0, want_dx=True, chunk=0,
                 I = I0 if k // D == 0 else D * H
                 assert dw_ih[k].is_contiguous() and dw_ih[k].shape == (3 * H, I) and dw_hh[k].is_contiguous()
                 assert dw_hh[k].shape == (3 * H, H) and db_ih[k].numel() == 3 * H and db_hh[k].numel() == 3 * H
-            check(lib.sa_gru_stack_bwd_wgrad(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
-                                             _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk,
-                                             ptr(x), _ptr_array(h_out), _ptr_array(dw_ih), _ptr_array(dw_hh),
-                                             _ptr_array(db_ih), _ptr_array(db_hh), ptr(ws), ws.numel(), cur_stream()),
-                  "sa_gru_stack_bwd_wgrad")
+            if drop is not None and drop[0] > 0.0 and L > 1:
+                assert h_drop is not None and len(h_drop) == L - 1
+                check(lib.sa_gru_stack_bwd_wgrad_dropout(
+                    ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(dai),
+                    _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk, ptr(x), _ptr_array(h_out),
+                    _ptr_array(list(h_drop) + [None]), _ptr_array(dw_ih), _ptr_array(dw_hh), _ptr_array(db_ih),
+                    _ptr_array(db_hh), ptr(ws), ws.numel(), float(drop[0]), int(drop[1]), int(drop[2]), cur_stream()),
+                    "sa_gru_stack_bwd_wgrad_dropout")
+            else:
+                check(lib.sa_gru_stack_bwd_wgrad(ptr(dh_top), _ptr_array(stash), _ptr_array(w_ih), _ptr_array(w_hh),
+                                                 _ptr_array(dai), _ptr_array(dah), ptr(dx), I0, L, D, B, T, H, chunk,
+                                                 ptr(x), _ptr_array(h_out), _ptr_array(dw_ih), _ptr_array(dw_hh),
+                                                 _ptr_array(db_ih), _ptr_array(db_hh), ptr(ws), ws.numel(),
+                                                 cur_stream()), "sa_gru_stack_bwd_wgrad")
     return dai, dah, dx
 
 
@@ -312,39 +376,65 @@ def persist_reset():
 class ScalarPipe:
     """Device scalars to the host WITHOUT stalling the launch queue (the reference's loop reads loss.data[0] every
     step, /root/reference/train.py:33: a full sync).  push(t) enqueues an async copy of the 1-element tensor into
-    pinned memory behind the work queued so far and returns the values of every EARLIER push whose copy has landed;
-    drain() waits for the rest.  Values come back in push order."""
+    pinned memory behind the work queued so far and returns the values of EARLIER pushes; drain() waits for the rest.
+    Values come back in push order.
+      lag=None: whatever has landed by now (timing dependent: fine for a progress bar);
+      lag=k   : exactly the pushes that are k or more pushes old, waiting for them if need be -- WHICH push a value is
+                reported at is then a function of the push count alone, identical on every data-parallel rank (the
+                training loop's failure replay must be: ranks that notice a skipped update at different iterations
+                would issue different numbers of gradient all-reduces).  k <= depth - 1.
+    CPU tensors are accepted (their value is taken at once, released under the same rules): the loop logic is tested
+    without a GPU."""
 
     def __init__(self, depth=4):
-        self._slots = [(torch.empty(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
-        self._pending = []  # (slot index, tag) in push order
+        self._depth = depth
+        self._slots = None  # pinned buffers + events, allocated at the first CUDA push
+        self._pending = []  # (slot index or None, tag, value or None) in push order
         self._n = 0
 
-    def _collect(self, wait):
+    def _value(self, entry, wait):
+        i, tag, val = entry
+        if i is None:
+            return val
+        buf, ev = self._slots[i]
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return None
+        return float(buf[0])
+
+    def _collect(self, wait, keep=0):
         out = []
-        while self._pending:
-            i, tag = self._pending[0]
-            buf, ev = self._slots[i]
-            if wait:
-                ev.synchronize()
-            elif not ev.query():
+        while len(self._pending) > keep:
+            v = self._value(self._pending[0], wait)
+            if v is None:
                 break
-            out.append((tag, float(buf[0])))
+            out.append((self._pending[0][1], v))
             self._pending.pop(0)
         return out
 
-    def push(self, t, tag=None):
-        done = self._collect(wait=False)
-        if len(self._pending) == len(self._slots):  # ring full: the oldest copy is `depth` steps old
-            i, tg = self._pending.pop(0)
-            self._slots[i][1].synchronize()
-            done.append((tg, float(self._slots[i][0][0])))
-        i = self._n % len(self._slots)
-        self._n += 1
-        buf, ev = self._slots[i]
-        buf.copy_(t.detach().reshape(1), non_blocking=True)
-        ev.record()
-        self._pending.append((i, tag))
+    def push(self, t, tag=None, lag=None):
+        if lag is None:
+            done = self._collect(wait=False)
+            if len(self._pending) == self._depth:  # ring full: the oldest copy is `depth` steps old
+                done += self._collect(wait=True, keep=self._depth - 1)
+        else:
+            assert 0 <= lag < self._depth
+            done = self._collect(wait=True, keep=max(lag - 1, 0)) if lag else self._collect(wait=True)
+        if t.is_cuda:
+            if self._slots is None:
+                self._slots = [(torch.empty(1, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                               for _ in range(self._depth)]
+            i = self._n % self._depth
+            self._n += 1
+            buf, ev = self._slots[i]
+            buf.copy_(t.detach().reshape(1), non_blocking=True)
+            ev.record()
+            self._pending.append((i, tag, None))
+        else:
+            self._pending.append((None, tag, float(t.detach().reshape(1)[0])))
+        if lag == 0:
+            done += self._collect(wait=True)
         return done
 
     def drain(self):

@@ -117,3 +117,58 @@ def test_global_batch_smaller_than_the_world(tmp_path):
     assert tuple(got["shape"]) == (2, 52, 3)
     torch.testing.assert_close(got["flat"], want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))  # fp32 sum order
     assert abs(got["loss"] - want_loss) <= 1e-5 * abs(want_loss)
+
+
+# ---- failure replay stays in lock-step (train.py) ------------------------------------------------------------
+def _replay_worker(rank, world, port, out_dir, fail_rank, fail_at, n_batches):
+    """train.run_epoch with host-only stand-ins for the step and the reset: `step` does what train_step's collective
+    structure does (one SUM all-reduce per call carrying this rank's sticky health flag, norm negative when the sum is
+    non-zero), so the number and order of collectives per rank is what the real loop would issue."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import time
+    import torch.distributed as td
+    import train
+    from speech_amd import dist
+    dist.init(backend="gloo")
+    state = {"word": 0, "calls": [], "resets": 0, "updates": []}
+
+    def step(batch):
+        if rank == fail_rank and batch == fail_at and state["resets"] == 0:
+            state["word"] = 1                      # a persistent kernel on THIS rank failed: sticky until the reset
+        if rank == 1:
+            time.sleep(0.002)                      # ranks do not run at the same speed
+        msg = torch.tensor([float(batch), float(state["word"])])
+        td.all_reduce(msg, op=td.ReduceOp.SUM)     # the gradient message with the health flag behind it
+        assert float(msg[0]) == world * batch      # every rank is in THIS collective with the same batch
+        ok = float(msg[1]) == 0.0
+        state["calls"].append(batch)
+        if ok:
+            state["updates"].append(batch)
+        return torch.tensor([1.0 + batch]), torch.tensor([2.0 if ok else -2.0])
+
+    def reset():
+        state["resets"] += 1
+        state["word"] = 0
+        return 1
+
+    it, _ = train.run_epoch(None, (torch.zeros(1),), None, list(range(n_batches)), 0, 0.0, world, rank,
+                            step_fn=step, reset_fn=reset)
+    dist.barrier()
+    torch.save({"it": it, **state}, os.path.join(out_dir, "r%d.pt" % rank))
+
+
+@pytest.mark.parametrize("fail_at", [4, 9])  # mid-epoch, and inside the epoch's last LAG steps (caught by the final drain)
+def test_failure_replay_is_lock_step_across_ranks(tmp_path, fail_at):
+    n = 10
+    mp.spawn(_replay_worker, args=(2, _free_port(), str(tmp_path), 1, fail_at, n), nprocs=2, join=True)
+    r0, r1 = torch.load(str(tmp_path / "r0.pt")), torch.load(str(tmp_path / "r1.pt"))
+    assert r0["calls"] == r1["calls"]                      # same collectives, same order, on both ranks
+    assert r0["resets"] == r1["resets"] == 1               # both ranks noticed (the flag rides the all-reduce) -- once
+    assert r0["it"] == r1["it"] == n
+    assert sorted(r0["updates"]) == list(range(n)) and r0["updates"] == r1["updates"]  # every batch applied exactly once
+    import train
+    first_seen = min(fail_at + train.LAG, n - 1)           # detection: LAG steps later, or the end-of-epoch drain
+    assert r0["calls"] == list(range(first_seen + 1)) + list(range(fail_at, first_seen + 1)) + list(range(first_seen + 1, n))

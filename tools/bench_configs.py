@@ -78,13 +78,13 @@ def m_step(name, F, V, cfg, B, T, L, iters):
             "forward_ms": fwd * 1e3, "loss": float(out["loss"].item())}
 
 
-def m_transducer(iters):
+def m_transducer(iters, dropout=0.0):
     """BASELINE config 5: RNN-Transducer on the S-LIBRI encoder (4 x GRU-512 uni), 1-layer prediction network,
     B=32, T=1000 -> T'=498, U=100: the loss alone on a (32, 498, 101, 29) lattice, and the full train step."""
     from speech_amd.models import Transducer
     from speech_amd.transducer import TransducerLabels, transducer_loss_raw
     B, T, F, V, L = 32, 1000, 80, 28, 100
-    cfg = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 512, "layers": 4, "bidirectional": False}},
+    cfg = {"dropout": dropout, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 512, "layers": 4, "bidirectional": False}},
            "decoder": {"embedding_dim": 256, "layers": 1}}
     torch.manual_seed(2017)
     model = Transducer(F, V, cfg).cuda()
@@ -109,19 +109,19 @@ def m_transducer(iters):
 
     sec = timed(step, iters, warmup=4)
     alg = 2 * lat.numel() * 4
-    return {"workload": "RNN-T S-LIBRI (config 5)", "B": B, "T_out": Tp, "U": L, "classes": V + 1,
+    return {"workload": "RNN-T S-LIBRI (config 5)" + (", dropout %g" % dropout if dropout else ""), "B": B, "T_out": Tp, "U": L, "classes": V + 1,
             "params": int(flat_p.numel()), "loss_fwd_bwd_ms": loss_ms, "loss_algorithmic_GBps": alg / loss_ms / 1e6,
             "train_step_ms": sec * 1e3, "train_utt_per_s": B / sec, "loss": float(out["loss"].item()),
             "note": "train step includes the host-side collate of the reference's loss(batch) API"}
 
 
-def m_seq2seq(iters):
+def m_seq2seq(iters, dropout=0.0):
     """BASELINE config 4: examples/wsj/seq2seq_config.json shapes (conv [[32,5,8,2],[32,5,8,2]], 4 x biGRU-256, F=161,
     batch 16, log_t, sample_prob 0.2), T=800 frames -> T'=197, 100 output tokens; train step, greedy infer, beam 8."""
     import random
     from speech_amd.models import Seq2Seq
     B, T, F, V, U = 16, 800, 161, 30, 100
-    cfg = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 8, 2], [32, 5, 8, 2]],
+    cfg = {"dropout": dropout, "encoder": {"conv": [[32, 5, 8, 2], [32, 5, 8, 2]],
                                        "rnn": {"dim": 256, "layers": 4, "bidirectional": True}},
            "decoder": {"sample_prob": 0.2, "embedding_dim": 256, "log_t": True, "layers": 1}}
     torch.manual_seed(2017)
@@ -147,7 +147,7 @@ def m_seq2seq(iters):
     one = (inputs[:1], labels[:1])
     greedy = timed(lambda: model.infer((inputs, labels), max_len=U), 2, warmup=1)
     beam = timed(lambda: model.beam_search(one, beam_size=8, max_len=U), 1, warmup=1)
-    return {"workload": "Seq2Seq WSJ config shapes (config 4)", "B": B, "T": T, "T_out": model.conv_out_size(T, 0),
+    return {"workload": "Seq2Seq WSJ config shapes (config 4)" + (", dropout %g" % dropout if dropout else ""), "B": B, "T": T, "T_out": model.conv_out_size(T, 0),
             "tokens": U, "params": int(flat_p.numel()), "train_step_ms": sec * 1e3, "train_utt_per_s": B / sec,
             "greedy_infer_batch_ms": greedy * 1e3, "beam8_one_utt_ms": beam * 1e3, "loss": float(out["loss"].item())}
 
@@ -161,11 +161,18 @@ def m_dec(beam, iters):
 
 
 def main():
+    # --only M-STEP,M-TIMIT,... restricts the run (GPU minutes are budgeted)
+    only = None
+    for i, a in enumerate(sys.argv):
+        if a == "--only" and i + 1 < len(sys.argv):
+            only = set(sys.argv[i + 1].split(","))
+    want = lambda k: only is None or k in only  # noqa: E731
     res = {"device": torch.cuda.get_device_name(0)}
     rng = np.random.RandomState(7)
-    res["M-CTC"] = [m_ctc(32, 1000, 29, [100] * 32, 50),
-                    m_ctc(32, 1000, 29, rng.randint(50, 151, 32), 50),
-                    m_ctc(4096, 1000, 29, [100] * 4096, 5)]
+    if want("M-CTC"):
+        res["M-CTC"] = [m_ctc(32, 1000, 29, [100] * 32, 50),
+                        m_ctc(32, 1000, 29, rng.randint(50, 151, 32), 50),
+                        m_ctc(4096, 1000, 29, [100] * 4096, 5)]
     uni = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]],
                                        "rnn": {"dim": 512, "layers": 4, "bidirectional": False}}}
     bi = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]],
@@ -175,16 +182,27 @@ def main():
                                          "rnn": {"dim": 256, "layers": 4, "bidirectional": True}}}
     small = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]],
                                          "rnn": {"dim": 256, "layers": 2, "bidirectional": False}}}
-    res["M-STEP"] = [m_step("S-LIBRI uni (bench.py)", 80, 28, uni, 32, 1000, 100, 5),
-                     m_step("S-LIBRI bidirectional", 80, 28, bi, 32, 1000, 100, 3)]
-    res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
-                      m_step("2xGRU-256 F=40 |V|=61", 40, 61, small, 32, 1000, 100, 5)]
-    res["M-RNNT"] = [m_transducer(8)]
-    res["M-S2S"] = [m_seq2seq(8)]
-    rng = np.random.RandomState(2017)
-    z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
-    greedy = timed(lambda: decoder.greedy_decode(z, blank=28), 20)
-    res["M-DEC"] = [m_dec(1, 5), m_dec(8, 3), {"greedy": True, "ms": greedy * 1e3, "utt_per_s": 32 / greedy}]
+    # the configs AS SHIPPED train with dropout (examples/timit/ctc_config.json:20 0.4, timit/transducer_config.json:20
+    # 0.5, wsj/seq2seq_config.json:20 0.2): every workload is measured without it (round-2 comparability) AND with it
+    drop = lambda cfg, p: dict(cfg, dropout=p)  # noqa: E731
+    if want("M-STEP"):
+        res["M-STEP"] = [m_step("S-LIBRI uni (bench.py)", 80, 28, uni, 32, 1000, 100, 5),
+                         m_step("S-LIBRI uni, dropout 0.2", 80, 28, drop(uni, 0.2), 32, 1000, 100, 5),
+                         m_step("S-LIBRI bidirectional", 80, 28, bi, 32, 1000, 100, 3),
+                         m_step("S-LIBRI bidirectional, dropout 0.2", 80, 28, drop(bi, 0.2), 32, 1000, 100, 3)]
+    if want("M-TIMIT"):
+        res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
+                          m_step("timit ctc_config AS SHIPPED (dropout 0.4)", 161, 48, drop(timit, 0.4), 8, 300, 40, 5),
+                          m_step("2xGRU-256 F=40 |V|=61", 40, 61, small, 32, 1000, 100, 5)]
+    if want("M-RNNT"):
+        res["M-RNNT"] = [m_transducer(8), m_transducer(8, 0.5)]
+    if want("M-S2S"):
+        res["M-S2S"] = [m_seq2seq(8), m_seq2seq(8, 0.2)]
+    if want("M-DEC"):
+        rng = np.random.RandomState(2017)
+        z = torch.from_numpy((4.0 * rng.randn(32, 498, 29)).astype(np.float32)).to(DEV)
+        greedy = timed(lambda: decoder.greedy_decode(z, blank=28), 20)
+        res["M-DEC"] = [m_dec(1, 5), m_dec(8, 3), {"greedy": True, "ms": greedy * 1e3, "utt_per_s": 32 / greedy}]
     print(json.dumps(res, indent=1))
 
 

@@ -12,7 +12,8 @@ Same CLI (`python train.py config.json [--deterministic]`), same JSON config sch
     per-step `loss.data[0]` sync (train.py:33): the progress bar shows them one or two steps late and the launch
     queue never drains;
   * a failed persistent-kernel hand-off cannot reach the parameters: the optimiser skips the update on the device
-    (negative norm), this loop then resets the library and replays the lost batches on the step kernels;
+    (negative norm, carried to every rank by the gradient all-reduce); this loop reads the norms at a FIXED lag, so all
+    ranks notice at the same iteration, reset the library and replay the same lost batches on the step kernels;
   * py3 / torch-2 fixes of SURVEY.md App. C (materialised batches, tensorboard optional).
 """
 import argparse
@@ -52,43 +53,65 @@ def train_step(model, flat, opt_cfg, batch):
     return loss, norm
 
 
-def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank):
+LAG = 3  # a step's loss / norm are read back exactly LAG steps later (ops.ScalarPipe, lag mode)
+
+
+def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank, step_fn=None, reset_fn=None):
+    """train.py:21-49.  step_fn / reset_fn default to train_step / ops.persist_reset (tests inject host-only stand-ins)."""
+    step_fn = step_fn or (lambda b: train_step(model, flat, opt_cfg, b))
+    reset_fn = reset_fn or ops.persist_reset
     model_t = 0.0
     data_t = 0.0
     end_t = time.time()
     tq = tqdm.tqdm(train_ldr, disable=rank != 0)
-    losses, norms = ops.ScalarPipe(), ops.ScalarPipe()
-    recent = collections.deque(maxlen=8)  # batches whose update has not been confirmed yet
+    losses, norms = ops.ScalarPipe(LAG + 1), ops.ScalarPipe(LAG + 1)
+    recent = collections.deque(maxlen=LAG + 2)  # batches whose update has not been confirmed yet
     zero = torch.zeros(1, device=flat[0].device)
     shown = {"loss": 0.0, "norm": 0.0}
 
     def consume(done_losses, done_norms):
         nonlocal avg_loss
-        for tag, v in done_losses:
-            shown["loss"] = v
+        lost = None
+        for (tag, v), (_, n) in zip(done_losses, done_norms):
+            if n < 0:  # the optimiser skipped this step: a persistent kernel (on some rank) reported a failure
+                lost = tag if lost is None else lost
+                continue
+            shown["loss"], shown["norm"] = v, n
             avg_loss = 0.99 * avg_loss + 0.01 * v
             if tb is not None and rank == 0:
                 tb.log_value("train_loss", v, tag)
-        lost = None
-        for tag, v in done_norms:
-            shown["norm"] = abs(v)
-            if v < 0 and lost is None:
-                lost = tag  # the optimiser skipped this step: a persistent kernel reported a failure
         return lost
+
+    def push(loss, norm, tag):
+        return consume(losses.push(loss if loss is not None else zero, tag, lag=LAG), norms.push(norm, tag, lag=LAG))
+
+    def replay(lost):
+        """Every rank gets here at the SAME iteration with the SAME `lost`: a norm's sign comes from the health flag
+        summed by the gradient all-reduce (identical on every rank) and is read at a fixed lag, not "when the copy has
+        landed" -- ranks noticing at different iterations would replay different spans and pair their all-reduces
+        with different batches.  The steps after `lost` were skipped too (the error word is sticky until the reset)."""
+        consume(losses.drain(), norms.drain())
+        code = reset_fn()
+        if rank == 0:
+            print("persistent GRU kernels failed (code %d) at iteration %d: replaying %d step(s) on the step kernels"
+                  % (code, lost, len([rb for rb in recent if rb[0] >= lost])))
+        bad = None
+        for tag, b in [rb for rb in recent if rb[0] >= lost]:
+            l2, n2 = step_fn(b)
+            r = push(l2, n2, tag)
+            bad = r if bad is None else bad
+        r = consume(losses.drain(), norms.drain())
+        bad = r if bad is None else bad
+        if bad is not None:
+            raise RuntimeError("update of iteration %d skipped again after the reset (step kernels): giving up" % bad)
 
     for batch in tq:
         start_t = time.time()
         recent.append((it, batch))
-        loss, norm = train_step(model, flat, opt_cfg, batch)
-        lost = consume(losses.push(loss if loss is not None else zero, it), norms.push(norm, it))
+        loss, norm = step_fn(batch)
+        lost = push(loss, norm, it)
         if lost is not None:
-            consume(losses.drain(), norms.drain())
-            code = ops.persist_reset()
-            print("persistent GRU kernels failed (code %d) at iteration %d: replaying from there on the step kernels"
-                  % (code, lost))
-            for tag, b in [rb for rb in recent if rb[0] >= lost]:
-                l2, n2 = train_step(model, flat, opt_cfg, b)
-                consume(losses.push(l2 if l2 is not None else zero, tag), norms.push(n2, tag))
+            replay(lost)
         prev_end_t = end_t
         end_t = time.time()
         model_t += end_t - start_t
@@ -96,7 +119,9 @@ def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank):
         tq.set_postfix(iter=it, loss=shown["loss"], avg_loss=avg_loss, grad_norm=shown["norm"], model_time=model_t,
                        data_time=data_t)
         it += 1
-    consume(losses.drain(), norms.drain())
+    lost = consume(losses.drain(), norms.drain())  # a failure in the epoch's last LAG steps
+    if lost is not None:
+        replay(lost)
     return it, avg_loss
 
 
@@ -110,7 +135,9 @@ def eval_dev(model, ldr, preproc, rank=0):
         if len(batch[0]) == 0:
             continue
         preds = model.infer(batch)
-        loss_sum += float(model.loss(batch).item())  # this rank's share of the global-mean loss
+        # this rank's share of the global-mean loss; forward-only, so there is no optimiser gate behind it: ask the
+        # library whether the persistent kernels ran clean and recompute on the step kernels if not (Model._healthy)
+        loss_sum += model._healthy(lambda: float(model.loss(batch).item()))
         results.extend((preproc.decode(l), preproc.decode(p)) for l, p in zip(batch[1], preds))
     model.set_train()
     model.set_global_batch()
