@@ -41,6 +41,8 @@ class EncoderPlan:
         self.input_dim = input_dim
         self.chunk = int(os.environ.get("SA_GRU_CHUNK", "0"))  # time steps per wavefront chunk (0: library default)
 
+        # Model.flatten_parameters_() opts in to by-reference gradient hand-over (see EncoderFunction.backward)
+        self.grad_by_reference = True
         # tests pin the masks: a fixed key instead of a fresh one per forward pass (None: draw from torch's CPU generator)
         self.fixed_seed = None
 
@@ -118,6 +120,11 @@ class EncoderFunction(torch.autograd.Function):
         nconv = len(plan.conv_cfg)
         slots = ctx.slots
         dl = dlogits.transpose(0, 1).contiguous().view(Tp * B, -1)  # no copy when it is the CTC gradient
+        # A parameter whose .grad already IS its slot (a second backward without zero_grad: gradient accumulation)
+        # expects "+=", but the kernels below OVERWRITE the slots: keep what is there and add it back at the end
+        by_ref = plan.grad_by_reference
+        carry = [(slot, slot.clone()) for p, slot in zip(ctx.param_refs, slots)
+                 if by_ref and slot is not None and p.grad is not None and p.grad.data_ptr() == slot.data_ptr()]
         fc_i = 2 * nconv + 4 * L * D
         grads = [None] * (fc_i + 2)
         grads[fc_i] = ops.gemm(dl, ctx.enc, trans_a=True, out=slots[fc_i])
@@ -154,14 +161,15 @@ class EncoderFunction(torch.autograd.Function):
                                              dw=slots[2 * i], db=slots[2 * i + 1], cols=cols, p_drop=ctx.p_drop)
             grads[2 * i], grads[2 * i + 1] = dw, db
             dy = dx
-        # A gradient that sits in its slot of the flat buffer is handed over by reference: autograd's accumulator would
-        # otherwise CLONE every returned view into a fresh p.grad (20 device copies per step, and a second copy of the
-        # whole gradient in memory).  A parameter whose .grad already IS its slot (no zero_grad in between) simply
-        # sees the fresh gradient there -- the flat buffer holds the LATEST gradient, it does not accumulate; one that
-        # holds some other gradient tensor takes the ordinary (accumulating) path.
+        # A gradient that sits in its slot of the flat buffer is handed over by reference (flatten_parameters_'s opt-in):
+        # autograd's accumulator would otherwise CLONE every returned view into a fresh p.grad (20 device copies per
+        # step, and a second copy of the whole gradient in memory).  A parameter that holds some OTHER gradient tensor
+        # takes the ordinary (accumulating) path.
+        for slot, old in carry:
+            ops.add_rows(slot.view(1, -1), old.view(1, -1), out=slot.view(1, -1))
         out = list(grads)
         for i, (p, slot) in enumerate(zip(ctx.param_refs, slots)):
-            if slot is None or out[i] is not slot or not p.requires_grad:
+            if not by_ref or slot is None or out[i] is not slot or not p.requires_grad:
                 continue
             if p.grad is None:
                 p.grad = slot

@@ -89,16 +89,27 @@ class Preprocessor:
         e = text.index(self.END) if text and text[-1] == self.END else len(text)
         return text[s:e]
 
-    def preprocess(self, wave_file, text):
-        """loader.py:65-69.  With `device_features` set (make_loader(..., device_features=True) sets it) the log
-        spectrogram and the z-normalisation run on the GPU (speech_amd.features.log_specgram -> sa_log_specgram) and
-        the features stay there as a float32 CUDA tensor: no host featuriser, no H2D copy of the features."""
-        if getattr(self, "device_features", False):
+    def preprocess(self, wave_file, text, device_features=False):
+        """loader.py:65-69.  With `device_features` (make_loader(..., device_features=True) passes it through its
+        dataset) the log spectrogram and the z-normalisation run on the GPU (speech_amd.features.log_specgram ->
+        sa_log_specgram) and the features stay there as a float32 CUDA tensor: no host featuriser, no H2D copy of the
+        features.  The switch belongs to the LOADER, never to this object: the Preprocessor is pickled next to the model
+        (speech.save -> preproc.pyc) and eval.py re-uses it with forked DataLoader workers, which cannot touch the GPU."""
+        if device_features:
             from . import features
             audio, sr = array_from_wave(wave_file)
             return features.log_specgram(audio, sr, mean=self.mean, std=self.std), self.encode(text)
         inputs = (log_specgram_from_file(wave_file) - self.mean) / self.std
         return inputs, self.encode(text)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("device_features", None)  # round-2 objects carried the loader's switch: keep it out of checkpoints
+        return state
+
+    def __setstate__(self, state):
+        state.pop("device_features", None)  # ... and ignore it in checkpoints written by round 2
+        self.__dict__.update(state)
 
     @property
     def input_dim(self):
@@ -113,9 +124,10 @@ class AudioDataset(tud.Dataset):
     """Examples bucketed by transcript length (bucket width 4), each bucket sorted by (duration, length)
     (loader.py:87-117), so that consecutive batches hold utterances of similar length."""
 
-    def __init__(self, data_json, preproc, batch_size):
+    def __init__(self, data_json, preproc, batch_size, device_features=False):
         data = read_data_json(data_json)
         self.preproc = preproc
+        self.device_features = bool(device_features)
         bucket_diff = 4
         num_buckets = max(max(len(x["text"]) for x in data) // bucket_diff, 1)
         buckets = [[] for _ in range(num_buckets)]
@@ -130,6 +142,8 @@ class AudioDataset(tud.Dataset):
 
     def __getitem__(self, idx):
         datum = self.data[idx]
+        if self.device_features:
+            return self.preproc.preprocess(datum["audio"], datum["text"], device_features=True)
         return self.preproc.preprocess(datum["audio"], datum["text"])
 
 
@@ -177,8 +191,7 @@ def make_loader(dataset_json, preproc, batch_size, num_workers=4, world=1, rank=
     DataLoader workers cannot use the device); batches then carry float32 CUDA tensors, which Model.collate pads on
     the device."""
     if device_features:
-        preproc.device_features = True
         num_workers = 0
-    dataset = AudioDataset(dataset_json, preproc, batch_size)
+    dataset = AudioDataset(dataset_json, preproc, batch_size, device_features=device_features)
     sampler = BatchRandomSampler(dataset, batch_size, world=world, rank=rank)
     return tud.DataLoader(dataset, batch_sampler=sampler, num_workers=num_workers, collate_fn=_collate)

@@ -140,10 +140,15 @@ class Model(nn.Module):
         zero = torch.zeros(H, dtype=torch.float32, device=x.device)
         return self._run(x, eye, zero)
 
-    def flatten_parameters_(self):
+    def flatten_parameters_(self, by_reference=True):
         """Re-home every parameter into ONE flat fp32 buffer and give each a slot in ONE flat gradient buffer: the
         fused clip+SGD step and the single RCCL all-reduce both operate on these.  Call after .cuda().
         Per step: p.grad = None for all p (model.zero_grad(set_to_none=True)); backward then fills every slot.
+        This call is the opt-in to FLAT-BUFFER gradient semantics (by_reference=True): the encoder's backward writes each
+        gradient into its slot and makes p.grad that slot instead of returning it to autograd (which would clone all
+        of them every step).  Accumulation still works -- a backward pass that finds p.grad already in its slot (no
+        zero_grad in between) adds to it -- but torch.autograd.grad(loss, params) gets None for those parameters;
+        by_reference=False keeps ordinary autograd hand-over (the slots are then just where the kernels write).
         The gradient buffer has ONE extra trailing element, the health flag (ops.stamp_health / ops.clip_sgd_step):
         it travels with the gradients through the all-reduce, so a failed persistent kernel on any rank stops every
         rank's update on the device.  Returns (flat_params [n], flat_grads [n + 1])."""
@@ -161,6 +166,7 @@ class Model(nn.Module):
             p.grad = None
             off += k
         self._flat = (flat_p, flat_g)
+        self._plan.grad_by_reference = bool(by_reference)
         return self._flat
 
 
@@ -361,11 +367,13 @@ class Transducer(Model):
         # prepend zeros (:61-66)
         inp = torch.cat([torch.zeros((b, 1, e), dtype=torch.float32, device=emb.device), emb], dim=1)
         p_drop = self._dec_dropout if self.training else 0.0
-        if p_drop and L > 1:  # nn.GRU's inter-layer dropout: one layer per call, a Bernoulli mask in between
+        if p_drop and L > 1:  # nn.GRU's inter-layer dropout: one layer per call, the library's mask in between
+            from . import ops
+            seed = ops.new_dropout_seed()
             for l in range(L):
                 inp = _tr.GRUStackFunction.apply(inp, H, *self._dec_params(l))
                 if l + 1 < L:
-                    inp = inp * ((torch.rand_like(inp) >= p_drop).to(inp.dtype) / (1.0 - p_drop))
+                    inp = _tr.DropoutFunction.apply(inp, p_drop, seed, ops.DROP_STREAM_PRED + l)
             yd = inp
         else:
             yd = _tr.GRUStackFunction.apply(inp, H, *[p for l in range(L) for p in self._dec_params(l)])

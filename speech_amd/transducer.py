@@ -123,6 +123,22 @@ class EmbeddingFunction(torch.autograd.Function):
         return None, dt
 
 
+class DropoutFunction(torch.autograd.Function):
+    """x * Bernoulli mask / (1 - p) with the library's counter-based mask (csrc/dropout.h): element i of the contiguous
+    tensor <-> index i of mask stream `stream_id` under key `seed`; backward re-applies the same mask.  Used between the
+    layers of a multi-layer prediction network (nn.GRU(dropout=p), transducer_model.py:23-26)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, stream_id):
+        _lib.require_cuda(x, "x")
+        ctx.args = (float(p), int(seed), int(stream_id))
+        return ops.dropout_apply(x.contiguous(), *ctx.args)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout_apply(dy.contiguous(), *ctx.args), None, None, None
+
+
 class GRUStackFunction(torch.autograd.Function):
     """Unidirectional nn.GRU(batch_first=True) stack (the prediction network, transducer_model.py:23-26,69) on the
     recurrence kernels: x (B, U, E) -> (B, U, H).  params per layer: w_ih, w_hh, b_ih, b_hh."""

@@ -72,7 +72,12 @@ def test_loader_device_feed_matches_the_host_featuriser(tmp_path):
     host = list(loader.make_loader(js, preproc, 2, num_workers=0))
     random.seed(1)
     dev = list(loader.make_loader(js, preproc, 2, device_features=True))
-    preproc.device_features = False
+    # the switch lives on the loader's dataset: the Preprocessor (pickled into checkpoints, re-used by eval.py with
+    # forked workers) is untouched and still featurises on the host
+    assert not hasattr(preproc, "device_features")
+    import pickle
+    again = pickle.loads(pickle.dumps(preproc))
+    assert isinstance(again.preprocess(lines[0]["audio"], lines[0]["text"])[0], np.ndarray)
     assert len(host) == len(dev) == 2
     for (hi, hl), (di, dl) in zip(host, dev):
         assert hl == dl

@@ -151,3 +151,26 @@ def test_dropout_training_path_runs_and_eval_is_deterministic():
     model.set_eval()
     a, b = model(batch), model(batch)
     assert torch.equal(a, b)
+
+
+def test_flat_buffer_gradients_accumulate_without_zero_grad():
+    """after flatten_parameters_() the encoder hands gradients over by reference (p.grad IS its slot of the
+    flat buffer).  A second backward without zero_grad must ADD to that gradient, as autograd does for any parameter
+    (gradient accumulation over micro-batches), not silently replace it."""
+    from speech_amd.models import CTC
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}}}
+    rng = np.random.RandomState(0)
+    batch = make_batch(rng, 3, 50, 40, 10, 5)
+    torch.manual_seed(0)
+    model = CTC(40, 10, cfg).cuda()
+    flat_p, flat_g = model.flatten_parameters_()
+    model.set_train()
+    model.zero_grad(set_to_none=True)
+    model.loss(batch).backward()
+    once = flat_g[:-1].clone()
+    assert all(p.grad.data_ptr() == p._grad_slot.data_ptr() for p in model.parameters())
+    model.loss(batch).backward()   # no zero_grad in between
+    torch.testing.assert_close(flat_g[:-1], 2 * once, rtol=1e-6, atol=1e-7 * float(once.abs().max()))
+    model.zero_grad(set_to_none=True)
+    model.loss(batch).backward()
+    torch.testing.assert_close(flat_g[:-1], once, rtol=0, atol=0)  # and a fresh step is exactly the single gradient

@@ -111,3 +111,28 @@ def test_import_shims():
     import transducer.functions.transducer as tf
     from speech.models import Transducer  # noqa: F401
     assert tf.TransducerLoss.__module__ == "speech_amd.transducer" and callable(td.decode_static)
+
+
+def test_training_mode_dropout_runs_on_the_library_masks():
+    """dropout != 0 (examples/timit/transducer_config.json:20 ships 0.5): encoder masks inside the HIP kernels, the
+    two-layer prediction network's inter-layer mask through the library's element-wise form.  Finite loss / gradients
+    in training mode, a reproducible pass under torch.manual_seed, and eval mode unaffected by the setting."""
+    from speech_amd.models import Transducer
+    g = fixture()
+    cfg = dict(CFG, dropout=0.5)
+    m = Transducer(40, 10, cfg)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")})
+    m = m.cuda()
+    x, y_mat = torch.from_numpy(g["x"]), torch.from_numpy(g["y_mat"])
+    m.set_eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m.forward_impl(x, y_mat).cpu().numpy(), g["out"], rtol=2e-4, atol=2e-5)
+    m.set_train()
+    torch.manual_seed(3)
+    a = m.forward_impl(x, y_mat)
+    torch.manual_seed(3)
+    b = m.forward_impl(x, y_mat)
+    c = m.forward_impl(x, y_mat)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    a.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

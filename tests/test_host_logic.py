@@ -48,6 +48,13 @@ def test_loader_surface(tiny_dataset):
     assert n == 8
     text = preproc.decode(preproc.encode("hello"))
     assert "".join(text) == "hello"
+    # the device-feed switch belongs to the loader's dataset, never to the (pickled) Preprocessor: a checkpoint trained
+    # with data.device_features must evaluate with eval.py's forked workers
+    import pickle
+    dev_ldr = loader.make_loader(tiny_dataset, preproc, batch_size=2, device_features=True)
+    assert dev_ldr.dataset.device_features and dev_ldr.num_workers == 0 and "device_features" not in preproc.__dict__
+    preproc.device_features = True  # what a round-2 object looked like
+    assert "device_features" not in pickle.loads(pickle.dumps(preproc)).__dict__
 
 
 def test_io_and_score_round_trip(tiny_dataset, tmp_path):
