@@ -13,6 +13,13 @@ One step = zero_grad + forward + CTC loss + backward + health stamp + (all-reduc
 the loss read-back of the shipped loop (train.py: asynchronous, ops.ScalarPipe), nothing skipped; inputs and labels are
 resident in HBM before the timed region (synthetic, seed 2017).  Rank 0 prints ONE JSON line.
 
+Beside the headline (SURVEY 8d excludes data loading from the metric) the line carries `train_loop_utt_s`: an extra,
+separately timed leg that runs the loop a user of train.py actually runs (/root/reference/train.py:21-49) -- per step
+`model.loss(batch)` on HOST batches (collate: zero-pad into pinned memory, flat labels, H2D copy), backward, health
+stamp, gradient all-reduce, clip + SGD, lagged loss read-back, and under --gpus N the agreement on the global batch's
+padded shape (dist.with_global_shapes: exchanged one step ahead on a host-side group) -- everything except reading
+audio files and featurising them.
+
 Matched loss (north_star: "at matched CTC loss (rtol 1e-4)"): before any update the GPU model's loss on the batch is
 recorded as `loss_step0`; the CPU baseline copies the SAME initial weights into oracle/torch_ref.py and its first
 step's loss is `cpu_baseline.loss_step0`; `loss_rel_err` is their relative difference.
@@ -123,6 +130,8 @@ def gpu_leg(args, world, rank, local):
            "step_us": step_us, "prof_steps": prof_steps,
            "params": int(flat_p.numel()), "Tp": Tp}
 
+    res.update(train_loop_leg(model, flat_p, flat_g, world, rank, dev, max(5, min(args.steps, 20))))
+
     if rank == 0:  # CTC-loss-only step time (M-CTC: logits (32, 1000, 29), L = 100), fwd + grad
         rng = np.random.RandomState(2017)
         acts = torch.from_numpy(rng.randn(B, T, V + 1).astype(np.float32)).to(dev)
@@ -139,6 +148,49 @@ def gpu_leg(args, world, rank, local):
         res["ctc_ms"] = e0.elapsed_time(e1) / 20
         res["stack_gemm"] = stack_gemm_rates(dev, Tp)
     return res
+
+
+def train_loop_leg(model, flat_p, flat_g, world, rank, dev, steps):
+    """The shipped loop on host batches (see the module docstring): `steps` steps after 3 untimed ones, bracketed by
+    barrier + synchronize, max over ranks.  Four distinct host batches are cycled (a real loader hands over fresh
+    arrays every step; the padded copy must not be a cache hit)."""
+    from speech_amd import dist, ops
+    rng = np.random.RandomState(4242 + rank)
+    host = []
+    for _ in range(4):
+        inputs = tuple(rng.randn(T, F).astype(np.float32) for _ in range(B))
+        labels = tuple(rng.randint(0, V, L).tolist() for _ in range(B))
+        host.append((inputs, labels))
+    norm = torch.zeros(1, device=dev)
+    pipe = ops.ScalarPipe()
+    warm = 3
+
+    def batches():
+        for k in range(warm + steps):
+            yield host[k % len(host)]
+
+    t0 = None
+    for k, (batch, shape) in enumerate(dist.with_global_shapes(batches())):
+        if k == warm:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        model.set_global_batch(*shape)
+        model.zero_grad(set_to_none=True)
+        loss = model.loss(batch)
+        loss.backward()
+        ops.stamp_health(flat_g)
+        dist.allreduce_gradients(flat_g)
+        ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
+        pipe.push(loss, k, lag=3)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    pipe.drain()
+    model.set_global_batch()
+    return {"train_loop_dt": dt, "train_loop_steps": steps}
 
 
 CPU_THREADS = 16  # best of {8, 16, 32, 64, 128} on the GPU box's 256 host threads (tools/cpu_baseline_threads.py:
@@ -211,16 +263,30 @@ def stack_gemm_rates(dev, Tp):
             "frac": ach / MFMA_F32_PEAK_TFS, "traffic": None, "gflop_per_step": flops / 1e9, "shapes": out}
 
 
+def kernel_source_sha():
+    """Hash of the recurrence kernels' source (what profiles/hbm_traffic.json entries are stamped with)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gru.hip", "dropout.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "speech_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def roofline(prof, step_us, steps):
     """Roofline of the dominant kernel: the GRU backward step kernel (largest share of the step in every rocprof
     summary under profiles/).  Duration = mean launch-to-launch interval of the full-width step launches inside the
     timed region, from device-side clock stamps (HIP events around single launches perturb the stream by several us);
     work = the algorithmic bytes one launch moves (17*B*H*4 per layer-step x 4 layer-jobs)."""
     out = {}
-    try:  # HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json documents how they were taken)
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot run inside this process):
+    # profiles/hbm_traffic.json, each entry stamped with the hash of the kernel source it was measured on
+    # (tools/pmc_traffic.py --stamp).  An entry whose stamp does not match the tree being benchmarked is STALE and is
+    # not reported (traffic = null, traffic_stale = true) -- a number from another kernel would be worse than none.
+    try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     except Exception:
         traffic = {}
+    sha_now = kernel_source_sha()
     for name, per_job in (("gru_bwd_step_kernel", 17), ("gru_fwd_step_kernel", 10)):
         us, kern_us, n, nsteps = step_us.get(name, (0.0, 0.0, 0, 1))
         if n == 0:
@@ -234,10 +300,13 @@ def roofline(prof, step_us, steps):
             continue
         nbytes = 4.0 * B * 512 * per_job * 4 * nsteps  # 4 layer-jobs x nsteps steps per launch, B x H fp32 each
         ach = nbytes / (us * 1e-6) / 1e9
-        tr = traffic.get(name, {}).get("bytes_per_launch")
+        entry = traffic.get(name, {})
+        stale = entry.get("source_sha") != sha_now
+        tr = None if stale else entry.get("bytes_per_launch")
         key = name.replace("_persist_", "_step_").replace("_fused_", "_step_")
         out[key] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": tr, "avg_launch_us": us, "block0_kernel_us": kern_us,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_stale": bool(stale and entry),
+                    "avg_launch_us": us, "block0_kernel_us": kern_us,
                     "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps}
     g = prof.get("gemm")
     gemm = None
@@ -291,6 +360,11 @@ def main():
                    "global_batch": B * world, "parallelism": "dp%d" % world},
         "ctc_loss_step_ms": r.get("ctc_ms"), "loss": r["loss"], "grad_norm": r["grad_norm"],
         "loss_step0": r["loss_step0"], "loss_rel_err": None, "persist_status": r["persist_status"],
+        "train_loop_utt_s": B * world * r["train_loop_steps"] / r["train_loop_dt"],
+        "train_loop_ms_per_step": r["train_loop_dt"] / r["train_loop_steps"] * 1e3,
+        "train_loop_note": "untimed-by-the-headline extra leg: train.py's loop on HOST batches (model.loss(batch): collate "
+                           "into pinned memory + H2D, backward, all-reduce, clip+SGD, lagged read-back; global-shape "
+                           "exchange one step ahead under --gpus N); %d steps" % r["train_loop_steps"],
         "roofline": None,
         "kernel_time_ms_per_step": {k: v["ms"] / r["prof_steps"] for k, v in sorted(r["prof"].items())},
     }

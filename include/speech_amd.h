@@ -2,10 +2,17 @@
  * speech_amd.h -- C ABI of libspeech_amd.so: the MI355X (gfx950) implementation of the awni/speech CTC hot path.
  *
  * Plain C: pointers, sizes, a stream handle.  No torch types, no C++ in the signatures.  Every pointer named
- * d_* / acts / grads / workspace is DEVICE memory owned by the caller; the library allocates nothing and keeps no
- * global state, so every entry point is re-entrant.  All work is enqueued on the caller's stream (a hipStream_t
- * passed as void*; NULL = the default stream); only the entry points that return HOST results (marked SYNC)
- * wait for it.  Every function returns a ctcStatus_t; nothing throws.
+ * d_* / acts / grads / workspace is DEVICE memory owned by the caller.  All work is enqueued on the caller's stream (a
+ * hipStream_t passed as void*; NULL = the default stream); only the entry points that return HOST results (marked
+ * SYNC) wait for it.  Every function returns a ctcStatus_t; nothing throws.
+ * State: the entry points allocate nothing and keep no state between calls -- they are re-entrant -- with ONE stated
+ * exception, the GRU stack entry points (sa_gru_stack_*, sa_gru_health_flag, sa_gru_persist_*).  Those own, PER
+ * DEVICE (the device current at the call; 16 at most) and created at first use: a two-word sticky health word in
+ * device memory with a ring of 8 pinned host words and events behind it, one non-blocking side stream with 64 events
+ * (weight-gradient / projection GEMMs beside a recurrence), and a per-device mutex that serialises the stack calls of
+ * several host threads on one device (held while launches are enqueued: microseconds).  Different devices share
+ * nothing.  The opt-in profiler (sa_gru_profile_*) is the one piece of process-wide state and serves one device.
+ * Environment switches are read at call time.
  *
  * Each entry point names the reference interface it replaces (paths relative to /root/reference).
  */

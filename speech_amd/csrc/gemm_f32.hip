@@ -596,7 +596,10 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     // recurrence blocks then always find room, before and after this launch's blocks arrive.
     size_t dyn = 0;
     if (opts && opts->pad_lds) {
-        static bool attr_set = false;
+        static bool attr_set_dev[16] = {false};  // function attributes are per device
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
+        bool& attr_set = attr_set_dev[devid];
         dyn = 81 * 1024 - sizeof(float) * 2 * 2 * TILE_F;
         if (!attr_set) {
             const void* fns[4] = {(const void*)gemm_f32_kernel<true, true>, (const void*)gemm_f32_kernel<true, false>,

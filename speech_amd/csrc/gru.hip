@@ -21,6 +21,8 @@
 //             gradients of step t-1 in the epilogue (they become the next launch's A operand).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "dropout.h"
 #include "internal.h"
@@ -1472,7 +1474,16 @@ struct SideStream {
         return hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
     }
 };
-SideStream g_side;
+// One per DEVICE (a process normally drives one GPU -- one rank per GPU, speech_amd/dist.py -- but nothing here assumes
+// it): streams, events and the health word belong to the device that was current when they were created.
+constexpr int kMaxDevices = 16;
+static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+SideStream g_side_dev[kMaxDevices];
+#define g_side (g_side_dev[current_device()])
 
 // Holds the side stream back for ~`ticks` x 10 ns: enqueued in front of a batch of XCD-filtered GEMM launches so that the
 // persistent recurrence launch issued at the same moment on the caller's stream is DISPATCHED first -- its exit-at-once
@@ -1651,8 +1662,13 @@ struct PersistHealth {
         code = 0;  // `disabled` stays
     }
 };
-PersistHealth g_health;
-StepProfiler g_prof;
+PersistHealth g_health_dev[kMaxDevices];  // per device: see g_side_dev
+#define g_health (g_health_dev[current_device()])
+StepProfiler g_prof;                       // bench.py's opt-in profiler: one device at a time (configure() binds it)
+// Serialises the stack entry points per device: they enqueue on library-owned objects (side stream, event rings, the
+// health ring).  Launches are asynchronous, so the lock is held for microseconds of host time; two threads driving the
+// SAME device through sa_gru_stack_* are safe, two devices never contend.
+std::mutex g_stack_mutex[kMaxDevices];
 }  // namespace
 
 extern "C" void sa_gru_profile_configure(int enable) {
@@ -1720,7 +1736,8 @@ extern "C" ctcStatus_t sa_gru_health_flag(float* d_flag, void* stream_) {
 constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
 
 static int device_cus() {
-    static int cus = 0;
+    static int cus_of[kMaxDevices] = {0};
+    int& cus = cus_of[current_device()];
     if (cus == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -1869,6 +1886,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                            void* workspace, size_t workspace_bytes, void* stream_,
                            void* const* aux_streams, int n_aux, const DropCtx& dc) {
     SA_CLEAR_ERR();
+    std::lock_guard<std::mutex> device_lock(g_stack_mutex[current_device()]);
     if (!x || !w_ih || !b_ih || !w_hh || !b_hh || !h_out || !workspace) return CTC_STATUS_INVALID_VALUE;
     const bool drop_on = dc.on() && L > 1;
     if (drop_on) {
@@ -2320,6 +2338,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                            size_t workspace_bytes, void* stream_, void* const* aux_streams, int n_aux,
                            const WGrad* wg, const DropCtx& dc) {
     SA_CLEAR_ERR();
+    std::lock_guard<std::mutex> device_lock(g_stack_mutex[current_device()]);
     if (!dh_top || !stash || !w_ih || !w_hh || !dai || !dah || !workspace) return CTC_STATUS_INVALID_VALUE;
     const bool drop_on = dc.on() && L > 1;
     if (drop_on) {

@@ -96,6 +96,49 @@ def global_shape(shard):
     return int(total[0]), int(most[0]), int(most[1])
 
 
+class _Shape:
+    """Result handle of global_shape_async(): .result() waits for the exchange (normally long finished)."""
+
+    def __init__(self, local, works=None, tensors=None):
+        self._local, self._works, self._tensors = local, works, tensors
+
+    def result(self):
+        if self._works is None:
+            return self._local
+        for w in self._works:
+            w.wait()
+        total, most = self._tensors
+        return int(total[0]), int(most[0]), int(most[1])
+
+
+def global_shape_async(shard):
+    """global_shape() without the wait: the two host all-reduces are started (gloo, async_op) and a handle comes back.
+    The training loop starts the exchange for batch k+1 as soon as the loader has produced it -- before it enqueues
+    step k -- and collects the result when step k+1 begins, so the agreement on the next batch's padded shape is never
+    on the launch path of a step.  Every rank must call it for the same batches in the same order."""
+    local = batch_shape(shard)
+    if not active():
+        return _Shape(local)
+    g = _meta_group()
+    total = torch.tensor([local[0]], dtype=torch.int64)
+    most = torch.tensor([local[1], local[2]], dtype=torch.int64)
+    works = [td.all_reduce(total, op=td.ReduceOp.SUM, group=g, async_op=True),
+             td.all_reduce(most, op=td.ReduceOp.MAX, group=g, async_op=True)]
+    return _Shape(local, works, (total, most))
+
+
+def with_global_shapes(batches):
+    """Iterate (batch, global shape) with the shape exchange of batch k+1 in flight while batch k is being used."""
+    prev = None
+    for batch in batches:
+        handle = global_shape_async(batch)
+        if prev is not None:
+            yield prev[0], prev[1].result()
+        prev = (batch, handle)
+    if prev is not None:
+        yield prev[0], prev[1].result()
+
+
 def allreduce_gradients(flat_grads):
     """SUM all-reduce of the flat fp32 gradient buffer, in place (RCCL ring/tree chosen by the library)."""
     if active():

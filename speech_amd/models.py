@@ -59,6 +59,7 @@ class Model(nn.Module):
         self.loss_denominator = None
         self.pad_frames = None
         self.pad_labels = None
+        self._stage = None  # pinned staging ring of collate(), created once the model sits on the GPU
 
     # ---- reference API -------------------------------------------------------------------------------------------
     def conv_out_size(self, n, dim):
@@ -96,6 +97,22 @@ class Model(nn.Module):
         self.loss_denominator = size
         self.pad_frames = max_frames
         self.pad_labels = max_label_len
+
+    def _to_device(self, x):
+        """The batch's H2D copy (ctc_model.py:26-27 `x.cuda()`): asynchronous when collate() staged it in pinned memory."""
+        if x.is_cuda or not self.is_cuda:
+            return x
+        xd = x.cuda(non_blocking=True)
+        if self._stage is not None:
+            self._stage.copied(x)
+        return xd
+
+    def _pad_inputs(self, inputs):
+        if self.is_cuda and not torch.is_tensor(inputs[0]):
+            if self._stage is None:
+                self._stage = _PinnedStage()
+            return zero_pad_concat(inputs, self.pad_frames, stage=self._stage)
+        return _as_tensor(zero_pad_concat(inputs, self.pad_frames))
 
     def _healthy(self, fn):
         """Forward-only use (infer, dev-set loss): there is no optimiser whose device-side gate would catch a failed
@@ -224,19 +241,78 @@ class _LinearFunction(torch.autograd.Function):
         return dx, ops.gemm(dy, x, trans_a=True, out=ctx.slots[0]), ops.colsum(dy, out=ctx.slots[1])
 
 
-def zero_pad_concat(inputs, min_t=0):
+def zero_pad_concat(inputs, min_t=0, stage=None):
     """model.py:135-141.  `min_t`: pad at least this far (the global-batch maximum of a data-parallel shard).
     Inputs that already live on the GPU (loader.make_loader(..., device_features=True)) are padded there and come back
-    as a float32 CUDA tensor; host arrays give the reference's float32 ndarray."""
+    as a float32 CUDA tensor; host arrays give the reference's float32 ndarray -- or, with `stage` (a _PinnedStage), a
+    float32 tensor in PINNED host memory, so that the model's H2D copy is a real asynchronous DMA (a pageable source
+    makes `.cuda(non_blocking=True)` a staged, blocking copy)."""
     max_t = max(max(inp.shape[0] for inp in inputs), int(min_t or 0))
     shape = (len(inputs), max_t, inputs[0].shape[1])
     if torch.is_tensor(inputs[0]):
         input_mat = torch.zeros(shape, dtype=torch.float32, device=inputs[0].device)
-    else:
-        input_mat = np.zeros(shape, dtype=np.float32)
+        for e, inp in enumerate(inputs):
+            input_mat[e, :inp.shape[0], :] = inp
+        return input_mat
+    if stage is not None:
+        out = stage.get(shape)
+        input_mat = out.numpy()
+        for e, inp in enumerate(inputs):  # only the padding tail is zeroed, not the whole batch twice
+            input_mat[e, :inp.shape[0], :] = inp
+            input_mat[e, inp.shape[0]:, :] = 0.0
+        return out
+    input_mat = np.zeros(shape, dtype=np.float32)
     for e, inp in enumerate(inputs):
         input_mat[e, :inp.shape[0], :] = inp
     return input_mat
+
+
+class _PinnedStage:
+    """A small ring of pinned host buffers for the padded feature batch (train.py's loop: collate on the host, copy,
+    launch).  A buffer is handed out again only after the H2D copy that read it has completed (one event per slot), so
+    the host can pad batch k+1 while batch k's copy and kernels are still in flight."""
+
+    def __init__(self, depth=3):
+        self._bufs = [None] * depth
+        self._events = [None] * depth
+        self._next = 0
+        self._by_ptr = {}
+
+    def get(self, shape):
+        i = self._next
+        self._next = (i + 1) % len(self._bufs)
+        n = int(np.prod(shape))
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+            self._events[i] = None
+        buf = self._bufs[i]
+        if buf is None or buf.numel() < n:
+            if buf is not None:
+                self._by_ptr.pop(buf.data_ptr(), None)
+            buf = torch.empty(int(n * 1.25) + 16, dtype=torch.float32).pin_memory()
+            self._bufs[i] = buf
+            self._by_ptr[buf.data_ptr()] = i
+        return buf[:n].view(shape)
+
+    def copied(self, host_tensor):
+        """Call right after enqueueing the H2D copy of a tensor handed out by get()."""
+        i = self._by_ptr.get(host_tensor.data_ptr())
+        if i is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[i] = ev
+
+
+def _flat_labels(labels):
+    """ctc_model.py:47-48 (`[l for label in labels for l in label]`) without a Python loop per label."""
+    n = sum(len(l) for l in labels)
+    out = np.empty(n, dtype=np.int32)
+    o = 0
+    for l in labels:
+        k = len(l)
+        out[o:o + k] = l
+        o += k
+    return torch.from_numpy(out)
 
 
 def _as_tensor(x):
@@ -264,8 +340,7 @@ class CTC(Model):
         return self.forward_impl(x)
 
     def forward_impl(self, x, softmax=False):
-        if self.is_cuda:
-            x = x.cuda(non_blocking=True)
+        x = self._to_device(x)
         x = self._run(x, self.fc.fc.weight, self.fc.fc.bias)
         if softmax:
             return torch.nn.functional.softmax(x, dim=2)
@@ -282,9 +357,9 @@ class CTC(Model):
         max_t = max(max(i.shape[0] for i in inputs), int(self.pad_frames or 0))
         max_t = self.conv_out_size(max_t, 0)
         x_lens = torch.IntTensor([max_t] * len(inputs))
-        x = _as_tensor(zero_pad_concat(inputs, self.pad_frames))
+        x = self._pad_inputs(inputs)
         y_lens = torch.IntTensor([len(l) for l in labels])
-        y = torch.IntTensor([int(l) for label in labels for l in label])
+        y = _flat_labels(labels)
         return [x, y, x_lens, y_lens]
 
     def infer(self, batch):
@@ -341,7 +416,7 @@ class Transducer(Model):
 
     def forward_impl(self, x, y):
         if self.is_cuda:
-            x = x.cuda(non_blocking=True)
+            x = self._to_device(x)
             y = y.cuda(non_blocking=True)
         x = self.encode(x)
         return self.decode(x, y)
@@ -395,7 +470,7 @@ class Transducer(Model):
         max_t = max(max(i.shape[0] for i in inputs), int(self.pad_frames or 0))
         max_t = self.conv_out_size(max_t, 0)
         x_lens = torch.IntTensor([max_t] * len(inputs))
-        x = _as_tensor(zero_pad_concat(inputs, self.pad_frames))
+        x = self._pad_inputs(inputs)
         y_lens = torch.IntTensor([len(l) for l in labels])
         y = torch.IntTensor([int(l) for label in labels for l in label])
         return [x, y, x_lens, y_lens]
@@ -498,7 +573,7 @@ class Seq2Seq(Model):
     def loss(self, batch):
         x, y = self.collate(*batch)
         if self.is_cuda:
-            x = x.cuda(non_blocking=True)
+            x = self._to_device(x)
             y = y.cuda(non_blocking=True)
         with torch.set_grad_enabled(not self.volatile):
             out, alis = self.forward_impl(x, y)
@@ -515,7 +590,7 @@ class Seq2Seq(Model):
     def forward(self, batch):
         x, y = self.collate(*batch)
         if self.is_cuda:
-            x = x.cuda(non_blocking=True)
+            x = self._to_device(x)
             y = y.cuda(non_blocking=True)
         return self.forward_impl(x, y)[0]
 
@@ -559,7 +634,7 @@ class Seq2Seq(Model):
 
         def run():
             with torch.no_grad():
-                enc = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
+                enc = self.encode(self._to_device(x))
                 y0 = y[:, 0:1].to(enc.device)
                 _, argmaxs = self.infer_decode(enc, y0, end_tok, max_len)
             return [seq.tolist() for seq in argmaxs.cpu().numpy()]
@@ -574,7 +649,7 @@ class Seq2Seq(Model):
         x, y = self.collate(*batch)
         start_tok, end_tok = int(y[0, 0]), int(y[0, -1])
         with torch.no_grad():
-            x = self.encode(x.cuda(non_blocking=True) if self.is_cuda else x)
+            x = self.encode(self._to_device(x))
         dev = x.device
         x_rep = x.expand(beam_size, x.shape[1], x.shape[2]).contiguous()
         beam = [((start_tok,), 0, None)]  # (hypothesis, score, row state (hx, ax, sx) or None)
@@ -611,6 +686,6 @@ class Seq2Seq(Model):
         return [hyp]
 
     def collate(self, inputs, labels):
-        inputs = zero_pad_concat(inputs, self.pad_frames)
+        inputs = self._pad_inputs(inputs)
         labels = end_pad_concat(labels, self.pad_labels)
-        return _as_tensor(inputs), torch.from_numpy(labels)
+        return inputs, torch.from_numpy(labels)

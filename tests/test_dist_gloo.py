@@ -135,7 +135,9 @@ def _replay_worker(rank, world, port, out_dir, fail_rank, fail_at, n_batches):
     dist.init(backend="gloo")
     state = {"word": 0, "calls": [], "resets": 0, "updates": []}
 
-    def step(batch):
+    def step(batch_, shape):
+        batch = int(batch_[0][0].shape[0]) - 1      # the batch's index is encoded in its frame count
+        assert shape == (world, batch + 1, 1)        # ... and the shape exchange (one step ahead) paired the SAME batches
         if rank == fail_rank and batch == fail_at and state["resets"] == 0:
             state["word"] = 1                      # a persistent kernel on THIS rank failed: sticky until the reset
         if rank == 1:
@@ -154,8 +156,8 @@ def _replay_worker(rank, world, port, out_dir, fail_rank, fail_at, n_batches):
         state["word"] = 0
         return 1
 
-    it, _ = train.run_epoch(None, (torch.zeros(1),), None, list(range(n_batches)), 0, 0.0, world, rank,
-                            step_fn=step, reset_fn=reset)
+    batches = [((np.zeros((k + 1, 1), np.float32),), ([0],)) for k in range(n_batches)]
+    it, _ = train.run_epoch(None, (torch.zeros(1),), None, batches, 0, 0.0, world, rank, step_fn=step, reset_fn=reset)
     dist.barrier()
     torch.save({"it": it, **state}, os.path.join(out_dir, "r%d.pt" % rank))
 

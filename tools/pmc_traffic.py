@@ -1,13 +1,39 @@
 """HBM traffic per dispatch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection CSVs) of the
 same command: mean per dispatch grouped by (kernel, grid size).  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- gfx950's
 FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads (MI355X_MICROARCH.md, HBM section).
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> [name-filter ...]"""
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> [name-filter ...]
+       python tools/pmc_traffic.py --stamp <json-from-above> [kernel-name ...]
+           merges the entries (keys reduced to the kernel name; of several grid sizes the one with the most launches)
+           into profiles/hbm_traffic.json, each stamped with bench.kernel_source_sha() of the CURRENT tree -- bench.py
+           reports roofline.traffic only from entries whose stamp matches the tree it runs on."""
 import csv
 import glob
 import json
 import os
 import sys
 from collections import defaultdict
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--stamp":
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    new = json.load(open(sys.argv[2]))
+    want = sys.argv[3:]
+    path = os.path.join(root, "profiles", "hbm_traffic.json")
+    table = json.load(open(path))
+    best = {}
+    for key, v in new.items():
+        name = key.split("|")[0].split("<")[0]
+        if want and name not in want:
+            continue
+        if name not in best or v["launches_averaged"] > best[name]["launches_averaged"]:
+            best[name] = v
+    for name, v in best.items():
+        table[name] = dict(v, source_sha=bench.kernel_source_sha())
+        print("stamped", name, table[name])
+    json.dump(table, open(path, "w"), indent=1)
+    sys.exit(0)
 
 
 def load(d, counter):

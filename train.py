@@ -36,10 +36,11 @@ except ImportError:  # optional, as in requirements.txt of the reference
     tb = None
 
 
-def train_step(model, flat, opt_cfg, batch):
-    """One train.py:28-35 step on this rank's shard.  Returns (loss tensor or None for an empty shard, norm tensor)."""
+def train_step(model, flat, opt_cfg, batch, shape=None):
+    """One train.py:28-35 step on this rank's shard.  Returns (loss tensor or None for an empty shard, norm tensor).
+    `shape`: the GLOBAL batch's (size, frames, label length), normally exchanged a step ahead (dist.with_global_shapes)."""
     flat_p, flat_g, mom = flat
-    model.set_global_batch(*dist.global_shape(batch))
+    model.set_global_batch(*(shape if shape is not None else dist.global_shape(batch)))
     model.zero_grad(set_to_none=True)
     loss = None
     if len(batch[0]) == 0:
@@ -57,8 +58,9 @@ LAG = 3  # a step's loss / norm are read back exactly LAG steps later (ops.Scala
 
 
 def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank, step_fn=None, reset_fn=None):
-    """train.py:21-49.  step_fn / reset_fn default to train_step / ops.persist_reset (tests inject host-only stand-ins)."""
-    step_fn = step_fn or (lambda b: train_step(model, flat, opt_cfg, b))
+    """train.py:21-49.  step_fn(batch, global_shape) / reset_fn default to train_step / ops.persist_reset (tests inject
+    host-only stand-ins)."""
+    step_fn = step_fn or (lambda batch, shape: train_step(model, flat, opt_cfg, batch, shape))
     reset_fn = reset_fn or ops.persist_reset
     model_t = 0.0
     data_t = 0.0
@@ -97,7 +99,7 @@ def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank, step_f
                   % (code, lost, len([rb for rb in recent if rb[0] >= lost])))
         bad = None
         for tag, b in [rb for rb in recent if rb[0] >= lost]:
-            l2, n2 = step_fn(b)
+            l2, n2 = step_fn(*b)
             r = push(l2, n2, tag)
             bad = r if bad is None else bad
         r = consume(losses.drain(), norms.drain())
@@ -105,10 +107,11 @@ def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank, step_f
         if bad is not None:
             raise RuntimeError("update of iteration %d skipped again after the reset (step kernels): giving up" % bad)
 
-    for batch in tq:
+    # (batch, global shape) pairs: the shape exchange of batch k+1 runs while step k is being enqueued
+    for batch, shape in dist.with_global_shapes(tq):
         start_t = time.time()
-        recent.append((it, batch))
-        loss, norm = step_fn(batch)
+        recent.append((it, (batch, shape)))
+        loss, norm = step_fn(batch, shape)
         lost = push(loss, norm, it)
         if lost is not None:
             replay(lost)
