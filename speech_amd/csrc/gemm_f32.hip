@@ -24,6 +24,8 @@
 //   * interior blocks (full tiles, aligned operands) run a guard-free instance of the loop; edge blocks a guarded one.
 // Tall-K products with few output tiles (dW = dA^T X, K = B*T' ~ 16k) are split along K across blockIdx.z into a
 // workspace and reduced by a second kernel in a fixed order (deterministic, unlike atomics).
+#include <stdlib.h>
+
 #include "common.h"
 #include "internal.h"
 
@@ -367,8 +369,292 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
     }
 }
 
+// ------------------------------------------------------------------------------- split-bf16 GEMM on packed operands ("x6")
+// The f32-input MFMA runs at the fp32 VECTOR rate (157 TFLOP/s); the bf16 MFMA is 16x faster.  An fp32 number is the
+// exact sum of three bf16 pieces, a = a1 + a2 + a3 (each piece the round-to-nearest bf16 of what the previous ones left,
+// v_cvt_pk_bf16_f32; 3 x 8 significant bits and a sign each cover the 24), so an fp32 product is the sum of nine
+// bf16 x bf16 products, every one of them EXACT in the fp32 accumulator.  Six of them carry everything down to 2^-26 of
+// the product:
+//     a b  =  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)  +  [a2 b3 + a3 b2 + a3 b3:  < 2^-26 |a b|, dropped]
+// -- a quarter of an fp32 ulp of the product, below the rounding of the fp32 accumulation every GEMM has.  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 192 instead of
+// 512 matrix-pipe cycles per 16 k.  Accumulation is fp32 throughout, as in the exact kernel (measured against an fp64
+// product the split kernel's error is the exact kernel's: tools/gemm_bench.py, tests/test_gpu_blocks.py).
+// SA_GEMM_EXACT=1 selects the f32-input MFMA kernel everywhere; small products, the XCD-filtered launches, the direct
+// convolutions and the recurrence kernels always use f32-input MFMAs.
+//
+// Splitting costs ~5.5 VALU instructions per element.  Done while a tile is staged (first version of this kernel) every
+// block redoes it for every tile it touches and the loop is issue-bound at 39 % of the matrix pipe (163 TFLOP/s on
+// k-contiguous operands, less with a transposing store).  So an operand is split ONCE, by a PACK kernel, into the
+// layout the main loop wants, and the main loop is nothing but LDS-DMA, fragment reads and MFMAs:
+//   * packed operand of a logical X[R][K] (R = M or N): tiles of 128 rows x 16 k, tile (rb, kb) at (rb KB + kb) 12 KB;
+//     inside a tile  chunk(plane p, row r, half h) = p 4096 + r 32 + (h ^ ((r >> 3) & 1)) 16  bytes holds the eight
+//     bf16 pieces k = 8 h .. 8 h + 7 of row r (the XOR keeps the 16 lanes of a ds_read_b128 group on disjoint banks).
+//     Rows beyond R and k beyond K are zero, so the main loop has no edge cases; both memory orientations of an
+//     operand (k-contiguous, m/n-contiguous) pack into the same layout, so ONE kernel serves all four transpose forms;
+//   * a block streams its A and B tiles -- consecutive in memory along k -- into a 3-stage LDS ring with
+//     global_load_lds_dwordx4 (no registers, no ds_write; 6 per wave and stage), two stages ahead of the MFMAs;
+//   * lane (h, r) feeds an MFMA the chunk (p, r, h) of A and of B alike, so the hardware's own k numbering never matters.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PK_K = 16;                       // k per packed tile
+constexpr int PK_PLANE = BM * PK_K * 2;        // 4096 bytes: one bf16 plane of a tile
+constexpr int PK_TILE = 3 * PK_PLANE;          // 12288 bytes
+constexpr int PK_STAGE = 2 * PK_TILE;          // A tile + B tile
+constexpr int PK_NST = 3;                      // LDS ring: 72 KB per block, two blocks per CU
+
+__host__ __device__ inline size_t pk_bytes(int R, int K) {
+    return (size_t)((R + BM - 1) / BM) * (size_t)((K + PK_K - 1) / PK_K) * PK_TILE;
+}
+__host__ __device__ __forceinline__ int pk_off(int p, int row, int h) {
+    return p * PK_PLANE + row * 32 + ((h ^ ((row >> 3) & 1)) << 4);
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // {bf16(lo), bf16(hi)}, round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf16_hi_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+// (x, y) -> three packed bf16 pairs whose sums are x and y
+__device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = cvt_pk_bf16(x, y);
+    const float rx = x - bf16_lo_as_f32(p1), ry = y - bf16_hi_as_f32(p1);  // exact
+    p2 = cvt_pk_bf16(rx, ry);
+    const float sx = rx - bf16_lo_as_f32(p2), sy = ry - bf16_hi_as_f32(p2);  // exact
+    p3 = cvt_pk_bf16(sx, sy);
+}
+
+struct PackArgs {
+    const float* src[kMaxGroup];
+    char* dst;             // problem p at dst + p * dst_stride
+    size_t dst_stride;
+    long ld;
+    int R, K, KB, kt;      // rows, reduction length, k-tiles, k-tiles per block
+    int vec;               // 16-byte loads are legal (k-contiguous form)
+    float* cs_part;        // m-contiguous form: row sums [problem][part][Rpad] (part = 2 blockIdx.x + wave / 2), or null
+    int Rpad;
+};
+
+// X[r][k] = src[r * ld + k] (k-contiguous memory).  grid (ceil(KB / kt), RB, nprob); thread t: rows t/4 and t/4 + 64,
+// k = 4 (t % 4) .. + 3: a wave reads 16 rows x 64 bytes and writes 16 rows x 32 bytes (contiguous) per plane.
+__global__ __launch_bounds__(256) void pk_pack_kcontig_kernel(PackArgs a) {
+    const float* __restrict__ src = a.src[blockIdx.z];
+    char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.KB * PK_TILE;
+    const int tid = threadIdx.x, k4 = tid & 3;
+    const int kb_end = min(a.KB, ((int)blockIdx.x + 1) * a.kt);
+    for (int kb = blockIdx.x * a.kt; kb < kb_end; ++kb) {
+        char* tile = dst + (size_t)kb * PK_TILE;
+        const int k = kb * PK_K + 4 * k4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = (tid >> 2) + 64 * i, row = blockIdx.y * BM + rl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.R) {
+                const float* q = src + (long)row * a.ld + k;
+                if (a.vec && k + 3 < a.K) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (k + 0 < a.K) v.x = q[0];
+                    if (k + 1 < a.K) v.y = q[1];
+                    if (k + 2 < a.K) v.z = q[2];
+                    if (k + 3 < a.K) v.w = q[3];
+                }
+            }
+            unsigned a1, a2, a3, b1, b2, b3;
+            split2(v.x, v.y, a1, a2, a3);
+            split2(v.z, v.w, b1, b2, b3);
+            char* d = tile + pk_off(0, rl, k4 >> 1) + 8 * (k4 & 1);
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(d + PK_PLANE) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(d + 2 * PK_PLANE) = make_uint2(a3, b3);
+        }
+    }
+}
+
+// X[r][k] = src[k * ld + r] (m/n-contiguous memory).  grid (ceil(KB / kt), RB, nprob); wave w: rows (w & 1) 64 + lane of
+// the block's 128, k-tiles of parity w >> 1: a wave reads 64 consecutive floats per k (coalesced) and each thread
+// ends up with the 16 k of ITS row -- the transposition costs nothing.  Optional row sums (the bias gradients that
+// belong to a weight gradient dW = dA^T X: column sums of dA): one partial per (block, tile parity), folded in order.
+__global__ __launch_bounds__(256) void pk_pack_mcontig_kernel(PackArgs a) {
+    const float* __restrict__ src = a.src[blockIdx.z];
+    char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.KB * PK_TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rl = (wave & 1) * 64 + lane, row = blockIdx.y * BM + rl;
+    const bool live = row < a.R;
+    const float* __restrict__ col = src + (live ? row : 0);
+    const int kb_end = min(a.KB, ((int)blockIdx.x + 1) * a.kt);
+    float rsum = 0.f;
+    for (int kb = blockIdx.x * a.kt + (wave >> 1); kb < kb_end; kb += 2) {
+        float v[PK_K];
+#pragma unroll
+        for (int kk = 0; kk < PK_K; ++kk) {
+            const int k = kb * PK_K + kk;
+            v[kk] = (live && k < a.K) ? col[(long)k * a.ld] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < PK_K; ++kk) rsum += v[kk];
+        unsigned p1[8], p2[8], p3[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) split2(v[2 * q], v[2 * q + 1], p1[q], p2[q], p3[q]);
+        char* tile = dst + (size_t)kb * PK_TILE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            char* d = tile + pk_off(0, rl, h);
+            *reinterpret_cast<uint4*>(d) = make_uint4(p1[4 * h], p1[4 * h + 1], p1[4 * h + 2], p1[4 * h + 3]);
+            *reinterpret_cast<uint4*>(d + PK_PLANE) = make_uint4(p2[4 * h], p2[4 * h + 1], p2[4 * h + 2], p2[4 * h + 3]);
+            *reinterpret_cast<uint4*>(d + 2 * PK_PLANE) = make_uint4(p3[4 * h], p3[4 * h + 1], p3[4 * h + 2], p3[4 * h + 3]);
+        }
+    }
+    if (a.cs_part)
+        a.cs_part[((size_t)blockIdx.z * (2 * gridDim.x) + 2 * blockIdx.x + (wave >> 1)) * a.Rpad + blockIdx.y * BM + rl] = rsum;
+}
+
+// colsum[p][m] = (beta ? beta * colsum : 0) + sum over the parts: 16 lanes per column add every 16th part in order,
+// then a fixed xor tree folds the 16 sums (deterministic; a serial loop over ~250 parts per thread took 95 us).
+// grid (ceil(M / 16), nprob), 256 threads: lane j = tid & 15 of column m = 16 blockIdx.x + (tid >> 4).
+__global__ __launch_bounds__(256) void pk_colsum_fold_kernel(const float* __restrict__ part, int nparts, int Rpad, int M,
+                                                             GemmArgs g) {
+    const int m = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15, prob = blockIdx.y;
+    float t = 0.f;
+    if (m < M)
+        for (int q = j; q < nparts; q += 16) t += part[((size_t)prob * nparts + q) * Rpad + m];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (m >= M || j != 0 || !g.colsumg[prob]) return;
+    float* o = g.colsumg[prob] + m;
+    *o = g.beta != 0.f ? g.beta * *o + t : t;
+}
+
+struct SFrag { bf16x8 a[2][3], b[2][3]; };  // [tile][plane]
+__device__ __forceinline__ void sread_frag(const char* __restrict__ s, bf16x8 (&f)[2][3]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            f[t][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(s + t * 1024 + pl * PK_PLANE));
+}
+// 24 MFMAs: (2 x 2) tiles x the six piece products, the smallest first
+__device__ __forceinline__ void smma_tile(const SFrag& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+        const int pa = o == 0 ? 2 : (o == 1 ? 0 : (o == 2 ? 1 : (o == 3 ? 0 : (o == 4 ? 1 : 0))));
+        const int pb = o == 0 ? 0 : (o == 1 ? 2 : (o == 2 ? 1 : (o == 3 ? 1 : (o == 4 ? 0 : 0))));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[j][pb], acc[i][j], 0, 0, 0);
+    }
+}
+// one stage = the A tile and the B tile of one k-tile: 24 KB = 24 wave-instructions of 1 KB, 6 per wave
+__device__ __forceinline__ void pk_issue(const char* __restrict__ At, const char* __restrict__ Bt, char* slot, int wave,
+                                         int lane) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ci = wave * 6 + j;  // wave-uniform: 1 KB piece of the stage (0 .. 11: A, 12 .. 23: B)
+        const char* src = (ci < 12 ? At + ci * 1024 : Bt + (ci - 12) * 1024) + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(slot + ci * 1024), 16, 0, 0);
+    }
+}
+// k-tiles [kb0, kb1) of row block `by` of A and `bx` of B
+__device__ __forceinline__ void pk_mainloop(const char* __restrict__ Apk, const char* __restrict__ Bpk, int KB, char* smem,
+                                            int by, int bx, int kb0, int kb1, int tid, f32x16 (&acc)[2][2]) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt = kb1 - kb0;
+    if (nt <= 0) return;
+    const char* At = Apk + ((size_t)by * KB + kb0) * PK_TILE;
+    const char* Bt = Bpk + ((size_t)bx * KB + kb0) * PK_TILE;
+    const int fa = pk_off(0, wm * 64 + (lane & 31), lane >> 5);
+    const int fb = PK_TILE + pk_off(0, wn * 64 + (lane & 31), lane >> 5);
+    pk_issue(At, Bt, smem, wave, lane);
+    {
+        const size_t o1 = (size_t)(nt > 1 ? 1 : 0) * PK_TILE;
+        pk_issue(At + o1, Bt + o1, smem + PK_STAGE, wave, lane);
+    }
+    // Per tile: [wait: tile it + 1 has landed, the fragments of tile `it` are in registers] -> barrier -> DMA of tile
+    // it + 3 into the slot tile `it` just left -> fragment reads of tile it + 1 (they land during the MFMAs) -> 24 MFMAs
+    // on tile `it`.  PK_NST = 3 slots hold tiles it + 1, it + 2 and (arriving) it + 3.
+    {
+        const size_t o2 = (size_t)(nt > 2 ? 2 : nt - 1) * PK_TILE;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile 0 (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        pk_issue(At + o2, Bt + o2, smem + 2 * PK_STAGE, wave, lane);
+    }
+    SFrag f0, f1;
+    sread_frag(smem + fa, f0.a);
+    sread_frag(smem + fb, f0.b);
+    int nxt = 1;  // ring slot of tile it + 1
+    auto step = [&](int it, SFrag& fc, SFrag& fn) {
+        // tile it + 1 landed (it + 2 and it + 3... are the 12 newest); fc's reads returned; everyone's likewise after the barrier
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int nx = it + 3 < nt ? it + 3 : nt - 1;      // past the end: re-read the last tile into a slot nobody reads
+        const int free_slot = nxt == 0 ? 2 : nxt - 1;      // the slot of tile `it`
+        sread_frag(smem + nxt * PK_STAGE + fa, fn.a);
+        sread_frag(smem + nxt * PK_STAGE + fb, fn.b);
+        __builtin_amdgcn_sched_barrier(0);  // the 12 fragment reads go out FIRST (hipcc would sink them to their use)
+        pk_issue(At + (size_t)nx * PK_TILE, Bt + (size_t)nx * PK_TILE, smem + free_slot * PK_STAGE, wave, lane);
+        smma_tile(fc, acc);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {  // one LDS-DMA instruction behind every fourth MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        nxt = nxt == 2 ? 0 : nxt + 1;
+    };
+    int it = 0;
+    for (; it + 1 < nt; it += 2) {  // unrolled by two: the fragment sets swap roles without moves
+        step(it, f0, f1);
+        step(it + 1, f1, f0);
+    }
+    if (it < nt) step(it, f0, f1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring is reused by the epilogue of nothing, but leave it quiet
+}
+
+// Epilogue of a wave's TI x TJ accumulator tiles whose first element is (row0, col0).
+// 32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+template <int TI, int TJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int prob, int bz, int row0, int col0, int lane,
+                                              f32x16 (&acc)[TI][TJ]) {
+    const bool splitk = g.partial != nullptr;
+    float* __restrict__ gC = g.Cg[prob];
+    const float* __restrict__ gbias = g.biasg[prob];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = col0 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            float bv = 0.f;
+            if (!splitk && gbias) bv = gbias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                if (splitk) {
+                    g.partial[((long)bz * g.M + row) * g.N + col] = acc[i][j][r];
+                } else {
+                    float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride
+                                             : gC + (long)row * g.ldc + col;
+                    float v = g.alpha * acc[i][j][r] + bv;
+                    if (g.beta != 0.f) v += g.beta * *c;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
 // TA: A is stored (K, M) (m-contiguous);  !TA: A is stored (M, K) (k-contiguous)
 // TB: B is stored (N, K) (k-contiguous);  !TB: B is stored (K, N) (n-contiguous)
+// DEPTH 2 / 1: the f32-input MFMA main loops; DEPTH 0: the split-bf16 main loop
 template <bool TA, bool TB, int DEPTH = 2>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int bx, int by, int bz) {
     const int tid = threadIdx.x;
@@ -391,9 +677,12 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const bool fast = g.vecA && g.vecB && m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
-    const bool do_colsum = TA && g.colsumg[prob] != nullptr && bx == 0;
+    const bool do_colsum = DEPTH != 0 && TA && g.colsumg[prob] != nullptr && bx == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DEPTH == 2) {
+    if (DEPTH == 0) {  // packed split-bf16 operands: g.Ag / g.Bg hold PACKED tiles (see pk_mainloop), no edge cases
+        pk_mainloop(reinterpret_cast<const char*>(gA), reinterpret_cast<const char*>(gB), (g.K + PK_K - 1) / PK_K,
+                    reinterpret_cast<char*>(smem), by, bx, kbeg / PK_K, (kend + PK_K - 1) / PK_K, tid, acc);
+    } else if (DEPTH == 2) {
         if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
         else gemm_mainloop<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
     } else {
@@ -417,35 +706,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
         }
     }
 
-    // epilogue.  32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const bool splitk = g.partial != nullptr;
-    float* __restrict__ gC = g.Cg[prob];
-    const float* __restrict__ gbias = g.biasg[prob];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            float bv = 0.f;
-            if (!splitk && gbias) bv = gbias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
-                if (splitk) {
-                    g.partial[((long)bz * g.M + row) * g.N + col] = acc[i][j][r];
-                } else {
-                    float* c = g.m_inner > 0 ? gC + remap_row(g, row) + col * g.col_stride
-                                             : gC + (long)row * g.ldc + col;
-                    float v = g.alpha * acc[i][j][r] + bv;
-                    if (g.beta != 0.f) v += g.beta * *c;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    *c = v;
-                }
-            }
-        }
-    }
+    gemm_epilogue<2, 2>(g, prob, bz, m0 + wm * 64, n0 + wn * 64, lane, acc);
 }
 
 __device__ __forceinline__ int gemm_xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
@@ -456,6 +717,113 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE_F];
     gemm_block<TA, TB>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The same product with 256 x 256 block tiles: 512 threads = 8 waves as 2 (M) x 4 (N), a wave 128 x 64 = 4 x 2 MFMA tiles.
+// Why: the bf16 pieces are 1.5 x the bytes of the fp32 operands and the matrix pipe runs 2.67 x faster, so a 128 x 128 tile
+// (21 flop per byte moved into LDS) asks the L2 -> LDS path for ~20 TB/s at the matrix pipe's rate -- more than half of
+// what the L2s deliver at best; measured, the 128-tile kernel stalls at 47 % of the pipe.  256 x 256 tiles move half the
+// bytes per flop (44 flop / byte) and issue half the LDS-DMA instructions per MFMA (6 per wave per 48).  One block per
+// CU (3 x 48 KB of LDS); fragments are read at the top of a k-tile in the order the MFMAs use them (B first, then the A
+// tiles one by one), so only the first nine reads are exposed, and the second wave of the SIMD covers them.
+constexpr int PKB_STAGE = 4 * PK_TILE;  // two A row blocks + two B row blocks of one k-tile: 48 KB
+__device__ __forceinline__ void pkb_issue(const char* __restrict__ A0, const char* __restrict__ A1,
+                                          const char* __restrict__ B0, const char* __restrict__ B1, char* slot, int wave,
+                                          int lane) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ci = wave * 6 + j;  // wave-uniform 1 KB piece: 0..11 A0, 12..23 A1, 24..35 B0, 36..47 B1
+        const char* base = ci < 12 ? A0 : (ci < 24 ? A1 : (ci < 36 ? B0 : B1));
+        const char* src = base + (ci % 12) * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(slot + ci * 1024), 16, 0, 0);
+    }
+}
+__global__ __launch_bounds__(512, 2) void gemm_pk256_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char pkbsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int prob = bz / g.splits, split = bz - prob * g.splits;
+    const int KB = (g.K + PK_K - 1) / PK_K;
+    const int RBA = (g.M + BM - 1) / BM, RBB = (g.N + BN - 1) / BN;  // packed row blocks of A and B
+    const int kb0 = split * g.k_per_split / PK_K, kb1 = min(KB, (split + 1) * g.k_per_split / PK_K);
+    const int nt = kb1 - kb0;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (nt > 0) {
+        const char* Apk = reinterpret_cast<const char*>(g.Ag[prob]);
+        const char* Bpk = reinterpret_cast<const char*>(g.Bg[prob]);
+        // a block's second row block may lie beyond the matrix (odd number of row blocks): read the first one again
+        const int ra0 = 2 * by, ra1 = min(2 * by + 1, RBA - 1), rb0 = 2 * bx, rb1 = min(2 * bx + 1, RBB - 1);
+        const char* A0 = Apk + ((size_t)ra0 * KB + kb0) * PK_TILE;
+        const char* A1 = Apk + ((size_t)ra1 * KB + kb0) * PK_TILE;
+        const char* B0 = Bpk + ((size_t)rb0 * KB + kb0) * PK_TILE;
+        const char* B1 = Bpk + ((size_t)rb1 * KB + kb0) * PK_TILE;
+        // this wave's fragments: A rows = row block wm of the stage, B rows = 64 (wn & 1) .. of row block 2 + (wn >> 1)
+        const int fa = wm * PK_TILE + pk_off(0, lane & 31, lane >> 5);
+        const int fb = (2 + (wn >> 1)) * PK_TILE + pk_off(0, (wn & 1) * 64 + (lane & 31), lane >> 5);
+        pkb_issue(A0, A1, B0, B1, pkbsm, wave, lane);
+        {
+            const size_t o1 = (size_t)(nt > 1 ? 1 : 0) * PK_TILE;
+            pkb_issue(A0 + o1, A1 + o1, B0 + o1, B1 + o1, pkbsm + PKB_STAGE, wave, lane);
+        }
+        int cur = 0;
+        for (int it = 0; it < nt; ++it) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile `it` (this wave's pieces; tile it + 1 may be in flight)
+            __builtin_amdgcn_s_barrier();                      // ... everyone's; and everyone has read tile it - 1
+            asm volatile("" ::: "memory");
+            const char* sb = pkbsm + cur * PKB_STAGE;
+            bf16x8 fbv[2][3], fav[4][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fbv[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb + j * 1024 + pl * PK_PLANE));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fav[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa + i * 1024 + pl * PK_PLANE));
+            __builtin_amdgcn_sched_barrier(0);  // the 18 fragment reads go out first, in the order the MFMAs want them
+            const int nx = it + 2 < nt ? it + 2 : nt - 1;
+            const size_t on = (size_t)nx * PK_TILE;
+            const int slot = cur == 0 ? 2 : cur - 1;  // (it + 2) % 3: the slot tile it - 1 has left
+            pkb_issue(A0 + on, A1 + on, B0 + on, B1 + on, pkbsm + slot * PKB_STAGE, wave, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int o = 0; o < 6; ++o) {  // the six piece products, the smallest first
+                    const int pa = o == 0 ? 2 : (o == 1 ? 0 : (o == 2 ? 1 : (o == 3 ? 0 : (o == 4 ? 1 : 0))));
+                    const int pb = o == 0 ? 0 : (o == 1 ? 2 : (o == 2 ? 1 : (o == 3 ? 1 : (o == 4 ? 0 : 0))));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fav[i][pa], fbv[j][pb], acc[i][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {  // one LDS-DMA instruction behind every eighth MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    gemm_epilogue<4, 2>(g, prob, bz, by * 256 + wm * 128, bx * 256 + wn * 64, lane, acc);
+}
+
+// The split-bf16 kernel on packed operands (see "split-bf16 GEMM on packed operands" above): one kernel for all four
+// transpose forms -- the orientation went away in the pack kernels.
+__global__ __launch_bounds__(256, 2) void gemm_pk_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float pksm[];
+    gemm_block<false, false, 0>(g, pksm, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // The XCD-filtered launches (see GemmArgs::xcc_mask) run this copy with ONE register stage (<= 232 registers per lane):
@@ -509,6 +877,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
     if (g.beta != 0.f) v += g.beta * *c;
     if (g.relu) v = fmaxf(v, 0.f);
     *c = v;
+}
+
+// Products big enough that two pack launches (and a pass over both operands) pay: >= 8 GFLOP per launch, a reduction of
+// at least 256, and an output at least half a tile wide in both directions.  SA_GEMM_EXACT=1 switches the path off,
+// SA_GEMM_EXACT=0 forces it for every unfiltered product.
+bool pk_worth_it(int M, int N, int K, int nprob) {
+    const char* e = getenv("SA_GEMM_EXACT");  // "1": never; "0": always (tests: small shapes through the packed path)
+    if (e && (e[0] == '1' || e[0] == '0')) return e[0] == '0';
+    return 2.0 * M * N * K * nprob >= 8.0e9 && K >= 256 && M >= 64 && N >= 64;
 }
 
 int choose_splits(int M, int N, int K, int nprob = 1) {
@@ -566,6 +943,21 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.s_mid = ep ? ep->s_mid : 0;
     g.col_stride = ep ? ep->col_stride : 1;
     g.relu = ep ? ep->relu : 0;
+    // The split-bf16 kernel on packed operands for every product that is worth two pack launches, when the caller's
+    // workspace has room for the packed copies; SA_GEMM_EXACT=1 (read per call): the f32-input MFMA kernel everywhere.
+    const bool filtered = opts && opts->xcc_mask && opts->tile_counter;
+    bool use_pk = pk_worth_it(M, N, K, nprob) && !filtered && !(opts && opts->pad_lds);
+    const size_t pkA = sa_align_up(pk_bytes(M, K), 256), pkB = sa_align_up(pk_bytes(N, K), 256);
+    const int pk_kt = 8, pk_parts = 2 * ((((K + PK_K - 1) / PK_K) + pk_kt - 1) / pk_kt);
+    const int Mpad = (M + BM - 1) / BM * BM;
+    const size_t pk_cs = (opts && opts->colsum) ? sa_align_up((size_t)nprob * pk_parts * Mpad * sizeof(float), 256) : 0;
+    const size_t pk_need = (size_t)nprob * (pkA + pkB) + pk_cs;
+    if (use_pk && (!workspace || workspace_bytes < pk_need)) use_pk = false;
+    char* pk_base = (char*)workspace;
+    if (use_pk) {  // the packed copies sit in front of the split-K partials
+        workspace = (char*)workspace + pk_need;
+        workspace_bytes -= pk_need;
+    }
     int splits = choose_splits(M, N, K, nprob);
     if (opts && opts->no_split) splits = 1;
     if (splits > 1) {
@@ -621,6 +1013,64 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         if (opts->err_word)
             hipLaunchKernelGGL(gemm_filtered_check_kernel, dim3(1), dim3(1), 0, stream, (const unsigned*)g.tile_counter,
                                (unsigned)(g.grid_x * g.grid_y * g.grid_z), opts->err_word);
+    } else if (use_pk) {
+        // pack A (logical [M][K]) and B (logical [N][K]) of every problem, then ONE kernel whatever the transposes were
+        const int KB = (K + PK_K - 1) / PK_K;
+        PackArgs pa;
+        pa.K = K; pa.KB = KB; pa.kt = pk_kt; pa.cs_part = nullptr; pa.Rpad = Mpad;
+        for (int side = 0; side < 2; ++side) {
+            const bool kcontig = side == 0 ? !trans_a : (trans_b != 0);
+            const int R = side == 0 ? M : N;
+            for (int p = 0; p < nprob; ++p) pa.src[p] = side == 0 ? A[p] : B[p];
+            pa.dst = pk_base + (side == 0 ? 0 : (size_t)nprob * pkA);
+            pa.dst_stride = side == 0 ? pkA : pkB;
+            pa.ld = side == 0 ? lda : ldb;
+            pa.R = R;
+            pa.vec = side == 0 ? g.vecA : g.vecB;
+            pa.cs_part = (side == 0 && pk_cs) ? (float*)(pk_base + (size_t)nprob * (pkA + pkB)) : nullptr;
+            const dim3 pgrid((KB + pk_kt - 1) / pk_kt, (R + BM - 1) / BM, nprob);
+            if (kcontig) hipLaunchKernelGGL(pk_pack_kcontig_kernel, pgrid, dim3(256), 0, stream, pa);
+            else hipLaunchKernelGGL(pk_pack_mcontig_kernel, pgrid, dim3(256), 0, stream, pa);
+        }
+        if (pk_cs)
+            hipLaunchKernelGGL(pk_colsum_fold_kernel, dim3((M + 15) / 16, nprob), dim3(256), 0, stream,
+                               (const float*)(pk_base + (size_t)nprob * (pkA + pkB)), pk_parts, Mpad, M, g);
+        static bool pk_attr_dev[32] = {false};
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
+        if (!pk_attr_dev[devid]) {
+            if (hipFuncSetAttribute((const void*)gemm_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    PK_NST * PK_STAGE) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+            pk_attr_dev[devid] = true;
+        }
+        GemmArgs gp = g;
+        for (int p = 0; p < nprob; ++p) {
+            gp.Ag[p] = (const float*)(pk_base + (size_t)p * pkA);
+            gp.Bg[p] = (const float*)(pk_base + (size_t)nprob * pkA + (size_t)p * pkB);
+            gp.colsumg[p] = nullptr;  // done by the pack kernel
+        }
+        // 256 x 256 block tiles (half the LDS traffic per flop, one block per CU) when they fill the chip: no split-K and
+        // >= 85 % of whole rounds of 256 CUs; else 128 x 128 tiles, two blocks per CU (measured, tools/gemm_bench.py:
+        // 4096^3 191 vs 182 TFLOP/s, d x of layer 0 132 vs 130; but the layer-0 projection 136 vs 156 and the
+        // weight gradients 89 vs 122).  SA_GEMM_TILE=128 / 256 forces either (experiments).
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
+        const char* tile_e = getenv("SA_GEMM_TILE");
+        const bool big_tile = tile_e ? atoi(tile_e) == 256
+                                     : (splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85);
+        if (big_tile) {
+            if (!pk_attr_dev[devid + 16]) {
+                if (hipFuncSetAttribute((const void*)gemm_pk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        PK_NST * PKB_STAGE) != hipSuccess)
+                    return CTC_STATUS_EXECUTION_FAILED;
+                pk_attr_dev[devid + 16] = true;
+            }
+            const dim3 bgrid((N + 255) / 256, (M + 255) / 256, nprob * splits);
+            hipLaunchKernelGGL(gemm_pk256_kernel, bgrid, dim3(512), PK_NST * PKB_STAGE, stream, gp);
+        } else {
+            hipLaunchKernelGGL(gemm_pk_kernel, grid, dim3(256), PK_NST * PK_STAGE, stream, gp);
+        }
+        g = gp;  // the split-K reduce below must not fold column sums either
     } else if (trans_a) {
         if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), dyn, stream, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), dyn, stream, g);
@@ -641,7 +1091,13 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
 size_t sa_gemm_group_workspace_bytes(int nprob, int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || nprob <= 0) return 0;
     const int s = choose_splits(M, N, K, nprob);
-    return s > 1 ? (size_t)nprob * s * ((size_t)M * N + M) * sizeof(float) : 0;
+    size_t w = s > 1 ? (size_t)nprob * s * ((size_t)M * N + M) * sizeof(float) : 0;
+    if (pk_worth_it(M, N, K, nprob)) {  // packed split-bf16 copies of both operands (+ the row-sum partials)
+        const int parts = 2 * ((((K + PK_K - 1) / PK_K) + 7) / 8);
+        w += (size_t)nprob * (sa_align_up(pk_bytes(M, K), 256) + sa_align_up(pk_bytes(N, K), 256)) +
+             sa_align_up((size_t)nprob * parts * ((M + BM - 1) / BM * BM) * sizeof(float), 256);
+    }
+    return w;
 }
 
 ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
@@ -652,11 +1108,7 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
                                   workspace, workspace_bytes, stream, nullptr);
 }
 
-extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int s = choose_splits(M, N, K);
-    return s > 1 ? (size_t)s * ((size_t)M * N + M) * sizeof(float) : 0;
-}
+extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) { return sa_gemm_group_workspace_bytes(1, M, N, K); }
 
 extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                                    long lda, const float* B, long ldb, float beta, float* C, long ldc,

@@ -1522,6 +1522,18 @@ bool overlap_enabled(bool uni) {
 }
 
 
+// A whole-sequence product (input projection / input gradient: tall M, short K) with room for the packed split-bf16
+// copies of its operands, never split along K (these calls had no workspace before the packed path existed: the
+// summation order of the f32 kernel stays what the bit-identity tests of the recurrence kernels were written against).
+static ctcStatus_t gemm_whole(int trans_a, int trans_b, int M, int N, int K, const float* A, long lda, const float* B,
+                              long ldb, float beta, float* C, long ldc, const float* bias, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+    SaGemmOpts o;
+    o.no_split = 1; o.pad_lds = 0; o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr;
+    return sa_gemm_f32_group_impl(1, trans_a, trans_b, M, N, K, 1.f, &A, lda, &B, ldb, beta, &C, ldc, &bias, nullptr, ws,
+                                  ws_bytes, stream, &o);
+}
+
 // ------------------------------------------------------------------------------------------------- the layer stack
 // A step launch is a dependent-latency chain that leaves the chip mostly idle (profiles/r01_pmc_gru_step_kernels.txt:
 // >60 % of wave cycles in s_waitcnt), so the batch is cut into independent groups of rows ("chains"), each advanced on
@@ -1864,6 +1876,11 @@ extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, i
     if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, true); if (w > gw) gw = w; }
+    // the whole-layer input projections (layer 0 of a unidirectional stack; every layer of a bidirectional one, both
+    // directions grouped): the packed split-bf16 copies of their operands live here (gemm_f32.hip)
+    const int Imax = I0 > D * H ? I0 : D * H;
+    const size_t pw = sa_align_up(sa_gemm_group_workspace_bytes(D, T * B, 3 * H, D == 1 ? I0 : Imax), 256);
+    if (pw > gw) gw = pw;
     return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + kSyncBytes;
 }
 
@@ -1966,7 +1983,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 o.tile_counter = mask ? sync + kSyncTiles + side_launch++ : nullptr;
                 o.err_word = g_health.dev;  // a filtered launch that did not cover its tiles stops the step's update
                 return sa_gemm_f32_group_impl(2, 0, 1, n * B, 3 * H, I, 1.f, gA, I, gB, I, 0.f, gC, 3 * H, gbias, nullptr,
-                                              nullptr, 0, on, &o);
+                                              mask ? nullptr : gws, mask ? 0 : gws_bytes, on, &o);
             };
             hipEvent_t ready[16];
             if (fside) {
@@ -1983,8 +2000,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 }
             } else {
                 for (int d = 0; d < 2; ++d) {
-                    st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I, 1.f, in, I, w_ih[l * 2 + d], I, 0.f, ai_of(l, d), 3 * H,
-                                          b_ih[l * 2 + d], nullptr, nullptr, 0, stream);
+                    st = gemm_whole(0, 1, T * B, 3 * H, I, in, I, w_ih[l * 2 + d], I, 0.f, ai_of(l, d), 3 * H, b_ih[l * 2 + d],
+                                    gws, gws_bytes, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
                 }
             }
@@ -2032,8 +2049,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     }
 
     // unidirectional: chunked layer wavefront.  Layer 0's input projection for all t up front.
-    st = sa_gemm_f32_impl(0, 1, T * B, 3 * H, I0, 1.f, x, I0, w_ih[0], I0, 0.f, ai_of(0, 0), 3 * H, b_ih[0], nullptr,
-                          nullptr, 0, stream);
+    st = gemm_whole(0, 1, T * B, 3 * H, I0, x, I0, w_ih[0], I0, 0.f, ai_of(0, 0), 3 * H, b_ih[0], gws, gws_bytes, stream);
     if (st != CTC_STATUS_SUCCESS) return st;
     Chains ch(stream, aux_streams, n_aux, B);
     if (!ch.ok) return CTC_STATUS_EXECUTION_FAILED;
@@ -2227,6 +2243,12 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
+    {   // the whole-sequence input-gradient products (d x of layer 0; every layer of a bidirectional stack): packed copies
+        const size_t a = sa_align_up(sa_gemm_group_workspace_bytes(1, T * B, I0, 3 * H), 256);
+        const size_t b = D == 2 ? sa_align_up(sa_gemm_group_workspace_bytes(1, T * B, 2 * H, 3 * H), 256) : 0;
+        if (a > gw) gw = a;
+        if (b > gw) gw = b;
+    }
     // the fused backward kernel: W_ih^T of the upper layers, and a tiled exchange copy of dai per layer
     const size_t wih_t = (D == 1 && L > 1 ? (size_t)(L - 1) * sa_align_up((size_t)3 * H * H * sizeof(float), 256) : 0) +
                          (size_t)L * D * sa_align_up((size_t)T * ((B + 15) / 16) * 16 * 3 * H * sizeof(float), 256) +
@@ -2471,8 +2493,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             const int I = l > 0 ? 2 * H : I0;
             if (din)
                 for (int d = 0; d < 2; ++d) {
-                    st = sa_gemm_f32_impl(0, 0, T * B, I, 3 * H, 1.f, dai[l * 2 + d], 3 * H, w_ih[l * 2 + d], I,
-                                          d ? 1.f : 0.f, din, I, nullptr, nullptr, nullptr, 0, stream);
+                    st = gemm_whole(0, 0, T * B, I, 3 * H, dai[l * 2 + d], 3 * H, w_ih[l * 2 + d], I, d ? 1.f : 0.f, din, I,
+                                    nullptr, gws, gws_bytes, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
                 }
             if (drop_on && l > 0) {  // the layer below fed this one its dropped output: the same mask routes the gradient
@@ -2687,8 +2709,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     SA_CHECK_LAUNCH();
     if (xcd) g_health.submit(stream);
     if (dx) {
-        st = sa_gemm_f32_impl(0, 0, T * B, I0, 3 * H, 1.f, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, nullptr,
-                              nullptr, 0, stream);
+        st = gemm_whole(0, 0, T * B, I0, 3 * H, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, gws, gws_bytes, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
     }
     if (side && !g_side.order(g_side.s, stream)) return CTC_STATUS_EXECUTION_FAILED;  // join

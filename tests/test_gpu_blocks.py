@@ -48,6 +48,58 @@ def test_gemm_is_exact_fp32_on_integers():
     assert np.array_equal(c.cpu().numpy(), a @ b)
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 700, 300, 520), (0, 0, 333, 800, 1536), (1, 0, 1536, 512, 4000),
+                                         (1, 1, 130, 257, 77)])
+def test_split_bf16_gemm_error_budget(monkeypatch, ta, tb, M, N, K):
+    """The GEMM kernel of the large products multiplies three-piece bf16 splits of the fp32 operands on the bf16 MFMA (six
+    of the nine piece products, fp32 accumulate; operands packed once per call; csrc/gemm_f32.hip).  The dropped terms are < 2^-26 of each product -- below the
+    rounding of the fp32 accumulation itself -- so against an fp64 product its error must sit where the f32-input MFMA
+    kernel's (SA_GEMM_EXACT=1: exact fp32 products, fp32 accumulate) does: both within the fp32 accumulation bound,
+    the split kernel within 3x of the exact kernel plus one part in 10^7."""
+    from speech_amd import ops
+    rng = np.random.RandomState(M + N + K)
+    # wide dynamic range and mixed signs: mantissas of all lengths, cancellation in the sums
+    a = (rng.randn(K, M) if ta else rng.randn(M, K)) * np.exp(rng.randn(1, M if ta else K))
+    b = (rng.randn(N, K) if tb else rng.randn(K, N)) * np.exp(rng.randn(N if tb else K, 1) if tb else rng.randn(1, N))
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    A, Bm = (a.T if ta else a).astype(np.float64), (b.T if tb else b).astype(np.float64)
+    ref = A @ Bm
+    scale = np.abs(A) @ np.abs(Bm)          # the scale rounding errors live on
+    got = {}
+    for mode in ("split", "exact"):
+        monkeypatch.setenv("SA_GEMM_EXACT", "1" if mode == "exact" else "0")  # "0": the packed path whatever the size
+        c = ops.gemm(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy().astype(np.float64)
+        got[mode] = float((np.abs(c - ref) / scale).max()), float(np.linalg.norm(c - ref) / np.linalg.norm(ref))
+    bound = 2.0 ** -24 * (2.0 + np.sqrt(K))  # generous statistical fp32 accumulation bound, relative to |A||B|
+    assert got["exact"][0] <= bound and got["split"][0] <= bound, (got, bound)
+    assert got["split"][0] <= 3.0 * got["exact"][0] + 1e-7 and got["split"][1] <= 3.0 * got["exact"][1] + 1e-7, got
+
+
+def test_packed_gemm_all_forms_edges_and_exact_integers(monkeypatch):
+    """Every transpose form, ragged M / N / K (zero-padded tiles), bias, alpha / beta and split-K through the packed
+    split-bf16 path (forced: SA_GEMM_EXACT=0); products of small integers stay bit-exact (every piece product is exact)."""
+    from speech_amd import ops
+    monkeypatch.setenv("SA_GEMM_EXACT", "0")
+    rng = np.random.RandomState(5)
+    for ta, tb, M, N, K in [(0, 1, 200, 72, 96), (1, 0, 130, 300, 77), (0, 0, 64, 129, 250), (1, 1, 257, 65, 33)]:
+        a = rng.randn(K, M) if ta else rng.randn(M, K)
+        b = rng.randn(N, K) if tb else rng.randn(K, N)
+        bias = rng.randn(N)
+        c = ops.gemm(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb), bias=dev(bias))
+        close(c, (a.T if ta else a) @ (b.T if tb else b) + bias, rtol=1e-5, atol_scale=1e-6 * np.sqrt(K))
+    ai = rng.randint(-8, 9, (200, 96)).astype(np.float32)
+    bi = rng.randint(-8, 9, (96, 72)).astype(np.float32)
+    assert np.array_equal(ops.gemm(dev(ai), dev(bi)).cpu().numpy(), ai @ bi)
+    K, M, N = 5000, 96, 200   # split-K with alpha / beta
+    a, b, c0 = rng.randn(K, M), rng.randn(K, N), rng.randn(M, N)
+    out = dev(c0)
+    ops.gemm(dev(a), dev(b), trans_a=True, out=out, alpha=0.5, beta=2.0)
+    close(out, 0.5 * a.T @ b + 2.0 * c0, rtol=1e-5, atol_scale=1e-6 * np.sqrt(K))
+    out2 = dev(c0)
+    ops.gemm(dev(a), dev(b), trans_a=True, out=out2, alpha=0.5, beta=2.0)
+    assert torch.equal(out, out2)  # deterministic
+
+
 def test_gemm_split_k_alpha_beta_and_strided():
     from speech_amd import ops
     rng = np.random.RandomState(1)

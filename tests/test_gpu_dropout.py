@@ -104,8 +104,10 @@ def test_fused_one_launch_kernels_apply_the_masks():
 
 
 @pytest.mark.parametrize("env", [{"SA_GRU_FUSED": "0"}, {"SA_GRU_BWD_ONE": "0"}, {"SA_GRU_FUSE_DX": "0"},
-                                 {"SA_GRU_PERSIST": "0"}, {"SA_GRU_TILED": "0"}],
-                         ids=["chunked_fwd", "chunked_fused_bwd", "gemm_dx", "step_kernels", "round1_bwd"])
+                                 {"SA_GRU_PERSIST": "0"}, {"SA_GRU_TILED": "0"}, {"SA_GEMM_EXACT": "0"},
+                                 {"SA_GEMM_EXACT": "1"}],
+                         ids=["chunked_fwd", "chunked_fused_bwd", "gemm_dx", "step_kernels", "round1_bwd",
+                              "every_gemm_packed_split_bf16", "every_gemm_exact_f32"])
 def test_every_gru_path_applies_the_same_masks(monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)

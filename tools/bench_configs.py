@@ -69,7 +69,7 @@ def m_step(name, F, V, cfg, B, T, L, iters):
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         out["loss"] = loss
 
-    sec = timed(step, iters, warmup=2)
+    sec = timed(step, iters, warmup=3)
     with torch.no_grad():
         model.set_eval()
         fwd = timed(lambda: model.forward_impl(x), iters, warmup=1)
@@ -188,8 +188,8 @@ def main():
     if want("M-STEP"):
         res["M-STEP"] = [m_step("S-LIBRI uni (bench.py)", 80, 28, uni, 32, 1000, 100, 5),
                          m_step("S-LIBRI uni, dropout 0.2", 80, 28, drop(uni, 0.2), 32, 1000, 100, 5),
-                         m_step("S-LIBRI bidirectional", 80, 28, bi, 32, 1000, 100, 3),
-                         m_step("S-LIBRI bidirectional, dropout 0.2", 80, 28, drop(bi, 0.2), 32, 1000, 100, 3)]
+                         m_step("S-LIBRI bidirectional", 80, 28, bi, 32, 1000, 100, 5),
+                         m_step("S-LIBRI bidirectional, dropout 0.2", 80, 28, drop(bi, 0.2), 32, 1000, 100, 5)]
     if want("M-TIMIT"):
         res["M-TIMIT"] = [m_step("timit ctc_config shapes", 161, 48, timit, 8, 300, 40, 5),
                           m_step("timit ctc_config AS SHIPPED (dropout 0.4)", 161, 48, drop(timit, 0.4), 8, 300, 40, 5),
