@@ -13,6 +13,19 @@
 //     sort (ctc_decoder.py:107-110).
 // Prefixes are nodes of a trie (parent, symbol) made canonical by a hash table, so "same prefix" is "same node id".
 //
+//
+// Round 3 (latency: M-DEC beam 1 was 3.0 ms for (32, 498, 29), as long as the encoder forward it follows):
+//   * the per-frame log-probabilities no longer sit on the T-step chain: ctc_logprob_kernel computes all B x T rows in
+//     parallel (one wave per row, the SAME arithmetic and reduction order as before, so the values are bit-identical)
+//     into the workspace, and a decode step just reads its row (requested a step ahead);
+//   * beam_size = 1 (what CTC.infer asks for, ctc_model.py:59) has its own kernel: with one beam entry the dict of a
+//     step is "stay" + one extension per symbol, nothing ever merges, the survivor is the arg-max under the reference's
+//     tie order, and a prefix is just the labels appended so far -- no trie, no hash table, no LDS, the state in
+//     registers; a log-sum-exp costs ONE double exp and one double log (the largest term's exp(0) = 1 and the -inf
+//     terms' 0 are exact, so the reference's three-term sums are reproduced bit for bit);
+//   * the general kernel runs 4 waves per utterance: the W x S candidates of a step (1 .. 3 double log-sum-exps each)
+//     are spread over 256 threads instead of walked four at a time by one wave; selection and the trie stay on wave 0.
+//
 // sa_ctc_greedy_decode: argmax per frame + CTC.max_decode collapse (ctc_model.py:62-70), one wave per utterance.
 #include "common.h"
 
@@ -33,8 +46,43 @@ __device__ __forceinline__ float ref_lse3(float a, float b, float c, int n) {
     return m + (float)log(tot);
 }
 
+// ctc_decoder.py:27-36 on two arguments: identical in value to ref_lse3(-inf, x, y, 3) and to ref_lse3(x, y, ., 2) --
+// the term of the maximum is exp(0.0) = 1.0 exactly, a -inf term contributes 0.0 exactly, and the double sum of the two
+// remaining terms does not depend on their order -- with one exp instead of two or three.
+__device__ __forceinline__ float ref_lse2(float x, float y) {
+    const float m = fmaxf(x, y), lo = fminf(x, y);
+    if (m == NEG_INF_F) return NEG_INF_F;
+    const double e = (lo == NEG_INF_F) ? 0.0 : exp((double)(lo - m));
+    return m + (float)log(1.0 + e);
+}
+
+// log-probabilities of every frame, one wave per (utterance, frame) row: ctc_decoder.py:52 after ctc_model.py:30-31.
+// grid: ceil(B * T_max / 4) blocks of 4 waves.  lp: (B, T_max, S).
+__global__ __launch_bounds__(256) void ctc_logprob_kernel(const float* __restrict__ in, long st, long sb,
+                                                          const int* __restrict__ in_lens, int S, int B, int T_max,
+                                                          int is_logits, float* __restrict__ lp) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)B * T_max) return;
+    const int b = (int)(r / T_max), t = (int)(r - (long)b * T_max);
+    if (t >= in_lens[b]) return;
+    const float* row = in + (long)b * sb + (long)t * st;
+    float* out = lp + r * S;
+    if (is_logits) {
+        float m = -3.0e38f;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, row[s]);
+        m = sa_wave_max(m);
+        float z = 0.f;
+        for (int s = lane; s < S; s += 64) z += expf(row[s] - m);
+        z = sa_wave_sum(z);
+        for (int s = lane; s < S; s += 64) out[s] = logf(expf(row[s] - m) / z);
+    } else {
+        for (int s = lane; s < S; s += 64) out[s] = logf(row[s]);  // log(0) = -inf, as np.log
+    }
+}
+
 struct BeamArgs {
-    const float* in;
+    const float* in;    // the log-probabilities (B, T_max, S) written by ctc_logprob_kernel
     long st, sb;
     const int* in_lens;
     int S, B, T_max, W, blank, is_logits;
@@ -54,8 +102,62 @@ __device__ __forceinline__ unsigned hash_u64(unsigned long long k) {
     return (unsigned)k;
 }
 
-// one wave (64 threads) per utterance
-__global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
+// beam_size = 1 (CTC.infer): one wave per utterance, lane = symbol (S <= 64), state in registers.  Mirrors
+// ctc_beam_kernel for W = 1 term by term: the blank lane carries the prefix's "stay" entry (p_b from the blank, p_nb
+// from repeating the last symbol), every other lane the extension by its symbol (from p_b only when it repeats the last
+// symbol); nothing can merge (the beam holds no other prefix); first-touch order of an entry = 2 s (its symbol's turn in
+// the vocab-major loop), of the stay entry also 2 last + 1 (the repeat-merge) -- ctc_decoder.py:65-103.
+__global__ __launch_bounds__(64) void ctc_beam1_kernel(BeamArgs A) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int S = A.S, T = A.in_lens[b];
+    const float* lp = A.in + (long)b * A.sb;
+    int* out = A.out_labels + (long)b * A.T_max;
+    float pb = 0.0f, pnb = NEG_INF_F;
+    int last = -1, len = 0;
+    const bool live = lane < S;
+    float p_next = (live && T > 0) ? lp[lane] : NEG_INF_F;
+    for (int t = 0; t < T; ++t) {
+        const float p = p_next;
+        if (t + 1 < T) p_next = live ? lp[(long)(t + 1) * A.st + lane] : NEG_INF_F;  // the next row, a step ahead
+        float npb = NEG_INF_F, npnb = NEG_INF_F, score = NEG_INF_F, ord = 3.0e38f;
+        // log-probability of the prefix's last symbol (`last` is wave-uniform: v_readlane, outside divergent flow)
+        const float q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), last >= 0 ? last : 0));
+        if (live) {
+            ord = (float)(2 * lane);
+            if (lane == A.blank) {
+                npb = ref_lse2(pb + p, pnb + p);
+                if (last >= 0) {
+                    npnb = pnb + q;                       // ref_lse3(-inf, merge, ., 2) = merge exactly
+                    ord = fminf(ord, (float)(2 * last + 1));
+                }
+                score = ref_lse2(npb, npnb);
+            } else {
+                npnb = (lane != last) ? ref_lse2(pb + p, pnb + p) : pb + p;   // ctc_decoder.py:88-96
+                score = npnb;                             // ref_lse3(-inf, npnb, ., 2) = npnb exactly
+            }
+        }
+        // stable descending arg-max: score first, then the smallest first-touch order (unique per entry)
+        const float wbest = sa_wave_max_dpp(score);
+        const bool tie = live && score == wbest;
+        const float word = -sa_wave_max_dpp(tie ? -ord : -3.0e38f);
+        const unsigned long long win = __ballot(tie && ord == word);
+        const int w = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(win | (1ULL << 63)));
+        pb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, npb), w));
+        pnb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, npnb), w));
+        if (w != A.blank) {
+            last = w;
+            if (lane == 0 && len < A.T_max) out[len] = w;
+            ++len;
+        }
+    }
+    if (lane == 0) {
+        A.out_lens[b] = len < A.T_max ? len : A.T_max;
+        if (A.out_nll) A.out_nll[b] = -ref_lse2(pb, pnb);
+    }
+}
+
+// 4 waves per utterance: the candidate phase on all 256 threads, everything else on wave 0
+__global__ __launch_bounds__(256) void ctc_beam_kernel(BeamArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int S = A.S, W = A.W;
     const int ncand_max = W * S;
@@ -75,9 +177,11 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
     float* c_ord = c_score + ncand_max;                         // first-touch order (exact small integers in fp32)
     int* c_state = reinterpret_cast<int*>(c_ord + ncand_max);   // 0 = void, 1 = live, 2 = taken
     int* node_count = c_state + ncand_max;                      // [1]
+    int* s_nsel = node_count + 1;                               // [1] survivors of this step (written by wave 0)
 
     const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave0 = tid < 64;
     const int T = A.in_lens[b];
     int* node_parent = A.node_parent + (long)b * A.max_nodes;
     int* node_sym = A.node_sym + (long)b * A.max_nodes;
@@ -85,30 +189,20 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
     int* hvals = A.hvals + (long)b * A.hsize;
     const unsigned hmask = (unsigned)A.hsize - 1;
 
-    if (lane == 0) {
+    if (tid == 0) {
         b_pb[0] = 0.0f; b_pnb[0] = NEG_INF_F; b_node[0] = 0; b_last[0] = -1;
         node_parent[0] = -1; node_sym[0] = -1;
         *node_count = 1;
     }
-    int nb = 1;  // beam entries in use (wave-uniform)
+    int nb = 1;  // beam entries in use (block-uniform)
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        // ---- log-probabilities of this frame (ctc_decoder.py:52 after ctc_model.py:30-31)
+        // ---- log-probabilities of this frame: computed by ctc_logprob_kernel (ctc_decoder.py:52 after ctc_model.py:30-31)
         const float* row = A.in + (long)b * A.sb + (long)t * A.st;
-        if (A.is_logits) {
-            float m = -3.0e38f;
-            for (int s = lane; s < S; s += 64) m = fmaxf(m, row[s]);
-            m = sa_wave_max(m);
-            float z = 0.f;
-            for (int s = lane; s < S; s += 64) z += expf(row[s] - m);
-            z = sa_wave_sum(z);
-            for (int s = lane; s < S; s += 64) lp[s] = logf(expf(row[s] - m) / z);
-        } else {
-            for (int s = lane; s < S; s += 64) lp[s] = logf(row[s]);  // log(0) = -inf, as np.log
-        }
+        for (int s = tid; s < S; s += 256) lp[s] = row[s];
         // ---- where is each beam prefix's parent in the beam?
-        if (lane < nb) {
+        if (tid < nb) {
             const int par = node_parent[b_node[lane]];
             int ip = -1;
             for (int k = 0; k < nb; ++k)
@@ -119,7 +213,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
 
         // ---- candidates: slot (i, s); the blank slot of beam entry i carries its "stay" entry
         const int ncand = nb * S;
-        for (int c = lane; c < ncand; c += 64) {
+        for (int c = tid; c < ncand; c += 256) {
             const int i = c / S, s = c - i * S;
             const float pb = b_pb[i], pnb = b_pnb[i];
             const int last = b_last[i];
@@ -171,11 +265,13 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
         }
         __syncthreads();
 
-        // ---- stable descending selection of the top W (ctc_decoder.py:107-110)
+        // ---- stable descending selection of the top W (ctc_decoder.py:107-110): wave 0
+        if (wave0) {
         int nlive = 0;
         for (int c = lane; c < ncand; c += 64) nlive += c_state[c] != 0;
         nlive = (int)sa_wave_sum((float)nlive);
         const int nsel = min(W, nlive);
+        if (lane == 0) *s_nsel = nsel;
         for (int r = 0; r < nsel; ++r) {
             float best = NEG_INF_F, bord = 3.0e38f;
             int bidx = -1;
@@ -200,10 +296,14 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
                     n_last[r] = s;
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its next reads
+            __builtin_amdgcn_wave_barrier();
         }
+        }
+        __syncthreads();
+        const int nsel = *s_nsel;
         // ---- canonical trie nodes for the surviving extensions (hash table keyed by (parent node, symbol))
-        if (lane < nsel && n_node[lane] < 0) {
+        if (tid < nsel && n_node[tid] < 0) {
             const int code = -(n_node[lane] + 1);
             const int i = code / S, s = code - i * S;
             const int par = b_node[i];
@@ -224,7 +324,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
             n_node[lane] = id;
         }
         __syncthreads();
-        if (lane < nsel) {
+        if (tid < nsel) {
             b_pb[lane] = n_pb[lane]; b_pnb[lane] = n_pnb[lane];
             b_node[lane] = n_node[lane]; b_last[lane] = n_last[lane];
         }
@@ -233,7 +333,7 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(BeamArgs A) {
     }
 
     // ---- best prefix: walk the trie back to the root
-    if (lane == 0) {
+    if (tid == 0) {
         int node = b_node[0];
         int len = 0;
         for (int n = node; n > 0 && len < A.T_max; n = node_parent[n]) ++len;
@@ -277,13 +377,13 @@ __global__ __launch_bounds__(64) void ctc_greedy_kernel(const float* __restrict_
 }
 
 size_t beam_lds_bytes(int S, int W) {
-    return (size_t)(S + 9 * W + 5 * W * S + 4) * sizeof(float);
+    return (size_t)(S + 9 * W + 5 * W * S + 8) * sizeof(float);
 }
 
 }  // namespace
 
-static void beam_ws_layout(int max_T, int B, int W, int* max_nodes, int* hsize, size_t* o_par, size_t* o_sym,
-                           size_t* o_keys, size_t* o_vals, size_t* total) {
+static void beam_ws_layout(int max_T, int S, int B, int W, int* max_nodes, int* hsize, size_t* o_par, size_t* o_sym,
+                           size_t* o_keys, size_t* o_vals, size_t* o_lp, size_t* total) {
     *max_nodes = max_T * W + 2;
     int h = 64;
     while (h < 2 * (*max_nodes)) h <<= 1;
@@ -293,14 +393,15 @@ static void beam_ws_layout(int max_T, int B, int W, int* max_nodes, int* hsize, 
     *o_vals = o; o += sa_align_up((size_t)B * h * sizeof(int), 256);
     *o_par = o;  o += sa_align_up((size_t)B * (*max_nodes) * sizeof(int), 256);
     *o_sym = o;  o += sa_align_up((size_t)B * (*max_nodes) * sizeof(int), 256);
+    *o_lp = o;   o += sa_align_up((size_t)B * max_T * S * sizeof(float), 256);  // log-probabilities of every frame
     *total = o;
 }
 
 extern "C" size_t sa_ctc_beam_workspace_bytes(int max_T, int alphabet_size, int minibatch, int beam_size) {
     if (max_T <= 0 || alphabet_size <= 0 || minibatch <= 0 || beam_size <= 0) return 0;
     int mn, hs;
-    size_t a, b, c, d, total;
-    beam_ws_layout(max_T, minibatch, beam_size, &mn, &hs, &a, &b, &c, &d, &total);
+    size_t a, b, c, d, e, total;
+    beam_ws_layout(max_T, alphabet_size, minibatch, beam_size, &mn, &hs, &a, &b, &c, &d, &e, &total);
     return total;
 }
 
@@ -318,22 +419,32 @@ extern "C" ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long s
     if ((long)alphabet_size * beam_size * 2 + 2 * beam_size >= (1 << 24)) return CTC_STATUS_INVALID_VALUE;
     hipStream_t stream = (hipStream_t)stream_;
     BeamArgs A;
-    size_t o_par, o_sym, o_keys, o_vals, total;
-    beam_ws_layout(max_T, minibatch, beam_size, &A.max_nodes, &A.hsize, &o_par, &o_sym, &o_keys, &o_vals, &total);
+    size_t o_par, o_sym, o_keys, o_vals, o_lp, total;
+    beam_ws_layout(max_T, alphabet_size, minibatch, beam_size, &A.max_nodes, &A.hsize, &o_par, &o_sym, &o_keys, &o_vals,
+                   &o_lp, &total);
     if (workspace_bytes < total) return CTC_STATUS_INVALID_VALUE;
     char* ws = (char*)workspace;
-    A.in = in; A.st = stride_t; A.sb = stride_b; A.in_lens = d_input_lengths;
+    // every frame's log-probabilities, all rows in parallel: off the decode kernels' T-step chain
+    float* lpbuf = (float*)(ws + o_lp);
+    hipLaunchKernelGGL(ctc_logprob_kernel, dim3((unsigned)(((long)minibatch * max_T + 3) / 4)), dim3(256), 0, stream, in,
+                       stride_t, stride_b, d_input_lengths, alphabet_size, minibatch, max_T, input_is_logits, lpbuf);
+    A.in = lpbuf; A.st = alphabet_size; A.sb = (long)max_T * alphabet_size; A.in_lens = d_input_lengths;
     A.S = alphabet_size; A.B = minibatch; A.T_max = max_T; A.W = beam_size; A.blank = blank_label;
     A.is_logits = input_is_logits;
     A.out_labels = d_out_labels; A.out_lens = d_out_lens; A.out_nll = d_out_nll;
     A.node_parent = (int*)(ws + o_par); A.node_sym = (int*)(ws + o_sym);
     A.hkeys = (unsigned long long*)(ws + o_keys); A.hvals = (int*)(ws + o_vals);
+    if (beam_size == 1 && alphabet_size <= 64) {  // CTC.infer: no trie, no hash table
+        hipLaunchKernelGGL(ctc_beam1_kernel, dim3(minibatch), dim3(64), 0, stream, A);
+        SA_CHECK_LAUNCH();
+        return CTC_STATUS_SUCCESS;
+    }
     if (hipMemsetAsync(A.hkeys, 0, (size_t)minibatch * A.hsize * sizeof(unsigned long long), stream) != hipSuccess)
         return CTC_STATUS_MEMOPS_FAILED;
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds) != hipSuccess)
         return CTC_STATUS_EXECUTION_FAILED;
-    hipLaunchKernelGGL(ctc_beam_kernel, dim3(minibatch), dim3(64), lds, stream, A);
+    hipLaunchKernelGGL(ctc_beam_kernel, dim3(minibatch), dim3(256), lds, stream, A);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
