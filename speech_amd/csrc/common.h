@@ -76,3 +76,40 @@ __device__ __forceinline__ float sa_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- exact three-piece bf16 split of an fp32 number (the "x6" products of gemm_f32.hip and the fused recurrence kernels)
+// a = a1 + a2 + a3 exactly, each piece the round-to-nearest-even bf16 of what the previous ones left.  A product of two
+// split numbers is the sum of nine piece products, each exact in an fp32 accumulator; the six largest carry everything
+// down to 2^-26 of the product (a quarter of an fp32 ulp).
+typedef __bf16 sa_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned sa_cvt_pk_bf16(float lo, float hi) {  // {bf16(lo), bf16(hi)}
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sa_bf16_lo_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float sa_bf16_hi_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+// (x, y) -> three packed bf16 pairs whose sums are x and y
+__device__ __forceinline__ void sa_split2(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = sa_cvt_pk_bf16(x, y);
+    const float rx = x - sa_bf16_lo_as_f32(p1), ry = y - sa_bf16_hi_as_f32(p1);  // exact
+    p2 = sa_cvt_pk_bf16(rx, ry);
+    const float sx = rx - sa_bf16_lo_as_f32(p2), sy = ry - sa_bf16_hi_as_f32(p2);  // exact
+    p3 = sa_cvt_pk_bf16(sx, sy);
+}
+struct SaBf3 { sa_bf16x8 p[3]; };  // eight consecutive k of one row, as three bf16 planes
+__device__ __forceinline__ SaBf3 sa_split8(float4 lo, float4 hi) {
+    unsigned a[4], b[4], c[4];
+    sa_split2(lo.x, lo.y, a[0], b[0], c[0]);
+    sa_split2(lo.z, lo.w, a[1], b[1], c[1]);
+    sa_split2(hi.x, hi.y, a[2], b[2], c[2]);
+    sa_split2(hi.z, hi.w, a[3], b[3], c[3]);
+    SaBf3 r;
+    r.p[0] = __builtin_bit_cast(sa_bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+    r.p[1] = __builtin_bit_cast(sa_bf16x8, make_uint4(b[0], b[1], b[2], b[3]));
+    r.p[2] = __builtin_bit_cast(sa_bf16x8, make_uint4(c[0], c[1], c[2], c[3]));
+    return r;
+}
+// the six piece products in ascending size: (plane of A, plane of B)
+#define SA_X6_PA(o) ((o) == 0 ? 2 : ((o) == 1 ? 0 : ((o) == 2 ? 1 : ((o) == 3 ? 0 : ((o) == 4 ? 1 : 0)))))
+#define SA_X6_PB(o) ((o) == 0 ? 0 : ((o) == 1 ? 2 : ((o) == 2 ? 1 : ((o) == 3 ? 1 : ((o) == 4 ? 0 : 0)))))

@@ -409,20 +409,9 @@ __host__ __device__ __forceinline__ int pk_off(int p, int row, int h) {
     return p * PK_PLANE + row * 32 + ((h ^ ((row >> 3) & 1)) << 4);
 }
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // {bf16(lo), bf16(hi)}, round to nearest even
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float bf16_lo_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
-__device__ __forceinline__ float bf16_hi_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
-// (x, y) -> three packed bf16 pairs whose sums are x and y
+// the split itself: sa_split2 / sa_cvt_pk_bf16 (common.h)
 __device__ __forceinline__ void split2(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = cvt_pk_bf16(x, y);
-    const float rx = x - bf16_lo_as_f32(p1), ry = y - bf16_hi_as_f32(p1);  // exact
-    p2 = cvt_pk_bf16(rx, ry);
-    const float sx = rx - bf16_lo_as_f32(p2), sy = ry - bf16_hi_as_f32(p2);  // exact
-    p3 = cvt_pk_bf16(sx, sy);
+    sa_split2(x, y, p1, p2, p3);
 }
 
 struct PackArgs {
