@@ -34,15 +34,20 @@ namespace {
 #define NEG_INF_F (-__builtin_inff())
 
 // ctc_decoder.py:27-36 on up to three arguments, in order.  Arguments are float32 values or -inf.
+// A term equal to the maximum contributes exp(0.0) = 1.0 exactly and is not sent through exp (round 3: one double exp
+// fewer per call on the T-step chain; the value is unchanged bit for bit -- the terms are still added in argument order).
+__device__ __forceinline__ double ref_lse_term(float x, float m) {
+    return (x == NEG_INF_F) ? 0.0 : (x == m ? 1.0 : exp((double)(x - m)));
+}
 __device__ __forceinline__ float ref_lse3(float a, float b, float c, int n) {
     float m = a;
     if (n > 1 && b > m) m = b;
     if (n > 2 && c > m) m = c;
     if (m == NEG_INF_F) return NEG_INF_F;
     double tot = 0.0;
-    tot += (a == NEG_INF_F) ? 0.0 : exp((double)(a - m));
-    if (n > 1) tot += (b == NEG_INF_F) ? 0.0 : exp((double)(b - m));
-    if (n > 2) tot += (c == NEG_INF_F) ? 0.0 : exp((double)(c - m));
+    tot += ref_lse_term(a, m);
+    if (n > 1) tot += ref_lse_term(b, m);
+    if (n > 2) tot += ref_lse_term(c, m);
     return m + (float)log(tot);
 }
 
@@ -94,6 +99,8 @@ struct BeamArgs {
     int* node_sym;     // [B][max_nodes]
     unsigned long long* hkeys;  // [B][hsize]   (0 = empty)
     int* hvals;        // [B][hsize]
+    int trie_in_lds;   // the trie and its hash table fit the workgroup's LDS (the common case): no global atomics, no
+                       // dependent global loads on the T-step chain; else they live in the workspace arrays above
     int max_nodes, hsize;
 };
 
@@ -156,6 +163,8 @@ __global__ __launch_bounds__(64) void ctc_beam1_kernel(BeamArgs A) {
     }
 }
 
+__host__ __device__ inline size_t beam_lds_bytes_dev(int S, int W) { return (size_t)(S + 9 * W + 5 * W * S + 8) * sizeof(float); }
+
 // 4 waves per utterance: the candidate phase on all 256 threads, everything else on wave 0
 __global__ __launch_bounds__(256) void ctc_beam_kernel(BeamArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -187,6 +196,13 @@ __global__ __launch_bounds__(256) void ctc_beam_kernel(BeamArgs A) {
     int* node_sym = A.node_sym + (long)b * A.max_nodes;
     unsigned long long* hkeys = A.hkeys + (long)b * A.hsize;
     int* hvals = A.hvals + (long)b * A.hsize;
+    if (A.trie_in_lds) {
+        hkeys = reinterpret_cast<unsigned long long*>(smem_raw + ((beam_lds_bytes_dev(S, W) + 15) & ~(size_t)15));
+        hvals = reinterpret_cast<int*>(hkeys + A.hsize);
+        node_parent = hvals + A.hsize;
+        node_sym = node_parent + A.max_nodes;
+        for (int k = tid; k < A.hsize; k += 256) hkeys[k] = 0ULL;
+    }
     const unsigned hmask = (unsigned)A.hsize - 1;
 
     if (tid == 0) {
@@ -197,10 +213,18 @@ __global__ __launch_bounds__(256) void ctc_beam_kernel(BeamArgs A) {
     int nb = 1;  // beam entries in use (block-uniform)
     __syncthreads();
 
+    // a frame's log-probabilities (computed by ctc_logprob_kernel: ctc_decoder.py:52 after ctc_model.py:30-31) are
+    // requested a step ahead: the global load is not on the step's chain (S <= 256: one value per thread)
+    const float* rows = A.in + (long)b * A.sb;
+    float lp_next = (tid < S && T > 0) ? rows[tid] : 0.f;
     for (int t = 0; t < T; ++t) {
-        // ---- log-probabilities of this frame: computed by ctc_logprob_kernel (ctc_decoder.py:52 after ctc_model.py:30-31)
-        const float* row = A.in + (long)b * A.sb + (long)t * A.st;
-        for (int s = tid; s < S; s += 256) lp[s] = row[s];
+        const float* row = rows + (long)t * A.st;
+        if (S <= 256) {
+            if (tid < S) lp[tid] = lp_next;
+            if (tid < S && t + 1 < T) lp_next = row[A.st + tid];
+        } else {
+            for (int s = tid; s < S; s += 256) lp[s] = row[s];
+        }
         // ---- where is each beam prefix's parent in the beam?
         if (tid < nb) {
             const int par = node_parent[b_node[lane]];
@@ -376,9 +400,7 @@ __global__ __launch_bounds__(64) void ctc_greedy_kernel(const float* __restrict_
     if (lane == 0) out_lens[b] = base;
 }
 
-size_t beam_lds_bytes(int S, int W) {
-    return (size_t)(S + 9 * W + 5 * W * S + 8) * sizeof(float);
-}
+size_t beam_lds_bytes(int S, int W) { return beam_lds_bytes_dev(S, W); }
 
 }  // namespace
 
@@ -439,12 +461,19 @@ extern "C" ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long s
         SA_CHECK_LAUNCH();
         return CTC_STATUS_SUCCESS;
     }
-    if (hipMemsetAsync(A.hkeys, 0, (size_t)minibatch * A.hsize * sizeof(unsigned long long), stream) != hipSuccess)
+    // the prefix trie + its hash table in LDS when they fit (T' = 498, beam 8: 128 KB): a survivor's node is found / made
+    // with LDS atomics and a prefix's parent read from LDS, instead of global atomics and dependent global loads per step
+    const size_t trie = (size_t)A.hsize * 12 + (size_t)A.max_nodes * 8;
+    const size_t lds_all = ((lds + 15) & ~(size_t)15) + trie;
+    A.trie_in_lds = lds_all <= 150 * 1024 ? 1 : 0;
+    const size_t lds_req = A.trie_in_lds ? lds_all : lds;
+    if (!A.trie_in_lds &&
+        hipMemsetAsync(A.hkeys, 0, (size_t)minibatch * A.hsize * sizeof(unsigned long long), stream) != hipSuccess)
         return CTC_STATUS_MEMOPS_FAILED;
-    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds) != hipSuccess)
+    if (lds_req > 48 * 1024 && hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds_req) != hipSuccess)
         return CTC_STATUS_EXECUTION_FAILED;
-    hipLaunchKernelGGL(ctc_beam_kernel, dim3(minibatch), dim3(256), lds, stream, A);
+    hipLaunchKernelGGL(ctc_beam_kernel, dim3(minibatch), dim3(256), lds_req, stream, A);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }

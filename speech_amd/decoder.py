@@ -30,8 +30,10 @@ def _prep(x, lengths):
 
 
 def _to_lists(labels, lens):
-    labels, lens = labels.cpu().numpy(), lens.cpu().numpy()
-    return [tuple(int(v) for v in labels[b, :lens[b]]) for b in range(len(lens))]
+    """(B, T) int32 labels + (B,) lengths on the GPU -> list of tuples: ONE device-to-host copy (the lengths ride in an
+    extra column), then NumPy slicing (no per-label Python loop)."""
+    both = torch.cat([lens.view(-1, 1), labels], dim=1).cpu().numpy()
+    return [tuple(both[b, 1:1 + both[b, 0]].tolist()) for b in range(both.shape[0])]
 
 
 def beam_decode(x, beam_size=10, blank=0, input_is_logits=False, lengths=None):
