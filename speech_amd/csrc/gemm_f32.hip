@@ -935,7 +935,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     // The split-bf16 kernel on packed operands for every product that is worth two pack launches, when the caller's
     // workspace has room for the packed copies; SA_GEMM_EXACT=1 (read per call): the f32-input MFMA kernel everywhere.
     const bool filtered = opts && opts->xcc_mask && opts->tile_counter;
-    bool use_pk = pk_worth_it(M, N, K, nprob) && !filtered && !(opts && opts->pad_lds);
+    bool use_pk = pk_worth_it(M, N, K, nprob) && !filtered;
     const size_t pkA = sa_align_up(pk_bytes(M, K), 256), pkB = sa_align_up(pk_bytes(N, K), 256);
     const int pk_kt = 8, pk_parts = 2 * ((((K + PK_K - 1) / PK_K) + pk_kt - 1) / pk_kt);
     const int Mpad = (M + BM - 1) / BM * BM;
@@ -972,25 +972,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         // block b lands on XCD b % 8: launch enough blocks that the allowed XCDs alone receive `tiles` of them
         grid = dim3((unsigned)((tiles + allowed - 1) / allowed * 8 + 8), 1, 1);
     }
-    // "polite" launches (opts->pad_lds): dynamic LDS on top of the kernel's 66 KB so that a CU admits ONE block of this
-    // launch -- what a side-stream GEMM wants while a persistent recurrence kernel holds every CU (gru.hip): the
-    // recurrence blocks then always find room, before and after this launch's blocks arrive.
-    size_t dyn = 0;
-    if (opts && opts->pad_lds) {
-        static bool attr_set_dev[16] = {false};  // function attributes are per device
-        int devid = 0;
-        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
-        bool& attr_set = attr_set_dev[devid];
-        dyn = 81 * 1024 - sizeof(float) * 2 * 2 * TILE_F;
-        if (!attr_set) {
-            const void* fns[4] = {(const void*)gemm_f32_kernel<true, true>, (const void*)gemm_f32_kernel<true, false>,
-                                  (const void*)gemm_f32_kernel<false, true>, (const void*)gemm_f32_kernel<false, false>};
-            for (int i = 0; i < 4; ++i)
-                if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
-                    return CTC_STATUS_EXECUTION_FAILED;
-            attr_set = true;
-        }
-    }
+    const size_t dyn = 0;
     if (g.xcc_mask) {
         if (trans_a) {
             if (trans_b) hipLaunchKernelGGL((gemm_f32_filtered_kernel<true, true>), grid, dim3(256), 0, stream, g);

@@ -246,7 +246,8 @@ __device__ __forceinline__ int xcc_id() {  // s_getreg_b32 hwreg(HW_REG_XCC_ID =
     return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;
 }
 
-template <bool WREG>  // W_hh fragments resident in registers (XCD-local mode, H <= 512) instead of LDS
+template <bool WREG>  // W_hh fragments resident in registers (always true: the LDS-weights variant served the retired
+                      // chip-wide groups)
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     if (WREG) SA_PERSIST_EXCLUSIVE(P.prio);
@@ -881,8 +882,8 @@ struct PBwdJobs {
 //           them (lane g reads float4 #g of the pieces it = g mod 4: a quarter of the bytes, every (row, piece)
 //           still probed) -- then ONE full trip, checked in full (a torn piece just sends the wave back to polling).
 // SLEEP: s_sleep between failed trips (64-cycle units): yields issue slots and memory bandwidth to the co-resident block.
-template <int POLL, int SLEEP>
 __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
+    constexpr int POLL = 0, SLEEP = 0;  // the light-trip / s_sleep polling variants of round 2 (measured 17 % slower) are retired
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
     SA_PERSIST_EXCLUSIVE(P.prio);
@@ -1494,17 +1495,11 @@ __global__ void side_delay_kernel(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-int wgrad_every() {  // persistent launches between two hand-overs of weight-gradient work to the side stream
-    const char* e = getenv("SA_GRU_WG_EVERY");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 4;
-}
-
 // uni = the layer wavefront of a unidirectional stack (all 8 XCDs busy: the GEMM blocks share CUs with recurrence
 // blocks); bidirectional layers keep half the chip idle.  Measured at S-LIBRI (profiles/r02_overlap_*): beside a GEMM
 // block a recurrence launch takes 230-310 us instead of 169 (its MFMAs queue behind the GEMM's 64-cycle ones, its
 // exchange loads behind the GEMM's tile loads) and the GEMM runs at a third of its speed -- 15.4 ms per step against
-// 12.1 -- so the unidirectional default is OFF (SA_GRU_OVERLAP=1 switches it on).
+// 12.1 -- so unidirectional stacks run their weight gradients behind the recurrence (that side-stream path is retired).
 // Bidirectional layers leave XCDs idle (a layer's groups sit on XCDs 0 .. u-1), and XCD-FILTERED side GEMMs keep off the
 // busy ones.  Three things had to hold before that paid (profiles/r02_bidirectional_overlap_trace.txt):
 //   * one tile per block, not a persistent tile loop: the dispatcher walks a grid in order, so long-lived GEMM blocks on
@@ -1513,12 +1508,11 @@ int wgrad_every() {  // persistent launches between two hand-overs of weight-gra
 //   * the filtered GEMM must fit BESIDE a recurrence block (<= 232 registers: the one-stage kernel), or its own surplus
 //     blocks on the busy XCDs -- and the launch's completion -- wait for the recurrence to end.
 // With all three: bidirectional S-LIBRI 36.3 -> 30.9 ms per step (backward stack 22.2 -> 17.7 ms: the 2.9 ms of weight-
-// gradient products of a layer run entirely inside the next layer's 2.96 ms recurrence).  ON by default for
-// bidirectional stacks, OFF for unidirectional ones (all 8 XCDs busy: see above); SA_GRU_OVERLAP=0 / 1 forces either.
-bool overlap_enabled(bool uni) {
+// gradient products of a layer run entirely inside the next layer's 2.96 ms recurrence).  ON for bidirectional stacks;
+// SA_GRU_OVERLAP=0 switches it off (A/B runs).
+bool overlap_enabled() {
     const char* e = getenv("SA_GRU_OVERLAP");
-    if (e) return e[0] != '0';
-    return !uni;
+    return !(e && e[0] == '0');
 }
 
 
@@ -1529,7 +1523,7 @@ static ctcStatus_t gemm_whole(int trans_a, int trans_b, int M, int N, int K, con
                               long ldb, float beta, float* C, long ldc, const float* bias, void* ws, size_t ws_bytes,
                               hipStream_t stream) {
     SaGemmOpts o;
-    o.no_split = 1; o.pad_lds = 0; o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr;
+    o.no_split = 1; o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr;
     return sa_gemm_f32_group_impl(1, trans_a, trans_b, M, N, K, 1.f, &A, lda, &B, ldb, beta, &C, ldc, &bias, nullptr, ws,
                                   ws_bytes, stream, &o);
 }
@@ -1760,13 +1754,11 @@ static int device_cus() {
     return cus;
 }
 
-// Opt-in experiment (SA_GRU_PERSIST=1).  Measured on MI355X at S-LIBRI (tools/gru_persist_check.py,
-// tools/gru_persist_timing.py): bit-identical to the step kernels but 8.1 ms vs 7.0 ms per stack forward -- an
-// in-kernel step costs ~10 us (4.9 us waiting for the group's publish, 2.7 us reading the fresh 32 KB h rows with
-// sc1 loads, 1.3 us MFMA, 1 us epilogue + drain), i.e. the all-to-all seam is as expensive as the kernel boundary.
-static int persist_mode() {  // 2 XCD-local groups (default where eligible), 1 chip-wide groups, 0 off
+// (Round 1's chip-wide persistent groups -- SA_GRU_PERSIST=1: one sync group spanning XCDs, an in-kernel step of ~10 us
+// against a 9 us kernel boundary -- are retired; the finding is in DESIGN.md 3.3.)
+static int persist_mode() {  // 2: XCD-local groups (default where eligible); 0: off (SA_GRU_PERSIST=0, or after a failure)
     const char* e = getenv("SA_GRU_PERSIST");
-    const int m = e ? (e[0] == '1' ? 1 : ((e[0] == '2' || e[0] == '3') ? 2 : 0)) : 2;
+    const int m = e ? ((e[0] == '2' || e[0] == '3') ? 2 : 0) : 2;
     return (m == 2 && g_health.disabled) ? 0 : m;
 }
 static bool flagless_mode() {  // the flag-less (sentinel) hand-off is the default; SA_GRU_PERSIST=2 keeps the counters
@@ -1800,20 +1792,10 @@ static bool xcd_shape_ok(int jobs, int B, int H) {
 // batch tiles one persistent launch can host next to `jobs` concurrent jobs: 8 XCDs x (32 / ntile_u) groups
 static int tiles_per_pass(int jobs, int H) { return (8 * (32 / (H / 16))) / jobs; }
 // XCD-local kernels are one-per-CU through their register reservation (SA_PERSIST_EXCLUSIVE), so they ask for the LDS
-// they use and nothing more: <= 79 KB leaves room for one "polite" (81 KB) side-stream GEMM block beside them
-static size_t xcd_lds(size_t need) {
-    const char* e = getenv("SA_GRU_LDS_KB");  // experiment: a floor on the request
-    const size_t fl = e ? (size_t)atoi(e) * 1024 : 0;
-    return need < fl ? fl : need;
-}
+// they use and nothing more (an XCD-filtered side-stream GEMM block fits beside them)
+static size_t xcd_lds(size_t need) { return need; }
 typedef void (*BwdPersistFn)(PBwdJobs);
-static BwdPersistFn bwd_persist_fn() {  // SA_GRU_POLL = 0 / 1 (light trips), SA_GRU_SLEEP = 0 / 1 / 2
-    const char* pe = getenv("SA_GRU_POLL");
-    const char* se = getenv("SA_GRU_SLEEP");
-    const int poll = pe ? atoi(pe) : 0, sl = se ? atoi(se) : 0;  // measured: light trips cost 17 % (r2c)
-    if (poll == 0) return sl >= 1 ? gru_bwd_persist_kernel<0, 1> : gru_bwd_persist_kernel<0, 0>;
-    return sl >= 2 ? gru_bwd_persist_kernel<1, 2> : (sl == 1 ? gru_bwd_persist_kernel<1, 1> : gru_bwd_persist_kernel<1, 0>);
-}
+static BwdPersistFn bwd_persist_fn() { return gru_bwd_persist_kernel; }
 static int fwd_chunks(int T) {  // bidirectional forward: time chunks per layer for the projection / recurrence overlap
     const char* e = getenv("SA_GRU_FWD_CHUNKS");
     const int v = e ? atoi(e) : 0;
@@ -1835,10 +1817,7 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false) {
     if (H == 256) return fuse ? (drop ? gru_bwd_fused_kernel<4, true, true> : gru_bwd_fused_kernel<4, true>) : gru_bwd_fused_kernel<4, false>;
     return nullptr;
 }
-static int persist_prio() {
-    const char* e = getenv("SA_GRU_PRIO");
-    return e ? atoi(e) : 1;
-}
+static int persist_prio() { return 1; }  // the recurrence waves issue at raised priority (s_setprio 3)
 
 static int clamp_chunk(int chunk, int T) {
     // measured on MI355X at S-LIBRI, whole train step: step kernels 16 -> 19.6 ms, 32 -> 19.9, 8 -> 20.5;
@@ -1960,7 +1939,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
         const int bi_used = (2 * min(bi_tpp, bi_nbt) + per_xcd - 1) / per_xcd;
         const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
         const int nck = fwd_chunks(T);
-        const bool fside = bi_xcd && bi_mask && nck > 1 && T >= 16 * nck && bi_nbt <= bi_tpp && overlap_enabled(false) &&
+        const bool fside = bi_xcd && bi_mask && nck > 1 && T >= 16 * nck && bi_nbt <= bi_tpp && overlap_enabled() &&
                            L * (nck - 1) <= kSyncTileWords && g_side.init();
         const int S = (T + nck - 1) / nck;
         int side_launch = 0;
@@ -1979,7 +1958,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                     gA[d] = in + r0 * I; gB[d] = w_ih[l * 2 + d]; gC[d] = ai_of(l, d) + r0 * 3 * H; gbias[d] = b_ih[l * 2 + d];
                 }
                 SaGemmOpts o;
-                o.no_split = 1; o.pad_lds = 0; o.colsum = nullptr; o.xcc_mask = mask;
+                o.no_split = 1; o.colsum = nullptr; o.xcc_mask = mask;
                 o.tile_counter = mask ? sync + kSyncTiles + side_launch++ : nullptr;
                 o.err_word = g_health.dev;  // a filtered launch that did not cover its tiles stops the step's update
                 return sa_gemm_f32_group_impl(2, 0, 1, n * B, 3 * H, I, 1.f, gA, I, gB, I, 0.f, gC, 3 * H, gbias, nullptr,
@@ -2057,14 +2036,13 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     const int nch = (T + chunk - 1) / chunk;
     // persistent chunk kernel: needs every block co-resident (one per CU) and its W_hh slice in LDS
     const int nbt = (B + 15) / 16, ntile_u = H / 16;
-    size_t plds = ((size_t)48 * (H + 4) + 2 * 4 * 3 * 256) * sizeof(float);
+    size_t plds = 0;
     const bool persist_common = persist_mode() != 0 && g_health.init() && ch.n == 1 && (H % 64) == 0 &&
                                 L * nbt <= kSyncErr && (long)T * B * H * 4 < 0x7fffffffL;
     // XCD-local groups: 8 XCDs x 32 CUs, 32 / ntile_u (layer, batch tile) groups per XCD; larger batches run in passes over
     // their batch tiles (tiles_per_pass), so the chip-wide "every block co-resident" bound does not apply to them
     const bool xcd = persist_common && xcd_shape_ok(L, B, H);
-    bool persist = xcd || (persist_common && plds <= 160 * 1024 && (long)L * ntile_u * nbt <= device_cus());
-    if (persist_mode() == 2 && !xcd) persist = false;
+    const bool persist = xcd;
     if (xcd) plds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
     unsigned persist_launches = 0;
     const bool flagless = xcd && flagless_mode();
@@ -2107,8 +2085,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     }
     if (persist) {
         if (hipMemsetAsync(sync, 0, kSyncBytes, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
-        if (hipFuncSetAttribute(xcd ? (const void*)gru_fwd_persist_kernel<true> : (const void*)gru_fwd_persist_kernel<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gru_fwd_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
     }
     for (int w = 0; w < nch + L - 1; ++w) {
@@ -2170,8 +2148,6 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                     if (bt0 > 0) Q.stamp = nullptr;
                     hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), plds, stream, Q);
                 }
-            } else {
-                hipLaunchKernelGGL(gru_fwd_persist_kernel<false>, dim3(ntile_u, nbt, n), dim3(256), plds, stream, Q);
             }
             continue;
         }
@@ -2263,12 +2239,10 @@ namespace {
 // Parameter gradients of the stack, produced INSIDE the backward call so that the library can schedule them:
 //   dW_ih[l,d] = dai[l,d]^T in_l      (in_0 = x, in_l = h_out[l-1])        db_ih[l,d] = column sums of dai[l,d]
 //   dW_hh[l,d] = dah[l,d]^T h_prev    (h_prev = stash[l,d][:, 4H:5H])      db_hh[l,d] = column sums of dah[l,d]
-// As soon as a span of time steps of a layer is final (its persistent launch has retired) these products go out on a
-// SIDE stream as "polite" GEMM launches (one block per CU, bias gradients fused in): the recurrence kernels are
-// latency-bound -- their blocks use ~20 % of a CU's matrix-pipe time and 264 of its 512 registers per lane -- so a GEMM
-// block fits beside each of them and the weight gradients ride on the idle MFMA cycles instead of queueing behind the
-// whole backward pass (2.8 ms of 12.4 at S-LIBRI in round 1).  SA_GRU_OVERLAP=0: same products, issued on the
-// caller's stream after the recurrence.
+// Same-shaped products of all layers share grouped launches with the bias gradients fused in (row sums taken by the
+// pack kernel of the split-bf16 path, gemm_f32.hip).  Bidirectional stacks: a finished layer's products go out on a SIDE
+// stream as XCD-filtered launches that run on the XCDs the next layer's recurrence leaves idle (SA_GRU_OVERLAP=0: on the
+// caller's stream after the recurrence, as unidirectional stacks always do -- their recurrence holds all 8 XCDs).
 struct WGrad {
     const float* x;               // (T, B, I0)
     const float* const* h_out;    // [L] (T, B, D*H)
@@ -2286,7 +2260,6 @@ struct WGradIssuer {
     float* const* dai;
     float* const* dah;
     int L, D, B, T, H, I0;
-    bool polite;
     const float* lower[kMaxJobs]; // layer l's input as the forward pass fed it (l >= 1): h_out[l-1], or its dropped copy
     unsigned xcc_mask = 0;        // != 0: the launches keep to these XCDs (the ones the recurrence leaves idle)
     unsigned* counters = nullptr; // zeroed device words, one per filtered launch
@@ -2296,8 +2269,8 @@ struct WGradIssuer {
     size_t ws_bytes = 0;
     bool first_ih[2 * kMaxJobs], first_hh[2 * kMaxJobs];
     WGradIssuer(const WGrad& w, const float* const* st, float* const* da, float* const* dh, int L_, int D_, int B_,
-                int T_, int H_, int I0_, bool pol)
-        : wg(w), stash(st), dai(da), dah(dh), L(L_), D(D_), B(B_), T(T_), H(H_), I0(I0_), polite(pol) {
+                int T_, int H_, int I0_)
+        : wg(w), stash(st), dai(da), dah(dh), L(L_), D(D_), B(B_), T(T_), H(H_), I0(I0_) {
         for (int i = 0; i < 2 * kMaxJobs; ++i) first_ih[i] = first_hh[i] = true;
         for (int l = 0; l < kMaxJobs; ++l) lower[l] = l >= 1 && l < L && wg.h_out ? wg.h_out[l - 1] : nullptr;
     }
@@ -2307,7 +2280,7 @@ struct WGradIssuer {
         bool done_ih[2 * kMaxJobs], done_hh[2 * kMaxJobs];
         for (int k = 0; k < n; ++k) done_ih[k] = done_hh[k] = spans[k][1] <= spans[k][0];
         SaGemmOpts o;
-        o.no_split = allow_split ? 0 : 1; o.pad_lds = polite ? 1 : 0;
+        o.no_split = allow_split ? 0 : 1;
         o.xcc_mask = 0; o.tile_counter = nullptr;
         for (int pass = 0; pass < 2; ++pass) {      // 0: dW_hh (N = H, B operand = stash h_prev), 1: dW_ih
             bool* done = pass == 0 ? done_hh : done_ih;
@@ -2336,7 +2309,7 @@ struct WGradIssuer {
                 }
                 o.colsum = gS;
                 if (xcc_mask && counters && next_counter < max_counters) {
-                    o.xcc_mask = xcc_mask; o.tile_counter = counters + next_counter++; o.pad_lds = 0;
+                    o.xcc_mask = xcc_mask; o.tile_counter = counters + next_counter++;
                     o.err_word = err_word;
                 } else {
                     o.xcc_mask = 0; o.tile_counter = nullptr;
@@ -2388,7 +2361,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const size_t wws_bytes = wgrad_ws_bytes(L, D, B, T, H, I0);
     const size_t gws_bytes = workspace_bytes - fixed_bytes - kSyncBytes - wws_bytes;
     char* wws = gws + gws_bytes;
-    WGradIssuer issuer(wg ? *wg : WGrad{}, stash, dai, dah, L, D, B, T, H, I0, false);
+    WGradIssuer issuer(wg ? *wg : WGrad{}, stash, dai, dah, L, D, B, T, H, I0);
     issuer.ws = wws; issuer.ws_bytes = wws_bytes;
     if (drop_on) for (int l = 1; l < L; ++l) issuer.lower[l] = dc.h_drop[l - 1];
     // everything that is still owed when the recurrence is done goes out on the caller's stream (the fallback path)
@@ -2398,7 +2371,6 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         if (!wg) return CTC_STATUS_SUCCESS;
         int spans[2 * kMaxJobs][2];
         for (int k = 0; k < L * D; ++k) { spans[k][0] = 0; spans[k][1] = wg_hi[k]; wg_hi[k] = 0; }
-        issuer.polite = false;
         return issuer.issue(spans, stream, true);
     };
     unsigned* sync = (unsigned*)(ws + workspace_bytes - kSyncBytes);
@@ -2439,7 +2411,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         // the layer above run on the OTHER XCDs meanwhile (XCD-filtered persistent-tile GEMM launches on the side stream)
         const int bi_used = (2 * min(bi_tpp, bi_nbt) + (32 / (H / 16)) - 1) / (32 / (H / 16));
         const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
-        const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled(false) && g_side.init();
+        const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled() && g_side.init();
         issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords; issuer.err_word = g_health.dev;
         // tiled exchange, operands a step ahead (gru_bwd_fused_kernel without the second product): H = 512 / 256
         const BwdPersistFn bi_tiled_fn = bi_xcd && flagless_mode() && (long)T * bi_nbt * 16 * 3 * H * 4 < 0x7fffffffL
@@ -2460,7 +2432,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                         if (!sentinel_fill(bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : dah[l * 2 + d],
                                            bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
@@ -2512,7 +2484,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 for (int d = 0; d < 2; ++d) { spans[l * 2 + d][1] = T; wg_hi[l * 2 + d] = 0; }
                 if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
                 hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // ~40 us
-                issuer.polite = false; issuer.xcc_mask = bi_mask;
+                issuer.xcc_mask = bi_mask;
                 st = issuer.issue(spans, g_side.s, true);
                 issuer.xcc_mask = 0;
                 if (st != CTC_STATUS_SUCCESS) return st;
@@ -2555,10 +2527,9 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     }
     if (tiled && hipFuncSetAttribute((const void*)tiled_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds) != hipSuccess)
         return CTC_STATUS_EXECUTION_FAILED;
-    // weight gradients ride beside the persistent launches: every kWgEvery launches, the time steps that have become
-    // final since the last hand-over go to the side stream
-    const bool side = wg && xcd && overlap_enabled(true) && g_side.init();
-    const int wg_every = wgrad_every();
+    // (unidirectional stacks hold all 8 XCDs: weight-gradient GEMMs beside the recurrence slowed both -- 12.1 -> 15.1 ms
+    // per step in round 2, profiles/r02_overlap_experiments.txt -- and that side-stream path is retired; the products
+    // run behind the recurrence, wgrad_rest below)
     if (xcd) {
         if (hipMemsetAsync(sync, 0, getenv("SA_GRU_TIMING") ? kSyncBytes : 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2576,7 +2547,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr; Q.drop = dc.drop;
-        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
             PBwdJob& J = Q.j[n];
             J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
@@ -2637,7 +2608,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
             Q.drop = dc.drop;
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = getenv("SA_GRU_PACKED") ? atoi(getenv("SA_GRU_PACKED")) : 1; Q.reg = sync + kSyncReg;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
@@ -2663,24 +2634,6 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     if (bt0 > 0) Q.stamp = nullptr;
                     if (tiled) hipLaunchKernelGGL(tiled_fn, dim3(256), dim3(256), flds, stream, Q);
                     else hipLaunchKernelGGL(bwd_persist_fn(), dim3(256), dim3(256), plds, stream, Q);
-                }
-            }
-            if (side && ((w + 1) % wg_every == 0 || w == nch + L - 2)) {
-                int spans[2 * kMaxJobs][2];
-                bool any = false;
-                for (int l = 0; l < L; ++l) {
-                    int cc = w - (L - 1 - l);           // chunks 0 .. cc (counted from the end) of layer l are final
-                    if (cc > nch - 1) cc = nch - 1;
-                    const int lo = cc >= 0 ? (nch - 1 - cc) * chunk : T;
-                    spans[l][0] = lo; spans[l][1] = wg_hi[l];
-                    any = any || lo < wg_hi[l];
-                    wg_hi[l] = lo;
-                }
-                if (any) {
-                    if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
-                    issuer.polite = true;
-                    st = issuer.issue(spans, g_side.s, false);
-                    if (st != CTC_STATUS_SUCCESS) return st;
                 }
             }
             continue;
@@ -2712,7 +2665,6 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         st = gemm_whole(0, 0, T * B, I0, 3 * H, dai[0], 3 * H, w_ih[0], I0, 0.f, dx, I0, nullptr, gws, gws_bytes, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
     }
-    if (side && !g_side.order(g_side.s, stream)) return CTC_STATUS_EXECUTION_FAILED;  // join
     return wgrad_rest();
 }
 }  // namespace

@@ -368,26 +368,6 @@ def test_multi_stream_chains_are_bit_identical():
         assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
 
 
-def test_persistent_chunk_kernel_is_bit_identical():
-    """SA_GRU_PERSIST=1 (LDS-resident W_hh, in-kernel hand-offs; measured slower) vs the step kernels."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "from tests.test_gpu_blocks import _stack_case\nfrom speech_amd import ops\n"
-            "x, w_ih, b_ih, w_hh, b_hh = _stack_case(4, 32, 50, 40, 128)\n"
-            "h, st = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, 4, 1, 128, want_stash=True)\n"
-            "torch.cuda.synchronize(); torch.save([t.cpu() for t in h + st], sys.argv[1])\n") % (root, root)
-    res = []
-    for mode in ("0", "1"):
-        out = "/tmp/sa_persist_%s.pt" % mode
-        env = dict(os.environ, SA_GRU_PERSIST=mode)
-        subprocess.run([sys.executable, "-c", code, out], env=env, check=True, timeout=120)
-        res.append(torch.load(out))
-    assert len(res[0]) == len(res[1]) and all(torch.equal(a, b) for a, b in zip(*res))
-
-
 def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     """The default recurrence path at 512-wide unidirectional stacks (XCD-local persistent chunk kernels, forward and
     backward) against the one-launch-per-step kernels (SA_GRU_PERSIST=0): every output bit-identical,
