@@ -41,6 +41,7 @@ S_LIBRI = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2]],
 B, T, F, V, L = 32, 1000, 80, 28, 100
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFS = 157.3    # f32-input MFMA = fp32 vector peak
+BF16_MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def synthetic(rank):
@@ -258,9 +259,18 @@ def stack_gemm_rates(dev, Tp):
         flops += 2.0 * M * N * K * count
         secs += ms * 1e-3 * count
     ach = flops / secs / 1e12
-    return {"kernel": "gemm_f32_kernel (the GEMM families inside the GRU stack, standalone launches, weighted by their "
-                      "count per step)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_F32_PEAK_TFS, "traffic": None, "gflop_per_step": flops / 1e9, "shapes": out}
+    # These shapes run the split-bf16 kernel on packed operands (csrc/gemm_f32.hip): three bf16 pieces per fp32 operand,
+    # six piece products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulate.  `achieved` counts the ALGORITHMIC
+    # fp32 flops (2 M N K) over the whole call (pack launches included); the roofline that bounds it is the dense bf16
+    # MFMA peak divided by the six MFMA flops an fp32 flop costs -- not the f32-input MFMA peak, which it exceeds on
+    # some shapes.
+    peak = BF16_MFMA_PEAK_TFS / 6.0
+    return {"kernel": "gemm_pk_kernel / gemm_pk256_kernel + pack kernels (the GEMM families inside the GRU stack, standalone "
+                      "calls incl. their pack launches, weighted by their count per step)", "bound": "mfma",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent: 2*M*N*K per call)", "frac": ach / peak,
+            "peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 piece products per fp32 product",
+            "frac_of_f32_mfma_peak": ach / MFMA_F32_PEAK_TFS, "traffic": None, "gflop_per_step": flops / 1e9,
+            "shapes": out}
 
 
 def kernel_source_sha():
@@ -354,6 +364,9 @@ def main():
         "value": B * world * args.steps / r["dt"], "unit": "utt/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seed 2017; random-init weights)",
+        "dtype_note": "fp32 storage and accumulation throughout; recurrences, convolutions and small products on the "
+                      "f32-input MFMA; the large GEMMs multiply exact three-piece bf16 splits of their fp32 operands on "
+                      "the bf16 MFMA (six piece products per fp32 product, dropped terms < 2^-26 of it)",
         "config": {"workload": "S-LIBRI M-STEP: full CTC train step (fwd + CTC loss + bwd + clip 200 + SGD), "
                                "B=32 per GPU, T=1000, F=80, |V|+1=29, L=100, conv [32,5,32,2] -> T'=%d, "
                                "4xGRU-512 uni, fc->29, %d params" % (r["Tp"], r["params"]),
