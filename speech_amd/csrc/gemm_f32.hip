@@ -77,7 +77,15 @@ struct GemmArgs {
     unsigned xcc_mask;
     unsigned* tile_counter;
     int grid_x, grid_y, grid_z;
+    // packed kernels only: A's packed row block of output row block `by` is by (by < a_rb_split) or by + a_rb_jump -- a
+    // product that uses rows [0, s) and [s + j, ...) of a packed operand shared with another product (sa_gemm_pk_group)
+    int a_rb_split, a_rb_jump;
+    unsigned a_jump_probs;  // bit p: problem p of the group uses the jump
 };
+
+__device__ __forceinline__ int pk_a_rb(const GemmArgs& g, int prob, int rb) {
+    return (rb >= g.a_rb_split && ((g.a_jump_probs >> prob) & 1u)) ? rb + g.a_rb_jump : rb;
+}
 
 __device__ __forceinline__ long remap_row(const GemmArgs& g, int row) {
     const int q = row / g.m_inner;
@@ -423,6 +431,9 @@ struct PackArgs {
     int vec;               // 16-byte loads are legal (k-contiguous form)
     float* cs_part;        // m-contiguous form: row sums [problem][part][Rpad] (part = 2 blockIdx.x + wave / 2), or null
     int Rpad;
+    // m-contiguous form: rows >= R_lo come from src_hi (same ld), row r at src_hi[p][k * ld + (r - R_lo)]; R_lo = R: unused
+    const float* src_hi[kMaxGroup];
+    int R_lo;
 };
 
 // X[r][k] = src[r * ld + k] (k-contiguous memory).  grid (ceil(KB / kt), RB, nprob); thread t: rows t/4 and t/4 + 64,
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(256) void pk_pack_mcontig_kernel(PackArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rl = (wave & 1) * 64 + lane, row = blockIdx.y * BM + rl;
     const bool live = row < a.R;
-    const float* __restrict__ col = src + (live ? row : 0);
+    const float* __restrict__ col = !live ? src : (row < a.R_lo ? src + row : a.src_hi[blockIdx.z] + (row - a.R_lo));
     const int kb_end = min(a.KB, ((int)blockIdx.x + 1) * a.kt);
     float rsum = 0.f;
     for (int kb = blockIdx.x * a.kt + (wave >> 1); kb < kb_end; kb += 2) {
@@ -688,7 +699,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (DEPTH == 0) {  // packed split-bf16 operands: g.Ag / g.Bg hold PACKED tiles (see pk_mainloop), no edge cases
         pk_mainloop(reinterpret_cast<const char*>(gA), reinterpret_cast<const char*>(gB), (g.K + PK_K - 1) / PK_K,
-                    reinterpret_cast<char*>(smem), by, bx, kbeg / PK_K, (kend + PK_K - 1) / PK_K, tid, acc);
+                    reinterpret_cast<char*>(smem), pk_a_rb(g, prob, by), bx, kbeg / PK_K,
+                    (kend + PK_K - 1) / PK_K, tid, acc);
     } else if (DEPTH == 2) {
         if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
         else gemm_mainloop<TA, TB, false>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
@@ -768,7 +780,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pk256_kernel(GemmArgs g) {
         const char* Apk = reinterpret_cast<const char*>(g.Ag[prob]);
         const char* Bpk = reinterpret_cast<const char*>(g.Bg[prob]);
         // a block's second row block may lie beyond the matrix (odd number of row blocks): read the first one again
-        const int ra0 = 2 * by, ra1 = min(2 * by + 1, RBA - 1), rb0 = 2 * bx, rb1 = min(2 * bx + 1, RBB - 1);
+        const int la0 = 2 * by, la1 = min(2 * by + 1, RBA - 1), rb0 = 2 * bx, rb1 = min(2 * bx + 1, RBB - 1);
+        const int ra0 = pk_a_rb(g, prob, la0), ra1 = pk_a_rb(g, prob, la1);
         const char* A0 = Apk + ((size_t)ra0 * KB + kb0) * PK_TILE;
         const char* A1 = Apk + ((size_t)ra1 * KB + kb0) * PK_TILE;
         const char* B0 = Bpk + ((size_t)rb0 * KB + kb0) * PK_TILE;
@@ -922,6 +935,42 @@ int choose_splits(int M, int N, int K, int nprob = 1) {
     return best;
 }
 
+// Launch the packed split-bf16 kernel for GemmArgs whose Ag / Bg hold PACKED operands.
+// 256 x 256 block tiles (half the LDS traffic per flop, one block per CU) when they fill the chip: no split-K and >= 85 %
+// of whole rounds of 256 CUs; else 128 x 128 tiles, two blocks per CU (measured, tools/gemm_bench.py: 4096^3 191 vs 182
+// TFLOP/s, d x of layer 0 132 vs 130; but the layer-0 projection 136 vs 156 and the weight gradients 89 vs 122).
+// SA_GEMM_TILE=128 / 256 forces either (experiments).
+ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream) {
+    static bool pk_attr_dev[32] = {false};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
+    const int M = gp.M, N = gp.N, nprob = gp.nprob;
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
+    const char* tile_e = getenv("SA_GEMM_TILE");
+    const bool big_tile = tile_e ? atoi(tile_e) == 256
+                                 : (splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85);
+    if (big_tile) {
+        if (!pk_attr_dev[devid + 16]) {
+            if (hipFuncSetAttribute((const void*)gemm_pk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    PK_NST * PKB_STAGE) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+            pk_attr_dev[devid + 16] = true;
+        }
+        const dim3 bgrid((N + 255) / 256, (M + 255) / 256, nprob * splits);
+        hipLaunchKernelGGL(gemm_pk256_kernel, bgrid, dim3(512), PK_NST * PKB_STAGE, stream, gp);
+    } else {
+        if (!pk_attr_dev[devid]) {
+            if (hipFuncSetAttribute((const void*)gemm_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    PK_NST * PK_STAGE) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+            pk_attr_dev[devid] = true;
+        }
+        const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
+        hipLaunchKernelGGL(gemm_pk_kernel, grid, dim3(256), PK_NST * PK_STAGE, stream, gp);
+    }
+    return CTC_STATUS_SUCCESS;
+}
+
 }  // namespace
 
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
@@ -984,6 +1033,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.cs_partial = splits > 1 ? (float*)workspace + (size_t)nprob * splits * M * N : nullptr;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
     g.xcc_mask = 0; g.tile_counter = nullptr;
+    g.a_rb_split = 1 << 30; g.a_rb_jump = 0; g.a_jump_probs = 0u;
     g.grid_x = (int)grid.x; g.grid_y = (int)grid.y; g.grid_z = (int)grid.z;
     if (opts && opts->xcc_mask && opts->tile_counter) {
         g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter;
@@ -1010,6 +1060,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         const int KB = (K + PK_K - 1) / PK_K;
         PackArgs pa;
         pa.K = K; pa.KB = KB; pa.kt = pk_kt; pa.cs_part = nullptr; pa.Rpad = Mpad;
+        for (int p = 0; p < kMaxGroup; ++p) pa.src_hi[p] = nullptr;
         for (int side = 0; side < 2; ++side) {
             const bool kcontig = side == 0 ? !trans_a : (trans_b != 0);
             const int R = side == 0 ? M : N;
@@ -1017,7 +1068,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
             pa.dst = pk_base + (side == 0 ? 0 : (size_t)nprob * pkA);
             pa.dst_stride = side == 0 ? pkA : pkB;
             pa.ld = side == 0 ? lda : ldb;
-            pa.R = R;
+            pa.R = R; pa.R_lo = R;
             pa.vec = side == 0 ? g.vecA : g.vecB;
             pa.cs_part = (side == 0 && pk_cs) ? (float*)(pk_base + (size_t)nprob * (pkA + pkB)) : nullptr;
             const dim3 pgrid((KB + pk_kt - 1) / pk_kt, (R + BM - 1) / BM, nprob);
@@ -1027,41 +1078,14 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         if (pk_cs)
             hipLaunchKernelGGL(pk_colsum_fold_kernel, dim3((M + 15) / 16, nprob), dim3(256), 0, stream,
                                (const float*)(pk_base + (size_t)nprob * (pkA + pkB)), pk_parts, Mpad, M, g);
-        static bool pk_attr_dev[32] = {false};
-        int devid = 0;
-        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
-        if (!pk_attr_dev[devid]) {
-            if (hipFuncSetAttribute((const void*)gemm_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    PK_NST * PK_STAGE) != hipSuccess)
-                return CTC_STATUS_EXECUTION_FAILED;
-            pk_attr_dev[devid] = true;
-        }
         GemmArgs gp = g;
         for (int p = 0; p < nprob; ++p) {
             gp.Ag[p] = (const float*)(pk_base + (size_t)p * pkA);
             gp.Bg[p] = (const float*)(pk_base + (size_t)nprob * pkA + (size_t)p * pkB);
             gp.colsumg[p] = nullptr;  // done by the pack kernel
         }
-        // 256 x 256 block tiles (half the LDS traffic per flop, one block per CU) when they fill the chip: no split-K and
-        // >= 85 % of whole rounds of 256 CUs; else 128 x 128 tiles, two blocks per CU (measured, tools/gemm_bench.py:
-        // 4096^3 191 vs 182 TFLOP/s, d x of layer 0 132 vs 130; but the layer-0 projection 136 vs 156 and the
-        // weight gradients 89 vs 122).  SA_GEMM_TILE=128 / 256 forces either (experiments).
-        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
-        const char* tile_e = getenv("SA_GEMM_TILE");
-        const bool big_tile = tile_e ? atoi(tile_e) == 256
-                                     : (splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85);
-        if (big_tile) {
-            if (!pk_attr_dev[devid + 16]) {
-                if (hipFuncSetAttribute((const void*)gemm_pk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        PK_NST * PKB_STAGE) != hipSuccess)
-                    return CTC_STATUS_EXECUTION_FAILED;
-                pk_attr_dev[devid + 16] = true;
-            }
-            const dim3 bgrid((N + 255) / 256, (M + 255) / 256, nprob * splits);
-            hipLaunchKernelGGL(gemm_pk256_kernel, bgrid, dim3(512), PK_NST * PKB_STAGE, stream, gp);
-        } else {
-            hipLaunchKernelGGL(gemm_pk_kernel, grid, dim3(256), PK_NST * PK_STAGE, stream, gp);
-        }
+        const ctcStatus_t pst = pk_launch(gp, splits, stream);
+        if (pst != CTC_STATUS_SUCCESS) return pst;
         g = gp;  // the split-K reduce below must not fold column sums either
     } else if (trans_a) {
         if (trans_b) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), dyn, stream, g);
@@ -1108,4 +1132,112 @@ extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     SA_CLEAR_ERR();
     return sa_gemm_f32_impl(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, nullptr, workspace,
                             workspace_bytes, (hipStream_t)stream);
+}
+
+
+// ---- packed operands as a caller-visible (library-internal) object: internal.h ----------------------------------------
+size_t sa_pk_operand_bytes(int R, int K) { return sa_align_up(pk_bytes(R, K), 256); }
+int sa_pk_rowsum_parts(int K) { return 2 * ((((K + PK_K - 1) / PK_K) + 7) / 8); }
+bool sa_pk_enabled(int M, int N, int K, int nprob) { return pk_worth_it(M, N, K, nprob); }
+
+ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* src_hi, int R_lo, long ld, int R, int K,
+                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream) {
+    if (nprob < 1 || nprob > kMaxGroup || !dst || R <= 0 || K <= 0) return CTC_STATUS_INVALID_VALUE;
+    PackArgs pa;
+    const int KB = (K + PK_K - 1) / PK_K;
+    pa.K = K; pa.KB = KB; pa.kt = 8; pa.cs_part = cs_part; pa.Rpad = (R + BM - 1) / BM * BM;
+    pa.dst = dst; pa.dst_stride = dst_stride; pa.ld = ld; pa.R = R; pa.R_lo = src_hi ? R_lo : R;
+    pa.vec = (ld & 3) == 0;
+    for (int p = 0; p < kMaxGroup; ++p) { pa.src[p] = nullptr; pa.src_hi[p] = nullptr; }
+    for (int p = 0; p < nprob; ++p) {
+        if (!src[p]) return CTC_STATUS_INVALID_VALUE;
+        pa.src[p] = src[p];
+        pa.src_hi[p] = src_hi ? src_hi[p] : nullptr;
+        pa.vec = pa.vec && (((uintptr_t)src[p] & 15) == 0);
+    }
+    const dim3 pgrid((KB + pa.kt - 1) / pa.kt, (R + BM - 1) / BM, nprob);
+    if (kcontig) {
+        if (cs_part || src_hi) return CTC_STATUS_INVALID_VALUE;
+        hipLaunchKernelGGL(pk_pack_kcontig_kernel, pgrid, dim3(256), 0, stream, pa);
+    } else {
+        hipLaunchKernelGGL(pk_pack_mcontig_kernel, pgrid, dim3(256), 0, stream, pa);
+    }
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+namespace {
+// out[p][m] = (beta ? beta * out : 0) + sum over the parts of row (m < split ? m : m + jump), in a fixed order
+struct RowsumOut { float* out[kMaxGroup]; };
+__global__ __launch_bounds__(256) void pk_rowsum_fold_kernel(const float* __restrict__ part, int nparts, int Rpad, int M,
+                                                             int split, int jump, RowsumOut o, float beta) {
+    const int m = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15, prob = blockIdx.y;
+    const int r = m < split ? m : m + jump;
+    float t = 0.f;
+    if (m < M)
+        for (int q = j; q < nparts; q += 16) t += part[((size_t)prob * nparts + q) * Rpad + r];
+#pragma unroll
+    for (int sft = 8; sft > 0; sft >>= 1) t += __shfl_xor(t, sft, 64);
+    if (m >= M || j != 0 || !o.out[prob]) return;
+    float* dstp = o.out[prob] + m;
+    *dstp = beta != 0.f ? beta * *dstp + t : t;
+}
+}  // namespace
+
+ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int Rpad, int M, int split, int jump,
+                              float* const* out, float beta, hipStream_t stream) {
+    if (nprob < 1 || nprob > kMaxGroup || !cs_part || !out) return CTC_STATUS_INVALID_VALUE;
+    RowsumOut o;
+    for (int p = 0; p < kMaxGroup; ++p) o.out[p] = p < nprob ? out[p] : nullptr;
+    hipLaunchKernelGGL(pk_rowsum_fold_kernel, dim3((M + 15) / 16, nprob), dim3(256), 0, stream, cs_part, nparts, Rpad, M,
+                       split, jump, o, beta);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K) {
+    const int s = choose_splits(M, N, K, nprob);
+    return s > 1 ? (size_t)nprob * s * ((size_t)M * N + M) * sizeof(float) : 0;
+}
+
+// C[p] (M x N) = (beta C[p]) + A[p] B[p]^T on operands that are ALREADY packed (sa_pk_pack): A[p] rows [0, a_split) and
+// [a_split + a_jump, ...) of its packed operand when bit p of a_jump_probs is set (row counts in multiples of 128), else
+// rows [0, M); B[p] rows [0, N).
+ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* Apk, int a_split, int a_jump,
+                             unsigned a_jump_probs, const char* const* Bpk, float beta, float* const* C, long ldc, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
+    SA_CLEAR_ERR();
+    if (nprob < 1 || nprob > kMaxGroup || M <= 0 || N <= 0 || K <= 0 || (a_split % BM) || (a_jump % BM))
+        return CTC_STATUS_INVALID_VALUE;
+    GemmArgs g;
+    g.nprob = nprob; g.vecA = g.vecB = 1;
+    for (int p = 0; p < kMaxGroup; ++p) { g.Ag[p] = g.Bg[p] = nullptr; g.Cg[p] = nullptr; g.biasg[p] = nullptr; g.colsumg[p] = nullptr; }
+    for (int p = 0; p < nprob; ++p) {
+        if (!Apk[p] || !Bpk[p] || !C[p]) return CTC_STATUS_INVALID_VALUE;
+        g.Ag[p] = (const float*)Apk[p]; g.Bg[p] = (const float*)Bpk[p]; g.Cg[p] = C[p];
+    }
+    g.lda = g.ldb = 0; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.beta = beta;
+    g.m_inner = 0; g.m_mid = 1; g.s_outer = g.s_mid = 0; g.col_stride = 1; g.relu = 0;
+    int splits = choose_splits(M, N, K, nprob);
+    if (splits > 1 && (!workspace || workspace_bytes < (size_t)nprob * splits * ((size_t)M * N + M) * sizeof(float))) splits = 1;
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    if (kps < BK) kps = BK;
+    splits = (K + kps - 1) / kps;
+    g.k_per_split = kps; g.splits = splits;
+    g.partial = splits > 1 ? (float*)workspace : nullptr;
+    g.cs_partial = nullptr;
+    g.xcc_mask = 0; g.tile_counter = nullptr;
+    g.a_rb_split = a_split / BM; g.a_rb_jump = a_jump / BM; g.a_jump_probs = a_jump ? a_jump_probs : 0u;
+    g.grid_x = (N + BN - 1) / BN; g.grid_y = (M + BM - 1) / BM; g.grid_z = nprob * splits;
+    const ctcStatus_t st = pk_launch(g, splits, stream);
+    if (st != CTC_STATUS_SUCCESS) return st;
+    SA_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long total = (long)M * N + M;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), nprob), dim3(256), 0, stream, g,
+                           splits);
+        SA_CHECK_LAUNCH();
+    }
+    return CTC_STATUS_SUCCESS;
 }

@@ -2199,6 +2199,40 @@ extern "C" ctcStatus_t sa_gru_stack_fwd_dropout(const float* x, int I0, const fl
                           stream_, nullptr, 0, dc);
 }
 
+// The weight gradients of a unidirectional stack on SHARED packed operands (WGradIssuer::issue_shared): every matrix is
+// split into its bf16 planes once -- the gate gradients of a layer as ONE 4H-row operand [dpr, dpz, dpn | dqn] (dai's
+// three gates, then dah's third: dah's first two ARE dai's), which dW_ih reads as rows [0, 3H) and dW_hh as rows [0, 2H) +
+// [3H, 4H).  0 = the shape does not take this path.
+static bool shared_pack_enabled() {
+    const char* e = getenv("SA_GRU_SHARED_PACK");
+    return !(e && e[0] == '0');
+}
+struct SharedPackLayout { size_t g_each, h_each, x_bytes, cs_bytes, g_off, hp_off, lo_off, x_off, cs_off, sk_off, total; int parts; };
+static bool shared_pack_layout(int L, int D, int B, int T, int H, int I0, SharedPackLayout& y) {
+    const long K = (long)T * B;
+    if (D != 1 || (H % 128) || K > 0x7fffffffL || 2 * L - 1 > 8 || !shared_pack_enabled()) return false;
+    if (!sa_pk_enabled(3 * H, H, (int)K, L) || !sa_pk_enabled(3 * H, I0, (int)K, 1)) return false;
+    y.g_each = sa_pk_operand_bytes(4 * H, (int)K);
+    y.h_each = sa_pk_operand_bytes(H, (int)K);
+    y.x_bytes = sa_pk_operand_bytes(I0, (int)K);
+    y.parts = sa_pk_rowsum_parts((int)K);
+    y.cs_bytes = sa_align_up((size_t)L * y.parts * 4 * H * sizeof(float), 256);
+    y.g_off = 0;
+    y.hp_off = y.g_off + (size_t)L * y.g_each;
+    y.lo_off = y.hp_off + (size_t)L * y.h_each;
+    y.x_off = y.lo_off + (size_t)(L - 1) * y.h_each;
+    y.cs_off = y.x_off + y.x_bytes;
+    y.sk_off = y.cs_off + y.cs_bytes;
+    const size_t a = sa_gemm_pk_group_workspace_bytes(2 * L - 1, 3 * H, H, (int)K);
+    const size_t b = sa_gemm_pk_group_workspace_bytes(1, 3 * H, I0, (int)K);
+    y.total = y.sk_off + sa_align_up(a > b ? a : b, 256);
+    return true;
+}
+static size_t shared_pack_ws_bytes(int L, int D, int B, int T, int H, int I0) {
+    SharedPackLayout y;
+    return shared_pack_layout(L, D, B, T, H, I0, y) ? y.total : 0;
+}
+
 // split-K workspace of the weight-gradient products (one region: the products of a call run on ONE stream, in order)
 static size_t wgrad_ws_bytes(int L, int D, int B, int T, int H, int I0) {
     const int nmax = I0 > D * H ? I0 : D * H;
@@ -2209,7 +2243,8 @@ static size_t wgrad_ws_bytes(int L, int D, int B, int T, int H, int I0) {
         if (a > w) w = a;
         if (b > w) w = b;
     }
-    return sa_align_up(w, 256);
+    const size_t sp = shared_pack_ws_bytes(L, D, B, T, H, I0);
+    return sa_align_up(w > sp ? w : sp, 256);
 }
 
 extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, int H, int I0) {
@@ -2274,9 +2309,56 @@ struct WGradIssuer {
         for (int i = 0; i < 2 * kMaxJobs; ++i) first_ih[i] = first_hh[i] = true;
         for (int l = 0; l < kMaxJobs; ++l) lower[l] = l >= 1 && l < L && wg.h_out ? wg.h_out[l - 1] : nullptr;
     }
+    // Every product of a unidirectional stack over the whole sequence, on operands packed ONCE (shared_pack_layout):
+    // 4 pack launches (gate gradients of all layers with their row sums; h_prev; the layer inputs; x), one fold launch per
+    // bias family, one grouped product for dW_hh of all layers + dW_ih of the upper ones, one for dW_ih of layer 0.
+    ctcStatus_t issue_shared(const SharedPackLayout& y, hipStream_t stream) {
+        const int K = T * B;
+        char* base = (char*)ws;
+        const float* src[kMaxJobs]; const float* hi[kMaxJobs];
+        for (int l = 0; l < L; ++l) { src[l] = dai[l]; hi[l] = dah[l] + 2 * H; }
+        float* cs = (float*)(base + y.cs_off);
+        ctcStatus_t st = sa_pk_pack(L, src, hi, 3 * H, 3 * H, 4 * H, K, 0, base + y.g_off, y.g_each, cs, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        st = sa_pk_rowsum_fold(L, cs, y.parts, 4 * H, 3 * H, 3 * H, 0, wg.db_ih, 0.f, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        st = sa_pk_rowsum_fold(L, cs, y.parts, 4 * H, 3 * H, 2 * H, H, wg.db_hh, 0.f, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        for (int l = 0; l < L; ++l) src[l] = stash[l] + 4 * H;
+        st = sa_pk_pack(L, src, nullptr, 0, 5 * H, H, K, 0, base + y.hp_off, y.h_each, nullptr, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        if (L > 1) {
+            for (int l = 1; l < L; ++l) src[l - 1] = lower[l];
+            st = sa_pk_pack(L - 1, src, nullptr, 0, H, H, K, 0, base + y.lo_off, y.h_each, nullptr, stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+        }
+        src[0] = wg.x;
+        st = sa_pk_pack(1, src, nullptr, 0, I0, I0, K, 0, base + y.x_off, y.x_bytes, nullptr, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        const char* pa[kMaxJobs]; const char* pb[kMaxJobs]; float* pc[kMaxJobs];
+        int np = 0;
+        for (int l = 0; l < L; ++l, ++np) { pa[np] = base + y.g_off + l * y.g_each; pb[np] = base + y.hp_off + l * y.h_each; pc[np] = wg.dw_hh[l]; }
+        const unsigned jump_probs = (1u << L) - 1u;
+        for (int l = 1; l < L; ++l, ++np) { pa[np] = base + y.g_off + l * y.g_each; pb[np] = base + y.lo_off + (l - 1) * y.h_each; pc[np] = wg.dw_ih[l]; }
+        st = sa_gemm_pk_group(np, 3 * H, H, K, pa, 2 * H, H, jump_probs, pb, 0.f, pc, H, base + y.sk_off, ws_bytes - y.sk_off, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        pa[0] = base + y.g_off; pb[0] = base + y.x_off; pc[0] = wg.dw_ih[0];
+        st = sa_gemm_pk_group(1, 3 * H, I0, K, pa, 0, 0, 0u, pb, 0.f, pc, I0, base + y.sk_off, ws_bytes - y.sk_off, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        for (int k = 0; k < L; ++k) first_ih[k] = first_hh[k] = false;
+        return CTC_STATUS_SUCCESS;
+    }
     // spans[k] = {t0, t1} (t1 <= t0: nothing).  Same-shaped problems share a grouped launch.
     ctcStatus_t issue(const int (*spans)[2], hipStream_t stream, bool allow_split) {
         const int n = L * D;
+        if (D == 1 && allow_split && !xcc_mask && wg.x && wg.dw_ih && wg.dw_hh && wg.db_ih && wg.db_hh) {
+            bool whole = true;
+            for (int k = 0; k < n; ++k)
+                whole = whole && spans[k][0] == 0 && spans[k][1] == T && first_ih[k] && first_hh[k] && wg.dw_ih[k] &&
+                        wg.dw_hh[k] && wg.db_ih[k] && wg.db_hh[k] && (k == 0 || lower[k]);
+            SharedPackLayout y;
+            if (whole && shared_pack_layout(L, D, B, T, H, I0, y) && y.total <= ws_bytes) return issue_shared(y, stream);
+        }
         bool done_ih[2 * kMaxJobs], done_hh[2 * kMaxJobs];
         for (int k = 0; k < n; ++k) done_ih[k] = done_hh[k] = spans[k][1] <= spans[k][0];
         SaGemmOpts o;

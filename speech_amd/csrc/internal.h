@@ -41,3 +41,20 @@ ctcStatus_t sa_dropout_nchw_strided_impl(float* y, int B, int O, int To, int Fo,
 // out[i] = (in ? in[i] : 1) * factor(idx0 + i); in == out allowed
 ctcStatus_t sa_dropout_apply_impl(const float* in, float* out, size_t n, size_t idx0, const SaDrop& d,
                                   unsigned stream_id, hipStream_t stream);
+
+// Packed split-bf16 operands as objects (gemm_f32.hip, "split-bf16 GEMM on packed operands"): a caller that multiplies the
+// same matrix several times packs it once.  Layout: tiles of 128 rows x 16 k x 3 bf16 planes; R rows, reduction length K.
+size_t sa_pk_operand_bytes(int R, int K);
+int sa_pk_rowsum_parts(int K);                    // partial row sums per row written by sa_pk_pack(cs_part)
+bool sa_pk_enabled(int M, int N, int K, int nprob);  // the size / SA_GEMM_EXACT rule of sa_gemm_f32_group_impl
+// nprob matrices of R logical rows x K.  kcontig: src[p][r * ld + k]; else src[p][k * ld + r], and rows r >= R_lo are taken
+// from src_hi[p][k * ld + (r - R_lo)] when src_hi != NULL.  cs_part (m-contiguous form only, or NULL):
+// [nprob][sa_pk_rowsum_parts(K)][ceil128(R)] partial row sums (fold them with sa_pk_rowsum_fold).
+ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* src_hi, int R_lo, long ld, int R, int K,
+                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream);
+ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int Rpad, int M, int split, int jump,
+                              float* const* out, float beta, hipStream_t stream);
+size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K);
+ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* Apk, int a_split, int a_jump,
+                             unsigned a_jump_probs, const char* const* Bpk, float beta, float* const* C, long ldc, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream);

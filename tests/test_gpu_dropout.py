@@ -105,13 +105,42 @@ def test_fused_one_launch_kernels_apply_the_masks():
 
 @pytest.mark.parametrize("env", [{"SA_GRU_FUSED": "0"}, {"SA_GRU_BWD_ONE": "0"}, {"SA_GRU_FUSE_DX": "0"},
                                  {"SA_GRU_PERSIST": "0"}, {"SA_GRU_TILED": "0"}, {"SA_GEMM_EXACT": "0"},
-                                 {"SA_GEMM_EXACT": "1"}],
+                                 {"SA_GEMM_EXACT": "0", "SA_GRU_SHARED_PACK": "0"}, {"SA_GEMM_EXACT": "1"}],
                          ids=["chunked_fwd", "chunked_fused_bwd", "gemm_dx", "step_kernels", "round1_bwd",
-                              "every_gemm_packed_split_bf16", "every_gemm_exact_f32"])
+                              "every_gemm_packed_split_bf16", "packed_split_bf16_one_pack_per_product",
+                              "every_gemm_exact_f32"])
 def test_every_gru_path_applies_the_same_masks(monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     run_case(F=40, V=20, B=20, T=150, L=8, cfg=UNI256)
+
+
+def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatch):
+    # WGradIssuer::issue_shared (gru.hip): the gate gradients of a layer packed ONCE as a 4H-row operand that dW_ih reads
+    # as rows [0, 3H) and dW_hh as rows [0, 2H) + [3H, 4H) (a row-block jump), bias gradients from the pack kernel's row
+    # sums through the same row map -- against one pack per product.  Same kernels, same pieces: only the split-K
+    # partition of the sums differs, so the two agree to fp32 summation-order noise.  H = 128, B = 9, T' = 58: a reduction
+    # length (522) that is not a multiple of the 16-wide packed k tile, one ragged batch tile, I0 = 32 * 18.
+    from speech_amd.models import CTC
+    cfg = {"dropout": 0.3, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 128, "layers": 4, "bidirectional": False}}}
+    monkeypatch.setenv("SA_GEMM_EXACT", "0")
+    rng = np.random.RandomState(5)
+    x = rng.randn(9, 120, 40).astype(np.float32)
+    labels = tuple(rng.randint(0, 20, 6) for _ in range(9))
+    batch = (tuple(x[b] for b in range(9)), labels)
+    grads = {}
+    for shared in ("1", "0"):
+        monkeypatch.setenv("SA_GRU_SHARED_PACK", shared)
+        torch.manual_seed(3)
+        model = CTC(40, 20, cfg).cuda()
+        model.set_train()
+        model._plan.fixed_seed = 99
+        model.loss(batch).backward()
+        grads[shared] = {k: q.grad.clone() for k, q in model.named_parameters()}
+    for k, a in grads["1"].items():
+        b = grads["0"][k]
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-20))
+        assert rel <= 2e-6, (k, rel)
 
 
 def test_h128_stack_and_two_convs():
