@@ -855,6 +855,8 @@ struct PBwdJob {
     float* dump;           // gru_bwd_fused_kernel: 256 x 256 floats nobody reads (where predicated-off stores go)
     long xs_b, xs_t;
     unsigned dx_drop_stream;  // gru_bwd_fused_kernel: mask stream of dx_out (= the dropped output of the layer below)
+    char* gpk;             // gru_bwd_fused_kernel<.., PACKG>: the layer's 4H-row packed gate-gradient operand (gemm_f32.hip)
+    float* gsum;           // gru_bwd_fused_kernel<.., PACKG>: its row sums per batch tile, [nbt_all][4H] (the bias gradients)
     int t0, nsteps;        // first time index this launch unwinds, number of steps
     int dt, t_first;       // -1 for a forward-in-time chain (unwinds from T-1), +1 for a reverse chain; the very first index
     unsigned base;
@@ -870,6 +872,7 @@ struct PBwdJobs {
     int spin_limit, fault, prio;  // see PFwdJobs
     int packed;                   // gru_bwd_fused_kernel: 1 = publish with plain stores (default), 0 = write-through
     SaDrop drop;                  // gru_bwd_fused_kernel: inter-layer dropout -- d h_out[l-1] = mask * (dai[l] W_ih[l])
+    long pk_kb;                   // gru_bwd_fused_kernel<.., PACKG>: k-tiles of the packed operands, T * B / 16
     unsigned long long* timing;   // debug (SA_GRU_TIMING=1): per block {poll+load, mfma, reduce+barrier, gates+publish} in
                                   // 10 ns ticks and the number of polling trips; else null
     PBwdJob j[kMaxJobs];
@@ -1067,7 +1070,15 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // DROP (with FUSE): inter-layer dropout -- the row of d h_out[l-1] is multiplied by the mask the forward pass applied to
 // h_out[l-1] (recomputed from (seed, stream, index), dropout.h) before it is stored.  A template parameter, so that the
 // kernel without dropout keeps its branch-free tail.
-template <int IPG, bool FUSE, bool DROP = false>
+// PACKG (with FUSE, B a multiple of 16): the weight-gradient products run on split-bf16 PACKED operands (gemm_f32.hip), and
+// the layout they want -- operand row = (gate, unit), 16 consecutive k = the 16 rows of a batch tile at one time step, as
+// three bf16 planes -- is what a block holds at the end of a step, transposed.  Instead of the six row-major stores (dai,
+// dah: 2 x 3H floats per row, re-read and re-laid-out by a pack launch afterwards: 0.26 ms per S-LIBRI step) the block
+// stages {dpr, dpz, dpn, dqn} through LDS (5 KB per step parity; read back behind the NEXT step's barrier, so no
+// barrier is added), wave w splits gate w -- each thread four values -- and stores 3 x 8 bytes into the layer's 4H-row
+// operand; the bias gradients are per-thread running sums, folded over the batch tile after the last step.  dai of the
+// bottom layer is still written row-major (the d x product reads it); nothing else is.
+template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
@@ -1101,6 +1112,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     if (stamper) P.stamp[0] = wall_clock64();
     float* red = psm;          // [2][4][256]: the four waves' partial sums of the recurrent product, per step parity
     float* red2 = psm + 2048;  // [2][4][256]: the same for the input-gradient product
+    float* pks = psm + 4096;   // PACKG: [2][4 gates][16 units][20]: a step's gate gradients, unit-major (16 used of 20)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int u0 = role_x * 16, b0 = role_y * 16;
@@ -1108,6 +1120,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const int b = b0 + bi, u = u0 + uj;
     const bool live = b < B;
     const bool fuse = FUSE && J.dx_out != nullptr;
+    const bool bottom = !fuse;  // PACKG: the layer whose dai the caller's d x product reads
     int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
     const int kw = wave * (H / 4) + 4 * g;  // the lane's column offset inside a gate; fragment `it` adds 16 (it % IPG)
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
@@ -1186,6 +1199,31 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     // slot: a BRANCH around a vector-memory instruction makes hipcc wait vmcnt(0) at the join, i.e. here for the
     // store's own acknowledgement -- 1.2 us per step when the d h_out store sat under `if (pending && live)`.
     float* p_dump = J.dump + blockIdx.x * 256 + tid;
+    // PACKG: wave w packs gate w; thread (unit pu = lane / 4, quarter pq = lane % 4) takes batch rows 4 pq .. 4 pq + 3 of
+    // the tile = k 4 pq .. + 3 of the 16-k tile (t B + b0) / 16 of operand row w H + u0 + pu
+    char* p_pk = nullptr;
+    long s_pk = 0;
+    const float* pk_src = nullptr;
+    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gs3 = 0.f;
+    if constexpr (PACKG) {
+        const int pu = lane >> 2, pq = lane & 3;
+        const int prow = wave * H + u0 + pu, prl = prow & 127;
+        p_pk = J.gpk + ((size_t)(prow >> 7) * P.pk_kb + role_y) * 12288 + prl * 32 + ((((pq >> 1) ^ (prl >> 3)) & 1) << 4) +
+               (pq & 1) * 8;
+        s_pk = (long)(B / 16) * 12288;
+        pk_src = pks + wave * 320 + pu * 20 + 4 * pq;
+    }
+    auto pack_row = [&](int par, bool on, int trow) {  // the step staged in pks[par]: split, store (behind a barrier)
+        const float4 v = *reinterpret_cast<const float4*>(pk_src + par * 1280);
+        unsigned a0, a1, b0_, b1, c0, c1;
+        sa_split2(v.x, v.y, a0, b0_, c0);
+        sa_split2(v.z, v.w, a1, b1, c1);
+        char* dst = on ? p_pk + (long)trow * s_pk : reinterpret_cast<char*>(J.dump + ((blockIdx.x * 256 + tid) & ~1));
+        const long pl = on ? 4096 : 0;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, a1);
+        *reinterpret_cast<uint2*>(dst + pl) = make_uint2(b0_, b1);
+        *reinterpret_cast<uint2*>(dst + 2 * pl) = make_uint2(c0, c1);
+    };
     const SaDrop drop = P.drop;
     const unsigned dx_stream = J.dx_drop_stream;
     const long dx_idx0 = (long)bl * H + u;  // mask index of element (trow, b, u) of the layer below: (trow B + b) H + u
@@ -1287,7 +1325,17 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         // back to back, measured) is dealt out between the 96 MFMAs of the second product instead.  The product runs
         // unconditionally (bottom layer: zero weights; first step: no row -- the result goes to the dump slot).
         if constexpr (FUSE) flush2((s - 1) & 1, pend_t >= 0, pend_t);
-        {  // the row-major copies the weight-gradient products read
+        if constexpr (PACKG) {  // the packed operand the weight-gradient products read
+            float* ps = pks + (s & 1) * 1280 + uj * 20 + bi;
+            ps[0] = dpr; ps[320] = dpz; ps[640] = dpn; ps[960] = dqn;
+            gs0 += dpr; gs1 += dpz; gs2 += dpn; gs3 += dqn;
+            pack_row((s - 1) & 1, s > 0, t - dt);
+            float* di = (live && bottom) ? p_di + (long)t * s_d : p_dump;  // the d x product of layer 0 reads dai row-major
+            const int g1 = (live && bottom) ? H : 0, g2 = (live && bottom) ? 2 * H : 0;
+            di[0] = dpr; di[g1] = dpz; di[g2] = dpn;
+            dh_run = dh;
+            z_next = z;
+        } else {  // the row-major copies the weight-gradient products read
             float* di = live ? p_di + (long)t * s_d : p_dump;
             float* dhh = live ? p_dhh + (long)t * s_d : p_dump;
             const int g1 = live ? H : 0, g2 = live ? 2 * H : 0;
@@ -1320,6 +1368,23 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         __syncthreads();
         flush2((nsteps - 1) & 1, pend_t >= 0, pend_t);
         flush2(nsteps & 1, true, tl);
+    } else if (PACKG) {
+        __syncthreads();
+    }
+    if constexpr (PACKG) {  // the last step's values are staged (a barrier has passed on either branch above)
+        pack_row((nsteps - 1) & 1, nsteps > 0, t0 + (nsteps - 1) * dt);
+        __syncthreads();
+        // bias gradients: this batch tile's row sums, unit-major in LDS, 16 rows folded by the first 64 threads
+        float* ps = pks + uj * 20 + bi;
+        ps[0] = gs0; ps[320] = gs1; ps[640] = gs2; ps[960] = gs3;
+        __syncthreads();
+        if (tid < 64) {
+            const float* q = pks + (tid >> 4) * 320 + (tid & 15) * 20;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += q[k];
+            J.gsum[(long)role_y * 4 * H + (tid >> 4) * H + u0 + (tid & 15)] = t;
+        }
     }
     if (live) J.dh_state[(long)b * H + u] = dh_run;
     if (stamper) P.stamp[1] = wall_clock64();
@@ -1811,8 +1876,13 @@ static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels
     const char* e = getenv("SA_GRU_TILED");
     return !(e && e[0] == '0');
 }
-static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false) {
+static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
     if (!tiled_enabled()) return nullptr;
+    if (packg && fuse) {
+        if (H == 512) return drop ? gru_bwd_fused_kernel<8, true, true, true> : gru_bwd_fused_kernel<8, true, false, true>;
+        if (H == 256) return drop ? gru_bwd_fused_kernel<4, true, true, true> : gru_bwd_fused_kernel<4, true, false, true>;
+        if (H == 128) return drop ? gru_bwd_fused_kernel<2, true, true, true> : gru_bwd_fused_kernel<2, true, false, true>;
+    }
     if (H == 512) return fuse ? (drop ? gru_bwd_fused_kernel<8, true, true> : gru_bwd_fused_kernel<8, true>) : gru_bwd_fused_kernel<8, false>;
     if (H == 256) return fuse ? (drop ? gru_bwd_fused_kernel<4, true, true> : gru_bwd_fused_kernel<4, true>) : gru_bwd_fused_kernel<4, false>;
     return nullptr;
@@ -2303,6 +2373,8 @@ struct WGradIssuer {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     bool first_ih[2 * kMaxJobs], first_hh[2 * kMaxJobs];
+    bool gates_prepacked = false;  // gru_bwd_fused_kernel<PACKG> wrote the gate operands and their row sums (gsum_parts
+    int gsum_parts = 0;            // partial sums per row) into the shared-pack workspace
     WGradIssuer(const WGrad& w, const float* const* st, float* const* da, float* const* dh, int L_, int D_, int B_,
                 int T_, int H_, int I0_)
         : wg(w), stash(st), dai(da), dah(dh), L(L_), D(D_), B(B_), T(T_), H(H_), I0(I0_) {
@@ -2318,11 +2390,13 @@ struct WGradIssuer {
         const float* src[kMaxJobs]; const float* hi[kMaxJobs];
         for (int l = 0; l < L; ++l) { src[l] = dai[l]; hi[l] = dah[l] + 2 * H; }
         float* cs = (float*)(base + y.cs_off);
-        ctcStatus_t st = sa_pk_pack(L, src, hi, 3 * H, 3 * H, 4 * H, K, 0, base + y.g_off, y.g_each, cs, stream);
+        ctcStatus_t st = CTC_STATUS_SUCCESS;
+        if (!gates_prepacked) st = sa_pk_pack(L, src, hi, 3 * H, 3 * H, 4 * H, K, 0, base + y.g_off, y.g_each, cs, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
-        st = sa_pk_rowsum_fold(L, cs, y.parts, 4 * H, 3 * H, 3 * H, 0, wg.db_ih, 0.f, stream);
+        const int parts = gates_prepacked ? gsum_parts : y.parts;
+        st = sa_pk_rowsum_fold(L, cs, parts, 4 * H, 3 * H, 3 * H, 0, wg.db_ih, 0.f, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
-        st = sa_pk_rowsum_fold(L, cs, y.parts, 4 * H, 3 * H, 2 * H, H, wg.db_hh, 0.f, stream);
+        st = sa_pk_rowsum_fold(L, cs, parts, 4 * H, 3 * H, 2 * H, H, wg.db_hh, 0.f, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
         for (int l = 0; l < L; ++l) src[l] = stash[l] + 4 * H;
         st = sa_pk_pack(L, src, nullptr, 0, 5 * H, H, K, 0, base + y.hp_off, y.h_each, nullptr, stream);
@@ -2349,16 +2423,23 @@ struct WGradIssuer {
         return CTC_STATUS_SUCCESS;
     }
     // spans[k] = {t0, t1} (t1 <= t0: nothing).  Same-shaped problems share a grouped launch.
+    // issue_shared applies to this stack when every product is still owed in full
+    bool shared_ok(SharedPackLayout& y) const {
+        if (D != 1 || xcc_mask || !wg.x || !wg.dw_ih || !wg.dw_hh || !wg.db_ih || !wg.db_hh) return false;
+        for (int k = 0; k < L; ++k)
+            if (!first_ih[k] || !first_hh[k] || !wg.dw_ih[k] || !wg.dw_hh[k] || !wg.db_ih[k] || !wg.db_hh[k] || (k > 0 && !lower[k]))
+                return false;
+        return shared_pack_layout(L, D, B, T, H, I0, y) && y.total <= ws_bytes;
+    }
     ctcStatus_t issue(const int (*spans)[2], hipStream_t stream, bool allow_split) {
         const int n = L * D;
-        if (D == 1 && allow_split && !xcc_mask && wg.x && wg.dw_ih && wg.dw_hh && wg.db_ih && wg.db_hh) {
+        if (D == 1 && allow_split) {
             bool whole = true;
-            for (int k = 0; k < n; ++k)
-                whole = whole && spans[k][0] == 0 && spans[k][1] == T && first_ih[k] && first_hh[k] && wg.dw_ih[k] &&
-                        wg.dw_hh[k] && wg.db_ih[k] && wg.db_hh[k] && (k == 0 || lower[k]);
+            for (int k = 0; k < n; ++k) whole = whole && spans[k][0] == 0 && spans[k][1] == T;
             SharedPackLayout y;
-            if (whole && shared_pack_layout(L, D, B, T, H, I0, y) && y.total <= ws_bytes) return issue_shared(y, stream);
+            if (whole && shared_ok(y)) return issue_shared(y, stream);
         }
+        if (gates_prepacked) return CTC_STATUS_EXECUTION_FAILED;  // the row-major gate gradients were not written
         bool done_ih[2 * kMaxJobs], done_hh[2 * kMaxJobs];
         for (int k = 0; k < n; ++k) done_ih[k] = done_hh[k] = spans[k][1] <= spans[k][0];
         SaGemmOpts o;
@@ -2515,10 +2596,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                            bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
-                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
+                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull); Q.pk_kb = 0;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
-                    J.dx_drop_stream = 0u;
+                    J.dx_drop_stream = 0u; J.gpk = nullptr; J.gsum = nullptr;
                     const float* dho = (l == L - 1) ? dh_top : mid_of(l);
                     J.dh_out = dho + (long)d * H; J.ds_b = DH; J.ds_t = (long)B * DH;
                     J.stash = stash[l * 2 + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * 2 + d]; J.dah = dah[l * 2 + d];
@@ -2593,8 +2674,17 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // the lower layers' d h_out inside the recurrence kernel (gru_bwd_fused_kernel): no GEMM between the launches
     const bool tiled = flagless && bwd_fused_fn(H, false) != nullptr && (long)T * nbt * 16 * 3 * H * 4 < 0x7fffffffL;
     const bool fused = tiled && L > 1 && fuse_dx_enabled();
-    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on) : nullptr;
-    const size_t flds = xcd_lds((size_t)4 * 4 * 256 * sizeof(float));
+    // ONE launch for the whole backward recurrence of the stack (fused kernel only): every layer runs all T steps, a
+    // lower layer picks each row of its d h_out up as the layer above stores it (sentinel pre-fill, see the kernel) --
+    // T + a few steps per layer of lag instead of (T / chunk + L - 1) chunks, and no launch ramps in between.
+    const char* one_e = getenv("SA_GRU_BWD_ONE");
+    const bool one_launch = fused && !(one_e && one_e[0] == '0') && !getenv("SA_GRU_TIMING");
+    // ... and that launch writes the weight-gradient products' gate operand itself, packed (gru_bwd_fused_kernel<PACKG>)
+    SharedPackLayout spl;
+    const char* pg_e = getenv("SA_GRU_PACK_IN_KERNEL");
+    const bool packg = one_launch && wg && (B % 16) == 0 && !(pg_e && pg_e[0] == '0') && issuer.shared_ok(spl);
+    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
+    const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
     if (flagless)
@@ -2618,18 +2708,15 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                 (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
     }
-    // ONE launch for the whole backward recurrence of the stack (fused kernel only): every layer runs all T steps, a
-    // lower layer picks each row of its d h_out up as the layer above stores it (sentinel pre-fill, see the kernel) --
-    // T + a few steps per layer of lag instead of (T / chunk + L - 1) chunks, and no launch ramps in between.
-    const char* one_e = getenv("SA_GRU_BWD_ONE");
-    const bool one_launch = fused && !(one_e && one_e[0] == '0') && !getenv("SA_GRU_TIMING");
     if (one_launch) {
         for (int l = 0; l + 1 < L; ++l)
             if (!sentinel_fill(mid_of(l), (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr; Q.drop = dc.drop;
+        Q.pk_kb = packg ? (long)T * B / 16 : 0;
         Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
+        if (packg) { issuer.gates_prepacked = true; issuer.gsum_parts = nbt; }
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
             PBwdJob& J = Q.j[n];
             J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
@@ -2638,6 +2725,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             J.w_ih_t = l > 0 ? wih_t_of(l) : nullptr; J.dx_out = l > 0 ? mid_of(l - 1) : nullptr;
             J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = xch_of(l); J.dump = (float*)(ws + dump_off);
             J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
+            J.gpk = packg ? wws + spl.g_off + (size_t)l * spl.g_each : nullptr;
+            J.gsum = packg ? (float*)(wws + spl.cs_off) + (size_t)l * nbt * 4 * H : nullptr;
             J.t0 = T - 1; J.nsteps = T; J.dt = -1; J.t_first = T - 1; J.base = 0;
         }
         Q.n = L;
@@ -2689,6 +2778,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
+            Q.pk_kb = 0;
             Q.drop = dc.drop;
             Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
             int n = 0;
@@ -2702,6 +2792,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
                 J.w_ih_t = fused && l > 0 ? wih_t_of(l) : nullptr; J.dx_out = fused && l > 0 ? mid_of(l - 1) : nullptr;
                 J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = tiled ? xch_of(l) : nullptr; J.dump = (float*)(ws + dump_off);
+                J.gpk = nullptr; J.gsum = nullptr;
                 J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
                 J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
                 J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);

@@ -115,32 +115,41 @@ def test_every_gru_path_applies_the_same_masks(monkeypatch, env):
     run_case(F=40, V=20, B=20, T=150, L=8, cfg=UNI256)
 
 
-def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatch):
+@pytest.mark.parametrize("B,H,layers", [(9, 128, 4), (32, 128, 3), (48, 256, 2)])
+def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatch, B, H, layers):
     # WGradIssuer::issue_shared (gru.hip): the gate gradients of a layer packed ONCE as a 4H-row operand that dW_ih reads
-    # as rows [0, 3H) and dW_hh as rows [0, 2H) + [3H, 4H) (a row-block jump), bias gradients from the pack kernel's row
-    # sums through the same row map -- against one pack per product.  Same kernels, same pieces: only the split-K
-    # partition of the sums differs, so the two agree to fp32 summation-order noise.  H = 128, B = 9, T' = 58: a reduction
-    # length (522) that is not a multiple of the 16-wide packed k tile, one ragged batch tile, I0 = 32 * 18.
+    # as rows [0, 3H) and dW_hh as rows [0, 2H) + [3H, 4H) (a row-block jump), bias gradients from row sums through the
+    # same row map -- against one pack per product.  With B a multiple of 16 the backward recurrence kernel writes that
+    # operand itself (gru_bwd_fused_kernel<PACKG>: LDS transpose, split, bias sums in registers); SA_GRU_PACK_IN_KERNEL=0
+    # leaves it to the pack launch.  Same pieces, same product kernels: the three agree to fp32 summation-order noise
+    # (the weight gradients of the two shared forms bit for bit).  B = 9: a reduction length (522) that is not a multiple
+    # of the 16-wide packed k tile and a ragged batch tile; B = 48: three batch tiles (two passes of the one-launch kernel
+    # at H = 256 would be four).
     from speech_amd.models import CTC
-    cfg = {"dropout": 0.3, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 128, "layers": 4, "bidirectional": False}}}
+    cfg = {"dropout": 0.3, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": H, "layers": layers, "bidirectional": False}}}
     monkeypatch.setenv("SA_GEMM_EXACT", "0")
     rng = np.random.RandomState(5)
-    x = rng.randn(9, 120, 40).astype(np.float32)
-    labels = tuple(rng.randint(0, 20, 6) for _ in range(9))
-    batch = (tuple(x[b] for b in range(9)), labels)
+    x = rng.randn(B, 120, 40).astype(np.float32)
+    labels = tuple(rng.randint(0, 20, 6) for _ in range(B))
+    batch = (tuple(x[b] for b in range(B)), labels)
     grads = {}
-    for shared in ("1", "0"):
-        monkeypatch.setenv("SA_GRU_SHARED_PACK", shared)
+    for mode, env in (("kernel", {"SA_GRU_SHARED_PACK": "1", "SA_GRU_PACK_IN_KERNEL": "1"}),
+                      ("shared", {"SA_GRU_SHARED_PACK": "1", "SA_GRU_PACK_IN_KERNEL": "0"}),
+                      ("each", {"SA_GRU_SHARED_PACK": "0", "SA_GRU_PACK_IN_KERNEL": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         torch.manual_seed(3)
         model = CTC(40, 20, cfg).cuda()
         model.set_train()
         model._plan.fixed_seed = 99
         model.loss(batch).backward()
-        grads[shared] = {k: q.grad.clone() for k, q in model.named_parameters()}
-    for k, a in grads["1"].items():
-        b = grads["0"][k]
-        rel = float((a - b).norm() / b.norm().clamp_min(1e-20))
-        assert rel <= 2e-6, (k, rel)
+        grads[mode] = {k: q.grad.clone() for k, q in model.named_parameters()}
+    for k, want in grads["each"].items():
+        for mode in ("kernel", "shared"):
+            rel = float((grads[mode][k] - want).norm() / want.norm().clamp_min(1e-20))
+            assert rel <= 2e-6, (mode, k, rel)
+        if "weight" in k:
+            assert torch.equal(grads["kernel"][k], grads["shared"][k]), k
 
 
 def test_h128_stack_and_two_convs():
