@@ -849,7 +849,22 @@ __global__ __launch_bounds__(256, 2) void gemm_pk_kernel(GemmArgs g) {
     gemm_block<false, false, 0>(g, pksm, bx, by, bz);
 }
 
-// The XCD-filtered launches (see GemmArgs::xcc_mask) run this copy with ONE register stage (<= 232 registers per lane):
+// ... and its XCD-filtered form (see GemmArgs::xcc_mask): one tile per block, drawn off the launch's counter.  168 registers
+// per lane: a surplus block is admitted beside a persistent recurrence block (264 - 280) and leaves at once.
+__global__ __launch_bounds__(256, 2) void gemm_pk_filtered_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float pksm[];
+    if (!((g.xcc_mask >> gemm_xcc_id()) & 1u)) return;
+    __shared__ int s_tile;
+    const int total = g.grid_x * g.grid_y * g.grid_z;
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(g.tile_counter, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile >= total) return;
+    const int bx = tile % g.grid_x, r = tile / g.grid_x;
+    gemm_block<false, false, 0>(g, pksm, bx, r % g.grid_y, r / g.grid_y);
+}
+
+// The XCD-filtered launches of the f32-input kernel (see GemmArgs::xcc_mask) run this copy with ONE register stage (<= 232 registers per lane):
 // a block that lands on an XCD where a persistent recurrence block (264 - 280 registers) holds every CU must still be
 // ADMITTED there in order to leave -- 264 + 256 does not fit a SIMD's 512, so the two-stage kernel's surplus blocks (and
 // with them the launch's completion, and everything queued behind it on the side stream) would wait for the recurrence
@@ -940,11 +955,29 @@ int choose_splits(int M, int N, int K, int nprob = 1) {
 // of whole rounds of 256 CUs; else 128 x 128 tiles, two blocks per CU (measured, tools/gemm_bench.py: 4096^3 191 vs 182
 // TFLOP/s, d x of layer 0 132 vs 130; but the layer-0 projection 136 vs 156 and the weight gradients 89 vs 122).
 // SA_GEMM_TILE=128 / 256 forces either (experiments).
-ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream) {
-    static bool pk_attr_dev[32] = {false};
+ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsigned* err_word = nullptr) {
+    static bool pk_attr_dev[48] = {false};
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
     const int M = gp.M, N = gp.N, nprob = gp.nprob;
+    if (gp.xcc_mask && gp.tile_counter) {  // XCD-filtered: block b lands on XCD b % 8 -- enough blocks that the allowed
+                                           // XCDs alone receive one per tile
+        if (!pk_attr_dev[devid + 32]) {
+            if (hipFuncSetAttribute((const void*)gemm_pk_filtered_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    PK_NST * PK_STAGE) != hipSuccess)
+                return CTC_STATUS_EXECUTION_FAILED;
+            pk_attr_dev[devid + 32] = true;
+        }
+        int allowed = 0;
+        for (int x = 0; x < 8; ++x) allowed += (gp.xcc_mask >> x) & 1u;
+        const long tiles = (long)gp.grid_x * gp.grid_y * gp.grid_z;
+        const dim3 fgrid((unsigned)((tiles + allowed - 1) / allowed * 8 + 8), 1, 1);
+        hipLaunchKernelGGL(gemm_pk_filtered_kernel, fgrid, dim3(256), PK_NST * PK_STAGE, stream, gp);
+        if (err_word)
+            hipLaunchKernelGGL(gemm_filtered_check_kernel, dim3(1), dim3(1), 0, stream, (const unsigned*)gp.tile_counter,
+                               (unsigned)tiles, err_word);
+        return CTC_STATUS_SUCCESS;
+    }
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
     const char* tile_e = getenv("SA_GEMM_TILE");
     const bool big_tile = tile_e ? atoi(tile_e) == 256
@@ -1005,7 +1038,8 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     // The split-bf16 kernel on packed operands for every product that is worth two pack launches, when the caller's
     // workspace has room for the packed copies; SA_GEMM_EXACT=1 (read per call): the f32-input MFMA kernel everywhere.
     const bool filtered = opts && opts->xcc_mask && opts->tile_counter;
-    bool use_pk = pk_worth_it(M, N, K, nprob) && !filtered;
+    const char* fpk_e = getenv("SA_GEMM_FILTERED_PK");
+    bool use_pk = pk_worth_it(M, N, K, nprob) && (!filtered || !(fpk_e && fpk_e[0] == '0'));
     const size_t pkA = sa_align_up(pk_bytes(M, K), 256), pkB = sa_align_up(pk_bytes(N, K), 256);
     const int pk_kt = 8, pk_parts = 2 * ((((K + PK_K - 1) / PK_K) + pk_kt - 1) / pk_kt);
     const int Mpad = (M + BM - 1) / BM * BM;
@@ -1044,7 +1078,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         grid = dim3((unsigned)((tiles + allowed - 1) / allowed * 8 + 8), 1, 1);
     }
     const size_t dyn = 0;
-    if (g.xcc_mask) {
+    if (g.xcc_mask && !use_pk) {
         if (trans_a) {
             if (trans_b) hipLaunchKernelGGL((gemm_f32_filtered_kernel<true, true>), grid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((gemm_f32_filtered_kernel<true, false>), grid, dim3(256), 0, stream, g);
@@ -1084,7 +1118,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
             gp.Bg[p] = (const float*)(pk_base + (size_t)nprob * pkA + (size_t)p * pkB);
             gp.colsumg[p] = nullptr;  // done by the pack kernel
         }
-        const ctcStatus_t pst = pk_launch(gp, splits, stream);
+        const ctcStatus_t pst = pk_launch(gp, splits, stream, opts ? opts->err_word : nullptr);
         if (pst != CTC_STATUS_SUCCESS) return pst;
         g = gp;  // the split-K reduce below must not fold column sums either
     } else if (trans_a) {

@@ -2032,7 +2032,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 o.tile_counter = mask ? sync + kSyncTiles + side_launch++ : nullptr;
                 o.err_word = g_health.dev;  // a filtered launch that did not cover its tiles stops the step's update
                 return sa_gemm_f32_group_impl(2, 0, 1, n * B, 3 * H, I, 1.f, gA, I, gB, I, 0.f, gC, 3 * H, gbias, nullptr,
-                                              mask ? nullptr : gws, mask ? 0 : gws_bytes, on, &o);
+                                              gws, gws_bytes, on, &o);  // (side chunks run between the main stream's products)
             };
             hipEvent_t ready[16];
             if (fside) {

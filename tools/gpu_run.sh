@@ -8,6 +8,7 @@
 #   configs[:ONLY]   tools/bench_configs.py [--only ONLY] -> configs.json
 #   py:SCRIPT ARGS   python SCRIPT ARGS -> SCRIPT-basename.log         (tools/*.py experiments)
 #   profpy:SCRIPT ARGS  rocprofv3 --kernel-trace --stats of python SCRIPT ARGS -> SCRIPT-basename_kernel_stats.csv
+#   trace:SCRIPT ARGS  rocprofv3 --kernel-trace of python SCRIPT ARGS -> SCRIPT-basename_timeline.txt (the last step's kernels in time)
 #   pmc:COUNTERS:ARGS  rocprofv3 --pmc COUNTERS --kernel-trace of bench.py ARGS -> pmc_<first counter>.csv
 # Example: gpurun --timeout 1500 -- 'bash tools/gpu_run.sh r3a tests:dropout bench "configs:M-STEP,M-TIMIT"'
 set -u
@@ -59,6 +60,12 @@ PY
       ( cd /tmp && timeout 900 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$first -o p -- python $ROOT/bench.py ${bargs:---steps 4 --warmup 2 --no-cpu-baseline} > $ROOT/$O/pmc_$first.log 2>&1 )
       find /tmp/pmc_${TAG}_$first -name "*counter_collection.csv" -exec cp {} $O/pmc_$first.csv \;
       python tools/pmc_summary.py $O/pmc_$first.csv 2>/dev/null | head -30 ;;
+    trace)   # trace:SCRIPT ARGS -> rocprofv3 --kernel-trace (timestamps) of python SCRIPT ARGS, then tools/trace_timeline.py
+      script=${arg%% *}; rest=""; [[ "$arg" == *" "* ]] && rest=${arg#* }
+      base=$(basename ${script%.py})
+      ( cd /tmp && rm -rf /tmp/tr_${TAG}_$base && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_${TAG}_$base -o p -- python $ROOT/$script $rest > $ROOT/$O/${base}_trace.log 2>&1 )
+      f=$(find /tmp/tr_${TAG}_$base -name "*kernel_trace.csv" | head -1)
+      python tools/trace_timeline.py $f clip_sgd_kernel 25 > $O/${base}_timeline.txt 2>&1; head -150 $O/${base}_timeline.txt ;;
     *) echo "unknown stage $name" ;;
   esac
 done
