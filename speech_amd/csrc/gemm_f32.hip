@@ -1239,7 +1239,7 @@ size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K) {
 // rows [0, M); B[p] rows [0, N).
 ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* Apk, int a_split, int a_jump,
                              unsigned a_jump_probs, const char* const* Bpk, float beta, float* const* C, long ldc, void* workspace,
-                             size_t workspace_bytes, hipStream_t stream) {
+                             size_t workspace_bytes, hipStream_t stream, const SaGemmOpts* opts) {
     SA_CLEAR_ERR();
     if (nprob < 1 || nprob > kMaxGroup || M <= 0 || N <= 0 || K <= 0 || (a_split % BM) || (a_jump % BM))
         return CTC_STATUS_INVALID_VALUE;
@@ -1264,7 +1264,8 @@ ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* 
     g.xcc_mask = 0; g.tile_counter = nullptr;
     g.a_rb_split = a_split / BM; g.a_rb_jump = a_jump / BM; g.a_jump_probs = a_jump ? a_jump_probs : 0u;
     g.grid_x = (N + BN - 1) / BN; g.grid_y = (M + BM - 1) / BM; g.grid_z = nprob * splits;
-    const ctcStatus_t st = pk_launch(g, splits, stream);
+    if (opts && opts->xcc_mask && opts->tile_counter) { g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter; }
+    const ctcStatus_t st = pk_launch(g, splits, stream, opts ? opts->err_word : nullptr);
     if (st != CTC_STATUS_SUCCESS) return st;
     SA_CHECK_LAUNCH();
     if (splits > 1) {

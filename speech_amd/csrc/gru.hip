@@ -1878,6 +1878,11 @@ static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels
 }
 static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
     if (!tiled_enabled()) return nullptr;
+    if (packg && !fuse) {
+        if (H == 512) return gru_bwd_fused_kernel<8, false, false, true>;
+        if (H == 256) return gru_bwd_fused_kernel<4, false, false, true>;
+        return nullptr;
+    }
     if (packg && fuse) {
         if (H == 512) return drop ? gru_bwd_fused_kernel<8, true, true, true> : gru_bwd_fused_kernel<8, true, false, true>;
         if (H == 256) return drop ? gru_bwd_fused_kernel<4, true, true, true> : gru_bwd_fused_kernel<4, true, false, true>;
@@ -2298,8 +2303,34 @@ static bool shared_pack_layout(int L, int D, int B, int T, int H, int I0, Shared
     y.total = y.sk_off + sa_align_up(a > b ? a : b, 256);
     return true;
 }
+// Bidirectional stacks, layer by layer (WGradIssuer::issue_shared_bi): the backward recurrence kernel of a layer writes the
+// two directions' 4H-row gate operands and their row sums (gru_bwd_fused_kernel<.., PACKG>) into the slot of the layer's
+// PARITY -- the layer above's slot is still being read by its weight-gradient products on the side stream.  h_prev of the
+// two directions and the layer's input (2H or I0 rows, shared by both directions' dW_ih) are packed by launches.
+struct SharedPackLayoutBi { size_t g_each, h_each, lo_bytes, cs_each, slot, hp_off, lo_off, sk_off, total; };
+static bool shared_pack_layout_bi(int L, int D, int B, int T, int H, int I0, SharedPackLayoutBi& y) {
+    const long K = (long)T * B;
+    const int Imax = I0 > 2 * H ? I0 : 2 * H;
+    if (D != 2 || (H % 128) || (B % 16) || K > 0x7fffffffL || !shared_pack_enabled()) return false;
+    if (!sa_pk_enabled(3 * H, H, (int)K, 2) || !sa_pk_enabled(3 * H, I0, (int)K, 2)) return false;
+    y.g_each = sa_pk_operand_bytes(4 * H, (int)K);
+    y.h_each = sa_pk_operand_bytes(H, (int)K);
+    y.lo_bytes = sa_pk_operand_bytes(Imax, (int)K);
+    y.cs_each = sa_align_up((size_t)((B + 15) / 16) * 4 * H * sizeof(float), 256);
+    y.slot = 2 * (y.g_each + y.cs_each);   // per layer parity: G[d], then the row sums [d]
+    y.hp_off = 2 * y.slot;
+    y.lo_off = y.hp_off + 2 * y.h_each;
+    y.sk_off = y.lo_off + y.lo_bytes;
+    const size_t a = sa_gemm_pk_group_workspace_bytes(2, 3 * H, H, (int)K);
+    const size_t b = sa_gemm_pk_group_workspace_bytes(2, 3 * H, Imax, (int)K);
+    y.total = y.sk_off + sa_align_up(a > b ? a : b, 256);
+    (void)L;
+    return true;
+}
 static size_t shared_pack_ws_bytes(int L, int D, int B, int T, int H, int I0) {
     SharedPackLayout y;
+    SharedPackLayoutBi z;
+    if (D == 2) return shared_pack_layout_bi(L, D, B, T, H, I0, z) ? z.total : 0;
     return shared_pack_layout(L, D, B, T, H, I0, y) ? y.total : 0;
 }
 
@@ -2423,6 +2454,54 @@ struct WGradIssuer {
         return CTC_STATUS_SUCCESS;
     }
     // spans[k] = {t0, t1} (t1 <= t0: nothing).  Same-shaped problems share a grouped launch.
+    // One layer of a bidirectional stack on shared packed operands (shared_pack_layout_bi); the gate operands and their
+    // row sums are in the layer's parity slot already.  mask != 0: XCD-filtered launches (side stream).
+    bool shared_ok_bi(SharedPackLayoutBi& y) const {
+        if (D != 2 || !wg.x || !wg.h_out || !wg.dw_ih || !wg.dw_hh || !wg.db_ih || !wg.db_hh) return false;
+        for (int k = 0; k < 2 * L; ++k)
+            if (!wg.dw_ih[k] || !wg.dw_hh[k] || !wg.db_ih[k] || !wg.db_hh[k] || (k >= 2 && !lower[k / 2])) return false;
+        return shared_pack_layout_bi(L, D, B, T, H, I0, y) && y.total <= ws_bytes;
+    }
+    char* bi_gpk(const SharedPackLayoutBi& y, int l, int d) const { return (char*)ws + (size_t)(l & 1) * y.slot + (size_t)d * y.g_each; }
+    float* bi_gsum(const SharedPackLayoutBi& y, int l, int d) const {
+        return (float*)((char*)ws + (size_t)(l & 1) * y.slot + 2 * y.g_each + (size_t)d * y.cs_each);
+    }
+    ctcStatus_t issue_shared_bi(const SharedPackLayoutBi& y, int l, hipStream_t stream, unsigned mask) {
+        const int K = T * B, I = l == 0 ? I0 : 2 * H, nbt = (B + 15) / 16;
+        char* base = (char*)ws;
+        const float* src[2];
+        for (int d = 0; d < 2; ++d) src[d] = stash[l * 2 + d] + 4 * H;
+        ctcStatus_t st = sa_pk_pack(2, src, nullptr, 0, 5 * H, H, K, 0, base + y.hp_off, y.h_each, nullptr, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        src[0] = l == 0 ? wg.x : lower[l];
+        st = sa_pk_pack(1, src, nullptr, 0, I, I, K, 0, base + y.lo_off, y.lo_bytes, nullptr, stream);
+        if (st != CTC_STATUS_SUCCESS) return st;
+        for (int d = 0; d < 2; ++d) {  // (the two directions' row sums are not one [prob][part][row] array: a fold each)
+            float* o_ih[1] = {wg.db_ih[l * 2 + d]}; float* o_hh[1] = {wg.db_hh[l * 2 + d]};
+            st = sa_pk_rowsum_fold(1, bi_gsum(y, l, d), nbt, 4 * H, 3 * H, 3 * H, 0, o_ih, 0.f, stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+            st = sa_pk_rowsum_fold(1, bi_gsum(y, l, d), nbt, 4 * H, 3 * H, 2 * H, H, o_hh, 0.f, stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+        }
+        SaGemmOpts o;
+        o.no_split = 0; o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr; o.err_word = err_word;
+        const char* pa[2]; const char* pb[2]; float* pc[2];
+        for (int pass = 0; pass < 2; ++pass) {  // 0: dW_hh (rows [0, 2H) + [3H, 4H) of G, times h_prev), 1: dW_ih
+            for (int d = 0; d < 2; ++d) {
+                pa[d] = bi_gpk(y, l, d);
+                pb[d] = pass == 0 ? base + y.hp_off + (size_t)d * y.h_each : base + y.lo_off;
+                pc[d] = pass == 0 ? wg.dw_hh[l * 2 + d] : wg.dw_ih[l * 2 + d];
+            }
+            if (mask && counters && next_counter < max_counters) { o.xcc_mask = mask; o.tile_counter = counters + next_counter++; }
+            else { o.xcc_mask = 0; o.tile_counter = nullptr; }
+            const int N = pass == 0 ? H : I;
+            st = sa_gemm_pk_group(2, 3 * H, N, K, pa, 2 * H, H, pass == 0 ? 3u : 0u, pb, 0.f, pc, N, base + y.sk_off,
+                                  ws_bytes - y.sk_off, stream, &o);
+            if (st != CTC_STATUS_SUCCESS) return st;
+        }
+        first_ih[l * 2] = first_ih[l * 2 + 1] = first_hh[l * 2] = first_hh[l * 2 + 1] = false;
+        return CTC_STATUS_SUCCESS;
+    }
     // issue_shared applies to this stack when every product is still owed in full
     bool shared_ok(SharedPackLayout& y) const {
         if (D != 1 || xcc_mask || !wg.x || !wg.dw_ih || !wg.dw_hh || !wg.db_ih || !wg.db_hh) return false;
@@ -2577,15 +2656,28 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled() && g_side.init();
         issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords; issuer.err_word = g_health.dev;
         // tiled exchange, operands a step ahead (gru_bwd_fused_kernel without the second product): H = 512 / 256
-        const BwdPersistFn bi_tiled_fn = bi_xcd && flagless_mode() && (long)T * bi_nbt * 16 * 3 * H * 4 < 0x7fffffffL
-                                             ? bwd_fused_fn(H, false) : nullptr;
+        const bool bi_tiled = bi_xcd && flagless_mode() && (long)T * bi_nbt * 16 * 3 * H * 4 < 0x7fffffffL;
+        // ... which also writes the weight gradients' gate operands, packed (gru_bwd_fused_kernel<.., PACKG>); the products
+        // of a layer then run on shared operands (issue_shared_bi), filtered beside the next layer or plain on `stream`
+        SharedPackLayoutBi spb;
+        const char* bpg_e = getenv("SA_GRU_PACK_IN_KERNEL");
+        const bool bi_packg = bi_tiled && wg && !(bpg_e && bpg_e[0] == '0') && bi_nbt <= bi_tpp && issuer.shared_ok_bi(spb) &&
+                              bwd_fused_fn(H, false, false, true) != nullptr;
+        const BwdPersistFn bi_tiled_fn = bi_tiled ? bwd_fused_fn(H, false, false, bi_packg) : nullptr;
+        const size_t bi_lds_run = bi_packg ? xcd_lds((size_t)(4 * 4 * 256 + 2 * 4 * 16 * 20) * sizeof(float)) : bi_lds;
         if (bi_xcd) {
             if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
             if (hipFuncSetAttribute(bi_tiled_fn ? (const void*)bi_tiled_fn : (const void*)bwd_persist_fn(),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bi_lds) != hipSuccess)
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bi_lds_run) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
         }
+        hipEvent_t slot_read[2] = {nullptr, nullptr};
+        bool slot_busy[2] = {false, false};
         for (int l = L - 1; l >= 0; --l) {
+            if (bi_packg && slot_busy[l & 1]) {
+                if (hipStreamWaitEvent(stream, slot_read[l & 1], 0) != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
+                slot_busy[l & 1] = false;
+            }
             if (bi_xcd) {  // ONE persistent launch unwinds both directions of the layer over all T steps
                 PBwdJobs Q;
                 Q.B = B; Q.H = H; Q.nbt_all = bi_nbt; Q.ntile_u = H / 16; Q.rb = 1; Q.rt = B;
@@ -2596,10 +2688,13 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                            bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
-                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull); Q.pk_kb = 0;
+                Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
+                Q.pk_kb = bi_packg ? (long)T * B / 16 : 0;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
-                    J.dx_drop_stream = 0u; J.gpk = nullptr; J.gsum = nullptr;
+                    J.dx_drop_stream = 0u;
+                    J.gpk = bi_packg ? issuer.bi_gpk(spb, l, d) : nullptr;
+                    J.gsum = bi_packg ? issuer.bi_gsum(spb, l, d) : nullptr;
                     const float* dho = (l == L - 1) ? dh_top : mid_of(l);
                     J.dh_out = dho + (long)d * H; J.ds_b = DH; J.ds_t = (long)B * DH;
                     J.stash = stash[l * 2 + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * 2 + d]; J.dah = dah[l * 2 + d];
@@ -2613,7 +2708,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
                     Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
                     Q.reg_base = bi_launches++ * 32u;
-                    hipLaunchKernelGGL(bi_tiled_fn ? bi_tiled_fn : bwd_persist_fn(), dim3(256), dim3(256), bi_lds, stream, Q);
+                    hipLaunchKernelGGL(bi_tiled_fn ? bi_tiled_fn : bwd_persist_fn(), dim3(256), dim3(256), bi_lds_run, stream, Q);
                 }
             } else {
             P.n = 2; grid.z = 2;
@@ -2636,6 +2731,25 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 st = sa_dropout_apply_impl(din, din, (size_t)T * B * DH, 0, dc.drop, dc.stream0 + l - 1, stream);
                 if (st != CTC_STATUS_SUCCESS) return st;
             }
+            if (bi_packg) {  // the layer's products on the operands its recurrence kernel packed: beside the next layer's
+                             // recurrence (side stream, filtered) when there is one, else plain on the caller's stream
+                const bool side = bi_side && l > 0;
+                for (int d = 0; d < 2; ++d) wg_hi[l * 2 + d] = 0;
+                if (side) {
+                    if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
+                    hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // ~40 us
+                } else if (bi_side && !g_side.order(g_side.s, stream)) {  // the scratch operands are the side stream's
+                    return CTC_STATUS_EXECUTION_FAILED;
+                }
+                st = issuer.issue_shared_bi(spb, l, side ? g_side.s : stream, side ? bi_mask : 0u);
+                if (st != CTC_STATUS_SUCCESS) return st;
+                if (side) {  // layer l - 2 packs into this layer's slot: not before these products have read it
+                    slot_read[l & 1] = g_side.ev[g_side.next];
+                    g_side.next = (g_side.next + 1) % SideStream::kEvents;
+                    if (hipEventRecord(slot_read[l & 1], g_side.s) != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
+                    slot_busy[l & 1] = true;
+                }
+            } else
             if (bi_xcd && wg && bi_side && l > 0) {  // (layer 0's products have no recurrence left to hide behind: they
                                                       // run unfiltered on the caller's stream, wgrad_rest below)
                 // this layer's weight gradients go to the side stream NOW, behind the input-gradient products above

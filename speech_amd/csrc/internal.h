@@ -57,4 +57,5 @@ ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int R
 size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K);
 ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* Apk, int a_split, int a_jump,
                              unsigned a_jump_probs, const char* const* Bpk, float beta, float* const* C, long ldc, void* workspace,
-                             size_t workspace_bytes, hipStream_t stream);
+                             size_t workspace_bytes, hipStream_t stream, const SaGemmOpts* opts = nullptr);
+// (opts: only xcc_mask / tile_counter / err_word are read -- the XCD-filtered form of the launch)

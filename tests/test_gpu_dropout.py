@@ -115,8 +115,9 @@ def test_every_gru_path_applies_the_same_masks(monkeypatch, env):
     run_case(F=40, V=20, B=20, T=150, L=8, cfg=UNI256)
 
 
-@pytest.mark.parametrize("B,H,layers", [(9, 128, 4), (32, 128, 3), (48, 256, 2)])
-def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatch, B, H, layers):
+@pytest.mark.parametrize("B,H,layers,bi", [(9, 128, 4, False), (32, 128, 3, False), (48, 256, 2, False), (16, 256, 3, True),
+                                           (32, 256, 2, True)])
+def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatch, B, H, layers, bi):
     # WGradIssuer::issue_shared (gru.hip): the gate gradients of a layer packed ONCE as a 4H-row operand that dW_ih reads
     # as rows [0, 3H) and dW_hh as rows [0, 2H) + [3H, 4H) (a row-block jump), bias gradients from row sums through the
     # same row map -- against one pack per product.  With B a multiple of 16 the backward recurrence kernel writes that
@@ -124,9 +125,11 @@ def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatc
     # leaves it to the pack launch.  Same pieces, same product kernels: the three agree to fp32 summation-order noise
     # (the weight gradients of the two shared forms bit for bit).  B = 9: a reduction length (522) that is not a multiple
     # of the 16-wide packed k tile and a ragged batch tile; B = 48: three batch tiles (two passes of the one-launch kernel
-    # at H = 256 would be four).
+    # at H = 256 would be four).  Bidirectional stacks: the same, layer by layer and per direction (issue_shared_bi: both
+    # directions' dW_ih read ONE packed copy of the layer's input; XCD-filtered launches beside the next layer's
+    # recurrence), against the generic per-product path.
     from speech_amd.models import CTC
-    cfg = {"dropout": 0.3, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": H, "layers": layers, "bidirectional": False}}}
+    cfg = {"dropout": 0.3, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": H, "layers": layers, "bidirectional": bi}}}
     monkeypatch.setenv("SA_GEMM_EXACT", "0")
     rng = np.random.RandomState(5)
     x = rng.randn(B, 120, 40).astype(np.float32)
@@ -148,7 +151,7 @@ def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatc
         for mode in ("kernel", "shared"):
             rel = float((grads[mode][k] - want).norm() / want.norm().clamp_min(1e-20))
             assert rel <= 2e-6, (mode, k, rel)
-        if "weight" in k:
+        if "weight" in k and not bi:
             assert torch.equal(grads["kernel"][k], grads["shared"][k]), k
 
 
