@@ -857,6 +857,8 @@ struct PBwdJob {
     unsigned dx_drop_stream;  // gru_bwd_fused_kernel: mask stream of dx_out (= the dropped output of the layer below)
     char* gpk;             // gru_bwd_fused_kernel<.., PACKG>: the layer's 4H-row packed gate-gradient operand (gemm_f32.hip)
     float* gsum;           // gru_bwd_fused_kernel<.., PACKG>: its row sums per batch tile, [nbt_all][4H] (the bias gradients)
+    char* kpk;             // gru_bwd_fused_kernel<.., PACKK>: dai as the packed A operand of the input-gradient product
+                           // (rows = (t, b), k = (gate, unit): T * B rows x 3H)
     int t0, nsteps;        // first time index this launch unwinds, number of steps
     int dt, t_first;       // -1 for a forward-in-time chain (unwinds from T-1), +1 for a reverse chain; the very first index
     unsigned base;
@@ -1078,7 +1080,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // barrier is added), wave w splits gate w -- each thread four values -- and stores 3 x 8 bytes into the layer's 4H-row
 // operand; the bias gradients are per-thread running sums, folded over the batch tile after the last step.  dai of the
 // bottom layer is still written row-major (the d x product reads it); nothing else is.
-template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false>
+// PACKK (with PACKG, bidirectional layers): dai is ALSO written packed the other way round -- operand row = (t, b), 16
+// consecutive k = the block's 16 units of one gate -- the A operand of the layer's input-gradient product
+// d in = sum over directions of dai W_ih, which runs between this layer's recurrence and the next one's.  Waves 0 .. 2 take
+// {dpr, dpz, dpn} out of the same LDS staging; no row-major copy of dai is left.
+template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
@@ -1213,6 +1219,24 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         s_pk = (long)(B / 16) * 12288;
         pk_src = pks + wave * 320 + pu * 20 + 4 * pq;
     }
+    // PACKK: wave w < 3 packs gate w; thread (batch row kr = lane / 4, quarter pq = lane % 4) takes units 4 pq .. 4 pq + 3
+    const int kr = lane >> 2, kq = lane & 3;
+    const float* kk_src = PACKK ? pks + (wave < 3 ? wave : 0) * 320 + (4 * kq) * 20 + kr : nullptr;
+    const size_t kk_tile = PACKK ? ((size_t)(wave < 3 ? wave : 0) * (H / 16) + role_x) * 12288 + (kq & 1) * 8 : 0;
+    auto pack_row_k = [&](int par, bool on, int trow) {
+        const float* q = kk_src + par * 1280;
+        unsigned a0, a1, b0_, b1, c0, c1;
+        sa_split2(q[0], q[20], a0, b0_, c0);
+        sa_split2(q[40], q[60], a1, b1, c1);
+        const int m = (trow < 0 ? 0 : trow) * B + b0 + kr, rl = m & 127;
+        const bool go = on && wave < 3;
+        char* dst = go ? J.kpk + (size_t)(m >> 7) * (3 * H / 16) * 12288 + kk_tile + rl * 32 + ((((kq >> 1) ^ (rl >> 3)) & 1) << 4)
+                       : reinterpret_cast<char*>(J.dump + ((blockIdx.x * 256 + tid) & ~1));
+        const long pl = go ? 4096 : 0;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, a1);
+        *reinterpret_cast<uint2*>(dst + pl) = make_uint2(b0_, b1);
+        *reinterpret_cast<uint2*>(dst + 2 * pl) = make_uint2(c0, c1);
+    };
     auto pack_row = [&](int par, bool on, int trow) {  // the step staged in pks[par]: split, store (behind a barrier)
         const float4 v = *reinterpret_cast<const float4*>(pk_src + par * 1280);
         unsigned a0, a1, b0_, b1, c0, c1;
@@ -1330,9 +1354,13 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             ps[0] = dpr; ps[320] = dpz; ps[640] = dpn; ps[960] = dqn;
             gs0 += dpr; gs1 += dpz; gs2 += dpn; gs3 += dqn;
             pack_row((s - 1) & 1, s > 0, t - dt);
-            float* di = (live && bottom) ? p_di + (long)t * s_d : p_dump;  // the d x product of layer 0 reads dai row-major
-            const int g1 = (live && bottom) ? H : 0, g2 = (live && bottom) ? 2 * H : 0;
-            di[0] = dpr; di[g1] = dpz; di[g2] = dpn;
+            if constexpr (PACKK) {
+                pack_row_k((s - 1) & 1, s > 0, t - dt);
+            } else {
+                float* di = (live && bottom) ? p_di + (long)t * s_d : p_dump;  // the d x product of layer 0 reads dai row-major
+                const int g1 = (live && bottom) ? H : 0, g2 = (live && bottom) ? 2 * H : 0;
+                di[0] = dpr; di[g1] = dpz; di[g2] = dpn;
+            }
             dh_run = dh;
             z_next = z;
         } else {  // the row-major copies the weight-gradient products read
@@ -1373,6 +1401,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     }
     if constexpr (PACKG) {  // the last step's values are staged (a barrier has passed on either branch above)
         pack_row((nsteps - 1) & 1, nsteps > 0, t0 + (nsteps - 1) * dt);
+        if constexpr (PACKK) pack_row_k((nsteps - 1) & 1, nsteps > 0, t0 + (nsteps - 1) * dt);
         __syncthreads();
         // bias gradients: this batch tile's row sums, unit-major in LDS, 16 rows folded by the first 64 threads
         float* ps = pks + uj * 20 + bi;
@@ -1878,9 +1907,9 @@ static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels
 }
 static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
     if (!tiled_enabled()) return nullptr;
-    if (packg && !fuse) {
-        if (H == 512) return gru_bwd_fused_kernel<8, false, false, true>;
-        if (H == 256) return gru_bwd_fused_kernel<4, false, false, true>;
+    if (packg && !fuse) {  // bidirectional layers: gate operands and the input-gradient operand
+        if (H == 512) return gru_bwd_fused_kernel<8, false, false, true, true>;
+        if (H == 256) return gru_bwd_fused_kernel<4, false, false, true, true>;
         return nullptr;
     }
     if (packg && fuse) {
@@ -2307,7 +2336,8 @@ static bool shared_pack_layout(int L, int D, int B, int T, int H, int I0, Shared
 // two directions' 4H-row gate operands and their row sums (gru_bwd_fused_kernel<.., PACKG>) into the slot of the layer's
 // PARITY -- the layer above's slot is still being read by its weight-gradient products on the side stream.  h_prev of the
 // two directions and the layer's input (2H or I0 rows, shared by both directions' dW_ih) are packed by launches.
-struct SharedPackLayoutBi { size_t g_each, h_each, lo_bytes, cs_each, slot, hp_off, lo_off, sk_off, total; };
+struct SharedPackLayoutBi { size_t g_each, h_each, lo_bytes, cs_each, slot, hp_off, lo_off, sk_off, total;
+                            size_t k_each, w_each, kslot_off, w_off, skx_off, skx_bytes; };
 static bool shared_pack_layout_bi(int L, int D, int B, int T, int H, int I0, SharedPackLayoutBi& y) {
     const long K = (long)T * B;
     const int Imax = I0 > 2 * H ? I0 : 2 * H;
@@ -2323,7 +2353,16 @@ static bool shared_pack_layout_bi(int L, int D, int B, int T, int H, int I0, Sha
     y.sk_off = y.lo_off + y.lo_bytes;
     const size_t a = sa_gemm_pk_group_workspace_bytes(2, 3 * H, H, (int)K);
     const size_t b = sa_gemm_pk_group_workspace_bytes(2, 3 * H, Imax, (int)K);
-    y.total = y.sk_off + sa_align_up(a > b ? a : b, 256);
+    // the input-gradient products (the caller's stream): dai packed by the kernel (per layer parity and direction), W_ih
+    // packed per layer, split-K scratch of their own
+    if (!sa_pk_enabled((int)K, I0 < 2 * H ? I0 : 2 * H, 3 * H, 1)) return false;
+    y.k_each = sa_pk_operand_bytes((int)K, 3 * H);
+    y.w_each = sa_pk_operand_bytes(Imax, 3 * H);
+    y.kslot_off = y.sk_off + sa_align_up(a > b ? a : b, 256);
+    y.w_off = y.kslot_off + 4 * y.k_each;
+    y.skx_off = y.w_off + 2 * y.w_each;
+    y.skx_bytes = sa_align_up(sa_gemm_pk_group_workspace_bytes(1, (int)K, Imax, 3 * H), 256);
+    y.total = y.skx_off + y.skx_bytes;
     (void)L;
     return true;
 }
@@ -2463,6 +2502,20 @@ struct WGradIssuer {
         return shared_pack_layout_bi(L, D, B, T, H, I0, y) && y.total <= ws_bytes;
     }
     char* bi_gpk(const SharedPackLayoutBi& y, int l, int d) const { return (char*)ws + (size_t)(l & 1) * y.slot + (size_t)d * y.g_each; }
+    char* bi_kpk(const SharedPackLayoutBi& y, int l, int d) const { return (char*)ws + y.kslot_off + (size_t)(2 * (l & 1) + d) * y.k_each; }
+    // d in (T B, I) = sum over the directions of dai[l, d] W_ih[l, d], on the operands the recurrence kernel packed
+    ctcStatus_t input_grad_bi(const SharedPackLayoutBi& y, int l, const float* const* w_ih, float* din, hipStream_t stream) {
+        const int I = l == 0 ? I0 : 2 * H;
+        char* base = (char*)ws;
+        const float* src[2] = {w_ih[l * 2], w_ih[l * 2 + 1]};
+        ctcStatus_t st = sa_pk_pack(2, src, nullptr, 0, I, I, 3 * H, 0, base + y.w_off, y.w_each, nullptr, stream);
+        for (int d = 0; d < 2 && st == CTC_STATUS_SUCCESS; ++d) {
+            const char* pa[1] = {bi_kpk(y, l, d)}; const char* pb[1] = {base + y.w_off + (size_t)d * y.w_each};
+            float* pc[1] = {din};
+            st = sa_gemm_pk_group(1, T * B, I, 3 * H, pa, 0, 0, 0u, pb, d ? 1.f : 0.f, pc, I, base + y.skx_off, y.skx_bytes, stream);
+        }
+        return st;
+    }
     float* bi_gsum(const SharedPackLayoutBi& y, int l, int d) const {
         return (float*)((char*)ws + (size_t)(l & 1) * y.slot + 2 * y.g_each + (size_t)d * y.cs_each);
     }
@@ -2695,6 +2748,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     J.dx_drop_stream = 0u;
                     J.gpk = bi_packg ? issuer.bi_gpk(spb, l, d) : nullptr;
                     J.gsum = bi_packg ? issuer.bi_gsum(spb, l, d) : nullptr;
+                    J.kpk = bi_packg ? issuer.bi_kpk(spb, l, d) : nullptr;
                     const float* dho = (l == L - 1) ? dh_top : mid_of(l);
                     J.dh_out = dho + (long)d * H; J.ds_b = DH; J.ds_t = (long)B * DH;
                     J.stash = stash[l * 2 + d]; J.w_hh_t = wt_of(l, d); J.dai = dai[l * 2 + d]; J.dah = dah[l * 2 + d];
@@ -2721,7 +2775,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             // gradient wrt this layer's input = sum over directions of dai W_ih
             float* din = l > 0 ? mid_of(l - 1) : dx;
             const int I = l > 0 ? 2 * H : I0;
-            if (din)
+            if (din && bi_packg) {
+                st = issuer.input_grad_bi(spb, l, w_ih, din, stream);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            } else if (din)
                 for (int d = 0; d < 2; ++d) {
                     st = gemm_whole(0, 0, T * B, I, 3 * H, dai[l * 2 + d], 3 * H, w_ih[l * 2 + d], I, d ? 1.f : 0.f, din, I,
                                     nullptr, gws, gws_bytes, stream);
@@ -2841,6 +2898,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
             J.gpk = packg ? wws + spl.g_off + (size_t)l * spl.g_each : nullptr;
             J.gsum = packg ? (float*)(wws + spl.cs_off) + (size_t)l * nbt * 4 * H : nullptr;
+            J.kpk = nullptr;
             J.t0 = T - 1; J.nsteps = T; J.dt = -1; J.t_first = T - 1; J.base = 0;
         }
         Q.n = L;
@@ -2906,7 +2964,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
                 J.w_ih_t = fused && l > 0 ? wih_t_of(l) : nullptr; J.dx_out = fused && l > 0 ? mid_of(l - 1) : nullptr;
                 J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = tiled ? xch_of(l) : nullptr; J.dump = (float*)(ws + dump_off);
-                J.gpk = nullptr; J.gsum = nullptr;
+                J.gpk = nullptr; J.gsum = nullptr; J.kpk = nullptr;
                 J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
                 J.t0 = min(T, (c + 1) * chunk) - 1; J.nsteps = J.t0 - c * chunk + 1; J.dt = -1; J.t_first = T - 1;
                 J.base = (unsigned)ntile_u * (unsigned)(T - 1 - J.t0);
