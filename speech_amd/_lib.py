@@ -186,3 +186,83 @@ class Workspace:
 
 
 WORKSPACE = Workspace()
+
+
+class PinnedRing:
+    """A small ring of pinned host buffers for per-step host -> device traffic (the padded feature batch, the label /
+    length integers).  torch copies a PAGEABLE source through a staging buffer and blocks the host until the stream has
+    drained -- once per step that stalls the launch queue behind the whole forward pass; from pinned memory the copy is a
+    real asynchronous DMA.  A slot is handed out again only after the copy that read it has completed (one event per
+    slot), so the host fills batch k+1's slot while batch k's copy and kernels are still in flight."""
+
+    def __init__(self, dtype, depth=4):
+        self._dtype = dtype
+        self._bufs = [None] * depth
+        self._events = [None] * depth
+        self._next = 0
+        self._by_ptr = {}
+
+    def get(self, shape):
+        """A pinned tensor of `shape` (contents undefined)."""
+        i = self._next
+        self._next = (i + 1) % len(self._bufs)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+            self._events[i] = None
+        buf = self._bufs[i]
+        if buf is None or buf.numel() < n:
+            if buf is not None:
+                self._by_ptr.pop(buf.data_ptr(), None)
+            buf = torch.empty(int(n * 1.25) + 16, dtype=self._dtype).pin_memory()
+            self._bufs[i] = buf
+            self._by_ptr[buf.data_ptr()] = i
+        return buf[:n].view(tuple(int(d) for d in shape))
+
+    def copied(self, host_tensor, stream=None):
+        """Call right after enqueueing (on `stream`, default the current one) the H2D copy of a tensor from get()."""
+        i = self._by_ptr.get(host_tensor.data_ptr())
+        if i is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self._events[i] = ev
+
+
+_INT_RING = None
+_COPY_STREAMS = {}
+
+
+def copy_stream(device):
+    """The library's H2D stream of `device`: a step's input copy is issued there as soon as the host has padded the
+    batch -- normally while the previous step's kernels still run -- and the compute stream waits for it."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    s = _COPY_STREAMS.get(key)
+    if s is None:
+        s = _COPY_STREAMS[key] = torch.cuda.Stream(device=key)
+    return s
+
+
+def h2d_async(host_tensor, device, ring=None):
+    """host_tensor (pinned, from `ring`) -> a device tensor, copied on copy_stream(device); the CURRENT stream is made to
+    wait for the copy, and the allocator is told that it uses the result."""
+    cur = torch.cuda.current_stream(device)
+    cs = copy_stream(device)
+    with torch.cuda.stream(cs):
+        out = host_tensor.to(device, non_blocking=True)
+    if ring is not None:
+        ring.copied(host_tensor, cs)
+    cur.wait_stream(cs)
+    out.record_stream(cur)
+    return out
+
+
+def ints_to_device(arr, device):
+    """A small int32 host array -> device, through pinned memory (asynchronous; see PinnedRing)."""
+    global _INT_RING
+    if _INT_RING is None:
+        _INT_RING = PinnedRing(torch.int32, depth=8)
+    h = _INT_RING.get(arr.shape)
+    h.numpy()[...] = arr
+    return h2d_async(h, device, _INT_RING)

@@ -39,7 +39,8 @@ class CTCLabels:
             raise _lib.SpeechAmdError("CTCLoss: bad lengths")
         self.lab_h, self.alen_h = lab_h, alen_h
         self.max_T, self.max_L = max(int(alen_h.max()), 1), int(llen_h.max())
-        ints = torch.from_numpy(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)])).to(device)
+        # (through pinned memory: a pageable source would block the host until the stream -- the whole forward pass -- drains)
+        ints = _lib.ints_to_device(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)]), device)
         self.d_alen, self.d_llen, self.d_lab = ints[:self.B], ints[self.B:2 * self.B], ints[2 * self.B:]
         self._checked = None
 

@@ -102,10 +102,9 @@ class Model(nn.Module):
         """The batch's H2D copy (ctc_model.py:26-27 `x.cuda()`): asynchronous when collate() staged it in pinned memory."""
         if x.is_cuda or not self.is_cuda:
             return x
-        xd = x.cuda(non_blocking=True)
-        if self._stage is not None:
-            self._stage.copied(x)
-        return xd
+        if x.is_pinned():  # on the copy stream: it runs while the previous step's kernels still hold the compute stream
+            return _lib.h2d_async(x, list(self.parameters())[0].device, self._stage)
+        return x.cuda(non_blocking=True)
 
     def _pad_inputs(self, inputs):
         if self.is_cuda and not torch.is_tensor(inputs[0]):
@@ -267,40 +266,11 @@ def zero_pad_concat(inputs, min_t=0, stage=None):
     return input_mat
 
 
-class _PinnedStage:
-    """A small ring of pinned host buffers for the padded feature batch (train.py's loop: collate on the host, copy,
-    launch).  A buffer is handed out again only after the H2D copy that read it has completed (one event per slot), so
-    the host can pad batch k+1 while batch k's copy and kernels are still in flight."""
+class _PinnedStage(_lib.PinnedRing):
+    """The pinned ring of the padded feature batch (train.py's loop: collate on the host, copy, launch)."""
 
     def __init__(self, depth=3):
-        self._bufs = [None] * depth
-        self._events = [None] * depth
-        self._next = 0
-        self._by_ptr = {}
-
-    def get(self, shape):
-        i = self._next
-        self._next = (i + 1) % len(self._bufs)
-        n = int(np.prod(shape))
-        if self._events[i] is not None:
-            self._events[i].synchronize()
-            self._events[i] = None
-        buf = self._bufs[i]
-        if buf is None or buf.numel() < n:
-            if buf is not None:
-                self._by_ptr.pop(buf.data_ptr(), None)
-            buf = torch.empty(int(n * 1.25) + 16, dtype=torch.float32).pin_memory()
-            self._bufs[i] = buf
-            self._by_ptr[buf.data_ptr()] = i
-        return buf[:n].view(shape)
-
-    def copied(self, host_tensor):
-        """Call right after enqueueing the H2D copy of a tensor handed out by get()."""
-        i = self._by_ptr.get(host_tensor.data_ptr())
-        if i is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._events[i] = ev
+        super().__init__(torch.float32, depth)
 
 
 def _flat_labels(labels):
