@@ -166,6 +166,67 @@ __global__ __launch_bounds__(64) void ctc_beam1_kernel(BeamArgs A) {
 __host__ __device__ inline size_t beam_lds_bytes_dev(int S, int W) { return (size_t)(S + 9 * W + 5 * W * S + 8) * sizeof(float); }
 
 // 4 waves per utterance: the candidate phase on all 256 threads, everything else on wave 0
+// The stable descending selection of the top W of a step's candidates (ctc_decoder.py:107-110) by ONE wave with the
+// candidates in registers: lane l holds c = l, l + 64, ... (NPL of them), sorted once by (score descending, first-touch
+// order ascending: the order is unique per live candidate, so this is a total order; void candidates sink to the end).
+// A round then compares only the lanes' HEADS: two wave reductions (the best score; the smallest order among its
+// holders) and a pop in the winner's lane -- nothing on the W-round chain goes through LDS (the rounds of the LDS form
+// further down cost 1 us each: eight dependent LDS round trips and the winner's copies per round).  Same comparisons as
+// that form, hence the same survivors in the same order.  Returns in lane r < nsel the candidate of rank r.
+template <int NPL>
+__device__ __forceinline__ int beam_select_regs(const float* c_score, const float* c_ord, const int* c_state, int ncand,
+                                                int W, int lane, int& nsel) {
+    float sc[NPL], od[NPL];
+    int ix[NPL];
+    int nlive = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int c = lane + 64 * j;
+        const bool live = c < ncand && c_state[c < ncand ? c : 0] != 0;
+        sc[j] = live ? c_score[c] : NEG_INF_F;
+        od[j] = live ? c_ord[c] : 3.0e38f;
+        ix[j] = c;
+        nlive += live ? 1 : 0;
+    }
+    nlive = (int)sa_wave_sum((float)nlive);
+    nsel = min(W, nlive);
+    auto cmpx = [&](int a, int b) {  // after: slot a holds the better of the two
+        const bool swap = sc[b] > sc[a] || (sc[b] == sc[a] && od[b] < od[a]);
+        const float s0 = swap ? sc[b] : sc[a], s1 = swap ? sc[a] : sc[b];
+        const float o0 = swap ? od[b] : od[a], o1 = swap ? od[a] : od[b];
+        const int i0 = swap ? ix[b] : ix[a], i1 = swap ? ix[a] : ix[b];
+        sc[a] = s0; sc[b] = s1; od[a] = o0; od[b] = o1; ix[a] = i0; ix[b] = i1;
+    };
+    if constexpr (NPL == 4) {
+        cmpx(0, 1); cmpx(2, 3); cmpx(0, 2); cmpx(1, 3); cmpx(1, 2);
+    } else {  // 19-comparator network for 8
+        cmpx(0, 1); cmpx(2, 3); cmpx(4, 5); cmpx(6, 7);
+        cmpx(0, 2); cmpx(1, 3); cmpx(4, 6); cmpx(5, 7);
+        cmpx(1, 2); cmpx(5, 6); cmpx(0, 4); cmpx(3, 7);
+        cmpx(1, 5); cmpx(2, 6);
+        cmpx(1, 4); cmpx(3, 6);
+        cmpx(2, 4); cmpx(3, 5);
+        cmpx(3, 4);
+    }
+    int mine = -1;
+    for (int r = 0; r < nsel; ++r) {
+        const float wbest = sa_wave_max_dpp(sc[0]);
+        const bool tie = sc[0] == wbest && od[0] < 3.0e38f;
+        const float word = -sa_wave_max_dpp(tie ? -od[0] : -3.0e38f);
+        const bool win = tie && od[0] == word;
+        const unsigned long long wmask = __builtin_amdgcn_ballot_w64(win);
+        const int wl = __builtin_ctzll(wmask | (1ULL << 63));
+        const int widx = __builtin_amdgcn_readlane(ix[0], wl);
+        if (lane == r) mine = widx;
+        if (win) {  // pop
+#pragma unroll
+            for (int j = 0; j + 1 < NPL; ++j) { sc[j] = sc[j + 1]; od[j] = od[j + 1]; ix[j] = ix[j + 1]; }
+            sc[NPL - 1] = NEG_INF_F; od[NPL - 1] = 3.0e38f;
+        }
+    }
+    return mine;
+}
+
 __global__ __launch_bounds__(256) void ctc_beam_kernel(BeamArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int S = A.S, W = A.W;
@@ -290,7 +351,24 @@ __global__ __launch_bounds__(256) void ctc_beam_kernel(BeamArgs A) {
         __syncthreads();
 
         // ---- stable descending selection of the top W (ctc_decoder.py:107-110): wave 0
-        if (wave0) {
+        if (wave0 && ncand <= 512) {
+            int nsel;
+            const int mine = ncand <= 256 ? beam_select_regs<4>(c_score, c_ord, c_state, ncand, W, lane, nsel)
+                                          : beam_select_regs<8>(c_score, c_ord, c_state, ncand, W, lane, nsel);
+            if (lane == 0) *s_nsel = nsel;
+            if (lane < nsel) {  // the survivors' entries: all ranks at once
+                const int bidx = mine;
+                c_state[bidx] = 2;
+                const int i = bidx / S, sy = bidx - i * S;
+                n_pb[lane] = c_pb[bidx]; n_pnb[lane] = c_pnb[bidx];
+                if (sy == A.blank) {
+                    n_node[lane] = b_node[i]; n_last[lane] = b_last[i];
+                } else {
+                    n_node[lane] = -(i * S + sy) - 1;  // resolved to a trie node below
+                    n_last[lane] = sy;
+                }
+            }
+        } else if (wave0) {
         int nlive = 0;
         for (int c = lane; c < ncand; c += 64) nlive += c_state[c] != 0;
         nlive = (int)sa_wave_sum((float)nlive);

@@ -32,7 +32,7 @@ class TransducerLabels:
         if alen_h.min() < 1 or llen_h.min() < 0:
             raise _lib.SpeechAmdError("TransducerLoss: bad lengths")
         self.lab_h, self.alen_h, self.llen_h = lab_h, alen_h, llen_h
-        ints = torch.from_numpy(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)])).to(device)
+        ints = _lib.ints_to_device(np.concatenate([alen_h, llen_h, lab_h, np.zeros(1, np.int32)]).astype(np.int32), device)
         self.d_alen, self.d_llen, self.d_lab = ints[:self.B], ints[self.B:2 * self.B], ints[2 * self.B:]
 
     def check(self, B, T, U1, K, blank):
