@@ -212,8 +212,11 @@ __device__ __forceinline__ int beam_select_regs(const float* c_score, const floa
     for (int r = 0; r < nsel; ++r) {
         const float wbest = sa_wave_max_dpp(sc[0]);
         const bool tie = sc[0] == wbest && od[0] < 3.0e38f;
-        const float word = -sa_wave_max_dpp(tie ? -od[0] : -3.0e38f);
-        const bool win = tie && od[0] == word;
+        bool win = tie;
+        if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(tie)) != 1) {  // several heads hold the best score (rare: exact
+            const float word = -sa_wave_max_dpp(tie ? -od[0] : -3.0e38f);   // float ties, or only -inf left): the order decides
+            win = tie && od[0] == word;
+        }
         const unsigned long long wmask = __builtin_amdgcn_ballot_w64(win);
         const int wl = __builtin_ctzll(wmask | (1ULL << 63));
         const int widx = __builtin_amdgcn_readlane(ix[0], wl);
