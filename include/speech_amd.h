@@ -215,12 +215,15 @@ ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, con
 /* The same backward pass, plus the stack's PARAMETER gradients (what autograd derives for nn.GRU, train.py:30):
  *   dw_ih[l*D+d] (3H, I_l) = dai^T in_l (in_0 = x (T, B, I0), in_l = h_out[l-1] (T, B, D*H)),  db_ih = column sums of dai,
  *   dw_hh[l*D+d] (3H, H)   = dah^T h_prev (the stash's fifth block),                            db_hh = column sums of dah.
- * The library schedules them: as soon as a span of time steps of a layer is final its products are handed to a
- * library-owned side stream as one-block-per-CU GEMM launches (bias gradients fused into the same launches) that
- * run BESIDE the latency-bound persistent recurrence kernels, on the matrix-pipe cycles those leave idle; the call
- * joins the side stream before it returns (stream-ordered: everything is complete when `stream` reaches the end of
- * the call's work).  Deterministic: fixed hand-over points, fixed accumulation order.  SA_GRU_OVERLAP=0: the same
- * products on `stream` after the recurrence; SA_GRU_WG_EVERY=n: persistent launches between hand-overs (default 4). */
+ * The library schedules them (csrc/gru.hip, WGradIssuer).  Unidirectional stacks: on `stream` behind the recurrence, on
+ * split-bf16 operands packed once per layer -- with the one-launch backward kernel (B a multiple of 16, H a multiple of
+ * 128) the kernel writes the packed gate gradients and the bias sums itself.  Bidirectional stacks: a finished layer's
+ * products go to a library-owned side stream as XCD-filtered launches that run BESIDE the next layer's recurrence, on the
+ * XCDs it leaves idle (SA_GRU_OVERLAP=0: on `stream`); the call joins the side stream before it returns (stream-ordered:
+ * everything is complete when `stream` reaches the end of the call's work).  Deterministic: fixed accumulation order.
+ * dai / dah are SCRATCH for these entry points: when the recurrence kernel packs the gate gradients itself it writes no
+ * row-major copy (except dai of the bottom layer of a unidirectional stack, which the d x product reads); callers that
+ * want dai / dah use sa_gru_stack_bwd. */
 ctcStatus_t sa_gru_stack_bwd_wgrad(const float* dh_top, const float* const* stash, const float* const* w_ih,
                                    const float* const* w_hh, float* const* dai, float* const* dah, float* dx, int I0,
                                    int L, int D, int B, int T, int H, int chunk, const float* x,
