@@ -81,6 +81,11 @@ struct GemmArgs {
     // product that uses rows [0, s) and [s + j, ...) of a packed operand shared with another product (sa_gemm_pk_group)
     int a_rb_split, a_rb_jump;
     unsigned a_jump_probs;  // bit p: problem p of the group uses the jump
+    // optional dropout on the output (dropout.h): element at address c is multiplied by the mask factor of index
+    // c - drop_base (the output is a window of the masked tensor); off when drop.thresh == 0.  Not with split-K.
+    SaDrop drop;
+    unsigned drop_stream;
+    const float* drop_base;
 };
 
 __device__ __forceinline__ int pk_a_rb(const GemmArgs& g, int prob, int rb) {
@@ -434,13 +439,16 @@ struct PackArgs {
     // m-contiguous form: rows >= R_lo come from src_hi (same ld), row r at src_hi[p][k * ld + (r - R_lo)]; R_lo = R: unused
     const float* src_hi[kMaxGroup];
     int R_lo;
+    // tiles per packed row block (KB, or more: several operands interleaved along k -- problem p at k-tile offset
+    // p * dst_stride / tile bytes inside each row block, the products' reduction then runs over all of them)
+    int kb_stride;
 };
 
 // X[r][k] = src[r * ld + k] (k-contiguous memory).  grid (ceil(KB / kt), RB, nprob); thread t: rows t/4 and t/4 + 64,
 // k = 4 (t % 4) .. + 3: a wave reads 16 rows x 64 bytes and writes 16 rows x 32 bytes (contiguous) per plane.
 __global__ __launch_bounds__(256) void pk_pack_kcontig_kernel(PackArgs a) {
     const float* __restrict__ src = a.src[blockIdx.z];
-    char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.KB * PK_TILE;
+    char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.kb_stride * PK_TILE;
     const int tid = threadIdx.x, k4 = tid & 3;
     const int kb_end = min(a.KB, ((int)blockIdx.x + 1) * a.kt);
     for (int kb = blockIdx.x * a.kt; kb < kb_end; ++kb) {
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256) void pk_pack_kcontig_kernel(PackArgs a) {
 // belong to a weight gradient dW = dA^T X: column sums of dA): one partial per (block, tile parity), folded in order.
 __global__ __launch_bounds__(256) void pk_pack_mcontig_kernel(PackArgs a) {
     const float* __restrict__ src = a.src[blockIdx.z];
-    char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.KB * PK_TILE;
+    char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.kb_stride * PK_TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rl = (wave & 1) * 64 + lane, row = blockIdx.y * BM + rl;
     const bool live = row < a.R;
@@ -663,6 +671,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int prob, int b
                     float v = g.alpha * acc[i][j][r] + bv;
                     if (g.beta != 0.f) v += g.beta * *c;
                     if (g.relu) v = fmaxf(v, 0.f);
+                    if (g.drop.thresh) v *= sa_drop_factor(g.drop, g.drop_stream, (uint64_t)(c - g.drop_base));
                     *c = v;
                 }
             }
@@ -1068,6 +1077,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
     g.xcc_mask = 0; g.tile_counter = nullptr;
     g.a_rb_split = 1 << 30; g.a_rb_jump = 0; g.a_jump_probs = 0u;
+    g.drop = sa_drop_make(0.f, 0ull); g.drop_stream = 0u; g.drop_base = nullptr;
     g.grid_x = (int)grid.x; g.grid_y = (int)grid.y; g.grid_z = (int)grid.z;
     if (opts && opts->xcc_mask && opts->tile_counter) {
         g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter;
@@ -1093,7 +1103,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         // pack A (logical [M][K]) and B (logical [N][K]) of every problem, then ONE kernel whatever the transposes were
         const int KB = (K + PK_K - 1) / PK_K;
         PackArgs pa;
-        pa.K = K; pa.KB = KB; pa.kt = pk_kt; pa.cs_part = nullptr; pa.Rpad = Mpad;
+        pa.K = K; pa.KB = KB; pa.kb_stride = KB; pa.kt = pk_kt; pa.cs_part = nullptr; pa.Rpad = Mpad;
         for (int p = 0; p < kMaxGroup; ++p) pa.src_hi[p] = nullptr;
         for (int side = 0; side < 2; ++side) {
             const bool kcontig = side == 0 ? !trans_a : (trans_b != 0);
@@ -1175,11 +1185,12 @@ int sa_pk_rowsum_parts(int K) { return 2 * ((((K + PK_K - 1) / PK_K) + 7) / 8); 
 bool sa_pk_enabled(int M, int N, int K, int nprob) { return pk_worth_it(M, N, K, nprob); }
 
 ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* src_hi, int R_lo, long ld, int R, int K,
-                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream) {
+                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream, int kb_stride) {
     if (nprob < 1 || nprob > kMaxGroup || !dst || R <= 0 || K <= 0) return CTC_STATUS_INVALID_VALUE;
     PackArgs pa;
     const int KB = (K + PK_K - 1) / PK_K;
     pa.K = K; pa.KB = KB; pa.kt = 8; pa.cs_part = cs_part; pa.Rpad = (R + BM - 1) / BM * BM;
+    pa.kb_stride = kb_stride > 0 ? kb_stride : KB;
     pa.dst = dst; pa.dst_stride = dst_stride; pa.ld = ld; pa.R = R; pa.R_lo = src_hi ? R_lo : R;
     pa.vec = (ld & 3) == 0;
     for (int p = 0; p < kMaxGroup; ++p) { pa.src[p] = nullptr; pa.src_hi[p] = nullptr; }
@@ -1253,6 +1264,11 @@ ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* 
     g.lda = g.ldb = 0; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.f; g.beta = beta;
     g.m_inner = 0; g.m_mid = 1; g.s_outer = g.s_mid = 0; g.col_stride = 1; g.relu = 0;
     int splits = choose_splits(M, N, K, nprob);
+    g.drop = sa_drop_make(0.f, 0ull); g.drop_stream = 0u; g.drop_base = nullptr;
+    if (opts && opts->drop && opts->drop->on()) {
+        g.drop = *opts->drop; g.drop_stream = opts->drop_stream; g.drop_base = opts->drop_base;
+        splits = 1;  // the mask goes on in the epilogue that writes the result
+    }
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)nprob * splits * ((size_t)M * N + M) * sizeof(float))) splits = 1;
     int kps = (K + splits - 1) / splits;
     kps = (kps + BK - 1) / BK * BK;

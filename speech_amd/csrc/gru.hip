@@ -875,6 +875,8 @@ struct PBwdJobs {
     int packed;                   // gru_bwd_fused_kernel: 1 = publish with plain stores (default), 0 = write-through
     SaDrop drop;                  // gru_bwd_fused_kernel: inter-layer dropout -- d h_out[l-1] = mask * (dai[l] W_ih[l])
     long pk_kb;                   // gru_bwd_fused_kernel<.., PACKG>: k-tiles of the packed operands, T * B / 16
+    int kpk_kb;                   // gru_bwd_fused_kernel<.., PACKK>: k-tiles per row block of the kpk operand (3H / 16, or
+                                  // 6H / 16 when the two directions of a layer share one operand, side by side along k)
     unsigned long long* timing;   // debug (SA_GRU_TIMING=1): per block {poll+load, mfma, reduce+barrier, gates+publish} in
                                   // 10 ns ticks and the number of polling trips; else null
     PBwdJob j[kMaxJobs];
@@ -1230,7 +1232,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         sa_split2(q[40], q[60], a1, b1, c1);
         const int m = (trow < 0 ? 0 : trow) * B + b0 + kr, rl = m & 127;
         const bool go = on && wave < 3;
-        char* dst = go ? J.kpk + (size_t)(m >> 7) * (3 * H / 16) * 12288 + kk_tile + rl * 32 + ((((kq >> 1) ^ (rl >> 3)) & 1) << 4)
+        char* dst = go ? J.kpk + (size_t)(m >> 7) * P.kpk_kb * 12288 + kk_tile + rl * 32 + ((((kq >> 1) ^ (rl >> 3)) & 1) << 4)
                        : reinterpret_cast<char*>(J.dump + ((blockIdx.x * 256 + tid) & ~1));
         const long pl = go ? 4096 : 0;
         *reinterpret_cast<uint2*>(dst) = make_uint2(a0, a1);
@@ -1312,7 +1314,9 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             SA_TICK(1)
         }
         __syncthreads();
-        if constexpr (FUSE) {
+        if constexpr (FUSE || PACKK) {
+            // (PACKK, bidirectional layers: the layer above's input-gradient products may still be streaming rows in on the
+            // side stream, ends first -- same hand-off)
             // one-launch mode: the row of d h_out fetched a step ago may not have been there yet (the host pre-fills
             // the lower layers' d h_out with the sentinel; the layer above stores it two steps after it ran the same
             // time index, so a lower layer settles a few steps behind the one above and this loop seldom turns)
@@ -2355,13 +2359,14 @@ static bool shared_pack_layout_bi(int L, int D, int B, int T, int H, int I0, Sha
     const size_t b = sa_gemm_pk_group_workspace_bytes(2, 3 * H, Imax, (int)K);
     // the input-gradient products (the caller's stream): dai packed by the kernel (per layer parity and direction), W_ih
     // packed per layer, split-K scratch of their own
-    if (!sa_pk_enabled((int)K, I0 < 2 * H ? I0 : 2 * H, 3 * H, 1)) return false;
-    y.k_each = sa_pk_operand_bytes((int)K, 3 * H);
-    y.w_each = sa_pk_operand_bytes(Imax, 3 * H);
+    if (!sa_pk_enabled((int)K, I0 < 2 * H ? I0 : 2 * H, 6 * H, 1)) return false;
+    // (the two directions side by side along k: ONE operand of reduction length 6H, so an element of d in is written once)
+    y.k_each = sa_pk_operand_bytes((int)K, 6 * H);
+    y.w_each = sa_pk_operand_bytes(Imax, 6 * H);
     y.kslot_off = y.sk_off + sa_align_up(a > b ? a : b, 256);
-    y.w_off = y.kslot_off + 4 * y.k_each;
-    y.skx_off = y.w_off + 2 * y.w_each;
-    y.skx_bytes = sa_align_up(sa_gemm_pk_group_workspace_bytes(1, (int)K, Imax, 3 * H), 256);
+    y.w_off = y.kslot_off + 2 * y.k_each;
+    y.skx_off = y.w_off + y.w_each;
+    y.skx_bytes = sa_align_up(sa_gemm_pk_group_workspace_bytes(2, (int)K, Imax, 6 * H), 256);
     y.total = y.skx_off + y.skx_bytes;
     (void)L;
     return true;
@@ -2391,7 +2396,8 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
     if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +      // dh ping-pong
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);       // W_hh^T
-    const size_t mid = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);       // d h_out of a lower layer
+    const size_t mid = sa_align_up(((size_t)T * B + 128) * D * H * sizeof(float), 256);  // d h_out of a lower layer (+ one
+                                                                                          // row block: chunked products end on whole blocks)
     size_t gw = 0;
     for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
     {   // the whole-sequence input-gradient products (d x of layer 0; every layer of a bidirectional stack): packed copies
@@ -2502,19 +2508,40 @@ struct WGradIssuer {
         return shared_pack_layout_bi(L, D, B, T, H, I0, y) && y.total <= ws_bytes;
     }
     char* bi_gpk(const SharedPackLayoutBi& y, int l, int d) const { return (char*)ws + (size_t)(l & 1) * y.slot + (size_t)d * y.g_each; }
-    char* bi_kpk(const SharedPackLayoutBi& y, int l, int d) const { return (char*)ws + y.kslot_off + (size_t)(2 * (l & 1) + d) * y.k_each; }
-    // d in (T B, I) = sum over the directions of dai[l, d] W_ih[l, d], on the operands the recurrence kernel packed
-    ctcStatus_t input_grad_bi(const SharedPackLayoutBi& y, int l, const float* const* w_ih, float* din, hipStream_t stream) {
+    char* bi_kpk(const SharedPackLayoutBi& y, int l, int d) const {
+        return (char*)ws + y.kslot_off + (size_t)(l & 1) * y.k_each + (size_t)d * (3 * H / 16) * 12288;
+    }
+    // d in (T B, I) = [dai[l, 0] | dai[l, 1]] [W_ih[l, 0]; W_ih[l, 1]] on the operand the recurrence kernel packed (both
+    // directions side by side along k) -- first the weights, packed the same way ...
+    ctcStatus_t input_grad_bi_weights(const SharedPackLayoutBi& y, int l, const float* const* w_ih, hipStream_t stream) {
+        const int I = l == 0 ? I0 : 2 * H;
+        const float* src[2] = {w_ih[l * 2], w_ih[l * 2 + 1]};
+        return sa_pk_pack(2, src, nullptr, 0, I, I, 3 * H, 0, (char*)ws + y.w_off, (size_t)(3 * H / 16) * 12288, nullptr, stream,
+                          6 * H / 16);
+    }
+    // ... then the product over nrb row blocks from rb0[p], p < np (np = 2: the two ends of a chunk share a launch; the
+    // last block of the sequence may be partial -- its surplus rows land in the padding of the mid buffers); mask != 0:
+    // XCD-filtered (side stream)
+    ctcStatus_t input_grad_bi_rows(const SharedPackLayoutBi& y, int l, float* din, int np, const int* rb0, int nrb,
+                                   hipStream_t stream, unsigned mask, const SaDrop* drop = nullptr, unsigned drop_stream = 0) {
         const int I = l == 0 ? I0 : 2 * H;
         char* base = (char*)ws;
-        const float* src[2] = {w_ih[l * 2], w_ih[l * 2 + 1]};
-        ctcStatus_t st = sa_pk_pack(2, src, nullptr, 0, I, I, 3 * H, 0, base + y.w_off, y.w_each, nullptr, stream);
-        for (int d = 0; d < 2 && st == CTC_STATUS_SUCCESS; ++d) {
-            const char* pa[1] = {bi_kpk(y, l, d)}; const char* pb[1] = {base + y.w_off + (size_t)d * y.w_each};
-            float* pc[1] = {din};
-            st = sa_gemm_pk_group(1, T * B, I, 3 * H, pa, 0, 0, 0u, pb, d ? 1.f : 0.f, pc, I, base + y.skx_off, y.skx_bytes, stream);
+        const char* pa[2]; const char* pb[2]; float* pc[2];
+        for (int p = 0; p < np; ++p) {
+            pa[p] = bi_kpk(y, l, 0) + (size_t)rb0[p] * (6 * H / 16) * 12288;
+            pb[p] = base + y.w_off;
+            pc[p] = din + (size_t)rb0[p] * 128 * I;
         }
-        return st;
+        SaGemmOpts o;
+        o.no_split = 0; o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr; o.err_word = err_word;
+        if (mask && counters && next_counter < max_counters) { o.xcc_mask = mask; o.tile_counter = counters + next_counter++; }
+        // the layer below fed this layer its DROPPED output (nn.GRU(dropout=p)): the same mask routes the gradient -- in the
+        // product's epilogue (din is the masked tensor itself, so an element's mask index is its offset in din)
+        o.drop = drop; o.drop_stream = drop_stream; o.drop_base = din;
+        const int rows_total = T * B;
+        // whole-sequence call: the exact row count (the caller's dx has no padding); chunks: whole blocks
+        const int M = (np == 1 && rb0[0] == 0 && nrb * 128 >= rows_total) ? rows_total : nrb * 128;
+        return sa_gemm_pk_group(np, M, I, 6 * H, pa, 0, 0, 0u, pb, 0.f, pc, I, base + y.skx_off, y.skx_bytes, stream, &o);
     }
     float* bi_gsum(const SharedPackLayoutBi& y, int l, int d) const {
         return (float*)((char*)ws + (size_t)(l & 1) * y.slot + 2 * y.g_each + (size_t)d * y.cs_each);
@@ -2644,7 +2671,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     const size_t per_dir = sa_align_up((size_t)2 * B * H * sizeof(float), 256) +
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);
-    const size_t mid_bytes = sa_align_up((size_t)T * B * D * H * sizeof(float), 256);
+    const size_t mid_bytes = sa_align_up(((size_t)T * B + 128) * D * H * sizeof(float), 256);
     char* ws = (char*)workspace;
     const size_t wih_t_each = sa_align_up((size_t)3 * H * H * sizeof(float), 256);
     const size_t wih_t_off = (size_t)L * D * per_dir + (size_t)(L > 1 ? L - 1 : 0) * mid_bytes;
@@ -2743,6 +2770,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
                 Q.pk_kb = bi_packg ? (long)T * B / 16 : 0;
+                Q.kpk_kb = 6 * H / 16;
                 for (int d = 0; d < 2; ++d) {
                     PBwdJob& J = Q.j[d];
                     J.dx_drop_stream = 0u;
@@ -2775,16 +2803,54 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             // gradient wrt this layer's input = sum over directions of dai W_ih
             float* din = l > 0 ? mid_of(l - 1) : dx;
             const int I = l > 0 ? 2 * H : I0;
+            bool dx_streamed = false;
             if (din && bi_packg) {
-                st = issuer.input_grad_bi(spb, l, w_ih, din, stream);
+                st = issuer.input_grad_bi_weights(spb, l, w_ih, stream);
                 if (st != CTC_STATUS_SUCCESS) return st;
+                const int RB = (T * B + 127) / 128;
+                const SaDrop* dmask = (drop_on && l > 0) ? &dc.drop : nullptr;   // the mask of h_out[l-1], in the epilogue
+                const unsigned dstream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
+                const char* sx_e = getenv("SA_GRU_STREAM_DX");
+                // Streamed (layers above the bottom one, side stream available): the next layer's two chains start at the two
+                // ENDS of the sequence, so only the end rows have to exist before its recurrence is launched; the rest arrives
+                // chunk by chunk from the side stream (XCD-filtered, beside that recurrence, ahead of this layer's weight
+                // gradients) while the chains work inwards -- the consumer polls the sentinel this buffer is filled with
+                // (gru_bwd_fused_kernel<.., PACKK>).  Chunk 0 = a quarter of the rows on the whole chip.
+                const int nchunk = 4, per_end = (RB / 2 + nchunk - 1) / nchunk;
+                if (l > 0 && bi_side && RB >= 16 && !(sx_e && sx_e[0] == '0') && issuer.next_counter + nchunk + 4 <= issuer.max_counters) {
+                    if (!sentinel_fill(din, ((size_t)T * B + 128) * I, stream)) return CTC_STATUS_MEMOPS_FAILED;
+                    int lo = 0, hi = RB;  // row blocks [lo, hi) still owed
+                    const int n0 = min(per_end, (hi - lo) / 2);
+                    int ends[2] = {lo, hi - n0};
+                    st = issuer.input_grad_bi_rows(spb, l, din, 2, ends, n0, stream, 0u, dmask, dstream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                    lo += n0; hi -= n0;
+                    if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
+                    hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // the recurrence first
+                    while (hi - lo >= 2) {
+                        const int n = min(per_end, (hi - lo) / 2);
+                        int e2[2] = {lo, hi - n};
+                        st = issuer.input_grad_bi_rows(spb, l, din, 2, e2, n, g_side.s, bi_mask, dmask, dstream);
+                        if (st != CTC_STATUS_SUCCESS) return st;
+                        lo += n; hi -= n;
+                    }
+                    if (hi > lo) {
+                        st = issuer.input_grad_bi_rows(spb, l, din, 1, &lo, hi - lo, g_side.s, bi_mask, dmask, dstream);
+                        if (st != CTC_STATUS_SUCCESS) return st;
+                    }
+                    dx_streamed = true;
+                } else {
+                    const int zero = 0;
+                    st = issuer.input_grad_bi_rows(spb, l, din, 1, &zero, RB, stream, 0u, dmask, dstream);
+                    if (st != CTC_STATUS_SUCCESS) return st;
+                }
             } else if (din)
                 for (int d = 0; d < 2; ++d) {
                     st = gemm_whole(0, 0, T * B, I, 3 * H, dai[l * 2 + d], 3 * H, w_ih[l * 2 + d], I, d ? 1.f : 0.f, din, I,
                                     nullptr, gws, gws_bytes, stream);
                     if (st != CTC_STATUS_SUCCESS) return st;
                 }
-            if (drop_on && l > 0) {  // the layer below fed this one its dropped output: the same mask routes the gradient
+            if (drop_on && l > 0 && !bi_packg) {  // the layer below fed this one its dropped output: the same mask routes the gradient
                 st = sa_dropout_apply_impl(din, din, (size_t)T * B * DH, 0, dc.drop, dc.stream0 + l - 1, stream);
                 if (st != CTC_STATUS_SUCCESS) return st;
             }
@@ -2792,10 +2858,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                              // recurrence (side stream, filtered) when there is one, else plain on the caller's stream
                 const bool side = bi_side && l > 0;
                 for (int d = 0; d < 2; ++d) wg_hi[l * 2 + d] = 0;
-                if (side) {
+                if (side && !dx_streamed) {
                     if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
                     hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // ~40 us
-                } else if (bi_side && !g_side.order(g_side.s, stream)) {  // the scratch operands are the side stream's
+                } else if (!side && bi_side && !g_side.order(g_side.s, stream)) {  // the scratch operands are the side stream's
                     return CTC_STATUS_EXECUTION_FAILED;
                 }
                 st = issuer.issue_shared_bi(spb, l, side ? g_side.s : stream, side ? bi_mask : 0u);
@@ -2885,7 +2951,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr; Q.drop = dc.drop;
-        Q.pk_kb = packg ? (long)T * B / 16 : 0;
+        Q.pk_kb = packg ? (long)T * B / 16 : 0; Q.kpk_kb = 0;
         Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
         if (packg) { issuer.gates_prepacked = true; issuer.gsum_parts = nbt; }
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
@@ -2950,7 +3016,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
-            Q.pk_kb = 0;
+            Q.pk_kb = 0; Q.kpk_kb = 0;
             Q.drop = dc.drop;
             Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
             int n = 0;

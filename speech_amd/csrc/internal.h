@@ -26,6 +26,11 @@ struct SaGemmOpts {
     // sa_gru_health_flag) when fewer than all tiles were drawn -- the step's optimiser update is then skipped and the
     // caller replays it without the filtered path, exactly as for a failed persistent-kernel hand-off.
     unsigned* err_word = nullptr;
+    // sa_gemm_pk_group only: dropout on the output -- the element written at address c is multiplied by the mask factor of
+    // index c - drop_base of mask stream drop_stream (the output is a window of the masked tensor).  No split-K then.
+    const SaDrop* drop = nullptr;
+    unsigned drop_stream = 0;
+    const float* drop_base = nullptr;
 };
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
                                    const float* const* A, long lda, const float* const* B, long ldb, float beta,
@@ -51,7 +56,9 @@ bool sa_pk_enabled(int M, int N, int K, int nprob);  // the size / SA_GEMM_EXACT
 // from src_hi[p][k * ld + (r - R_lo)] when src_hi != NULL.  cs_part (m-contiguous form only, or NULL):
 // [nprob][sa_pk_rowsum_parts(K)][ceil128(R)] partial row sums (fold them with sa_pk_rowsum_fold).
 ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* src_hi, int R_lo, long ld, int R, int K,
-                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream);
+                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream, int kb_stride = 0);
+// kb_stride > 0: the packed row blocks are kb_stride k-tiles apart (default ceil(K / 16)) -- with dst_stride = a whole number
+// of tiles, the nprob matrices land side by side along k inside ONE operand whose reduction length is the sum of theirs.
 ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int Rpad, int M, int split, int jump,
                               float* const* out, float beta, hipStream_t stream);
 size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K);
