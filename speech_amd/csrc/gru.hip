@@ -2816,11 +2816,13 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 // chunk by chunk from the side stream (XCD-filtered, beside that recurrence, ahead of this layer's weight
                 // gradients) while the chains work inwards -- the consumer polls the sentinel this buffer is filled with
                 // (gru_bwd_fused_kernel<.., PACKK>).  Chunk 0 = a quarter of the rows on the whole chip.
-                const int nchunk = 4, per_end = (RB / 2 + nchunk - 1) / nchunk;
+                const char* nc_e = getenv("SA_GRU_DX_CHUNKS");
+                const char* f0_e = getenv("SA_GRU_DX_FIRST");
+                const int nchunk = nc_e && atoi(nc_e) > 1 ? min(atoi(nc_e), 12) : 4, per_end = (RB / 2 + nchunk - 1) / nchunk;
                 if (l > 0 && bi_side && RB >= 16 && !(sx_e && sx_e[0] == '0') && issuer.next_counter + nchunk + 4 <= issuer.max_counters) {
                     if (!sentinel_fill(din, ((size_t)T * B + 128) * I, stream)) return CTC_STATUS_MEMOPS_FAILED;
                     int lo = 0, hi = RB;  // row blocks [lo, hi) still owed
-                    const int n0 = min(per_end, (hi - lo) / 2);
+                    const int n0 = min(f0_e && atoi(f0_e) > 0 ? atoi(f0_e) : per_end, (hi - lo) / 2);
                     int ends[2] = {lo, hi - n0};
                     st = issuer.input_grad_bi_rows(spb, l, din, 2, ends, n0, stream, 0u, dmask, dstream);
                     if (st != CTC_STATUS_SUCCESS) return st;
