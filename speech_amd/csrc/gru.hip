@@ -266,7 +266,9 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
             return;
         }
         // an XCD hosts 32 / ntile_u groups (narrower layers: 16 or 8 unit tiles per group)
+        // (H / 16 not a divisor of 32 -- H = 192, 320, 384, 448: the CUs beyond an XCD's last whole group idle)
         const int sub = s_role[1] / P.ntile_u, g = s_role[0] * (32 / P.ntile_u) + sub;
+        if (sub >= 32 / P.ntile_u) return;
         role_x = s_role[1] - sub * P.ntile_u;
         role_z = g / P.nbt;
         role_y = g - role_z * P.nbt + P.bt0;
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    if (sub >= 32 / P.ntile_u) return;
     const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt + P.bt0;
     if (l >= P.L) return;
     if (P.fault && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
@@ -905,6 +908,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    if (sub >= 32 / P.ntile_u) return;
     const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
     if (role_z >= P.n) return;
     if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
@@ -1111,6 +1115,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    if (sub >= 32 / P.ntile_u) return;
     const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
     if (role_z >= P.n) return;
     if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
@@ -1883,7 +1888,9 @@ constexpr int kSyncErr = 200, kSyncReg = 201;  // word offsets in the sync page 
 constexpr int kSyncTiles = 210, kSyncTileWords = 46;  // tile counters of XCD-filtered GEMM launches: words [210, 256)
 static bool xcd_shape_ok(int jobs, int B, int H) {
     const int ntile_u = H / 16;
-    if (persist_mode() != 2 || (H != 512 && H != 256 && H != 128) || device_cus() != 256 || !g_health.init()) return false;
+    // H: a multiple of 64 (a wave's k-slice H / 4 in whole 16-wide fragments) from 128 to 512 (the weight fragments of a
+    // block's 16 units live in its register file)
+    if (persist_mode() != 2 || H < 128 || H > 512 || (H % 64) || device_cus() != 256 || !g_health.init()) return false;
     (void)B;
     return jobs <= 8 * (32 / ntile_u);  // at least one batch tile per pass (see tiles_per_pass)
 }
@@ -1921,10 +1928,14 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg
         if (H == 256) return drop ? gru_bwd_fused_kernel<4, true, true, true> : gru_bwd_fused_kernel<4, true, false, true>;
         if (H == 128) return drop ? gru_bwd_fused_kernel<2, true, true, true> : gru_bwd_fused_kernel<2, true, false, true>;
     }
-    if (H == 512) return fuse ? (drop ? gru_bwd_fused_kernel<8, true, true> : gru_bwd_fused_kernel<8, true>) : gru_bwd_fused_kernel<8, false>;
-    if (H == 256) return fuse ? (drop ? gru_bwd_fused_kernel<4, true, true> : gru_bwd_fused_kernel<4, true>) : gru_bwd_fused_kernel<4, false>;
+#define SA_BWD_FUSED(IPG) \
+    if (H == 64 * IPG) return fuse ? (drop ? gru_bwd_fused_kernel<IPG, true, true> : gru_bwd_fused_kernel<IPG, true>) : gru_bwd_fused_kernel<IPG, false>;
+    SA_BWD_FUSED(8) SA_BWD_FUSED(4) SA_BWD_FUSED(7) SA_BWD_FUSED(6) SA_BWD_FUSED(5) SA_BWD_FUSED(3)
+#undef SA_BWD_FUSED
     return nullptr;
 }
+// the backward kernel has a form that packs the weight gradients' operands itself (PACKG / PACKK) for these widths
+static bool packg_available(int H, bool fuse) { return H == 512 || H == 256 || (fuse && H == 128); }
 static int persist_prio() { return 1; }  // the recurrence waves issue at raised priority (s_setprio 3)
 
 static int clamp_chunk(int chunk, int T) {
@@ -2921,7 +2932,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // ... and that launch writes the weight-gradient products' gate operand itself, packed (gru_bwd_fused_kernel<PACKG>)
     SharedPackLayout spl;
     const char* pg_e = getenv("SA_GRU_PACK_IN_KERNEL");
-    const bool packg = one_launch && wg && (B % 16) == 0 && !(pg_e && pg_e[0] == '0') && issuer.shared_ok(spl);
+    const bool packg = one_launch && wg && (B % 16) == 0 && !(pg_e && pg_e[0] == '0') && packg_available(H, true) &&
+                       issuer.shared_ok(spl);
     const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
     const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1

@@ -399,8 +399,11 @@ def test_xcd_local_persistent_kernels_are_bit_identical_and_healthy():
     # narrower layers share an XCD (H = 256: two groups per XCD, H = 128: four), fewer groups than slots idle
     # ... and batches wider than the groups can host are walked in passes of batch tiles (4 x 512 at B = 48: 3 tiles,
     # 2 per pass; 4 x 256 at B = 80: 5 tiles, 4 per pass)
+    # ... and widths whose unit tiles do not divide an XCD's 32 CUs (H = 384: 24 tiles, one group per XCD, 8 CUs idle;
+    # H = 320: 20 tiles; H = 192: 12 tiles, two groups per XCD; H = 448: 28)
     for shape in ("2, 20, 33, 48, 512", "2, 32, 45, 40, 256", "3, 16, 37, 24, 128", "4, 64, 21, 24, 256",
-                  "4, 48, 37, 40, 512", "4, 80, 19, 24, 256"):
+                  "4, 48, 37, 40, 512", "4, 80, 19, 24, 256", "2, 32, 29, 40, 384", "3, 20, 21, 24, 320",
+                  "3, 40, 17, 24, 192", "2, 16, 15, 16, 448"):
         code2 = code.replace("L, B, T, I0, H = 4, 32, 70, 48, 512", "L, B, T, I0, H = " + shape)
         res = []
         for mode in ("0", "2", "3"):
@@ -436,7 +439,8 @@ def test_fused_backward_input_gradient():
             "torch.save([t.cpu() for t in dai + dah + [dx]], sys.argv[1])\n") % (root, root)
     for shape in ((4, 32, 70, 48, 512, 16), (4, 32, 90, 48, 512, 0), (2, 20, 33, 48, 512, 16), (2, 32, 45, 40, 256, 16),
                   (4, 64, 21, 24, 256, 16), (4, 48, 37, 40, 512, 16), (4, 80, 19, 24, 256, 16), (3, 5, 9, 16, 512, 1),
-                  (2, 32, 7, 16, 256, 64)):
+                  (2, 32, 7, 16, 256, 64), (3, 32, 41, 40, 384, 0), (2, 20, 33, 24, 320, 16), (3, 40, 25, 24, 192, 0),
+                  (2, 16, 19, 16, 448, 0)):
         res = []
         # the round-1 kernels (row-major exchange); the tiled kernel with the GEMM; the tiled kernel with the product fused
         # ... launched chunk by chunk; the same as ONE launch for the whole recurrence (the default)
@@ -475,7 +479,8 @@ def test_xcd_local_persistent_kernels_bidirectional():
             "torch.cuda.synchronize()\n"
             "assert _lib.lib().sa_gru_persist_status() == 0\n"
             "torch.save([t.cpu() for t in h + st + dai + dah + [dx]], sys.argv[1])\n") % (root,)
-    for shape in ((2, 8, 40, 24, 256), (2, 20, 31, 24, 512), (3, 48, 17, 16, 128), (1, 1, 5, 8, 256)):
+    for shape in ((2, 8, 40, 24, 256), (2, 20, 31, 24, 512), (3, 48, 17, 16, 128), (1, 1, 5, 8, 256), (2, 16, 23, 24, 384),
+                  (2, 20, 13, 16, 320)):
         res = []
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd_bi_%s.pt" % mode
@@ -561,7 +566,8 @@ def test_fused_forward_wavefront_matches_oracle_and_default():
             "dai, dah, dx = ops.gru_stack_bwd(dtop, st, w_ih, w_hh, L, 1, H, I0)\n"
             "torch.cuda.synchronize()\nassert _lib.lib().sa_gru_persist_status() == 0\n"
             "torch.save([t.cpu() for t in h + [dx]], sys.argv[1])\n") % (root, root)
-    for shape in ("4, 32, 90, 48, 512", "4, 64, 40, 48, 512"):  # B = 64: two passes of two batch tiles each
+    # B = 64: two passes of two batch tiles each; H = 384 / 320 / 192: widths whose unit tiles leave CUs of an XCD idle
+    for shape in ("4, 32, 90, 48, 512", "4, 64, 40, 48, 512", "3, 32, 33, 40, 384", "2, 20, 27, 24, 320", "4, 16, 21, 24, 192"):
         code2 = code.replace("L, B, T, I0, H = 4, 32, 90, 48, 512", "L, B, T, I0, H = " + shape)
         res = []
         for fused in ("0", "1"):

@@ -155,6 +155,15 @@ def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatc
             assert torch.equal(grads["kernel"][k], grads["shared"][k]), k
 
 
+@pytest.mark.parametrize("H,B", [(384, 32), (320, 20)])
+def test_widths_between_the_kernel_templates(H, B):
+    # the XCD-local kernels take every multiple of 64 from 128 to 512 (H / 16 unit tiles per sync group; the CUs of an XCD
+    # beyond its last whole group idle): H = 384 (weight gradients on shared packed operands, packed by launches), H = 320
+    # (one pack per product) -- whole train-mode forward + backward against the torch CPU oracle on the same masks
+    cfg = {"dropout": 0.2, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": H, "layers": 3, "bidirectional": False}}}
+    run_case(F=40, V=20, B=B, T=110, L=6, cfg=cfg)
+
+
 def test_h128_stack_and_two_convs():
     # H = 128: fused forward, chunked persistent backward with GEMM d h_out (+ element-wise mask per chunk);
     # two direct convs (the second on 32 channels): both epilogues mask, both backward passes scale
