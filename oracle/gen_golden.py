@@ -182,11 +182,90 @@ def seq2seq_case(models):
     print("seq2seq_tiny out", out.shape, "loss", float(loss), "infer", res["infer"].shape)
 
 
+def seq2seq_beam_cases(models):
+    """The reference's own Seq2Seq.beam_search (speech/models/seq2seq.py:180-227) run LIVE on CPU, beam 1 / 4 / 8 / 10.
+    The one line that does not run on python 3 -- `filter(...)[:beam_size]` (:213-214) -- is served by a module-level
+    `filter` that returns the list python 2 returned; nothing else is touched.  Models: random init (flat
+    distributions: long searches that end at max_len), the same with the output layer scaled up (peaked: hypotheses
+    complete and the stopping rule fires), and with DUPLICATED output rows (two classes -- one of them the end token in
+    the last model -- get bit-identical log-probabilities in any implementation, so the result depends on the
+    reference's tie order).  Stored per case: the hypothesis, its score (recomputed along the hypothesis with the
+    reference's decode_step), and the restatement's diagnostics; oracle/seq2seq_beam_ref.py driven by the live
+    decode_step must reproduce every hypothesis (asserted here)."""
+    import builtins
+    from speech.models import seq2seq
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import seq2seq_beam_ref as R
+    seq2seq.filter = lambda f, xs: list(builtins.filter(f, xs))
+    res = {}
+    names = []
+
+    def make(tag, freq_dim, vocab, dim, conv, T, seed, fc_scale=1.0, dup=()):
+        torch.manual_seed(seed)
+        rng = np.random.RandomState(seed)
+        cfg = {"dropout": 0.0, "encoder": {"conv": conv, "rnn": {"dim": dim, "bidirectional": True, "layers": 2}},
+               "decoder": {"embedding_dim": dim, "layers": 1, "log_t": True}}
+        model = seq2seq.Seq2Seq(freq_dim, vocab + 1, cfg)
+        with torch.no_grad():
+            model.fc.fc.weight.mul_(fc_scale)
+            model.fc.fc.bias.mul_(fc_scale)
+            for a, b in dup:                       # class b := class a
+                model.fc.fc.weight[b] = model.fc.fc.weight[a]
+                model.fc.fc.bias[b] = model.fc.fc.bias[a]
+        model.set_eval()
+        inputs = (rng.randn(T, freq_dim).astype(np.float32),)
+        labels = ([vocab, 0, vocab - 1],)           # start token = vocab, end token = vocab - 1 (only these are read)
+        for k, v in model.state_dict().items():
+            res["%s.param.%s" % (tag, k)] = v.numpy()
+        res[tag + ".x"] = inputs[0]
+        res[tag + ".cfg"] = np.array([freq_dim, vocab, dim, T], dtype=np.int64)
+        res[tag + ".conv"] = np.array(conv, dtype=np.int64)
+        return model, (inputs, labels)
+
+    def run(tag, model, batch, beam, max_len):
+        name = "%s.b%d.m%d" % (tag, beam, max_len)
+        with torch.no_grad():
+            hyp = model.beam_search(batch, beam_size=beam, max_len=max_len)[0]
+        hyp = tuple(int(t) for t in hyp)
+        x, y = model.collate(*batch)
+        with torch.no_grad():
+            enc = model.encode(x)
+        start, end = int(y[0, 0]), int(y[0, -1])
+        hyp2, score, info = R.beam_search(R.torch_step_fn(model, enc), start, end, beam, max_len)
+        assert hyp2 == hyp, (name, hyp, hyp2)
+        res[name + ".hyp"] = np.array(hyp, dtype=np.int64)
+        res[name + ".score"] = np.array(score, dtype=np.float64)
+        res[name + ".info"] = np.array([info["steps"], info["n_complete"]], dtype=np.int64)
+        res[name + ".min_margin"] = np.array(info["min_margin"], dtype=np.float64)
+        names.append(name)
+        print(name, "len", len(hyp), "score %.4f" % score, info)
+
+    conv = [[8, 5, 11, 2]]
+    m, b = make("flat", 40, 10, 16, conv, 61, 1337)
+    for beam, ml in ((1, 12), (4, 12), (8, 20), (10, 15)):
+        run("flat", m, b, beam, ml)
+    m, b = make("peaked", 40, 10, 16, conv, 61, 7, fc_scale=40.0)
+    for beam, ml in ((1, 30), (4, 30), (8, 30), (10, 30)):
+        run("peaked", m, b, beam, ml)
+    m, b = make("tie", 40, 10, 16, conv, 75, 11, fc_scale=30.0, dup=((2, 5), (1, 7)))
+    for beam, ml in ((1, 25), (4, 25), (8, 25)):
+        run("tie", m, b, beam, ml)
+    m, b = make("tie_end", 40, 10, 16, conv, 75, 23, fc_scale=30.0, dup=((9, 3),))   # the end token (9) ties class 3
+    for beam, ml in ((1, 25), (4, 25), (8, 25)):
+        run("tie_end", m, b, beam, ml)
+    m, b = make("wide", 40, 30, 32, [[8, 5, 11, 2]], 90, 5, fc_scale=25.0)
+    for beam, ml in ((4, 40), (8, 40), (10, 40)):
+        run("wide", m, b, beam, ml)
+    res["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "seq2seq_beam.npz"), **res)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     models, ctc_decoder = import_reference()
     transducer_case(models)
     seq2seq_case(models)
+    seq2seq_beam_cases(models)
     specgram_case()
     sys.path.insert(0, os.path.join(REF, "tests"))
     import shared  # the reference's own test config (tests/shared.py:4-16)
