@@ -440,6 +440,26 @@ ctcStatus_t sa_s2s_decoder_step(const float* eh, const long long* idx, const flo
                                 const float* sx_prev, const float* const* params, int B, int T, int H, int E, int KS,
                                 int K, float scale, float* hx, float* ax, float* sx, float* out, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* Beam search of the attention decoder, entirely on the device (Seq2Seq.beam_search, seq2seq.py:180-227; BASELINE config 4
+ * names beam = 8).  ONE utterance: eh (T,H) encoder states, shared by every hypothesis.  The live hypotheses are the rows
+ * of one batched decoder step (the arithmetic of sa_s2s_decoder_step); between two steps ONE kernel does what the
+ * reference does in python: log_softmax rows, candidate scores (DOUBLE sums of float32 log-probabilities, as python
+ * float + float32), the stable descending sort's first beam_size entries in the reference's (hypothesis rank, class)
+ * tie order, end-token candidates inside them -> `complete`, the first beam_size non-end candidates of the whole list ->
+ * the next beam, the stopping rule (:216-223), and the survivors' states / next inputs gathered by parent.
+ *   start_tok / end_tok: first / last label of the reference's collate (:182-183); end_tok < K, start_tok < V.
+ *   beam_size <= 32, beam_size * K <= 8192.  max_len: search steps at most (:180).
+ *   check_every > 0: the call synchronises `stream` every check_every tokens to read ONE word (has the search stopped?)
+ *   and stops enqueueing when it has; 0: never synchronises -- all max_len tokens are enqueued and a finished search
+ *   ignores the rest.
+ *   Outputs (DEVICE): d_hyp (max_len + 1) int64 = the winning hypothesis incl. the start token (and the end token when
+ *   it completed), d_len its length, d_score its score (double), d_info[2] = {search steps run, hypotheses completed}.
+ *   params as for sa_s2s_decoder_fwd. */
+size_t sa_s2s_beam_workspace_bytes(int T, int H, int E, int KS, int K, int beam_size, int max_len);
+ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* params, int T, int H, int E, int KS, int K,
+                               float scale, int start_tok, int end_tok, int beam_size, int max_len, int check_every,
+                               long long* d_hyp, int* d_len, double* d_score, int* d_info, void* workspace,
+                               size_t workspace_bytes, void* stream);
 ctcStatus_t sa_softmax_xent(const float* logits, const long long* targets, float scale, float* loss_rows,
                             float* dlogits, long rows, int K, void* stream);
 ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows, int K, void* stream);

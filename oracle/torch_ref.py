@@ -127,8 +127,10 @@ class TorchRefTransducer(TorchRefCTC):
         self.fc1.fc = nn.Linear(H, H)
         self.fc2.fc = nn.Linear(H, vocab_size + 1)
 
-    def forward(self, x, y_mat):
-        x = self.encode(x)
+    def forward(self, x, y_mat, masks=None):
+        """masks: the ENCODER's dropout factors (see TorchRefCTC.encode); a one-layer prediction network has no
+        dropout site (nn.GRU drops between layers only, transducer_model.py:23-26)."""
+        x = self.encode(x, masks)
         y = self.embedding(y_mat)
         b, t, h = y.shape
         y = torch.cat([torch.zeros((b, 1, h), dtype=y.dtype), y], dim=1)
@@ -151,9 +153,9 @@ class _TransducerRef(torch.autograd.Function):
         return ctx.g * go, None, None, None, None
 
 
-def transducer_loss(model, x, y_mat, labels, act_lens, label_lens):
+def transducer_loss(model, x, y_mat, labels, act_lens, label_lens, masks=None):
     """mean-over-batch Transducer loss of the restated model (the reduction speech_amd.transducer defaults to)."""
-    return _TransducerRef.apply(model(x, y_mat), labels, act_lens, label_lens, model.blank)
+    return _TransducerRef.apply(model(x, y_mat, masks), labels, act_lens, label_lens, model.blank)
 
 
 # ---- Seq2Seq (speech/models/seq2seq.py) -------------------------------------------------------------------------------
@@ -208,18 +210,24 @@ class TorchRefSeq2Seq(TorchRefCTC):
         sx, ax = self.attend(x, ox, ax)
         return self.fc.fc((ox + sx).squeeze(1)), (hx, ax, sx)
 
-    def forward(self, x, y):
-        """x (B, T, F) float, y (B, U) int64 with start / end tokens -> (logits (B, U-1, V-1), aligns (B, U-1, T'))."""
-        x = self.encode(x)
+    def forward(self, x, y, masks=None, sample=None):
+        """x (B, T, F) float, y (B, U) int64 with start / end tokens -> (logits (B, U-1, V-1), aligns (B, U-1, T')).
+        masks: the encoder's dropout factors (TorchRefCTC.encode).  sample: per-token flags (index t >= 1) -- where set,
+        token t's input is the argmax of token t-1's logits instead of y[:, t] (scheduled sampling, seq2seq.py:91-96;
+        the reference draws random.random() < sample_prob once per token after the first)."""
+        x = self.encode(x, masks)
         out, aligns, state = [], [], None
         for t in range(y.size()[1] - 1):
-            o, state = self.decode_step(x, y[:, t:t + 1], state)
+            inp = y[:, t:t + 1]
+            if t > 0 and sample is not None and sample[t]:
+                inp = torch.max(out[-1], dim=1)[1].unsqueeze(1)
+            o, state = self.decode_step(x, inp, state)
             out.append(o)
             aligns.append(state[1])
         return torch.stack(out, dim=1), torch.stack(aligns, dim=1)
 
-    def loss(self, x, y):
-        out, _ = self(x, y)
+    def loss(self, x, y, masks=None, sample=None):
+        out, _ = self(x, y, masks, sample)
         b, _, k = out.size()
         return nn.functional.cross_entropy(out.reshape(-1, k), y[:, 1:].reshape(-1), reduction="sum") / b
 

@@ -65,6 +65,7 @@ struct AttArgs {
     const float* nn_b;     // (1)
     float scale;           // log(T) if log_t else 1
     int B, T, H, KS;
+    int eh_shared = 0;     // != 0: every batch row reads the SAME (T, H) encoder states (the hypotheses of a beam search)
 };
 
 constexpr int kAttTB = 16;  // time steps per workgroup: grid (ceil(T / 16), B) fills the chip where one workgroup per
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
     float* axp = reinterpret_cast<float*>(smem_raw);
     float* cw = axp + kAttTB + A.KS - 1;
     const int b = blockIdx.y, t0 = blockIdx.x * kAttTB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* ehb = A.eh + (long)b * A.T * A.H;
+    const float* ehb = A.eh + (A.eh_shared ? 0l : (long)b * A.T * A.H);
     const float* oxb = A.ox + (long)b * A.H;
     att_stage(A, b, t0, axp, cw);
     __syncthreads();
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const
     float* red = a + A.T;
     float* part = a + ((A.T + 4 + 3) & ~3);  // 16-byte aligned: the context partials are written as float4
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* ehb = A.eh + (long)b * A.T * A.H;
+    const float* ehb = A.eh + (A.eh_shared ? 0l : (long)b * A.T * A.H);
     float m = -3.0e38f;
     for (int t = threadIdx.x; t < A.T; t += 256) {
         a[t] = score[(long)b * A.T + t];
@@ -943,5 +944,313 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     S2S_CHECK(sa_colsum_f32((float*)(ws + L.g_cb), H, B, H, grads[P_CB], 0, cws, cbytes, stream));
     S2S_CHECK(sa_colsum_f32((float*)(ws + L.g_nw), H, B, H, grads[P_NW], 0, cws, cbytes, stream));
     S2S_CHECK(sa_colsum_f32((float*)(ws + L.g_nb), 1, B, 1, grads[P_NB], 0, cws, cbytes, stream));
+    return CTC_STATUS_SUCCESS;
+}
+
+// =====================================================================================================================
+// Beam search of the attention decoder (Seq2Seq.beam_search, seq2seq.py:180-227) entirely on the device.
+//
+// The reference keeps python lists of (hypothesis tuple, score, state) and runs one decode_step per live hypothesis.
+// Here the live hypotheses are the ROWS of one batched decoder step -- they all attend over the same encoder states
+// (AttArgs::eh_shared), so nothing is replicated -- and what the reference does on the host between two steps is ONE
+// kernel (`s2s_beam_select_kernel`): log-softmax of the fc rows, candidate scores, the two selections, the
+// complete / live bookkeeping, the stopping rule, and the hand-over to the next token (the survivors' states gathered
+// by parent, their next embedding + context row formed).  Hypotheses are back-pointers (token, parent slot) per
+// search step; only the winner is ever materialised (`s2s_beam_final_kernel`).  No device -> host traffic per token:
+// the host loop enqueues `check_every` tokens (6 launches each), then reads ONE word (the search's `done` flag);
+// with check_every = 0 it never synchronises and enqueues all max_len tokens (a finished search ignores them).
+//
+// Reproduced from the reference, in its terms (the test suite holds a CPU restatement pinned to the live reference):
+//   * candidates of a step are ordered (live rank r, class i) -- index r * K + i -- and sorted by score descending with
+//     that order as the tie break (python's stable sort, :206);
+//   * a score is a DOUBLE sum of float32 log-probabilities (python float + float32 -> float, :203);
+//   * `complete` receives the end-token candidates among the first beam_size of the sorted list, in sorted order (:209-211);
+//   * the next beam is the first beam_size non-end candidates of the WHOLE sorted list (:213-214);
+//   * stop: empty beam, or beam_size complete hypotheses strictly better than the best live one (:216-223), or max_len;
+//   * answer: the best complete hypothesis, the earliest appended among equals (stable sort, :225); the best live
+//     hypothesis if nothing completed (:226-227).
+// Only the beam_size best complete SCORES are kept for the stopping rule (the count of completes above a threshold
+// reaches beam_size iff the beam_size-th best does), and only the best complete hypothesis is remembered.
+// =====================================================================================================================
+namespace {
+
+constexpr int kBeamMaxW = 32;       // beam_size limit (reference default 10)
+constexpr int kBeamMaxCand = 8192;  // beam_size * K limit: the candidates' scores sit in LDS as doubles (64 KB)
+
+struct BeamState {
+    int done, n_live, n_complete, steps;
+    int best_step, best_parent, pad0, pad1;
+    double best_score;
+    double scores[kBeamMaxW];   // live hypotheses' scores, in rank order
+    double cs[kBeamMaxW];       // the beam_size best complete scores, descending (-inf = none)
+};
+
+struct BeamBufs {
+    BeamState* st;
+    int* tok_hist;     // [max_len][W] token of the hypothesis that became slot j after step t
+    int* par_hist;     // [max_len][W] its parent's slot in the beam that ENTERED step t
+    const float* logits;  // (W, K) this step's fc rows
+    const float* hx_cur;  // (W, H) state rows written by this step ...
+    const float* ax_cur;  // (W, T)
+    const float* sx_cur;  // (W, H)
+    float* h_prev;        // (W, H) ... gathered by parent for the next step
+    float* ax_prev;       // (W, T)
+    float* ix;            // (W, E) next token's GRU input: embedding + context
+    const float* emb;     // (V, E)
+    int W, K, T, H, E, end_tok, step, max_len;
+};
+
+__global__ void s2s_beam_init_kernel(BeamState* st, float* ix, float* h_prev, const float* __restrict__ emb, int start_tok,
+                                     int W, int E, int H) {
+    const int j = blockIdx.x;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) ix[(long)j * E + e] = emb[(long)start_tok * E + e];
+    for (int h = threadIdx.x; h < H; h += blockDim.x) h_prev[(long)j * H + h] = 0.f;
+    if (j == 0 && threadIdx.x == 0) {
+        st->done = 0; st->n_live = 1; st->n_complete = 0; st->steps = 0;
+        st->best_step = -1; st->best_parent = -1; st->best_score = -INFINITY;
+        for (int k = 0; k < kBeamMaxW; ++k) { st->scores[k] = 0.0; st->cs[k] = -INFINITY; }
+    }
+}
+
+// does candidate (s, i) come before candidate (e, ei) in the reference's sorted list?
+__device__ __forceinline__ bool beam_precedes(double s, int i, double e, int ei) { return s > e || (s == e && i < ei); }
+
+// one workgroup of 256 threads; dynamic LDS: cand[W * K] doubles
+__global__ __launch_bounds__(256) void s2s_beam_select_kernel(BeamBufs Q) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* cand = reinterpret_cast<double*>(smem_raw);
+    __shared__ double ends[kBeamMaxW], sel_s[kBeamMaxW], comp_s[kBeamMaxW];
+    __shared__ int sel_i[kBeamMaxW], comp_r[kBeamMaxW];
+    __shared__ int n_new_s;
+    BeamState* st = Q.st;
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = Q.W, K = Q.K, n_live = st->n_live, N = W * K;
+    // ---- A: log-softmax rows (float32, as nn.functional.log_softmax) and candidate scores (double) ----
+    for (int r = wave; r < W; r += 4) {
+        if (r < n_live) {
+            const float* x = Q.logits + (long)r * K;
+            float m = -INFINITY;
+            for (int i = lane; i < K; i += 64) m = fmaxf(m, x[i]);
+            m = sa_wave_max(m);
+            float s = 0.f;
+            for (int i = lane; i < K; i += 64) s += expf(x[i] - m);
+            s = sa_wave_sum(s);
+            const float ls = logf(s);
+            const double base = st->scores[r];
+            for (int i = lane; i < K; i += 64) {
+                const float lp = (x[i] - m) - ls;
+                const double c = base + (double)lp;
+                if (i == Q.end_tok) { ends[r] = c; cand[r * K + i] = -INFINITY; }
+                else cand[r * K + i] = c;
+            }
+        } else {
+            for (int i = lane; i < K; i += 64) cand[r * K + i] = -INFINITY;
+            if (lane == 0) ends[r] = -INFINITY;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // ---- B: the first W non-end candidates of the sorted list ----
+        double bs; int bi;
+        auto scan = [&]() {
+            bs = -INFINITY; bi = 0x7fffffff;
+            for (int i = lane; i < N; i += 64) { const double s = cand[i]; if (s > bs) { bs = s; bi = i; } }
+        };
+        scan();
+        int n_new = 0;
+        for (int j = 0; j < W; ++j) {
+            double s = bs; int i = bi;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double so = __shfl_xor(s, o, 64);
+                const int io = __shfl_xor(i, o, 64);
+                if (so > s || (so == s && io < i)) { s = so; i = io; }
+            }
+            if (!(s > -INFINITY)) break;  // fewer live candidates than W (wave-uniform)
+            if (lane == 0) { sel_s[j] = s; sel_i[j] = i; }
+            if ((i & 63) == lane) { cand[i] = -INFINITY; scan(); }
+            n_new = j + 1;
+        }
+        // ---- C: end-token candidates inside the first W of the WHOLE sorted list become complete, in sorted order ----
+        // rank of an end candidate = (non-end candidates before it: only the selected ones can matter) + (end candidates
+        // before it)
+        const int r = lane;
+        const bool mine = r < n_live;
+        const double e = mine ? ends[r] : -INFINITY;
+        const int ei = r * K + Q.end_tok;
+        int before = 0;
+        for (int j = 0; j < n_new; ++j) before += beam_precedes(sel_s[j], sel_i[j], e, ei) ? 1 : 0;
+        for (int q = 0; q < n_live; ++q)
+            if (q != r) before += beam_precedes(ends[q], q * K + Q.end_tok, e, ei) ? 1 : 0;
+        const bool is_c = mine && before < W;
+        const unsigned long long cmask = __ballot(is_c);
+        int pos = 0;
+        for (int q = 0; q < n_live; ++q)
+            if (q != r && ((cmask >> q) & 1)) pos += beam_precedes(ends[q], q * K + Q.end_tok, e, ei) ? 1 : 0;
+        if (is_c) { comp_s[pos] = e; comp_r[pos] = r; }
+        const int ncomp = __popcll(cmask);
+        if (lane == 0) {
+            int nc = st->n_complete;
+            double best = st->best_score;
+            for (int c = 0; c < ncomp; ++c) {
+                const double sc = comp_s[c];
+                if (nc == 0 || sc > best) { best = sc; st->best_step = Q.step; st->best_parent = comp_r[c]; }
+                ++nc;
+                int p = W;  // insert into the W best complete scores (equal scores behind the earlier ones)
+                for (int k = 0; k < W; ++k) if (sc > st->cs[k]) { p = k; break; }
+                if (p < W) {
+                    for (int k = W - 1; k > p; --k) st->cs[k] = st->cs[k - 1];
+                    st->cs[p] = sc;
+                }
+            }
+            st->n_complete = nc;
+            st->best_score = best;
+            // ---- D: stopping rule ----
+            int done = 0;
+            if (n_new == 0) done = 1;
+            else if (st->cs[W - 1] > sel_s[0]) done = 1;
+            if (Q.step + 1 >= Q.max_len) done = 1;
+            st->steps = Q.step + 1;
+            st->n_live = n_new;
+            n_new_s = n_new;
+            // the flag is published last: a host that polls it sees a finished record
+            __threadfence();
+            st->done = done;
+        }
+    }
+    __syncthreads();
+    // ---- E: hand-over to the next token ----
+    const int n_new = n_new_s;
+    if (n_new == 0) return;
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        const int jj = j < n_new ? j : 0;
+        Q.tok_hist[(long)Q.step * W + j] = sel_i[jj] % K;
+        Q.par_hist[(long)Q.step * W + j] = sel_i[jj] / K;
+        if (j < n_new) st->scores[j] = sel_s[j];
+    }
+    for (int j = 0; j < W; ++j) {
+        const int jj = j < n_new ? j : 0;   // unused slots mirror slot 0: finite numbers, ignored by the next selection
+        const int par = sel_i[jj] / K, tok = sel_i[jj] % K;
+        for (int h = threadIdx.x; h < Q.H; h += blockDim.x) Q.h_prev[(long)j * Q.H + h] = Q.hx_cur[(long)par * Q.H + h];
+        for (int t = threadIdx.x; t < Q.T; t += blockDim.x) Q.ax_prev[(long)j * Q.T + t] = Q.ax_cur[(long)par * Q.T + t];
+        for (int e = threadIdx.x; e < Q.E; e += blockDim.x)
+            Q.ix[(long)j * Q.E + e] = Q.emb[(long)tok * Q.E + e] + Q.sx_cur[(long)par * Q.E + e];
+    }
+}
+
+// one wave: write the winner.  hyp (max_len + 1) int64, len, score, info = {steps, n_complete}
+__global__ void s2s_beam_final_kernel(const BeamState* st, const int* __restrict__ tok_hist, const int* __restrict__ par_hist,
+                                      int W, int start_tok, int end_tok, long long* __restrict__ hyp, int* __restrict__ len,
+                                      double* __restrict__ score, int* __restrict__ info) {
+    if (threadIdx.x != 0) return;
+    int t, j, n;
+    double sc;
+    if (st->n_complete > 0) {       // (live hypothesis (best_step - 1, best_parent)) + end token
+        n = st->best_step + 2;
+        hyp[n - 1] = end_tok;
+        t = st->best_step - 1; j = st->best_parent; sc = st->best_score;
+    } else {                        // the best live hypothesis of the last step
+        t = st->steps - 1; j = 0; n = t + 2; sc = st->scores[0];
+    }
+    for (; t >= 0; --t) {
+        hyp[t + 1] = tok_hist[(long)t * W + j];
+        j = par_hist[(long)t * W + j];
+    }
+    hyp[0] = start_tok;
+    *len = n;
+    *score = sc;
+    info[0] = st->steps;
+    info[1] = st->n_complete;
+}
+
+struct BeamLayout { size_t st, tok, par, ix, hprev, axprev, hx, ax, sx, oin, gi, gh, logits, score, done_host, total; };
+
+BeamLayout beam_layout(int T, int H, int E, int K, int W, int max_len) {
+    BeamLayout L;
+    size_t p = 0;
+    auto take = [&](size_t bytes) { size_t o = p; p += sa_align_up(bytes, 256); return o; };
+    const size_t f = sizeof(float);
+    L.st = take(sizeof(BeamState));
+    L.tok = take((size_t)max_len * W * sizeof(int)); L.par = take((size_t)max_len * W * sizeof(int));
+    L.ix = take((size_t)W * E * f); L.hprev = take((size_t)W * H * f); L.axprev = take((size_t)W * T * f);
+    L.hx = take((size_t)W * H * f); L.ax = take((size_t)W * T * f); L.sx = take((size_t)W * H * f);
+    L.oin = take((size_t)W * H * f); L.gi = take((size_t)W * 3 * H * f); L.gh = take((size_t)W * 3 * H * f);
+    L.logits = take((size_t)W * K * f); L.score = take((size_t)W * T * f);
+    L.total = p;
+    return L;
+}
+
+bool beam_ok(int T, int H, int E, int KS, int K, int W, int max_len) {
+    S2SDims d{W, T, 1, H, E, KS, K};
+    return s2s_ok(d) && W >= 1 && W <= kBeamMaxW && (long)W * K <= kBeamMaxCand && max_len >= 1;
+}
+
+}  // namespace
+
+extern "C" size_t sa_s2s_beam_workspace_bytes(int T, int H, int E, int KS, int K, int beam_size, int max_len) {
+    if (!beam_ok(T, H, E, KS, K, beam_size, max_len)) return 0;
+    return beam_layout(T, H, E, K, beam_size, max_len).total;
+}
+
+extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* params, int T, int H, int E, int KS, int K,
+                                          float scale, int start_tok, int end_tok, int beam_size, int max_len,
+                                          int check_every, long long* d_hyp, int* d_len, double* d_score, int* d_info,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+    SA_CLEAR_ERR();
+    const int W = beam_size;
+    if (!eh || !params || !d_hyp || !d_len || !d_score || !d_info || !workspace || !beam_ok(T, H, E, KS, K, W, max_len) ||
+        end_tok < 0 || end_tok >= K || start_tok < 0 || check_every < 0)
+        return CTC_STATUS_INVALID_VALUE;
+    const BeamLayout L = beam_layout(T, H, E, K, W, max_len);
+    if (workspace_bytes < L.total) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    BeamState* st = (BeamState*)(ws + L.st);
+    float* ix = (float*)(ws + L.ix);
+    float* hprev = (float*)(ws + L.hprev);
+    float* axprev = (float*)(ws + L.axprev);
+    float* hx = (float*)(ws + L.hx);
+    float* ax = (float*)(ws + L.ax);
+    float* sx = (float*)(ws + L.sx);
+    float* oin = (float*)(ws + L.oin);
+    float* gi = (float*)(ws + L.gi);
+    float* gh = (float*)(ws + L.gh);
+    float* logits = (float*)(ws + L.logits);
+    float* score = (float*)(ws + L.score);
+    const float* const* P = params;
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
+    const size_t smem3 = (size_t)W * K * sizeof(double);
+    if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2) ||
+        !att_smem((const void*)s2s_beam_select_kernel, smem3))
+        return CTC_STATUS_INVALID_VALUE;
+    hipLaunchKernelGGL(s2s_beam_init_kernel, dim3(W), dim3(256), 0, stream, st, ix, hprev, P[P_EMB], start_tok, W, E, H);
+    for (int t = 0; t < max_len; ++t) {
+        SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
+                            {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
+        skinny_launch(pr, 2, W, stream);
+        hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((W * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
+                           (float*)nullptr, W, H);
+        AttArgs A{eh, hx, t > 0 ? (const float*)axprev : (const float*)nullptr, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale,
+                  W, T, H, KS, 1};
+        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, W), dim3(256), smem1, stream, A, score);
+        hipLaunchKernelGGL(attention_context_kernel, dim3(W), dim3(256), smem2, stream, A, score, ax, sx, oin);
+        SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
+        skinny_launch(&q, 1, W, stream);
+        BeamBufs Q{st, (int*)(ws + L.tok), (int*)(ws + L.par), logits, hx, ax, sx, hprev, axprev, ix, P[P_EMB],
+                   W, K, T, H, E, end_tok, t, max_len};
+        hipLaunchKernelGGL(s2s_beam_select_kernel, dim3(1), dim3(256), smem3, stream, Q);
+        if (check_every > 0 && (t + 1) % check_every == 0 && t + 1 < max_len) {
+            int done = 0;
+            if (hipMemcpyAsync(&done, &st->done, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                return CTC_STATUS_MEMOPS_FAILED;
+            if (done) break;
+        }
+    }
+    hipLaunchKernelGGL(s2s_beam_final_kernel, dim3(1), dim3(64), 0, stream, (const BeamState*)st, (const int*)(ws + L.tok),
+                       (const int*)(ws + L.par), W, start_tok, end_tok, d_hyp, d_len, d_score, d_info);
+    SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }

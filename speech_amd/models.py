@@ -611,48 +611,22 @@ class Seq2Seq(Model):
         return self._healthy(run)
 
     def beam_search(self, batch, beam_size=10, max_len=200):
-        """seq2seq.py:180-229 for a batch of ONE utterance, with the reference's py2 `filter(...)[:n]` (:211-212)
-        read as the list it was written for.  The reference runs one decoder step per live hypothesis (a batch of 1
-        each); here the live hypotheses of a search step are ONE batched decoder step (their states stacked on the
-        batch axis, the encoder states repeated), and only the beam bookkeeping is host-side Python as in the
-        reference.  Hypotheses are independent rows of that step, so the search is the same search."""
+        """seq2seq.py:180-229 for a batch of ONE utterance (the reference's loop indexes row 0 only), on the device:
+        encoder, then ONE library call (speech_amd.seq2seq.beam_search -> sa_s2s_beam_search) that runs the whole search
+        -- hypotheses are rows of a batched decoder step, selection / completion / stopping rule in a kernel -- and
+        one copy of the winner back.  Returns [hypothesis tuple incl. the start token]; `last_beam_score` /
+        `last_beam_info` keep the score and (search steps, completed hypotheses) of the last call."""
         x, y = self.collate(*batch)
+        if x.shape[0] != 1:
+            raise ValueError("beam_search decodes a batch of one utterance (seq2seq.py:196-201), got %d" % x.shape[0])
         start_tok, end_tok = int(y[0, 0]), int(y[0, -1])
-        with torch.no_grad():
-            x = self.encode(self._to_device(x))
-        dev = x.device
-        x_rep = x.expand(beam_size, x.shape[1], x.shape[2]).contiguous()
-        beam = [((start_tok,), 0, None)]  # (hypothesis, score, row state (hx, ax, sx) or None)
-        complete = []
-        for _ in range(max_len):
-            n = len(beam)
-            toks = torch.tensor([[h[-1]] for h, _, _ in beam], dtype=torch.int64, device=dev)
-            if beam[0][2] is None:
-                state = None
-            else:
-                state = tuple(torch.stack([st[k] for _, _, st in beam], dim=0) for k in range(3))
-            out, (hx, ax, sx) = self.decode_step(x_rep[:n], toks, state=state, softmax=True)
-            out = out.cpu().numpy()
-            new_beam = []
-            for e, (hyp, score, _) in enumerate(beam):
-                st = (hx[e], ax[e], sx[e])
-                for i, p in enumerate(out[e].tolist()):
-                    new_beam.append((hyp + (i,), score + p, st))
-            new_beam = sorted(new_beam, key=lambda c: c[1], reverse=True)
-            # Remove complete hypotheses
-            for cand in new_beam[:beam_size]:
-                if cand[0][-1] == end_tok:
-                    complete.append(cand)
-            beam = [c for c in new_beam if c[0][-1] != end_tok][:beam_size]
-            if len(beam) == 0:
-                break
-            # Stopping criteria: complete contains beam_size more probable candidates than anything left in the beam
-            if sum(c[1] > beam[0][1] for c in complete) >= beam_size:
-                break
-        complete = sorted(complete, key=lambda c: c[1], reverse=True)
-        if len(complete) == 0:
-            complete = beam
-        hyp, score, _ = complete[0]
+
+        def run():
+            with torch.no_grad():
+                enc = self.encode(self._to_device(x))
+                return _s2s.beam_search(enc[0], self._param_dict(), self.attend.log_t, start_tok, end_tok, beam_size,
+                                        max_len)
+        hyp, self.last_beam_score, self.last_beam_info = self._healthy(run)
         return [hyp]
 
     def collate(self, inputs, labels):

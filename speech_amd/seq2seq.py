@@ -102,6 +102,35 @@ def step(eh, idx, state, P, log_t):
     return out, (hx, ax, sx)
 
 
+def beam_search(eh, P, log_t, start_tok, end_tok, beam_size, max_len, check_every=8):
+    """Seq2Seq.beam_search (seq2seq.py:180-227) for ONE utterance on the device (sa_s2s_beam_search): eh (T, H) encoder
+    states.  Returns (hypothesis tuple incl. the start token, score, (search steps, completed hypotheses)) after ONE
+    device -> host copy at the end."""
+    T, H = eh.shape
+    E, K, KS = P["emb"].shape[1], P["fc_w"].shape[0], P["conv_w"].shape[-1]
+    L = _L()
+    nbytes = L.sa_s2s_beam_workspace_bytes(T, H, E, KS, K, beam_size, max_len)
+    if nbytes == 0:
+        raise _lib.SpeechAmdError("Seq2Seq beam search: unsupported shape (embedding_dim == rnn dim, dims % 4 == 0, odd "
+                                  "location kernel <= 15 taps, beam_size <= 32, beam_size * classes <= 8192)")
+    ws = _lib.WORKSPACE.get(nbytes, eh.device, "s2s_beam")
+    # one result record: [hyp (max_len + 1) int64 | score double | len, steps, n_complete, pad int32]
+    rec = torch.empty(max_len + 1 + 1 + 2, dtype=torch.int64, device=eh.device)
+    base = rec.data_ptr()
+    p_score = base + 8 * (max_len + 1)
+    p_len, p_info = p_score + 8, p_score + 12
+    plist = [P[n].contiguous() for n in _NAMES]
+    _lib.check(L.sa_s2s_beam_search(_lib.ptr(eh.contiguous()), _ptr_array(plist), T, H, E, KS, K,
+                                    math.log(T) if log_t else 1.0, int(start_tok), int(end_tok), int(beam_size),
+                                    int(max_len), int(check_every), base, p_len, p_score, p_info, _lib.ptr(ws),
+                                    ws.numel(), _lib.cur_stream()), "sa_s2s_beam_search")
+    host = rec.cpu()
+    tail = host[max_len + 1:].numpy()
+    score = float(tail[:1].view("float64")[0])
+    n, steps, ncomp = (int(v) for v in tail[1:].view("int32")[:3])
+    return tuple(int(t) for t in host[:n].tolist()), score, (steps, ncomp)
+
+
 _NAMES = ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "conv_w", "conv_b", "nn_w", "nn_b", "fc_w", "fc_b")
 
 

@@ -101,14 +101,82 @@ def test_other_shapes_against_restatement_and_beam_search():
     for name, p in m.named_parameters():
         w = want[name].grad.numpy()
         assert np.abs(p.grad.cpu().numpy() - w).max() < 1e-3 * max(np.abs(w).max(), 1e-3), name
-    # beam search (batch of one): with beam 1 it follows the greedy path until the end token
+
+
+def _beam_model(g, tag):
+    from speech_amd.models import Seq2Seq
+    freq_dim, vocab, dim, _ = [int(v) for v in g[tag + ".cfg"]]
+    cfg = {"dropout": 0.0, "encoder": {"conv": g[tag + ".conv"].tolist(),
+                                       "rnn": {"dim": dim, "bidirectional": True, "layers": 2}},
+           "decoder": {"embedding_dim": dim, "layers": 1, "log_t": True}}
+    m = Seq2Seq(freq_dim, vocab + 1, cfg)
+    pre = tag + ".param."
+    m.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)})
+    m = m.cuda()
     m.set_eval()
-    one = (inputs[:1], labels[:1])
-    hyp = m.beam_search(one, beam_size=1, max_len=10)[0]
-    greedy = m.infer(one, max_len=10)[0]
-    n = min(len(hyp), len(greedy))
-    assert list(hyp[:n]) == list(greedy[:n]) and hyp[0] == 8
-    assert len(m.beam_search(one, beam_size=4, max_len=10)[0]) >= 2
+    return m, vocab
+
+
+def test_device_beam_search_equals_live_reference_hypotheses():
+    """Seq2Seq.beam_search (sa_s2s_beam_search: the whole search on the device) against the hypotheses the LIVE
+    reference's own beam_search returned (tests/golden/seq2seq_beam.npz, oracle/gen_golden.py; seq2seq.py:180-227):
+    beam 1 / 4 / 8 / 10 on flat, peaked and EXACTLY tied output distributions (duplicated output rows: the winner then
+    depends on the reference's (hypothesis rank, class) tie order; in `tie_end` the end token itself ties a class).
+    Hypotheses must be identical; scores (double sums of float32 log-probabilities) within 1e-4; the number of search
+    steps and of completed hypotheses -- i.e. the stopping rule -- identical.  Each case's smallest non-zero score gap at
+    a selection cut is in the fixture (min_margin, 7.7e-5 at worst): well above the fp32 noise of the decoder step."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "seq2seq_beam.npz"))
+    models = {}
+    for name in g["names"]:
+        name = str(name)
+        tag, b, ml = name.split(".")
+        if tag not in models:
+            models[tag] = _beam_model(g, tag)
+        m, vocab = models[tag]
+        batch = ((g[tag + ".x"],), ([vocab, 0, vocab - 1],))
+        for check_every in (8, 0):   # polling the stop flag every 8 tokens / never synchronising: same search
+            from speech_amd import seq2seq as s2s
+            x, y = m.collate(*batch)
+            with torch.no_grad():
+                enc = m.encode(x.cuda())
+            hyp, score, info = s2s.beam_search(enc[0], m._param_dict(), m.attend.log_t, vocab, vocab - 1, int(b[1:]),
+                                               int(ml[1:]), check_every=check_every)
+            assert hyp == tuple(g[name + ".hyp"].tolist()), (name, check_every, hyp, g[name + ".hyp"].tolist())
+            assert abs(score - float(g[name + ".score"])) < 1e-4, (name, score, float(g[name + ".score"]))
+            assert list(info) == g[name + ".info"].tolist(), (name, info, g[name + ".info"].tolist())
+        assert m.beam_search(batch, beam_size=int(b[1:]), max_len=int(ml[1:]))[0] == tuple(g[name + ".hyp"].tolist())
+
+
+def test_device_beam_search_equals_restatement_on_other_shapes():
+    """Shapes the fixtures do not hold (unidirectional encoder, no log_t, 33 classes, beams up to 16, a search that
+    completes early) against oracle/seq2seq_beam_ref.py driven by oracle/torch_ref.TorchRefSeq2Seq."""
+    from oracle import seq2seq_beam_ref as R
+    from speech_amd.models import Seq2Seq
+    for seed, dim, vocab, log_t, fc_scale in ((3, 24, 9, False, 20.0), (4, 32, 33, True, 30.0), (6, 64, 20, True, 12.0)):
+        cfg = {"dropout": 0.0, "encoder": {"conv": [[4, 5, 9, 2]],
+                                           "rnn": {"dim": dim, "bidirectional": seed % 2 == 0, "layers": 1}},
+               "decoder": {"embedding_dim": dim, "layers": 1, "log_t": log_t}}
+        torch.manual_seed(seed)
+        ref = torch_ref.TorchRefSeq2Seq(20, vocab + 1, cfg)
+        with torch.no_grad():
+            ref.fc.fc.weight.mul_(fc_scale)
+            ref.fc.fc.bias.mul_(fc_scale)
+        ref.eval()
+        m = Seq2Seq(20, vocab + 1, cfg)
+        m.load_state_dict(ref.state_dict())
+        m = m.cuda()
+        m.set_eval()
+        rng = np.random.RandomState(seed)
+        x = rng.randn(70 + 10 * seed, 20).astype(np.float32)
+        with torch.no_grad():
+            enc = ref.encode(torch.from_numpy(x)[None])
+        for beam in (1, 3, 8, 16):
+            want, score, info = R.beam_search(R.torch_step_fn(ref, enc), vocab, vocab - 1, beam, 30)
+            got = m.beam_search(((x,), ([vocab, 0, vocab - 1],)), beam_size=beam, max_len=30)[0]
+            if info["min_margin"] < 2e-5:
+                continue   # a cut inside fp32 noise: the winner is not defined at this precision
+            assert got == want, (seed, beam, got, want, info)
+            assert abs(m.last_beam_score - score) < 1e-4 and list(m.last_beam_info) == [info["steps"], info["n_complete"]]
 
 
 def test_scheduled_sampling_consumes_the_rng_like_the_reference_and_trains():
