@@ -147,8 +147,68 @@ def gpu_leg(args, world, rank, local):
         e1.record()
         torch.cuda.synchronize()
         res["ctc_ms"] = e0.elapsed_time(e1) / 20
+        del acts, lab
+        res["ctc_b4096_ms"] = ctc_b4096_leg(dev)
         res["stack_gemm"] = stack_gemm_rates(dev, Tp)
+        res.update(bidirectional_leg(dev))
     return res
+
+
+def ctc_b4096_leg(dev, Bw=4096):
+    """M-CTC at a saturating batch: the throughput-regime kernels, fwd + grad, ms per call."""
+    from speech_amd.ctc import CTCLabels, ctc_loss_raw
+    rng = np.random.RandomState(2017)
+    acts = torch.randn(Bw, T, V + 1, device=dev, generator=torch.Generator(device=dev).manual_seed(2017))
+    lab = CTCLabels(rng.randint(0, V, Bw * L).astype(np.int32), np.full(Bw, T, np.int32), np.full(Bw, L, np.int32), dev)
+    for _ in range(2):
+        ctc_loss_raw(acts, lab)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ctc_loss_raw(acts, lab)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 5
+
+
+def bidirectional_leg(dev, steps=8, warm=3):
+    """Untimed-by-the-headline extra leg: S-LIBRI BIDIRECTIONAL (4 x biGRU-512, 18.2 M parameters -- every shipped config
+    that sets the key uses bidirectional: true, /root/reference/examples/timit/ctc_config.json:28) with dropout 0.2, one
+    full train step (fwd + CTC loss + bwd + clip 200 + SGD), inputs resident, ms per step."""
+    from speech_amd import ops
+    from speech_amd.ctc import CTCLabels, CTCLoss
+    from speech_amd.models import CTC
+    cfg = {"dropout": 0.2, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 512, "layers": 4, "bidirectional": True}}}
+    torch.manual_seed(2017)
+    model = CTC(F, V, cfg).cuda()
+    model.set_train()
+    flat_p, flat_g = model.flatten_parameters_()
+    x_h, lab_h = synthetic(0)
+    x = torch.from_numpy(x_h).to(dev)
+    Tp = model.conv_out_size(T, 0)
+    labels = CTCLabels(lab_h, np.full(B, Tp, np.int32), np.full(B, L, np.int32), dev)
+    loss_fn = CTCLoss()
+    norm = torch.zeros(1, device=dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss = loss_fn(model.forward_impl(x), labels, None, None)
+        loss.backward()
+        ops.stamp_health(flat_g)
+        ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
+        return loss
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"bi_ms": ms, "bi_loss": float(loss.item()), "bi_params": int(flat_p.numel()),
+            "bi_status": ops.persist_status()}
 
 
 def train_loop_leg(model, flat_p, flat_g, world, rank, dev, steps):
@@ -316,7 +376,8 @@ def roofline(prof, step_us, steps):
         key = name.replace("_persist_", "_step_").replace("_fused_", "_step_")
         out[key] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_stale": bool(stale and entry),
-                    "avg_launch_us": us, "block0_kernel_us": kern_us,
+                    "avg_launch_us": us, "kernel_us": kern_us,
+                    "kernel_us_note": "entry of the first block to exit of the LAST block (device clock, atomic max)",
                     "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps}
     g = prof.get("gemm")
     gemm = None
@@ -371,7 +432,12 @@ def main():
                                "B=32 per GPU, T=1000, F=80, |V|+1=29, L=100, conv [32,5,32,2] -> T'=%d, "
                                "4xGRU-512 uni, fc->29, %d params" % (r["Tp"], r["params"]),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
-        "ctc_loss_step_ms": r.get("ctc_ms"), "loss": r["loss"], "grad_norm": r["grad_norm"],
+        "ctc_loss_step_ms": r.get("ctc_ms"), "ctc_b4096_ms": r.get("ctc_b4096_ms"),
+        "bi_ms_per_step": r.get("bi_ms"),
+        "bi_note": "untimed-by-the-headline extra leg: S-LIBRI BIDIRECTIONAL (4 x biGRU-512, %s params) with dropout 0.2, full "
+                   "train step, B=32, inputs resident; loss %s, persist status %s"
+                   % (r.get("bi_params"), r.get("bi_loss"), r.get("bi_status")),
+        "loss": r["loss"], "grad_norm": r["grad_norm"],
         "loss_step0": r["loss_step0"], "loss_rel_err": None, "persist_status": r["persist_status"],
         "train_loop_utt_s": B * world * r["train_loop_steps"] / r["train_loop_dt"],
         "train_loop_ms_per_step": r["train_loop_dt"] / r["train_loop_steps"] * 1e3,

@@ -87,6 +87,18 @@ ctcStatus_t sa_ctc_loss(const float* acts, float* grads /* or NULL */, long stri
                         int alphabet_size, int minibatch, int max_T, int max_L, int blank_label, float* d_costs,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same call with the reduction the model's loss applies folded in (CTC.loss, ctc_model.py:34-40 -> train.py:29-33:
+ * one scalar per batch): d_loss[0] = scale * sum_b d_costs[b] (fixed summation order) and every gradient element is
+ * multiplied by `scale` as it is written (scale = 1 / batch size for size_average; a data-parallel rank passes
+ * 1 / GLOBAL batch size).  No separate reduction / scaling pass over the gradient exists. */
+ctcStatus_t sa_ctc_loss_reduced(const float* acts, float* grads /* or NULL */, long stride_t, long stride_b,
+                                const int* d_flat_labels, const int* d_label_lengths, const int* d_input_lengths,
+                                int alphabet_size, int minibatch, int max_T, int max_L, int blank_label, float scale,
+                                float* d_costs, float* d_loss, void* workspace, size_t workspace_bytes, void* stream);
+
+/* y[i] *= *d_factor (a DEVICE scalar, e.g. the gradient autograd hands the loss), skipped when the factor is exactly 1. */
+ctcStatus_t sa_scale_by_device_scalar(float* y, size_t n, const float* d_factor, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * 3. CTC decoding.
  *    sa_ctc_beam_decode  replaces speech/models/ctc_decoder.py:38-113 decode(probs, beam_size, blank) as called per
@@ -109,7 +121,16 @@ ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, 
 
 /* ------------------------------------------------------------------------------------------------------------------
  * 4. Encoder building blocks (speech/models/model.py:60-79 Model.encode and ctc_model.py:19,29 fc).
- *    fp32 throughout; GEMMs on the f32-input MFMA (exact fp32 products).
+ *    fp32 storage and fp32 accumulation throughout.  Arithmetic of the matrix products:
+ *      - recurrences, convolutions, the decoder's small products and every GEMM below 8 GFLOP: the f32-input MFMA
+ *        (v_mfma_f32_*_f32: exact fp32 products);
+ *      - GEMMs of at least 8 GFLOP with K >= 256 and M, N >= 64 (sa_gemm_is_split_bf16 -- a function of the shape ONLY):
+ *        each fp32 operand is split exactly into three bf16 pieces (a = a1 + a2 + a3) and six of the nine piece products
+ *        run on the bf16 MFMA with fp32 accumulation; the dropped terms are below 2^-26 of each product, the result is
+ *        within the fp32 accumulation bound 2^-24 (2 + sqrt(K)) |A||B| and measures at or below the f32-input kernel's
+ *        error against fp64 (tests/test_gpu_blocks.py::test_split_bf16_gemm_error_budget); integer data stays bit-exact.
+ *        Environment SA_GEMM_EXACT=1 selects the f32-input kernel for every product, =0 the split path for every
+ *        product (tests); nothing else -- in particular not the workspace size -- changes the arithmetic.
  * ----------------------------------------------------------------------------------------------------------------*/
 
 /* C[M,N] = alpha * op(A) * op(B) (+ bias[N]) (+ beta * C),  row-major, leading dimensions in elements.
@@ -117,8 +138,12 @@ ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, 
  *   trans_b == 0: B is (K,N), ldb >= N;  trans_b != 0: B is stored (N,K), ldb >= K   (nn.Linear / GRU weight layout).
  * Replaces the cuBLAS calls under nn.Linear (model.py:126-133) and nn.GRU's input projections (model.py:35-39).
  * Products with few output tiles and a long K (the weight gradients, K = B*T') are split along K into `workspace`
- * (sa_gemm_workspace_bytes; may be NULL / too small, then K is not split) and reduced in a fixed order. */
+ * and reduced in a fixed order.  workspace >= sa_gemm_workspace_bytes(M, N, K).  A product that runs the split-bf16
+ * path (sa_gemm_is_split_bf16) NEEDS that workspace for its packed operands: with less the call returns
+ * CTC_STATUS_INVALID_VALUE (it never changes arithmetic silently).  An exact-path product accepts NULL / a smaller
+ * buffer: K is then not split -- another summation order of the same exact products. */
 size_t sa_gemm_workspace_bytes(int M, int N, int K);
+int sa_gemm_is_split_bf16(int M, int N, int K);
 ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, long lda,
                         const float* B, long ldb, float beta, float* C, long ldc, const float* bias /* or NULL */,
                         void* workspace, size_t workspace_bytes, void* stream);

@@ -38,12 +38,16 @@ SIGNATURES = {
     "sa_ctc_flags_offset": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sa_ctc_loss": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                             c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_ctc_loss_reduced": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sa_scale_by_device_scalar": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "sa_ctc_beam_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sa_ctc_beam_decode": (c_int, [c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sa_ctc_greedy_decode": (c_int, [c_void_p, c_long, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p]),
     "sa_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sa_gemm_is_split_bf16": (c_int, [c_int, c_int, c_int]),
     "sa_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_float,
                             c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sa_conv2d_is_direct": (c_int, [c_int] * 6),

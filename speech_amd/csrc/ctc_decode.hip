@@ -547,12 +547,21 @@ extern "C" ctcStatus_t sa_ctc_beam_decode(const float* in, long stride_t, long s
     const size_t trie = (size_t)A.hsize * 12 + (size_t)A.max_nodes * 8;
     const size_t lds_all = ((lds + 15) & ~(size_t)15) + trie;
     A.trie_in_lds = lds_all <= 150 * 1024 ? 1 : 0;
-    const size_t lds_req = A.trie_in_lds ? lds_all : lds;
+    size_t lds_req = A.trie_in_lds ? lds_all : lds;
+    if (A.trie_in_lds && lds_req > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) !=
+            hipSuccess) {
+        // a device (or a carve-out) that does not grant the LDS-resident trie: the global-memory trie is the same search
+        (void)hipGetLastError();
+        A.trie_in_lds = 0;
+        lds_req = lds;
+    }
     if (!A.trie_in_lds &&
         hipMemsetAsync(A.hkeys, 0, (size_t)minibatch * A.hsize * sizeof(unsigned long long), stream) != hipSuccess)
         return CTC_STATUS_MEMOPS_FAILED;
-    if (lds_req > 48 * 1024 && hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)lds_req) != hipSuccess)
+    if (!A.trie_in_lds && lds_req > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)ctc_beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) !=
+            hipSuccess)
         return CTC_STATUS_EXECUTION_FAILED;
     hipLaunchKernelGGL(ctc_beam_kernel, dim3(minibatch), dim3(256), lds_req, stream, A);
     SA_CHECK_LAUNCH();

@@ -174,6 +174,7 @@ struct AbArgs {
                           // included (ONE launch behind the probability-domain pass, returning at once when nothing is flagged)
     float* grads;         // gate only: where ctc_grad_row writes
     long g_st, g_sb;
+    float gscale;         // every gradient element is multiplied by this (the caller's 1 / batch size)
     unsigned long long* dbg;  // debug (SA_CTC_DBG): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
 };
 
@@ -875,7 +876,7 @@ __device__ __forceinline__ void ctc_grad_row(const AbArgs& A, float* __restrict_
         const int hi = ls[1 + Ppad + k], lo = k > 0 ? ls[Ppad + k] : 0;
         const float run = hi > lo ? srt[hi - 1] - (lo > 0 ? srt[lo - 1] : 0.f) : 0.f;
         const float o = (k == A.blank) ? accB : run;
-        g[k] = y - o;
+        g[k] = (y - o) * A.gscale;
     }
     if (PROB) {
         // certification (2) of the probability-domain pass: the occupancies of a row sum to one -- the paths through the
@@ -925,6 +926,7 @@ struct WaveArgs {
     float* costs;
     float* grads;
     long st, sb;
+    float gscale;  // every gradient element is multiplied by this
     const int* only;  // non-null: redo only the utterances whose flag is set (the pass behind ctc_wave_p_kernel)
 };
 
@@ -1218,7 +1220,7 @@ __device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane
                     // K <= 64: lanes past K repeat lane K-1's store (same address, same value)
                     const int c = min(lane, K - 1);
                     const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
-                    g[c] = sa_exp2(rowp[c]) - o;
+                    g[c] = (sa_exp2(rowp[c]) - o) * A.gscale;
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -1230,7 +1232,7 @@ __device__ __forceinline__ void ctc_wave_beta(const WaveArgs& A, int b, int lane
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     for (int c = lane; c < K; c += 64) {
                         const float o = c == A.blank ? gb : occ[c];
-                        g[c] = sa_exp2(rowp[c]) - o;
+                        g[c] = (sa_exp2(rowp[c]) - o) * A.gscale;
                         occ[c] = 0.f;
                     }
                 }
@@ -1607,7 +1609,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         const int c = min(lane, K - 1);  // K <= 64: lanes past K repeat lane K-1's store
                         const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
                         float* g = A.grads + (long)b * A.sb + (long)t * A.st;
-                        g[c] = rowp[c] - o;
+                        g[c] = (rowp[c] - o) * A.gscale;
                     }
                 }
             };
@@ -1729,11 +1731,70 @@ static ctcStatus_t launch_ab_any(const AbArgs& A, int B, int threads, size_t sme
                   : launch_alphabeta<false, false, PROB>(A, B, threads, smem, stream);
 }
 
+namespace {
+// *out = scale * sum_b costs[b], summed in a fixed order (one wave; B is a batch size)
+__global__ void ctc_cost_sum_kernel(const float* __restrict__ costs, int B, float scale, float* __restrict__ out) {
+    float v = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) v += costs[b];
+    v = sa_wave_sum_dpp(v);
+    if (threadIdx.x == 0) *out = v * scale;
+}
+ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long stride_b, const int* d_flat_labels,
+                          const int* d_label_lengths, const int* d_input_lengths, int alphabet_size, int minibatch,
+                          int max_T, int max_L, int blank_label, float* d_costs, float grad_scale, void* workspace,
+                          size_t workspace_bytes, void* stream_);
+}  // namespace
+
 extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_t, long stride_b,
                                    const int* d_flat_labels, const int* d_label_lengths,
                                    const int* d_input_lengths, int alphabet_size, int minibatch, int max_T,
                                    int max_L, int blank_label, float* d_costs, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
+    return ctc_loss_impl(acts, grads, stride_t, stride_b, d_flat_labels, d_label_lengths, d_input_lengths, alphabet_size,
+                         minibatch, max_T, max_L, blank_label, d_costs, 1.0f, workspace, workspace_bytes, stream_);
+}
+
+extern "C" ctcStatus_t sa_ctc_loss_reduced(const float* acts, float* grads, long stride_t, long stride_b,
+                                           const int* d_flat_labels, const int* d_label_lengths,
+                                           const int* d_input_lengths, int alphabet_size, int minibatch, int max_T,
+                                           int max_L, int blank_label, float scale, float* d_costs, float* d_loss,
+                                           void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!d_loss) return CTC_STATUS_INVALID_VALUE;
+    const ctcStatus_t s = ctc_loss_impl(acts, grads, stride_t, stride_b, d_flat_labels, d_label_lengths, d_input_lengths,
+                                        alphabet_size, minibatch, max_T, max_L, blank_label, d_costs, scale, workspace,
+                                        workspace_bytes, stream_);
+    if (s != CTC_STATUS_SUCCESS) return s;
+    hipLaunchKernelGGL(ctc_cost_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const float*)d_costs, minibatch,
+                       scale, d_loss);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+// y[i] *= *d_factor, skipped entirely when the factor is exactly 1 (what autograd hands a root loss): the reduced loss's
+// gradient is already scaled, so loss.backward() costs one early-out launch and no pass over the gradient
+namespace {
+__global__ __launch_bounds__(256) void scale_by_device_scalar_kernel(float* __restrict__ y, size_t n,
+                                                                     const float* __restrict__ d_factor) {
+    const float f = *d_factor;
+    if (f == 1.0f) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] *= f;
+}
+}  // namespace
+extern "C" ctcStatus_t sa_scale_by_device_scalar(float* y, size_t n, const float* d_factor, void* stream_) {
+    SA_CLEAR_ERR();
+    if (!y || !d_factor) return CTC_STATUS_INVALID_VALUE;
+    if (n == 0) return CTC_STATUS_SUCCESS;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, y, n, d_factor);
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}
+
+namespace {
+ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long stride_b, const int* d_flat_labels,
+                          const int* d_label_lengths, const int* d_input_lengths, int alphabet_size, int minibatch,
+                          int max_T, int max_L, int blank_label, float* d_costs, float grad_scale, void* workspace,
+                          size_t workspace_bytes, void* stream_) {
     SA_CLEAR_ERR();
     if (!acts || !d_flat_labels || !d_label_lengths || !d_input_lengths || !d_costs || !workspace)
         return CTC_STATUS_INVALID_VALUE;
@@ -1767,7 +1828,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     A.lsort = (int*)(ws + o_lsort);
     A.gate = 0;
     { const char* fe = getenv("SA_CTC_PROB_FAST"); A.no_fast = fe && fe[0] == '0'; }
-    A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b;
+    A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b; A.gscale = grad_scale;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
     if (K <= 64 && (long)B * max_T >= 256 * 1024) {  // K_A, one lane per row out of an LDS tile: the
@@ -1810,7 +1871,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
             W.K = K; W.T_max = max_T; W.blank = blank_label; W.B = B; W.nren = nren; W.nq = (max_T + KU - 1) / KU;
             W.wave_lds_floats = (int)wave_floats;
             W.ly_sb = A.ly_sb; W.stash = A.stash; W.costs = d_costs; W.grads = grads;
-            W.st = stride_t; W.sb = stride_b; W.only = nullptr;
+            W.st = stride_t; W.sb = stride_b; W.only = nullptr; W.gscale = grad_scale;
             const size_t smem = waves * wave_bytes;
             const dim3 grid((B + waves - 1) / waves), block(64 * waves);
             // probability-domain pass first (gradient calls, K <= 64, R <= 4), the log-domain kernel behind it for flagged
@@ -1892,6 +1953,7 @@ extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_
     }
     return CTC_STATUS_SUCCESS;
 }
+}  // namespace
 
 // ----------------------------------------------------------------------------------- the warp-ctc-shaped entry points
 extern "C" int get_warpctc_version(void) { return 2; }

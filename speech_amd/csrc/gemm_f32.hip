@@ -1048,13 +1048,15 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     // workspace has room for the packed copies; SA_GEMM_EXACT=1 (read per call): the f32-input MFMA kernel everywhere.
     const bool filtered = opts && opts->xcc_mask && opts->tile_counter;
     const char* fpk_e = getenv("SA_GEMM_FILTERED_PK");
-    bool use_pk = pk_worth_it(M, N, K, nprob) && (!filtered || !(fpk_e && fpk_e[0] == '0'));
+    bool use_pk = !(opts && opts->exact) && pk_worth_it(M, N, K, nprob) && (!filtered || !(fpk_e && fpk_e[0] == '0'));
     const size_t pkA = sa_align_up(pk_bytes(M, K), 256), pkB = sa_align_up(pk_bytes(N, K), 256);
     const int pk_kt = 8, pk_parts = 2 * ((((K + PK_K - 1) / PK_K) + pk_kt - 1) / pk_kt);
     const int Mpad = (M + BM - 1) / BM * BM;
     const size_t pk_cs = (opts && opts->colsum) ? sa_align_up((size_t)nprob * pk_parts * Mpad * sizeof(float), 256) : 0;
     const size_t pk_need = (size_t)nprob * (pkA + pkB) + pk_cs;
-    if (use_pk && (!workspace || workspace_bytes < pk_need)) use_pk = false;
+    // Which arithmetic a product runs in is a function of its shape (pk_worth_it; sa_gemm_is_split_bf16 tells a caller),
+    // never of the buffer it was handed: a split-bf16 product without room for its packed operands is an error.
+    if (use_pk && (!workspace || workspace_bytes < pk_need)) return CTC_STATUS_INVALID_VALUE;
     char* pk_base = (char*)workspace;
     if (use_pk) {  // the packed copies sit in front of the split-K partials
         workspace = (char*)workspace + pk_need;
@@ -1169,6 +1171,7 @@ ctcStatus_t sa_gemm_f32_impl(int trans_a, int trans_b, int M, int N, int K, floa
 }
 
 extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K) { return sa_gemm_group_workspace_bytes(1, M, N, K); }
+extern "C" int sa_gemm_is_split_bf16(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && pk_worth_it(M, N, K, 1) ? 1 : 0; }
 
 extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                                    long lda, const float* B, long ldb, float beta, float* C, long ldc,

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         unsigned long long* o = P.timing + 4 * ((role_z * (P.xcd_mode ? P.nbt : (int)gridDim.y) + role_y - P.bt0) * ntile_u + role_x);
         for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
     }
-    if (stamper) P.stamp[1] = wall_clock64();
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 #undef SA_TICK
 }
 
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (stamper) P.stamp[1] = wall_clock64();
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
 
 // Gate-gradient arithmetic shared by the step kernel and the persistent kernel.  Contraction is switched off inside:
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
         for (int k = 0; k < 5; ++k) atomicAdd(&o[k], tacc[k]);
     }
     if (live) J.dh_state[(long)b * H + u] = dh_run;
-    if (stamper) P.stamp[1] = wall_clock64();
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
 
 // --------------------------------------------------------------- persistent backward chunk with the input gradient fused
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         }
     }
     if (live) J.dh_state[(long)b * H + u] = dh_run;
-    if (stamper) P.stamp[1] = wall_clock64();
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
 
 // ------------------------------------------------------------------------------------------------------- small helpers
@@ -1687,7 +1687,10 @@ static size_t stack_ai_bytes(int B, int T, int H) { return sa_align_up((size_t)T
 
 // ---- opt-in launch profiler (bench.py's live roofline measurement).  When enabled, thread 0 of block (0,0,0) of
 // every step launch of the stack entry points writes the 100 MHz wall clock at kernel entry and exit into a device
-// ring; sa_gru_profile_read() copies the ring back and averages (a) entry-to-exit of that block = kernel time and
+// ring -- in the XCD-local persistent / fused kernels, whose blocks finish at different times (a layer-0 block of the
+// fused forward is done 0.35 ms before the top layer's), the exit word is the atomic MAX over every block's exit, so the
+// duration is the launch's, not one block's (the ring is zeroed whenever it is re-armed);
+// sa_gru_profile_read() copies the ring back and averages (a) entry-to-exit = kernel time and
 // (b) entry-to-entry of consecutive full-width launches = the per-launch interval including the dispatch gap.
 // HIP events around single launches perturb the stream by several microseconds each, device stamps do not.
 // This is the library's only process-global state and is off by default.
@@ -1790,6 +1793,8 @@ extern "C" void sa_gru_profile_configure(int enable) {
     }
     g_prof.on = enable != 0 && g_prof.ring[0] && g_prof.ring[1];
     g_prof.count[0] = g_prof.count[1] = 0;
+    if (g_prof.on)   // exit words are atomic maxima: start from zero
+        for (int k = 0; k < 2; ++k) (void)hipMemset(g_prof.ring[k], 0, sizeof(unsigned long long) * 2 * StepProfiler::kRing);
 }
 
 // kind 0 = forward step kernel, 1 = backward.  Returns the number of launches averaged.
@@ -1803,6 +1808,7 @@ extern "C" int sa_gru_profile_read(int kind, float* avg_interval_us, float* avg_
         free(h);
         return 0;
     }
+    (void)hipMemset(g_prof.ring[kind], 0, sizeof(unsigned long long) * 2 * n);  // the slots are handed out again
     double ti = 0.0, tk = 0.0;
     long ni = 0, nk = 0;
     for (long i = 0; i < n; ++i) {

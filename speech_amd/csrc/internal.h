@@ -17,6 +17,7 @@ extern "C" size_t sa_gemm_workspace_bytes(int M, int N, int K);
 // nprob (<= 8) problems of identical shape in one launch; array arguments are host arrays of device pointers
 struct SaGemmOpts {
     int no_split;           // never split K (no workspace, no reduce launch)
+    int exact = 0;          // != 0: the f32-input MFMA kernel whatever the shape (no packed operands, no workspace for them)
     float* const* colsum;   // trans_a products: per problem, also write the column sums of A (K x M) -> [M]; or null
     unsigned xcc_mask;      // != 0: run only on the XCDs in the mask (persistent tile loop); needs tile_counter
     unsigned* tile_counter; // device word, zero before the launch

@@ -86,8 +86,12 @@ extern "C" ctcStatus_t sa_log_specgram(const short* d_audio, int n, int sample_r
     hipLaunchKernelGGL(i16_to_f32_kernel, dim3(g), dim3(256), 0, stream, d_audio, af, (long)n);
     SA_CHECK_LAUNCH();
     // frames (rows overlap: lda = hop) x windowed DFT
-    ctcStatus_t st = sa_gemm_f32_impl(0, 0, frames, 2 * nbins, nperseg, 1.0f, af, hop, d_dft, 2 * nbins, 0.f, ri,
-                                      2 * nbins, nullptr, nullptr, nullptr, 0, stream);
+    // (the f32-input MFMA kernel whatever the batch size: no packed operands, no workspace)
+    SaGemmOpts gopts{};
+    gopts.no_split = 1; gopts.exact = 1;
+    const float* Ap = af; const float* Bp = d_dft; float* Cp = ri; const float* biasp = nullptr;
+    ctcStatus_t st = sa_gemm_f32_group_impl(1, 0, 0, frames, 2 * nbins, nperseg, 1.0f, &Ap, hop, &Bp, 2 * nbins, 0.f, &Cp,
+                                            2 * nbins, &biasp, nullptr, nullptr, 0, stream, &gopts);
     if (st != CTC_STATUS_SUCCESS) return st;
     // scipy 'density' scaling: 1 / (fs * sum(w^2)); a periodic Hann window of length N has sum(w^2) = 3N/8
     const float scale = (float)(1.0 / ((double)sample_rate * 0.375 * (double)nperseg));

@@ -55,9 +55,12 @@ class CTCLabels:
         self._checked = key
 
 
-def ctc_loss_raw(acts, labels, act_lens=None, label_lens=None, blank=None, batch_first=True, want_grad=True):
+def ctc_loss_raw(acts, labels, act_lens=None, label_lens=None, blank=None, batch_first=True, want_grad=True,
+                 reduce_scale=None):
     """Un-reduced face of the HIP kernels: returns (costs (B,), grads like acts or None), both on the GPU.
-    costs[b] = -log p(labels_b | acts_b);  grads = d costs[b] / d acts (no batch scaling)."""
+    costs[b] = -log p(labels_b | acts_b);  grads = d costs[b] / d acts (no batch scaling).
+    reduce_scale = s: the reduced form (sa_ctc_loss_reduced) -- returns (loss (1,) = s * sum_b costs[b], grads * s), the
+    scaling done by the kernels that write the gradient and the sum by the library: no torch kernel runs."""
     _lib.require_cuda(acts, "acts")
     if acts.dtype != torch.float32 or acts.dim() != 3:
         raise _lib.SpeechAmdError("acts must be a float32 (B, T, V) tensor")
@@ -87,6 +90,13 @@ def ctc_loss_raw(acts, labels, act_lens=None, label_lens=None, blank=None, batch
             grads.zero_()
     nbytes = L.sa_ctc_workspace_bytes(max_T, max_L, K, B)
     ws = _lib.WORKSPACE.get(nbytes, dev, "ctc")
+    if reduce_scale is not None:
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(L.sa_ctc_loss_reduced(_lib.ptr(a), _lib.ptr(grads), st, sb, _lib.ptr(d_lab), _lib.ptr(d_llen),
+                                         _lib.ptr(d_alen), K, B, max_T, max_L, blank, float(reduce_scale),
+                                         _lib.ptr(costs), _lib.ptr(loss), _lib.ptr(ws), ws.numel(),
+                                         _lib.cur_stream()), "sa_ctc_loss_reduced")
+        return loss, grads
     _lib.check(L.sa_ctc_loss(_lib.ptr(a), _lib.ptr(grads), st, sb, _lib.ptr(d_lab), _lib.ptr(d_llen),
                              _lib.ptr(d_alen), K, B, max_T, max_L, blank, _lib.ptr(costs), _lib.ptr(ws),
                              ws.numel(), _lib.cur_stream()), "sa_ctc_loss")
@@ -96,19 +106,24 @@ def ctc_loss_raw(acts, labels, act_lens=None, label_lens=None, blank=None, batch
 class _CTCFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, acts, labels, act_lens, label_lens, blank, size_average, batch_first, denom):
-        costs, grads = ctc_loss_raw(acts, labels, act_lens, label_lens, blank, batch_first,
-                                    want_grad=ctx.needs_input_grad[0])
-        B = costs.shape[0]
-        ctx.grads = grads
-        ctx.scale = 1.0 / (denom if denom else B) if size_average else 1.0
-        return (costs.sum() * ctx.scale).reshape(1)
+        B = acts.shape[0] if batch_first else acts.shape[1]
+        scale = 1.0 / (denom if denom else B) if size_average else 1.0
+        # the batch reduction and the 1 / batch factor are kernel arguments: the gradient is written already scaled
+        loss, ctx.grads = ctc_loss_raw(acts, labels, act_lens, label_lens, blank, batch_first,
+                                       want_grad=ctx.needs_input_grad[0], reduce_scale=scale)
+        return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         g = ctx.grads
         if g is None:
             return (None,) * 8
-        return (g * (grad_out.reshape(()) * ctx.scale),) + (None,) * 7
+        # d loss arrives as a device scalar (1 for loss.backward()): one early-out launch, no pass over the gradient
+        go = grad_out.reshape(-1)[:1].contiguous()
+        # (g is dense in the logits' own layout: numel() consecutive floats from its data pointer)
+        _lib.check(_lib.lib().sa_scale_by_device_scalar(_lib.ptr(g), g.numel(), _lib.ptr(go), _lib.cur_stream()),
+                   "sa_scale_by_device_scalar")
+        return (g,) + (None,) * 7
 
 
 class CTCLoss(torch.nn.Module):

@@ -98,6 +98,14 @@ class Model(nn.Module):
         self.pad_frames = max_frames
         self.pad_labels = max_label_len
 
+    def skipped_step(self):
+        """A data-parallel rank whose shard of a global batch is empty calls this INSTEAD of loss(batch): it consumes the
+        random draws a forward pass would have made (one dropout key per pass, ops.new_dropout_seed), so that every rank's
+        generator -- seeded identically from the config, train.py:137-138 -- stays in lock-step with the others'."""
+        from . import ops
+        if self.training and self._plan.dropout and self._plan.fixed_seed is None:
+            ops.new_dropout_seed()
+
     def _to_device(self, x):
         """The batch's H2D copy (ctc_model.py:26-27 `x.cuda()`): asynchronous when collate() staged it in pinned memory."""
         if x.is_cuda or not self.is_cuda:
@@ -106,8 +114,19 @@ class Model(nn.Module):
             return _lib.h2d_async(x, list(self.parameters())[0].device, self._stage)
         return x.cuda(non_blocking=True)
 
+    def _collate_staged(self, *batch):
+        """collate() for the model's OWN entry points (loss / forward / infer): the padded batch is staged in a small ring
+        of pinned buffers, consumed by the H2D copy issued right behind.  The PUBLIC collate() (the reference's API,
+        ctc_model.py:42-53) returns memory the caller owns, like the reference's: a caller that collates a whole dev
+        set before using any of it must not find the first batches overwritten."""
+        self._staged = True
+        try:
+            return self.collate(*batch)
+        finally:
+            self._staged = False
+
     def _pad_inputs(self, inputs):
-        if self.is_cuda and not torch.is_tensor(inputs[0]):
+        if self.is_cuda and getattr(self, "_staged", False) and not torch.is_tensor(inputs[0]):
             if self._stage is None:
                 self._stage = _PinnedStage()
             return zero_pad_concat(inputs, self.pad_frames, stage=self._stage)
@@ -306,7 +325,7 @@ class CTC(Model):
         self.loss_denominator = v
 
     def forward(self, batch):
-        x, y, x_lens, y_lens = self.collate(*batch)
+        x, y, x_lens, y_lens = self._collate_staged(*batch)
         return self.forward_impl(x)
 
     def forward_impl(self, x, softmax=False):
@@ -317,7 +336,7 @@ class CTC(Model):
         return x
 
     def loss(self, batch):
-        x, y, x_lens, y_lens = self.collate(*batch)
+        x, y, x_lens, y_lens = self._collate_staged(*batch)
         with torch.set_grad_enabled(not self.volatile):
             out = self.forward_impl(x)
             loss_fn = ctc.CTCLoss(denom=self.loss_denominator)
@@ -335,7 +354,7 @@ class CTC(Model):
     def infer(self, batch):
         """ctc_model.py:55-60: prefix beam search with beam_size=1 over the full padded T' of every utterance --
         on the device, from the logits (the softmax of :30-31 is fused into the decode kernel)."""
-        x, y, x_lens, y_lens = self.collate(*batch)
+        x, y, x_lens, y_lens = self._collate_staged(*batch)
 
         def run():
             with torch.no_grad():
@@ -380,7 +399,7 @@ class Transducer(Model):
         self.fc2 = LinearND(rnn_dim, vocab_size + 1)
 
     def forward(self, batch):
-        x, y, x_lens, y_lens = self.collate(*batch)
+        x, y, x_lens, y_lens = self._collate_staged(*batch)
         y_mat = self.label_collate(batch[1])
         return self.forward_impl(x, y_mat)
 
@@ -392,12 +411,18 @@ class Transducer(Model):
         return self.decode(x, y)
 
     def loss(self, batch):
-        x, y, x_lens, y_lens = self.collate(*batch)
+        x, y, x_lens, y_lens = self._collate_staged(*batch)
         y_mat = self.label_collate(batch[1])
         with torch.set_grad_enabled(not self.volatile):
             out = self.forward_impl(x, y_mat)
             loss_fn = _tr.TransducerLoss(denom=self.loss_denominator)
             return loss_fn(out, y, x_lens, y_lens)
+
+    def skipped_step(self):
+        super().skipped_step()
+        if self.training and self._dec_dropout and self.dec_rnn.num_layers > 1:
+            from . import ops
+            ops.new_dropout_seed()   # the prediction network's inter-layer masks (decode)
 
     def _dec_params(self, l):
         return [getattr(self.dec_rnn, "%s_l%d" % (n, l)) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
@@ -541,7 +566,7 @@ class Seq2Seq(Model):
         return P
 
     def loss(self, batch):
-        x, y = self.collate(*batch)
+        x, y = self._collate_staged(*batch)
         if self.is_cuda:
             x = self._to_device(x)
             y = y.cuda(non_blocking=True)
@@ -558,7 +583,7 @@ class Seq2Seq(Model):
         return self.decode(x, y)
 
     def forward(self, batch):
-        x, y = self.collate(*batch)
+        x, y = self._collate_staged(*batch)
         if self.is_cuda:
             x = self._to_device(x)
             y = y.cuda(non_blocking=True)
@@ -599,7 +624,7 @@ class Seq2Seq(Model):
 
     def infer(self, batch, max_len=200):
         """seq2seq.py:160-178: greedy decode from the start tokens (no beam search)."""
-        x, y = self.collate(*batch)
+        x, y = self._collate_staged(*batch)
         end_tok = int(y[0, -1])
 
         def run():
@@ -616,7 +641,7 @@ class Seq2Seq(Model):
         -- hypotheses are rows of a batched decoder step, selection / completion / stopping rule in a kernel -- and
         one copy of the winner back.  Returns [hypothesis tuple incl. the start token]; `last_beam_score` /
         `last_beam_info` keep the score and (search steps, completed hypotheses) of the last call."""
-        x, y = self.collate(*batch)
+        x, y = self._collate_staged(*batch)
         if x.shape[0] != 1:
             raise ValueError("beam_search decodes a batch of one utterance (seq2seq.py:196-201), got %d" % x.shape[0])
         start_tok, end_tok = int(y[0, 0]), int(y[0, -1])

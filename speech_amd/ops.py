@@ -5,6 +5,8 @@ CPU path: CPU tensors raise SpeechAmdError."""
 import ctypes
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -88,8 +90,13 @@ DROP_STREAM_CONV, DROP_STREAM_GRU, DROP_STREAM_PRED = 0, 64, 128
 
 def new_dropout_seed():
     """A fresh 64-bit Philox key for one forward pass, drawn from torch's CPU generator (so torch.manual_seed makes a
-    run reproducible); no device work, no sync."""
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    run reproducible); no device work, no sync.  Data-parallel ranks seed that generator identically (train.py seeds every
+    rank from the config) and index their masks by LOCAL element position, so the rank is mixed into the key: utterance b
+    of rank 0 and utterance b of rank 1 get independent masks.  A rank that skips a forward pass (empty shard) must still
+    call this once per step so that the ranks' generators stay in lock-step (train.py does)."""
+    draw = int(torch.randint(0, 2 ** 62, (1,)).item())
+    rank = int(os.environ.get("RANK", "0")) if "WORLD_SIZE" in os.environ else 0
+    return (draw ^ ((rank * 0x9E3779B97F4A7C15) & (2 ** 62 - 1))) if rank else draw
 
 
 def dropout_mask(n, p, seed, stream_id, device, idx0=0):

@@ -577,3 +577,33 @@ def test_fused_forward_wavefront_matches_oracle_and_default():
             res.append(torch.load(out))
         for a, b in zip(*res):
             assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(a.abs().max())), shape
+
+
+def test_gemm_arithmetic_is_a_function_of_the_shape_not_of_the_workspace(monkeypatch):
+    """include/speech_amd.h section 4: a product runs the split-bf16 path iff sa_gemm_is_split_bf16(M, N, K) (>= 8 GFLOP,
+    K >= 256, M, N >= 64; SA_GEMM_EXACT forces either way) -- a split-path product handed less workspace than
+    sa_gemm_workspace_bytes returns CTC_STATUS_INVALID_VALUE instead of quietly running the other kernel; an exact-path
+    product accepts no workspace at all (K is then simply not split)."""
+    from speech_amd import _lib
+    L = _lib.lib()
+    monkeypatch.delenv("SA_GEMM_EXACT", raising=False)
+    assert L.sa_gemm_is_split_bf16(4096, 1536, 800) == 1 and L.sa_gemm_is_split_bf16(512, 512, 512) == 0
+    assert L.sa_gemm_is_split_bf16(1 << 20, 32, 4096) == 0 and L.sa_gemm_is_split_bf16(4096, 4096, 128) == 0
+    M, N, K = 4096, 1536, 800
+    a, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    c = torch.empty(M, N, device="cuda")
+    need = L.sa_gemm_workspace_bytes(M, N, K)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+
+    def call(nbytes):
+        return L.sa_gemm_f32(0, 1, M, N, K, 1.0, a.data_ptr(), K, b.data_ptr(), K, 0.0, c.data_ptr(), N, None,
+                             ws.data_ptr() if nbytes else None, nbytes, _lib.cur_stream())
+    assert call(need) == 0
+    split = c.clone()
+    assert call(need // 2) == 2 and call(0) == 2          # CTC_STATUS_INVALID_VALUE: never a silent change of arithmetic
+    monkeypatch.setenv("SA_GEMM_EXACT", "1")
+    assert L.sa_gemm_is_split_bf16(M, N, K) == 0
+    assert call(0) == 0                                    # the exact path needs no workspace
+    ref = a.double() @ b.double().t()
+    for got in (split, c):
+        assert float((got.double() - ref).norm() / ref.norm()) < 2e-6

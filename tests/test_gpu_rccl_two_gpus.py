@@ -1,0 +1,97 @@
+"""The data-parallel path over RCCL itself.  Needs TWO GPUs: the test box the driver uses has one, so
+this test SKIPS there -- it exists so that the first box with two devices exercises `bench.py --gpus 2` (one rank per GPU,
+torch.distributed backend "nccl" = RCCL over xGMI) without anyone editing code:
+  * the JSON line reports n_gpus = the RCCL world size and a whole-job value = 2 ranks' utterances;
+  * a two-rank forward + backward + SUM all-reduce over RCCL on a ragged batch reproduces the single-process HIP
+    gradient of the whole batch (what tests/test_gpu_dist_two_ranks.py checks with gloo carrying the tensor).
+/root/reference has no multi-GPU path; the hook point is between train.py:30 and :32."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _need_two():
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_args, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_two_gpus_over_rccl_reports_the_world():
+    _need_two()
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+    assert line["persist_status"] == 0
+    assert abs(line["value"] - 64 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+
+
+WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["SA_ROOT"])
+from speech_amd import dist, ops
+from speech_amd.models import CTC
+world, rank, local = dist.init()          # backend nccl (RCCL), one rank per GPU
+assert world == 2 and torch.distributed.get_backend() == "nccl"
+cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 32, 2]], "rnn": {"dim": 128, "layers": 2, "bidirectional": False}}}
+torch.manual_seed(11)
+model = CTC(80, 20, cfg).cuda()
+flat_p, flat_g = model.flatten_parameters_()
+rng = np.random.RandomState(3)
+lens = [152, 140, 147, 133, 144]
+inputs = tuple(rng.randn(t, 80).astype(np.float32) for t in lens)
+labels = tuple(rng.randint(0, 20, 9 + i).tolist() for i in range(5))
+model.set_train()
+# the whole batch on this rank alone (reference result), then the rank's shard with the global shape
+model.zero_grad(set_to_none=True)
+model.loss((inputs, labels)).backward()
+whole = flat_g.clone()
+(shard_in, shard_lab), shape = dist.shard_batch((inputs, labels), world, rank)
+model.set_global_batch(*shape)
+model.zero_grad(set_to_none=True)
+if len(shard_in):
+    model.loss((shard_in, shard_lab)).backward()
+else:
+    flat_g.zero_()
+ops.stamp_health(flat_g)
+dist.allreduce_gradients(flat_g)
+torch.cuda.synchronize()
+n = whole.numel() - 1          # the last slot of the flat buffer is the health flag
+assert float(flat_g[-1]) == 0.0
+rel = float((flat_g[:n] - whole[:n]).norm() / whole[:n].norm())
+print("RANK %d REL %.3e" % (rank, rel))
+assert rel < 1e-5, rel
+'''
+
+
+def test_two_rank_gradient_over_rccl_equals_single_process(tmp_path):
+    _need_two()
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    os.environ["SA_ROOT"] = ROOT
+    r = _torchrun([str(w)])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert r.stdout.count("REL") == 2

@@ -45,6 +45,7 @@ def train_step(model, flat, opt_cfg, batch, shape=None):
     loss = None
     if len(batch[0]) == 0:
         flat_g.zero_()  # global batch smaller than the world: this rank adds nothing but still joins the collective
+        model.skipped_step()  # ... and keeps its random generator in step with the ranks that did run a forward pass
     else:
         loss = model.loss(batch)
         loss.backward()
