@@ -131,6 +131,9 @@ def gpu_leg(args, world, rank, local):
            "step_us": step_us, "prof_steps": prof_steps,
            "params": int(flat_p.numel()), "Tp": Tp}
 
+    if args.headline_only:  # A/B experiments (tools/ab_env.sh): the timed region and the device clocks, nothing else
+        res.update({"train_loop_dt": 1.0, "train_loop_steps": 0})
+        return res
     res.update(train_loop_leg(model, flat_p, flat_g, world, rank, dev, max(5, min(args.steps, 20))))
 
     if rank == 0:  # CTC-loss-only step time (M-CTC: logits (32, 1000, 29), L = 100), fwd + grad
@@ -398,6 +401,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra legs (train loop, M-CTC, GEMM rates, "
+                    "bidirectional): A/B experiments")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # run by hand: become the launcher (one rank per GPU over RCCL, rendezvous on the loopback address)
@@ -439,8 +444,8 @@ def main():
                    % (r.get("bi_params"), r.get("bi_loss"), r.get("bi_status")),
         "loss": r["loss"], "grad_norm": r["grad_norm"],
         "loss_step0": r["loss_step0"], "loss_rel_err": None, "persist_status": r["persist_status"],
-        "train_loop_utt_s": B * world * r["train_loop_steps"] / r["train_loop_dt"],
-        "train_loop_ms_per_step": r["train_loop_dt"] / r["train_loop_steps"] * 1e3,
+        "train_loop_utt_s": B * world * r["train_loop_steps"] / r["train_loop_dt"] if r["train_loop_steps"] else None,
+        "train_loop_ms_per_step": r["train_loop_dt"] / r["train_loop_steps"] * 1e3 if r["train_loop_steps"] else None,
         "train_loop_note": "untimed-by-the-headline extra leg: train.py's loop on HOST batches (model.loss(batch): collate "
                            "into pinned memory + H2D, backward, all-reduce, clip+SGD, lagged read-back; global-shape "
                            "exchange one step ahead under --gpus N); %d steps" % r["train_loop_steps"],

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         role_z = g / P.nbt;
         role_y = g - role_z * P.nbt + P.bt0;
         if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront, or fewer groups than slots
-        if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+        if ((P.fault & 1) && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     }
     const PFwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     if (sub >= 32 / P.ntile_u) return;
     const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt + P.bt0;
     if (l >= P.L) return;
-    if (P.fault && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
     int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
     const int H = P.H, B = P.B, T = P.T;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     if (sub >= 32 / P.ntile_u) return;
     const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
     if (role_z >= P.n) return;
-    if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     const PBwdJob& J = P.j[role_z];
     const int H = P.H, B = P.B, H3 = 3 * P.H;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     if (sub >= 32 / P.ntile_u) return;
     const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
     if (role_z >= P.n) return;
-    if (P.fault && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
     const PBwdJob& J = P.j[role_z];
     const int B = P.B;
     const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
@@ -1881,7 +1881,8 @@ static int spin_limit() {
 }
 static int fault_injection() {  // tests only: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave early
     const char* e = getenv("SA_GRU_FAULT");
-    return (e && e[0] == '1') ? 1 : 0;
+    const char* a = getenv("SA_GRU_ABLATE");  // experiments only (wrong results): kernel-specific ablation bits
+    return ((e && e[0] == '1') ? 1 : 0) | (a ? atoi(a) << 4 : 0);
 }
 static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
     return hipMemsetD32Async((hipDeviceptr_t)p, (int)kSentinel, n, stream) == hipSuccess;
