@@ -225,6 +225,7 @@ struct PFwdJobs {
 };
 
 constexpr unsigned kSentinel = 0x7fc0deadu;  // a quiet NaN no finite state or gradient can equal
+constexpr int kXRing = 4;  // time slots of the backward kernels' exchange ring (a power of two; see PBwdJobs::packed)
 __device__ __forceinline__ bool has_sentinel(f32x4v v) {
     return __builtin_bit_cast(unsigned, v.x) == kSentinel || __builtin_bit_cast(unsigned, v.y) == kSentinel ||
            __builtin_bit_cast(unsigned, v.z) == kSentinel || __builtin_bit_cast(unsigned, v.w) == kSentinel;
@@ -875,7 +876,11 @@ struct PBwdJobs {
     unsigned long long* stamp;
     unsigned* err;
     int spin_limit, fault, prio;  // see PFwdJobs
-    int packed;                   // gru_bwd_fused_kernel: 1 = publish with plain stores (default), 0 = write-through
+    int packed;                   // gru_bwd_fused_kernel: 0 = publish with write-through stores, 1 = plain stores, 2 = plain
+                                  // stores into a RING of kXRing time slots (default): a published tile is dead once every block
+                                  // has published the NEXT step, so its owner re-arms it with the sentinel two steps later --
+                                  // the exchange is 4 slots that live in the XCD's L2 instead of T slots that the host pre-fills
+                                  // and HBM writes back (0.39 GB per S-LIBRI step)
     SaDrop drop;                  // gru_bwd_fused_kernel: inter-layer dropout -- d h_out[l-1] = mask * (dai[l] W_ih[l])
     long pk_kb;                   // gru_bwd_fused_kernel<.., PACKG>: k-tiles of the packed operands, T * B / 16
     int kpk_kb;                   // gru_bwd_fused_kernel<.., PACKK>: k-tiles per row block of the kpk operand (3H / 16, or
@@ -1176,8 +1181,9 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     if (timed) tprev = wall_clock64();
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
     f32x4v a[NITG];  // the gathered row block: rows = the batch tile, this wave's fragments of every exchanged gate
+    const bool ring = packed >= 2;
     auto gather = [&](int trow) {  // returns once no fragment holds the sentinel (or the call is lost)
-        const int abase = a0 + trow * (int)(s_x * 4);
+        const int abase = a0 + (ring ? (trow & (kXRing - 1)) : trow) * (int)(s_x * 4);
         for (int spins = 0;; ++spins) {
             asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
 #pragma unroll
@@ -1341,7 +1347,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         {
             // The exchange: this block's three 16 x 16 tiles (rows beyond the batch publish zeros -- a tile has no
             // holes a reader could wait on).  Consecutive threads, consecutive addresses: 1 KB per store instruction.
-            float* xp = p_xs + (long)t * s_x;
+            float* xp = p_xs + (long)(ring ? (t & (kXRing - 1)) : t) * s_x;
             const float third = FUSE ? dpn : dqn;
             if (packed) {  // plain stores: the XCD's own L2 is where the group meets, nothing needs to reach memory
                 xp[0] = dpr; xp[(H / 16) * 256] = dpz; xp[2 * (H / 16) * 256] = third;
@@ -1350,6 +1356,17 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                 __hip_atomic_store(xp + (H / 16) * 256, dpz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(xp + 2 * (H / 16) * 256, third, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+        {
+            // ring: this step's gather found every block's tile of time t - dt, so every block had finished gathering time
+            // t - 2 dt before it published that: this block's tile of t - 2 dt is dead.  Re-armed here, it is visible before
+            // this block publishes again (the next gather's loads return behind this store: one in-order queue), i.e. two
+            // publishes before the slot's next use.  (No branch around the stores: the idle case hits the dump slot.)
+            const bool dead = ring && have_next && (t - dt) != t_first;
+            float* rp = dead ? p_xs + (long)((t - 2 * dt) & (kXRing - 1)) * s_x : p_dump;
+            const int q1 = dead ? (H / 16) * 256 : 0, q2 = dead ? 2 * (H / 16) * 256 : 0;
+            const float sv = __builtin_bit_cast(float, kSentinel);
+            rp[0] = sv; rp[q1] = sv; rp[q2] = sv;
         }
         SA_TICK(2)
         // ---- everything the other blocks wait for is out.  The rest of the step is one branch-free scheduling region:
@@ -1385,7 +1402,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         if constexpr (FUSE) {
             second(s & 1);
 #pragma unroll
-            for (int k = 0; k < 21; ++k) {
+            for (int k = 0; k < 24; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 vector-memory instruction
             }
@@ -1917,6 +1934,10 @@ static int fwd_chunks(int T) {  // bidirectional forward: time chunks per layer 
 }
 static bool fuse_dx_enabled() {  // SA_GRU_FUSE_DX=0: the per-wave grouped GEMM computes d h_out of the lower layers
     const char* e = getenv("SA_GRU_FUSE_DX");
+    return !(e && e[0] == '0');
+}
+static bool xring_enabled() {  // SA_GRU_XRING=0: the backward exchange as T pre-filled time slots (rounds 2-3)
+    const char* e = getenv("SA_GRU_XRING");
     return !(e && e[0] == '0');
 }
 static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels (row-major exchange; bit-identical to the step kernels)
@@ -2783,9 +2804,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 if (Q.flagless)
                     for (int d = 0; d < 2; ++d)
                         if (!sentinel_fill(bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : dah[l * 2 + d],
-                                           bi_tiled_fn ? (size_t)T * bi_nbt * 16 * 3 * H : (size_t)T * B * 3 * H, stream))
+                                           bi_tiled_fn ? (size_t)(xring_enabled() ? min(T, kXRing) : T) * bi_nbt * 16 * 3 * H
+                                                       : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = (bi_tiled_fn && xring_enabled()) ? 2 : 1; Q.reg = sync + kSyncReg;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
                 Q.pk_kb = bi_packg ? (long)T * B / 16 : 0;
                 Q.kpk_kb = 6 * H / 16;
@@ -2945,9 +2967,11 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
+    const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed
     if (flagless)
-        for (int l = 0; l < L; ++l)  // the exchanged values are their own flags
-            if (!sentinel_fill(tiled ? xch_of(l) : dah[l], tiled ? (size_t)T * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
+        for (int l = 0; l < L; ++l)  // the exchanged values are their own flags (ring: kXRing time slots, re-armed in the kernel)
+            if (!sentinel_fill(tiled ? xch_of(l) : dah[l],
+                               tiled ? (size_t)(xring == 2 ? min(T, kXRing) : T) * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
                                stream))
                 return CTC_STATUS_MEMOPS_FAILED;
     if (fused) {
@@ -2973,7 +2997,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr; Q.drop = dc.drop;
         Q.pk_kb = packg ? (long)T * B / 16 : 0; Q.kpk_kb = 0;
-        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
+        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg;
         if (packg) { issuer.gates_prepacked = true; issuer.gsum_parts = nbt; }
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
             PBwdJob& J = Q.j[n];
@@ -3039,7 +3063,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
             Q.pk_kb = 0; Q.kpk_kb = 0;
             Q.drop = dc.drop;
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = 1; Q.reg = sync + kSyncReg;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
