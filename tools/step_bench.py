@@ -25,6 +25,10 @@ CASES = {  # F, V, B, T, L, encoder
     "slibri_bi": (80, 28, 32, 1000, 100, enc([[32, 5, 32, 2]], 512, 4, True)),
     "timit": (161, 48, 8, 300, 40, enc([[32, 5, 32, 2], [32, 5, 32, 1]], 256, 4, True)),
     "config2": (40, 61, 32, 1000, 100, enc([[32, 5, 32, 2]], 256, 2, False)),
+    # eligibility: widths beyond the XCD-local kernels' register-resident weight fragments (H <= 512)
+    "h768": (80, 28, 32, 1000, 100, enc([[32, 5, 32, 2]], 768, 4, False)),
+    "h1024": (80, 28, 32, 1000, 100, enc([[32, 5, 32, 2]], 1024, 4, False)),
+    "h640": (80, 28, 32, 1000, 100, enc([[32, 5, 32, 2]], 640, 4, False)),
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("--case", action="append")
