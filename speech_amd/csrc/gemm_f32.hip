@@ -1015,6 +1015,181 @@ ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsign
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------- thin products
+// The classifier of the CTC model is (B T', H) x (H, |V| + 1) with 29 classes (ctc_model.py:19,29): forward, its input
+// gradient and its weight gradient are products with ONE dimension of at most 32 -- a quarter of a 128-wide tile, 9 TFLOP/s
+// on the tiled kernels (0.16 ms of the 8 ms step for 1.4 GFLOP).  They are bound by reading or writing the (B T', H)
+// matrix once (32.6 MB at S-LIBRI: ~8 us), so each gets a kernel shaped for that: 16-row MFMA tiles (v_mfma_f32_16x16x4_f32,
+// exact fp32 products as everywhere on this path), the thin operand held in LDS, the big one streamed once.
+//   thin_nt_kernel  C[M, N<=32]  = A[M, K] B[N, K]^T + bias      (forward: logits)
+//   thin_nn_kernel  C[M, N]      = A[M, K<=32] B[K, N]           (input gradient)
+//   thin_tn_kernel  C[M<=32, N]  = A[K, M]^T B[K, N]             (weight gradient; K = B T' split over the grid, partial
+//                                                                sums folded in a fixed order: deterministic)
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThinSplit = 64;  // K chunks of thin_tn_kernel
+
+__global__ __launch_bounds__(256) void thin_nt_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                      long ldb, const float* __restrict__ bias, float* __restrict__ C,
+                                                      long ldc, int M, int N, int K, float beta) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];  // Bs[32][K + 4]
+    const int pitch = K + 4;
+    for (int e = threadIdx.x; e < 32 * (K / 4); e += 256) {
+        const int n = e / (K / 4), k4 = e - n * (K / 4);
+        const float4 v = n < N ? *reinterpret_cast<const float4*>(B + (long)n * ldb + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(tsm + n * pitch + 4 * k4) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + wave) * 16;
+    if (m0 >= M) return;
+    const float* a_row = A + (long)min(m0 + i, M - 1) * lda + 4 * g;
+    const float* b0 = tsm + i * pitch + 4 * g;
+    const float* b1 = tsm + (16 + i) * pitch + 4 * g;
+    tf32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    const int nit = K / 16;
+    for (int it0 = 0; it0 < nit; it0 += 4) {  // four 16-byte loads of the streamed operand in flight
+        float4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = it0 + q < nit ? *reinterpret_cast<const float4*>(a_row + 16 * (it0 + q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (it0 + q < nit) {
+                const float4 w0 = *reinterpret_cast<const float4*>(b0 + 16 * (it0 + q));
+                const float4 w1 = *reinterpret_cast<const float4*>(b1 + 16 * (it0 + q));
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, w0.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, w1.x, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, w0.y, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, w1.y, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, w0.z, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, w1.z, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, w0.w, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, w1.w, c1, 0, 0, 0);
+            }
+        }
+    }
+    // C / D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * g + r;
+        if (m >= M) continue;
+        float* crow = C + (long)m * ldc;
+        if (i < N) { float v = c0[r] + (bias ? bias[i] : 0.f); if (beta != 0.f) v += beta * crow[i]; crow[i] = v; }
+        if (16 + i < N) { float v = c1[r] + (bias ? bias[16 + i] : 0.f); if (beta != 0.f) v += beta * crow[16 + i]; crow[16 + i] = v; }
+    }
+}
+
+__global__ __launch_bounds__(256) void thin_nn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                      long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
+                                                      float beta) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];  // Bt[N][36]: the thin operand transposed, k padded to 32
+    for (int e = threadIdx.x; e < N * 32; e += 256) {
+        const int k = e / N, n = e - k * N;  // consecutive threads read consecutive n of one k
+        tsm[n * 36 + k] = k < K ? B[(long)k * ldb + n] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + wave) * 16;
+    if (m0 >= M) return;
+    const float* a_row = A + (long)min(m0 + i, M - 1) * lda;
+    float a[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 16 * it + 4 * g + j;
+            a[it][j] = k < K ? a_row[k] : 0.f;
+        }
+    for (int c = 0; c < N / 16; ++c) {
+        const float* bt = tsm + (16 * c + i) * 36 + 4 * g;
+        const float4 w0 = *reinterpret_cast<const float4*>(bt), w1 = *reinterpret_cast<const float4*>(bt + 16);
+        tf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][0], w0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][1], w0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][2], w0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][3], w0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][0], w1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][1], w1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][2], w1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][3], w1.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * g + r;
+            if (m < M) {
+                float* cp = C + (long)m * ldc + 16 * c + i;
+                *cp = beta != 0.f ? acc[r] + beta * *cp : acc[r];
+            }
+        }
+    }
+}
+
+// grid (N / 16, kThinSplit): a wave = one 16-column tile of C, both 16-row tiles, a quarter of the block's K chunk
+__global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                      long ldb, float* __restrict__ part, int M, int N, int K) {
+    __shared__ float red[4][2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int c = blockIdx.x;
+    const int per = (((K + kThinSplit - 1) / kThinSplit) + 63) / 64 * 64;  // rows of K per block: four waves x whole 16-k trips
+    const int kb = blockIdx.y * per + wave * (per / 4);
+    const int kend = min(K, kb + per / 4);
+    tf32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    const bool r0 = i < M, r1 = 16 + i < M;
+    for (int k0 = kb; k0 < kend; k0 += 16) {
+        float a0[4], a1[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // (a wave's four lane groups read four different k: a 16-k slab per trip)
+            const int k = k0 + g + 4 * j;
+            const bool ok = k < kend;
+            const int kc = ok ? k : 0;
+            a0[j] = ok && r0 ? A[(long)kc * lda + i] : 0.f;
+            a1[j] = ok && r1 ? A[(long)kc * lda + 16 + i] : 0.f;
+            b[j] = ok ? B[(long)kc * ldb + 16 * c + i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[j], c1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wave][0][(4 * g + r) * 16 + i] = c0[r];
+        red[wave][1][(4 * g + r) * 16 + i] = c1[r];
+    }
+    __syncthreads();
+    // part[split][32][N]
+    for (int e = threadIdx.x; e < 512; e += 256) {
+        const int t = e >> 8, o = e & 255, row = 16 * t + (o >> 4), col = 16 * c + (o & 15);
+        const float v = (red[0][t][o] + red[1][t][o]) + (red[2][t][o] + red[3][t][o]);
+        part[((long)blockIdx.y * 32 + row) * N + col] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void thin_tn_fold_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc,
+                                                           int M, int N, float beta) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)M * N) return;
+    const int row = (int)(e / N), col = (int)(e - (long)row * N);
+    float v = 0.f;
+    for (int sblk = 0; sblk < kThinSplit; ++sblk) v += part[((long)sblk * 32 + row) * N + col];
+    float* cp = C + (long)row * ldc + col;
+    *cp = beta != 0.f ? v + beta * *cp : v;
+}
+
+// which thin kernel (0 = none) a single plain product takes; a function of the shape and the strides only
+int thin_kind(int trans_a, int trans_b, int M, int N, int K, long lda, long ldb) {
+    const char* e = getenv("SA_GEMM_THIN");
+    if (e && e[0] == '0') return 0;
+    if (!trans_a && trans_b && N <= 32 && M >= 2048 && K >= 16 && K <= 1024 && (K % 16) == 0 && (lda & 3) == 0 && (ldb & 3) == 0)
+        return 1;
+    if (!trans_a && !trans_b && K <= 32 && M >= 2048 && N >= 16 && N <= 1024 && (N % 16) == 0) return 2;
+    if (trans_a && !trans_b && M <= 32 && K >= 2048 && N >= 16 && (N % 16) == 0) return 3;
+    return 0;
+}
+size_t thin_workspace_bytes(int trans_a, int trans_b, int M, int N, int K) {
+    // (the strides of a contiguous operand; a caller with other strides that misses the kernel simply takes the tiled path)
+    return thin_kind(trans_a, trans_b, M, N, K, 4, 4) == 3 ? (size_t)kThinSplit * 32 * N * sizeof(float) : 0;
+}
+
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
                                    const float* const* A, long lda, const float* const* B, long ldb, float beta,
                                    float* const* C, long ldc, const float* const* bias, const SaGemmEpilogue* ep,
@@ -1024,6 +1199,39 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     if (opts && opts->colsum && (!trans_a || alpha != 1.f)) return CTC_STATUS_INVALID_VALUE;
     if (M < 0 || N < 0 || K < 0 || nprob < 1 || nprob > kMaxGroup) return CTC_STATUS_INVALID_VALUE;
     if (M == 0 || N == 0) return CTC_STATUS_SUCCESS;
+    if (nprob == 1 && alpha == 1.f && !ep && !(opts && (opts->colsum || opts->xcc_mask || opts->drop)) && A[0] && B[0] && C[0] &&
+        (((uintptr_t)A[0] | (uintptr_t)B[0]) & 15) == 0) {
+        const int kind = thin_kind(trans_a, trans_b, M, N, K, lda, ldb);
+        const float* bs = bias ? bias[0] : nullptr;
+        if (kind == 1) {
+            const size_t smem = (size_t)32 * (K + 4) * sizeof(float);
+            if (smem <= 48 * 1024 || hipFuncSetAttribute((const void*)thin_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)smem) == hipSuccess) {
+                hipLaunchKernelGGL(thin_nt_kernel, dim3((M + 63) / 64), dim3(256), smem, stream, A[0], lda, B[0], ldb, bs, C[0],
+                                   ldc, M, N, K, beta);
+                SA_CHECK_LAUNCH();
+                return CTC_STATUS_SUCCESS;
+            }
+            (void)hipGetLastError();
+        } else if (kind == 2 && !bs) {
+            const size_t smem = (size_t)N * 36 * sizeof(float);
+            if (smem <= 48 * 1024 || hipFuncSetAttribute((const void*)thin_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)smem) == hipSuccess) {
+                hipLaunchKernelGGL(thin_nn_kernel, dim3((M + 63) / 64), dim3(256), smem, stream, A[0], lda, B[0], ldb, C[0], ldc,
+                                   M, N, K, beta);
+                SA_CHECK_LAUNCH();
+                return CTC_STATUS_SUCCESS;
+            }
+            (void)hipGetLastError();
+        } else if (kind == 3 && !bs && workspace && workspace_bytes >= (size_t)kThinSplit * 32 * N * sizeof(float)) {
+            float* part = (float*)workspace;
+            hipLaunchKernelGGL(thin_tn_kernel, dim3(N / 16, kThinSplit), dim3(256), 0, stream, A[0], lda, B[0], ldb, part, M, N, K);
+            hipLaunchKernelGGL(thin_tn_fold_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream,
+                               (const float*)part, C[0], ldc, M, N, beta);
+            SA_CHECK_LAUNCH();
+            return CTC_STATUS_SUCCESS;
+        }
+    }
     GemmArgs g;
     g.nprob = nprob;
     g.vecA = (lda & 3) == 0;
@@ -1154,6 +1362,11 @@ size_t sa_gemm_group_workspace_bytes(int nprob, int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || nprob <= 0) return 0;
     const int s = choose_splits(M, N, K, nprob);
     size_t w = s > 1 ? (size_t)nprob * s * ((size_t)M * N + M) * sizeof(float) : 0;
+    if (nprob == 1) {  // the weight gradient of a thin layer (thin_tn_kernel): its partial sums; the query does not know the
+                       // transpose form, so it covers it whenever the shape could be that product
+        const size_t t = thin_workspace_bytes(1, 0, M, N, K);
+        if (t > w) w = t;
+    }
     if (pk_worth_it(M, N, K, nprob)) {  // packed split-bf16 copies of both operands (+ the row-sum partials)
         const int parts = 2 * ((((K + PK_K - 1) / PK_K) + 7) / 8);
         w += (size_t)nprob * (sa_align_up(pk_bytes(M, K), 256) + sa_align_up(pk_bytes(N, K), 256)) +

@@ -607,3 +607,46 @@ def test_gemm_arithmetic_is_a_function_of_the_shape_not_of_the_workspace(monkeyp
     ref = a.double() @ b.double().t()
     for got in (split, c):
         assert float((got.double() - ref).norm() / ref.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(15936, 29, 512), (2050, 7, 64), (4096, 32, 1024), (3000, 17, 48)])
+def test_thin_products_of_the_classifier(monkeypatch, M, N, K):
+    """The fc layer's three products (ctc_model.py:19,29: (B T', H) x (H, |V| + 1), one dimension <= 32) run on the thin
+    kernels of csrc/gemm_f32.hip (thin_nt / thin_nn / thin_tn: f32-input MFMA, the (B T', H) matrix streamed once).  Each
+    against an fp64 product, within the fp32 accumulation bound, and against the tiled kernels (SA_GEMM_THIN=0); integer data
+    bit-exact; beta / bias forms."""
+    from speech_amd import ops
+    rng = np.random.RandomState(M + N)
+    x = rng.randn(M, K).astype(np.float32)          # the big matrix (encoder states)
+    w = rng.randn(N, K).astype(np.float32)          # the classifier
+    b = rng.randn(N).astype(np.float32)
+    dl = rng.randn(M, N).astype(np.float32)         # gradient of the logits
+    X, W, Bv, DL = dev(x), dev(w), dev(b), dev(dl)
+    xd, wd, dld = x.astype(np.float64), w.astype(np.float64), dl.astype(np.float64)
+    cases = {
+        "fwd": (lambda: ops.gemm(X, W, trans_b=True, bias=Bv), xd @ wd.T + b, np.abs(xd) @ np.abs(wd.T) + np.abs(b), K),
+        "dx": (lambda: ops.gemm(DL, W), dld @ wd, np.abs(dld) @ np.abs(wd), N),
+        "dw": (lambda: ops.gemm(DL, X, trans_a=True), dld.T @ xd, np.abs(dld.T) @ np.abs(xd), M),
+    }
+    for name, (fn, ref, scale, red) in cases.items():
+        monkeypatch.delenv("SA_GEMM_THIN", raising=False)
+        got = fn().cpu().numpy().astype(np.float64)
+        monkeypatch.setenv("SA_GEMM_THIN", "0")
+        tiled = fn().cpu().numpy().astype(np.float64)
+        bound = 2.0 ** -24 * (2.0 + np.sqrt(red))
+        assert got.shape == ref.shape
+        assert float((np.abs(got - ref) / scale).max()) <= bound, (name, float((np.abs(got - ref) / scale).max()), bound)
+        assert float(np.linalg.norm(got - tiled) / np.linalg.norm(ref)) < 1e-6, name
+    monkeypatch.delenv("SA_GEMM_THIN", raising=False)
+    # exact on integers; beta accumulates; the thin dimension's edge columns / rows are left alone
+    xi = rng.randint(-4, 5, (M, K)).astype(np.float32)
+    wi = rng.randint(-4, 5, (N, K)).astype(np.float32)
+    di = rng.randint(-4, 5, (M, N)).astype(np.float32)
+    assert np.array_equal(ops.gemm(dev(xi), dev(wi), trans_b=True).cpu().numpy(), xi @ wi.T)
+    assert np.array_equal(ops.gemm(dev(di), dev(wi)).cpu().numpy(), di @ wi)
+    if M * 16 * 16 < 2 ** 24:   # the integer sums stay below 2^24: exact whatever the order
+        assert np.array_equal(ops.gemm(dev(di), dev(xi), trans_a=True).cpu().numpy(), di.T @ xi)
+    c0 = rng.randn(M, N).astype(np.float32)
+    out = dev(c0.copy())
+    ops.gemm(X, W, trans_b=True, bias=Bv, out=out, beta=0.5)
+    np.testing.assert_allclose(out.cpu().numpy(), (xd @ wd.T + b + 0.5 * c0), rtol=2e-5, atol=2e-4)
