@@ -485,6 +485,15 @@ ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* params, int 
                                float scale, int start_tok, int end_tok, int beam_size, int max_len, int check_every,
                                long long* d_hyp, int* d_len, double* d_score, int* d_info, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* Greedy decode of a batch as ONE call (Seq2Seq.infer / infer_decode, seq2seq.py:140-178): per token the decoder step above
+ * on ping-pong state buffers and one kernel that takes each row's arg-max (first maximum), appends it to d_tokens, feeds it
+ * back, and stops the decode when EVERY row emitted end_tok in the same step (:155-156) or after max_len steps.
+ *   d_tokens (B, max_len + 1) int64 DEVICE: column 0 holds the start tokens on entry; d_steps[0] (DEVICE int) = steps run --
+ *   the reference's result is the first d_steps[0] + 1 columns.  check_every as for sa_s2s_beam_search. */
+size_t sa_s2s_greedy_workspace_bytes(int B, int T, int H, int E, int KS, int K, int max_len);
+ctcStatus_t sa_s2s_greedy_decode(const float* eh, const float* const* params, int B, int T, int H, int E, int KS, int K,
+                                 float scale, int end_tok, int max_len, int check_every, long long* d_tokens, int* d_steps,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 ctcStatus_t sa_softmax_xent(const float* logits, const long long* targets, float scale, float* loss_rows,
                             float* dlogits, long rows, int K, void* stream);
 ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows, int K, void* stream);

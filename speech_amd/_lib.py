@@ -125,6 +125,9 @@ SIGNATURES = {
     "sa_s2s_beam_workspace_bytes": (c_size_t, [c_int] * 7),
     "sa_s2s_beam_search": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_float] + [c_int] * 5 + [c_void_p] * 5 +
                            [c_size_t, c_void_p]),
+    "sa_s2s_greedy_workspace_bytes": (c_size_t, [c_int] * 7),
+    "sa_s2s_greedy_decode": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_float] + [c_int] * 3 + [c_void_p, c_void_p,
+                                                                                                  c_void_p, c_size_t, c_void_p]),
     "sa_softmax_xent": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_argmax_rows": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "sa_sgd_workspace_bytes": (c_size_t, [c_size_t]),

@@ -1254,3 +1254,145 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
+
+// =====================================================================================================================
+// Greedy decode of a batch (Seq2Seq.infer -> infer_decode, seq2seq.py:140-178) as ONE library call: per token the
+// decoder step of sa_s2s_decoder_step on ping-pong state buffers, then one kernel that takes each row's arg-max (first
+// maximum, as torch.max), appends it to the token matrix, makes it the next input, and raises `done` when EVERY row
+// emitted the end token in this step (the reference's stopping rule, :155-156).  The host polls `done` every check_every
+// tokens (0: never; all max_len tokens are enqueued and a finished decode ignores the rest).
+//   eh (B,T,H); d_tokens (B, max_len + 1) int64, column 0 = the start tokens on entry (seq2seq.py:172-175);
+//   d_steps[0] = decoder steps run: the reference returns the first d_steps + 1 columns.
+// =====================================================================================================================
+namespace {
+
+struct GreedyState { int done, steps; };
+
+__global__ __launch_bounds__(64) void s2s_greedy_pick_kernel(GreedyState* st, const float* __restrict__ logits,
+                                                            long long* __restrict__ tokens, long long* __restrict__ idx,
+                                                            unsigned* __restrict__ count, int B, int K, int ncol, int step,
+                                                            int end_tok, int max_len) {
+    if (st->done) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* xr = logits + (long)b * K;
+    float best = -3.0e38f;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64)
+        if (xr[k] > best) { best = xr[k]; bi = k; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        tokens[(long)b * ncol + step + 1] = bi;
+        idx[b] = bi;
+        // the last row to arrive closes the step: count[step] = rows done, high half = rows that emitted the end token
+        const unsigned add = 1u + (bi == end_tok ? 0x10000u : 0u);
+        const unsigned seen = atomicAdd(&count[step], add) + add;
+        if ((int)(seen & 0xffffu) == B) {
+            st->steps = step + 1;
+            __threadfence();
+            if ((int)(seen >> 16) == B || step + 1 >= max_len) st->done = 1;
+        }
+    }
+}
+
+__global__ void s2s_greedy_init_kernel(GreedyState* st, unsigned* count, int max_len, const long long* __restrict__ tokens,
+                                       long long* __restrict__ idx, float* __restrict__ hzero, int B, int H, int ncol) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { st->done = 0; st->steps = 0; }
+    if (i < max_len) count[i] = 0;
+    if (i < B) idx[i] = tokens[(long)i * ncol];
+    for (int k = i; k < B * H; k += gridDim.x * blockDim.x) hzero[k] = 0.f;
+}
+
+struct GreedyLayout { size_t st, count, idx, ix, h[2], ax[2], sx[2], oin, gi, gh, logits, score, total; };
+
+GreedyLayout greedy_layout(int B, int T, int H, int E, int K, int max_len) {
+    GreedyLayout L;
+    size_t p = 0;
+    auto take = [&](size_t bytes) { size_t o = p; p += sa_align_up(bytes, 256); return o; };
+    const size_t f = sizeof(float);
+    L.st = take(sizeof(GreedyState)); L.count = take((size_t)max_len * sizeof(unsigned));
+    L.idx = take((size_t)B * sizeof(long long)); L.ix = take((size_t)B * E * f);
+    for (int k = 0; k < 2; ++k) { L.h[k] = take((size_t)B * H * f); L.ax[k] = take((size_t)B * T * f); L.sx[k] = take((size_t)B * H * f); }
+    L.oin = take((size_t)B * H * f); L.gi = take((size_t)B * 3 * H * f); L.gh = take((size_t)B * 3 * H * f);
+    L.logits = take((size_t)B * K * f); L.score = take((size_t)B * T * f);
+    L.total = p;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t sa_s2s_greedy_workspace_bytes(int B, int T, int H, int E, int KS, int K, int max_len) {
+    S2SDims d{B, T, 1, H, E, KS, K};
+    if (!s2s_ok(d) || max_len < 1 || B > 65535) return 0;
+    return greedy_layout(B, T, H, E, K, max_len).total;
+}
+
+extern "C" ctcStatus_t sa_s2s_greedy_decode(const float* eh, const float* const* params, int B, int T, int H, int E, int KS,
+                                            int K, float scale, int end_tok, int max_len, int check_every,
+                                            long long* d_tokens, int* d_steps, void* workspace, size_t workspace_bytes,
+                                            void* stream_) {
+    SA_CLEAR_ERR();
+    S2SDims d{B, T, 1, H, E, KS, K};
+    if (!eh || !params || !d_tokens || !d_steps || !workspace || !s2s_ok(d) || max_len < 1 || B > 65535 || check_every < 0)
+        return CTC_STATUS_INVALID_VALUE;
+    const GreedyLayout L = greedy_layout(B, T, H, E, K, max_len);
+    if (workspace_bytes < L.total) return CTC_STATUS_INVALID_VALUE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    GreedyState* st = (GreedyState*)(ws + L.st);
+    unsigned* count = (unsigned*)(ws + L.count);
+    long long* idx = (long long*)(ws + L.idx);
+    float* ix = (float*)(ws + L.ix);
+    float* gi = (float*)(ws + L.gi);
+    float* gh = (float*)(ws + L.gh);
+    float* oin = (float*)(ws + L.oin);
+    float* logits = (float*)(ws + L.logits);
+    float* score = (float*)(ws + L.score);
+    const float* const* P = params;
+    const int ncol = max_len + 1;
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
+    if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
+        return CTC_STATUS_INVALID_VALUE;
+    // (the zero state of the first token lives in slot 1's h)
+    hipLaunchKernelGGL(s2s_greedy_init_kernel, dim3(64), dim3(256), 0, stream, st, count, max_len, (const long long*)d_tokens,
+                       idx, (float*)(ws + L.h[1]), B, H, ncol);
+    for (int t = 0; t < max_len; ++t) {
+        const int cur = t & 1, prv = cur ^ 1;
+        float* hx = (float*)(ws + L.h[cur]);
+        float* ax = (float*)(ws + L.ax[cur]);
+        float* sx = (float*)(ws + L.sx[cur]);
+        const float* hprev = (const float*)(ws + L.h[prv]);
+        const float* ax_prev = t > 0 ? (const float*)(ws + L.ax[prv]) : nullptr;
+        const float* sx_prev = t > 0 ? (const float*)(ws + L.sx[prv]) : nullptr;
+        hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], (const long long*)idx, sx_prev, ix, E);
+        SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
+                            {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
+        skinny_launch(pr, 2, B, stream);
+        hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
+                           (float*)nullptr, B, H);
+        AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
+        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+        hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
+        SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
+        skinny_launch(&q, 1, B, stream);
+        hipLaunchKernelGGL(s2s_greedy_pick_kernel, dim3(B), dim3(64), 0, stream, st, (const float*)logits, d_tokens, idx, count, B,
+                           K, ncol, t, end_tok, max_len);
+        if (check_every > 0 && (t + 1) % check_every == 0 && t + 1 < max_len) {
+            int done = 0;
+            if (hipMemcpyAsync(&done, &st->done, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                return CTC_STATUS_MEMOPS_FAILED;
+            if (done) break;
+        }
+    }
+    if (hipMemcpyAsync(d_steps, &st->steps, sizeof(int), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return CTC_STATUS_MEMOPS_FAILED;
+    SA_CHECK_LAUNCH();
+    return CTC_STATUS_SUCCESS;
+}

@@ -630,9 +630,10 @@ class Seq2Seq(Model):
         def run():
             with torch.no_grad():
                 enc = self.encode(self._to_device(x))
-                y0 = y[:, 0:1].to(enc.device)
-                _, argmaxs = self.infer_decode(enc, y0, end_tok, max_len)
-            return [seq.tolist() for seq in argmaxs.cpu().numpy()]
+                # the whole token loop in the library (no device -> host round trip per token); infer_decode remains the
+                # step-by-step form of the reference's API
+                toks = _s2s.greedy_decode(enc, y[:, 0], self._param_dict(), self.attend.log_t, end_tok, max_len)
+            return [seq.tolist() for seq in toks.numpy()]
         return self._healthy(run)
 
     def beam_search(self, batch, beam_size=10, max_len=200):

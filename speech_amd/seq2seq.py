@@ -102,6 +102,29 @@ def step(eh, idx, state, P, log_t):
     return out, (hx, ax, sx)
 
 
+def greedy_decode(eh, y0, P, log_t, end_tok, max_len, check_every=8):
+    """Seq2Seq.infer_decode's token matrix (seq2seq.py:140-158) for a batch, the whole loop in the library
+    (sa_s2s_greedy_decode): eh (B, T, H), y0 (B,) start tokens.  Returns an int64 CPU tensor (B, steps + 1)."""
+    B, T, H = eh.shape
+    E, K, KS = P["emb"].shape[1], P["fc_w"].shape[0], P["conv_w"].shape[-1]
+    L = _L()
+    nbytes = L.sa_s2s_greedy_workspace_bytes(B, T, H, E, KS, K, max_len)
+    if nbytes == 0:
+        raise _lib.SpeechAmdError("Seq2Seq greedy decode: unsupported shape")
+    ws = _lib.WORKSPACE.get(nbytes, eh.device, "s2s_greedy")
+    rec = torch.zeros(B * (max_len + 1) + 1, dtype=torch.int64, device=eh.device)  # tokens | steps (low int32)
+    tokens = rec[:B * (max_len + 1)].view(B, max_len + 1)
+    tokens[:, 0] = y0.reshape(-1).to(eh.device)
+    plist = [P[n].contiguous() for n in _NAMES]
+    _lib.check(L.sa_s2s_greedy_decode(_lib.ptr(eh.contiguous()), _ptr_array(plist), B, T, H, E, KS, K,
+                                      math.log(T) if log_t else 1.0, int(end_tok), int(max_len), int(check_every),
+                                      tokens.data_ptr(), rec.data_ptr() + 8 * B * (max_len + 1), _lib.ptr(ws), ws.numel(),
+                                      _lib.cur_stream()), "sa_s2s_greedy_decode")
+    host = rec.cpu()
+    steps = int(host[-1:].numpy().view("int32")[0])
+    return host[:B * (max_len + 1)].view(B, max_len + 1)[:, :steps + 1]
+
+
 def beam_search(eh, P, log_t, start_tok, end_tok, beam_size, max_len, check_every=8):
     """Seq2Seq.beam_search (seq2seq.py:180-227) for ONE utterance on the device (sa_s2s_beam_search): eh (T, H) encoder
     states.  Returns (hypothesis tuple incl. the start token, score, (search steps, completed hypotheses)) after ONE

@@ -196,3 +196,32 @@ def test_scheduled_sampling_consumes_the_rng_like_the_reference_and_trains():
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
     m.set_eval()
     assert not m.scheduled_sampling
+
+
+def test_greedy_infer_in_the_library_equals_the_step_by_step_loop():
+    """Seq2Seq.infer runs the token loop inside the library (sa_s2s_greedy_decode: arg-max, feedback and the "every row
+    emitted the end token" stopping rule in a kernel); infer_decode is the reference's step-by-step loop (seq2seq.py:140-158)
+    on the same decoder step.  Same tokens, same number of columns -- on a model whose rows stop early and on one that
+    runs to max_len."""
+    from speech_amd.models import Seq2Seq
+    for seed, fc_scale, max_len in ((3, 25.0, 40), (5, 1.0, 9)):
+        cfg = {"dropout": 0.0, "encoder": {"conv": [[4, 5, 9, 2]], "rnn": {"dim": 32, "bidirectional": True, "layers": 1}},
+               "decoder": {"embedding_dim": 32, "layers": 1, "log_t": True}}
+        torch.manual_seed(seed)
+        m = Seq2Seq(20, 9, cfg)
+        with torch.no_grad():
+            m.fc.fc.weight.mul_(fc_scale)
+            m.fc.fc.bias.mul_(fc_scale)
+            m.fc.fc.bias[7] += 4.0 * fc_scale / 25.0   # the end token (7) is likely: rows stop, not always together
+        m = m.cuda()
+        m.set_eval()
+        rng = np.random.RandomState(seed)
+        B = 4
+        inputs = tuple(rng.randn(80 - 5 * i, 20).astype(np.float32) for i in range(B))
+        labels = tuple([8, 1, 7] for _ in range(B))
+        got = m.infer((inputs, labels), max_len=max_len)
+        x, y = m.collate(inputs, labels)
+        with torch.no_grad():
+            enc = m.encode(x.cuda())
+            _, want = m.infer_decode(enc, y[:, 0:1].cuda(), 7, max_len)
+        assert np.array_equal(np.array(got), want.cpu().numpy()), (seed, got, want)
