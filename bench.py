@@ -150,7 +150,26 @@ def gpu_leg(args, world, rank, local):
         e1.record()
         torch.cuda.synchronize()
         res["ctc_ms"] = e0.elapsed_time(e1) / 20
-        del acts, lab
+        # The same call with the chip BUSY in front of it (a 4096^3 GEMM per call, its own time subtracted): the alpha / beta
+        # chain is 1000 dependent steps on 32 of 256 CUs -- pure latency, i.e. clock rate -- and twenty such calls back to
+        # back leave the chip idle enough that its clocks drop (121 us per call against 61-78 us behind a GEMM,
+        # tools/ctc_latency_probe.py).  Inside a train step the chip is busy: kernel_time_ms_per_step.ctc_loss is that case.
+        ga, gb_ = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
+        gc = torch.empty(4096, 4096, device=dev)
+
+        def timed(fn, n=20):
+            for _ in range(2):
+                fn()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        t_gemm = timed(lambda: ops.gemm(ga, gb_, out=gc))
+        t_both = timed(lambda: (ops.gemm(ga, gb_, out=gc), ctc_loss_raw(acts, lab)))
+        res["ctc_busy_ms"] = t_both - t_gemm
+        del acts, lab, ga, gb_, gc
         res["ctc_b4096_ms"] = ctc_b4096_leg(dev)
         res["stack_gemm"] = stack_gemm_rates(dev, Tp)
         res.update(bidirectional_leg(dev))
@@ -437,7 +456,12 @@ def main():
                                "B=32 per GPU, T=1000, F=80, |V|+1=29, L=100, conv [32,5,32,2] -> T'=%d, "
                                "4xGRU-512 uni, fc->29, %d params" % (r["Tp"], r["params"]),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
-        "ctc_loss_step_ms": r.get("ctc_ms"), "ctc_b4096_ms": r.get("ctc_b4096_ms"),
+        "ctc_loss_step_ms": r.get("ctc_ms"), "ctc_loss_busy_chip_ms": r.get("ctc_busy_ms"),
+        "ctc_note": "M-CTC (B=32, T=1000, |V|+1=29, L=100) forward + gradient per call: ctc_loss_step_ms = twenty calls back to "
+                    "back on an otherwise idle chip (clocks drop: the 1000-step chain runs on 32 of 256 CUs); "
+                    "ctc_loss_busy_chip_ms = the same call behind a 4096^3 GEMM (its time subtracted), i.e. at the clocks a "
+                    "train step runs at; kernel_time_ms_per_step.ctc_loss = the call inside the timed train step (T'=498)",
+        "ctc_b4096_ms": r.get("ctc_b4096_ms"),
         "bi_ms_per_step": r.get("bi_ms"),
         "bi_note": "untimed-by-the-headline extra leg: S-LIBRI BIDIRECTIONAL (4 x biGRU-512, %s params) with dropout 0.2, full "
                    "train step, B=32, inputs resident; loss %s, persist status %s"
