@@ -1898,8 +1898,7 @@ static int spin_limit() {
 }
 static int fault_injection() {  // tests only: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave early
     const char* e = getenv("SA_GRU_FAULT");
-    const char* a = getenv("SA_GRU_ABLATE");  // experiments only (wrong results): kernel-specific ablation bits
-    return ((e && e[0] == '1') ? 1 : 0) | (a ? atoi(a) << 4 : 0);
+    return (e && e[0] == '1') ? 1 : 0;
 }
 static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
     return hipMemsetD32Async((hipDeviceptr_t)p, (int)kSentinel, n, stream) == hipSuccess;

@@ -59,3 +59,26 @@ def test_masked_torch_oracle_equals_the_reference_modules_without_dropout():
             masks = philox_ref.encoder_masks(0.3, 7, [tuple(c1.shape), tuple(c2.shape)], (3, c2.shape[2], 16 * D), 3)
             y = m(x, masks)
             assert torch.isfinite(y).all() and not torch.equal(y, m(x))
+
+
+def test_dropout_key_differs_per_rank_and_generators_stay_in_step(monkeypatch):
+    """every data-parallel rank seeds torch's generator from the same config seed and indexes its masks by LOCAL
+    position -- without the rank in the key, utterance b of every rank would get the same mask.  ops.new_dropout_seed mixes
+    the rank in; the DRAW itself stays the same on every rank (one draw per forward pass, also on a rank that skips the pass:
+    Model.skipped_step), so the generators stay in lock-step."""
+    import torch
+    from speech_amd import ops
+    keys = {}
+    for rank in (0, 1, 2):
+        monkeypatch.setenv("WORLD_SIZE", "3")
+        monkeypatch.setenv("RANK", str(rank))
+        torch.manual_seed(2017)
+        keys[rank] = [ops.new_dropout_seed() for _ in range(3)]
+        keys[rank].append(int(torch.randint(0, 2 ** 62, (1,)).item()))  # the generator's NEXT draw: same on every rank
+    assert keys[0][:3] != keys[1][:3] and keys[1][:3] != keys[2][:3]
+    assert all(a != b for a, b in zip(keys[0][:3], keys[1][:3]))
+    assert keys[0][3] == keys[1][3] == keys[2][3]
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.delenv("RANK")
+    torch.manual_seed(2017)
+    assert [ops.new_dropout_seed() for _ in range(3)] == keys[0][:3]   # a single process: the plain draw
