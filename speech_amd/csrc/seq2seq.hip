@@ -66,6 +66,21 @@ struct AttArgs {
     float scale;           // log(T) if log_t else 1
     int B, T, H, KS;
     int eh_shared = 0;     // != 0: every batch row reads the SAME (T, H) encoder states (the hypotheses of a beam search)
+    // (r4) the training loop's fusions -- all null outside sa_s2s_decoder_fwd:
+    // attention_score_kernel forms ox = GRUCell gates(gi, gh, h_prev) itself (every block for its utterance; the block of
+    // the first time chunk also writes it to `ox_out` and the gate stash), saving the gate kernel's launch ...
+    const float* gi = nullptr;      // (B, 3H)
+    const float* gh = nullptr;      // (B, 3H)
+    const float* h_prev = nullptr;  // (B, H)
+    float* ox_out = nullptr;        // (B, H)  == ox
+    float* gate_stash = nullptr;    // (B, 4H) r | z | n | gh_n
+    // ... and attention_context_kernel forms the NEXT token's GRU input emb[y_next] + sx (teacher forcing), saving the index
+    // and embedding launches
+    const long long* y_next = nullptr;  // y + (t + 1): element b * y_stride
+    long y_stride = 0;
+    const float* emb = nullptr;         // (V, E), E == H
+    float* ix_next = nullptr;           // (B, E)
+    long long* idx_next = nullptr;      // (B)
 };
 
 constexpr int kAttTB = 16;  // time steps per workgroup: grid (ceil(T / 16), B) fills the chip where one workgroup per
@@ -119,6 +134,27 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
     const float* ehb = A.eh + (A.eh_shared ? 0l : (long)b * A.T * A.H);
     const float* oxb = A.ox + (long)b * A.H;
     att_stage(A, b, t0, axp, cw);
+    if (A.gi) {  // fused GRUCell gates (grucell_gates_fwd_kernel's arithmetic): h of this utterance into LDS
+        float* oxs = cw + A.H * A.KS;
+        for (int j = threadIdx.x; j < A.H; j += blockDim.x) {
+            const float* a = A.gi + (long)b * 3 * A.H;
+            const float* c = A.gh + (long)b * 3 * A.H;
+            const float r = sigmoidf_(a[j] + c[j]);
+            const float z = sigmoidf_(a[A.H + j] + c[A.H + j]);
+            const float ghn = c[2 * A.H + j];
+            const float n = tanhf(a[2 * A.H + j] + r * ghn);
+            const float h = (1.0f - z) * n + z * A.h_prev[(long)b * A.H + j];
+            oxs[j] = h;
+            if (blockIdx.x == 0) {
+                A.ox_out[(long)b * A.H + j] = h;
+                if (A.gate_stash) {
+                    float* st = A.gate_stash + (long)b * 4 * A.H;
+                    st[j] = r; st[A.H + j] = z; st[2 * A.H + j] = n; st[3 * A.H + j] = ghn;
+                }
+            }
+        }
+        oxb = oxs;
+    }
     __syncthreads();
     const float nb = A.nn_b[0];
     // hidden unit outer, the wave's four time steps inner: the unit's conv taps are read from LDS once, the four eh
@@ -229,11 +265,14 @@ __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const
         }
     }
     __syncthreads();
+    const long long yn = A.ix_next ? A.y_next[(long)b * A.y_stride] : 0;
     for (int h = threadIdx.x; h < A.H; h += 256) {
         const float v = (part[h] + part[A.H + h]) + (part[2 * A.H + h] + part[3 * A.H + h]);
         sx[(long)b * A.H + h] = v;
         if (oin) oin[(long)b * A.H + h] = A.ox[(long)b * A.H + h] + v;
+        if (A.ix_next) A.ix_next[(long)b * A.H + h] = A.emb[yn * A.H + h] + v;   // s2s_embed_add_kernel's sum
     }
+    if (A.ix_next && threadIdx.x == 0) A.idx_next[b] = yn;
 }
 
 struct AttBwd {
@@ -252,6 +291,17 @@ struct AttBwd {
     float* part;             // workspace (B, nchunk, H, 2 + KS): per-chunk sums of d_pre, d_pre-weighted terms
     float* q;                // workspace (B, T, KS): sum_h d_pre[t,h] conv_w[h,k]
     int nchunk;
+    // (r4) fusions of the training loop (zero / null outside sa_s2s_decoder_bwd):
+    int fused_softmax = 0;   // attention_bwd_main_kernel goes through the softmax itself: dpax holds d ax (stage 1's output) and
+                             // every block recomputes the utterance's sum_t ax d ax (T values); no attention_bwd_softmax launch
+    // attention_bwd_fold_kernel's d_ox block continues with the GRUCell gate gradients of its utterance (grucell_gates_bwd_kernel's
+    // arithmetic): dh = dh_a + d_ox + dh_c
+    const float* gb_dh_a = nullptr;     // (B, H) gradient of the state from the fc (dOIN[t])
+    const float* gb_stash = nullptr;    // (B, 4H)
+    const float* gb_h_prev = nullptr;   // (B, H) or NULL (first token)
+    float* gb_dgi = nullptr;            // (B, 3H)
+    float* gb_dgh = nullptr;            // (B, 3H)
+    float* gb_dh_prev = nullptr;        // (B, H): read (dh_c, the gradient arriving from the next token's GRU) then written
 };
 
 // ---- backward, stage 1: d ax[t] = (from the next token) + d_sx . eh[t].  grid (ceil(T / 16), B), a wave per time step
@@ -306,10 +356,27 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
     const float* dsx = G.d_sx + (long)b * A.H;
     float* dehb = G.d_eh + (long)b * A.T * A.H;
     att_stage(A, b, t0, axp, cw);
+    float ssum = 0.f;
+    if (G.fused_softmax) {   // s = sum_t ax[t] d ax[t] over the WHOLE utterance (attention_bwd_softmax_kernel's first pass)
+        __shared__ float red[4];
+        const float* axb = G.ax + (long)b * A.T;
+        const float* dab = G.dpax + (long)b * A.T;
+        float sp = 0.f;
+        for (int t = threadIdx.x; t < A.T; t += 256) sp += axb[t] * dab[t];
+        ssum = block_reduce(sp, red, false);
+        if (chunk == 0) {   // the score bias' gradient: sum_t d score[t] (zero up to rounding: the softmax is shift invariant)
+            float sb = 0.f;
+            for (int t = threadIdx.x; t < A.T; t += 256) sb += axb[t] * (dab[t] - ssum) * A.scale;
+            sb = block_reduce(sb, red, false);
+            if (threadIdx.x == 0) G.g_nn_b[b] += sb;
+        }
+    }
     if ((int)threadIdx.x < kAttTB) {
         const bool ok = (int)threadIdx.x < nt;
-        dps[threadIdx.x] = ok ? G.dpax[(long)b * A.T + t0 + threadIdx.x] : 0.f;
-        axs[threadIdx.x] = ok ? G.ax[(long)b * A.T + t0 + threadIdx.x] : 0.f;
+        const float axv = ok ? G.ax[(long)b * A.T + t0 + threadIdx.x] : 0.f;
+        const float dv = ok ? G.dpax[(long)b * A.T + t0 + threadIdx.x] : 0.f;
+        dps[threadIdx.x] = G.fused_softmax ? axv * (dv - ssum) * A.scale : dv;
+        axs[threadIdx.x] = axv;
     }
     __syncthreads();
     const int W = 2 + A.KS;
@@ -401,6 +468,21 @@ __global__ __launch_bounds__(256) void attention_bwd_fold_kernel(AttArgs A, AttB
             if (j == 0) {
                 G.d_ox[(long)b * A.H + h] = acc;
                 if (A.ax_prev) G.g_conv_b[(long)b * A.H + h] += acc;
+                if (G.gb_dgi) {   // grucell_gates_bwd_kernel for (b, h): dh = dOIN + d_ox + (from the next token's GRU)
+                    const long i = (long)b * A.H + h;
+                    const float* sg = G.gb_stash + (long)b * 4 * A.H;
+                    const float r = sg[h], z = sg[A.H + h], n = sg[2 * A.H + h], ghn = sg[3 * A.H + h];
+                    const float g = G.gb_dh_a[i] + acc + G.gb_dh_prev[i];
+                    const float hp = G.gb_h_prev ? G.gb_h_prev[i] : 0.f;
+                    const float dn = g * (1.0f - z) * (1.0f - n * n);
+                    const float dz = g * (hp - n) * z * (1.0f - z);
+                    const float dr = dn * ghn * r * (1.0f - r);
+                    float* a = G.gb_dgi + (long)b * 3 * A.H;
+                    float* c = G.gb_dgh + (long)b * 3 * A.H;
+                    a[h] = dr; a[A.H + h] = dz; a[2 * A.H + h] = dn;
+                    c[h] = dr; c[A.H + h] = dz; c[2 * A.H + h] = dn * r;
+                    G.gb_dh_prev[i] = g * z;
+                }
             } else if (j == 1) {
                 G.g_nn_w[(long)b * A.H + h] += acc;
             } else {
@@ -770,6 +852,14 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
     (void)att_bytes;
+    // (r4) three launches per token instead of six: the projections; the score network, which forms the GRUCell gates itself;
+    // softmax + context, which also forms the NEXT token's index and embedding + context row when that token is teacher
+    // forced.  SA_S2S_FUSE=0: the six-launch loop.
+    const char* fuse_e = getenv("SA_S2S_FUSE");
+    const bool fuse = !(fuse_e && fuse_e[0] == '0');
+    const size_t smem1f = smem1 + (fuse ? (size_t)H * sizeof(float) : 0);
+    if (fuse && !att_smem((const void*)attention_score_kernel, smem1f)) return CTC_STATUS_INVALID_VALUE;
+    bool have_ix = false;   // token t's idx / ix were produced by token t-1's context kernel
     for (int t = 0; t < U1; ++t) {
         long long* idx = IDX + (long)t * B;
         float* ix = IX + (long)t * B * E;
@@ -779,20 +869,32 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
             SkinnyProb q{OIN + (long)(t - 1) * B * H, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
             skinny_launch(&q, 1, B, stream);
             hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, logits, idx, (long)B, K);
-        } else {
+        } else if (!have_ix) {
             hipLaunchKernelGGL(s2s_idx_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, y, idx, B, U, t);
         }
-        hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], idx,
-                           t > 0 ? (const float*)sx : (const float*)nullptr, ix, E);
+        if (!have_ix)
+            hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], idx,
+                               t > 0 ? (const float*)sx : (const float*)nullptr, ix, E);
         SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
                             {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
         skinny_launch(pr, 2, B, stream);
-        hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
-                           ST + (long)t * B * 4 * H, B, H);
+        if (!fuse)
+            hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
+                               ST + (long)t * B * 4 * H, B, H);
         AttArgs A{eh, hx, t > 0 ? AX + (long)(t - 1) * B * T : nullptr, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale,
                   B, T, H, KS};
+        have_ix = false;
+        if (fuse) {
+            A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx; A.gate_stash = ST + (long)t * B * 4 * H;
+            if (t + 1 < U1 && !(sample && sample[t + 1])) {
+                A.y_next = y + (t + 1); A.y_stride = U; A.emb = P[P_EMB];
+                A.ix_next = IX + (long)(t + 1) * B * E; A.idx_next = IDX + (long)(t + 1) * B;
+                have_ix = true;
+            }
+        }
         float* score = (float*)(ws + L.att);
-        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), fuse ? smem1f : smem1, stream,
+                           A, score);
         hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, AX + (long)t * B * T,
                            sx, OIN + (long)t * B * H);
     }
@@ -903,6 +1005,8 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     char* aws = ws + L.att;
     const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * H) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
+    const char* fuse_e = getenv("SA_S2S_FUSE");
+    const bool fuse_b = !(fuse_e && fuse_e[0] == '0');
     for (int t = U1 - 1; t >= 0; --t) {
         const bool has_next = t + 1 < U1;
         const float* hx = HX + (long)t * B * H;
@@ -913,16 +1017,24 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
                  has_next ? d_ax[(t + 1) & 1] : nullptr, d_eh, d_ox, t > 0 ? d_ax[t & 1] : nullptr, g_cw,
                  (float*)(ws + L.g_cb), (float*)(ws + L.g_nw), (float*)(ws + L.g_nb), (float*)(aws + ao[0]),
                  (float*)(aws + ao[1]), (float*)(aws + ao[2]), nchunk};
-        hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
-        hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
-        hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
-        hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(2 + KS + 1, B), dim3(256), 0, stream, A, G);
         // the state of token t fed the fc, the attention and the next token's GRU
         float* dgi = DGI + (long)t * B * 3 * H;
         float* dgh = DGH + (long)t * B * 3 * H;
-        hipLaunchKernelGGL(grucell_gates_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream,
-                           dOIN + (long)t * B * H, (const float*)d_ox, (const float*)d_hprev, ST + (long)t * B * 4 * H,
-                           t > 0 ? HX + (long)(t - 1) * B * H : (const float*)nullptr, dgi, dgh, d_hprev, B, H);
+        if (fuse_b) {   // (r4) four launches per token instead of six: the softmax inside the score-network kernel, the gate
+                        // gradients inside the fold kernel's d_ox block
+            G.fused_softmax = 1;
+            G.gb_dh_a = dOIN + (long)t * B * H; G.gb_stash = ST + (long)t * B * 4 * H;
+            G.gb_h_prev = t > 0 ? HX + (long)(t - 1) * B * H : nullptr;
+            G.gb_dgi = dgi; G.gb_dgh = dgh; G.gb_dh_prev = d_hprev;
+        }
+        hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
+        if (!fuse_b) hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
+        hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
+        hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(2 + KS + 1, B), dim3(256), 0, stream, A, G);
+        if (!fuse_b)
+            hipLaunchKernelGGL(grucell_gates_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream,
+                               dOIN + (long)t * B * H, (const float*)d_ox, (const float*)d_hprev, ST + (long)t * B * 4 * H,
+                               t > 0 ? HX + (long)(t - 1) * B * H : (const float*)nullptr, dgi, dgh, d_hprev, B, H);
         SkinnyProb pr[2] = {{dgh, whhT, nullptr, d_hprev, H, 3 * H, 1, 3 * H, 3 * H, H},
                             {dgi, wihT, nullptr, DIX + (long)t * B * E, E, 3 * H, 0, 3 * H, 3 * H, E}};
         skinny_launch(pr, 2, B, stream);
