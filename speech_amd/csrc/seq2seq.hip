@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void attention_bwd_softmax_kernel(AttArgs A, A
 // ---- backward, stage 3: the score network over one time chunk.  grid (nchunk, B), 256 threads.
 // phase 1, a thread per hidden unit, serial over the chunk's 16 steps: d_pre, d_eh, the chunk's per-unit partial sums;
 // phase 2, a thread per (step, tap): q[t][k] = sum_h d_pre[t,h] cw[h,k] out of an LDS tile of d_pre.
-// dynamic LDS: axp | cw | dps[kAttTB] | axs[kAttTB] | dp_tile[kAttTB][H]
+// dynamic LDS: axp | cw | dps[kAttTB] | axs[kAttTB] | dp_tile[kAttTB][H + 1]  (odd pitch: phase 2's lanes read different
+// frames of one hidden unit -- a pitch of H put all of them on one bank)
 __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttBwd G) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* axp = reinterpret_cast<float*>(smem_raw);
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
                         if (k < A.KS) a_cw[k] += dp * axr[tl + k];
                 }
                 dehb[(long)(t0 + tl) * A.H + h] = dv[tl] + (axsr[tl] * dsxh + dp);
-                dp_tile[tl * A.H + h] = dp;
+                dp_tile[tl * (A.H + 1) + h] = dp;
             }
         }
         float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + h) * W;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
     for (int i = threadIdx.x; i < nt * A.KS; i += 256) {
         const int tl = i / A.KS, k = i - tl * A.KS;
         float acc = 0.f;
-        for (int h = 0; h < A.H; ++h) acc += dp_tile[tl * A.H + h] * cw[h * A.KS + k];
+        for (int h = 0; h < A.H; ++h) acc += dp_tile[tl * (A.H + 1) + h] * cw[h * A.KS + k];
         G.q[((long)b * A.T + t0 + tl) * A.KS + k] = acc;
     }
 }
@@ -632,7 +633,7 @@ extern "C" ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const 
     AttArgs A{eh, ox, ax_prev, conv_w, conv_b, nn_w, nn_b, scale, B, T, H, KS};
     AttBwd G{ax, d_sx, nullptr, d_ax_next, d_eh, d_ox, d_ax_prev, g_conv_w, g_conv_b, g_nn_w, g_nn_b,
              (float*)(ws + o[0]), (float*)(ws + o[1]), (float*)(ws + o[2]), nchunk};
-    const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * H) * sizeof(float);
+    const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * (H + 1)) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
     hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
@@ -1003,7 +1004,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     size_t ao[4];
     att_layout(B, T, H, KS, ao);
     char* aws = ws + L.att;
-    const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * H) * sizeof(float);
+    const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * (H + 1)) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
     const char* fuse_e = getenv("SA_S2S_FUSE");
     const bool fuse_b = !(fuse_e && fuse_e[0] == '0');
@@ -1331,7 +1332,7 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
     float* logits = (float*)(ws + L.logits);
     float* score = (float*)(ws + L.score);
     const float* const* P = params;
-    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + (size_t)H) * sizeof(float);
     const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
     const size_t smem3 = (size_t)W * K * sizeof(double);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2) ||
@@ -1342,10 +1343,9 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
         SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
                             {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
         skinny_launch(pr, 2, W, stream);
-        hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((W * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
-                           (float*)nullptr, W, H);
         AttArgs A{eh, hx, t > 0 ? (const float*)axprev : (const float*)nullptr, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale,
                   W, T, H, KS, 1};
+        A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx;   // the GRUCell gates inside the score kernel
         hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, W), dim3(256), smem1, stream, A, score);
         hipLaunchKernelGGL(attention_context_kernel, dim3(W), dim3(256), smem2, stream, A, score, ax, sx, oin);
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
@@ -1383,7 +1383,8 @@ struct GreedyState { int done, steps; };
 __global__ __launch_bounds__(64) void s2s_greedy_pick_kernel(GreedyState* st, const float* __restrict__ logits,
                                                             long long* __restrict__ tokens, long long* __restrict__ idx,
                                                             unsigned* __restrict__ count, int B, int K, int ncol, int step,
-                                                            int end_tok, int max_len) {
+                                                            int end_tok, int max_len, const float* __restrict__ emb,
+                                                            const float* __restrict__ sx, float* __restrict__ ix, int E) {
     if (st->done) return;
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* xr = logits + (long)b * K;
@@ -1397,6 +1398,7 @@ __global__ __launch_bounds__(64) void s2s_greedy_pick_kernel(GreedyState* st, co
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
+    for (int e = lane; e < E; e += 64) ix[(long)b * E + e] = emb[(long)bi * E + e] + sx[(long)b * E + e];  // the next token's input
     if (lane == 0) {
         tokens[(long)b * ncol + step + 1] = bi;
         idx[b] = bi;
@@ -1467,7 +1469,7 @@ extern "C" ctcStatus_t sa_s2s_greedy_decode(const float* eh, const float* const*
     float* score = (float*)(ws + L.score);
     const float* const* P = params;
     const int ncol = max_len + 1;
-    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS) * sizeof(float);
+    const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + (size_t)H) * sizeof(float);
     const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
@@ -1482,19 +1484,19 @@ extern "C" ctcStatus_t sa_s2s_greedy_decode(const float* eh, const float* const*
         const float* hprev = (const float*)(ws + L.h[prv]);
         const float* ax_prev = t > 0 ? (const float*)(ws + L.ax[prv]) : nullptr;
         const float* sx_prev = t > 0 ? (const float*)(ws + L.sx[prv]) : nullptr;
-        hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], (const long long*)idx, sx_prev, ix, E);
+        if (t == 0)   // (later tokens: the pick kernel forms emb[arg-max] + context itself)
+            hipLaunchKernelGGL(s2s_embed_add_kernel, dim3(B), dim3(256), 0, stream, P[P_EMB], (const long long*)idx, sx_prev, ix, E);
         SkinnyProb pr[2] = {{ix, P[P_WIH], P[P_BIH], gi, 3 * H, E, 0, E, E, 3 * H},
                             {hprev, P[P_WHH], P[P_BHH], gh, 3 * H, H, 0, H, H, 3 * H}};
         skinny_launch(pr, 2, B, stream);
-        hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
-                           (float*)nullptr, B, H);
         AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
+        A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx;   // the GRUCell gates inside the score kernel
         hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
         hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
         skinny_launch(&q, 1, B, stream);
         hipLaunchKernelGGL(s2s_greedy_pick_kernel, dim3(B), dim3(64), 0, stream, st, (const float*)logits, d_tokens, idx, count, B,
-                           K, ncol, t, end_tok, max_len);
+                           K, ncol, t, end_tok, max_len, P[P_EMB], (const float*)sx, ix, E);
         if (check_every > 0 && (t + 1) % check_every == 0 && t + 1 < max_len) {
             int done = 0;
             if (hipMemcpyAsync(&done, &st->done, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
