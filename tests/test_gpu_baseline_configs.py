@@ -245,3 +245,58 @@ def test_transducer_at_baseline_config_5():
         err = float(np.abs(got[k] - want[k]).max())
         rel = float(np.linalg.norm((got[k] - want[k]).ravel()) / max(np.linalg.norm(want[k].ravel()), 1e-20))
         assert err <= 1e-3 * scale and rel <= 1e-3, ("rnnt", k, err, scale, rel)
+
+
+def test_seq2seq_decode_at_the_shipped_wsj_config():
+    """BASELINE config 4 is "seq2seq attention decoder, beam = 8": the decode paths at the shipped WSJ shapes (2 convs, 4 x
+    biGRU-256, T = 800 -> T' = 197, 31 classes, eval mode).  Greedy `infer` of 4 utterances against
+    oracle/torch_ref.TorchRefSeq2Seq.infer, and `beam_search` (beam 8 and the reference's default 10) of one utterance against
+    oracle/seq2seq_beam_ref.py driven by the same restated model -- token for token.  The classifier is scaled up so that the
+    distributions are peaked (a random-init model's are flat: every cut would sit inside fp32 noise); cases whose smallest
+    score gap at a selection cut is below 2e-5 are not decidable at this precision and are skipped."""
+    from oracle import seq2seq_beam_ref as R
+    from oracle.torch_ref import TorchRefSeq2Seq
+    from speech_amd.models import Seq2Seq
+    c = S2S_WSJ
+    F, V, T = c["F"], c["V"], c["T"]
+    cfg = dict(c["cfg"], dropout=0.0, decoder=dict(c["cfg"]["decoder"], sample_prob=0))
+    torch.manual_seed(2017)
+    model = Seq2Seq(F, V + 2, cfg)
+    with torch.no_grad():
+        model.fc.fc.weight.mul_(30.0)
+        model.fc.fc.bias.mul_(30.0)
+        model.fc.fc.bias[V] += 8.0   # the end token becomes likely enough that hypotheses complete and the stopping rule
+                                     # fires (17 search steps, 11 - 12 completed hypotheses, cuts 1e-3 apart on the CPU side)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    model.set_eval()
+    ref = TorchRefSeq2Seq(F, V + 2, cfg)
+    ref.load_state_dict(state)
+    ref.eval()
+    rng = np.random.RandomState(5)
+    B = 4
+    x = rng.randn(B, T, F).astype(np.float32)
+    labels = tuple([V + 1, 0, V] for _ in range(B))   # start = V + 1, end = V
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(16, prev))
+    try:
+        got = model.infer((tuple(x[b] for b in range(B)), labels), max_len=40)
+        with torch.no_grad():
+            want = ref.infer(torch.from_numpy(x), torch.full((B, 1), V + 1, dtype=torch.int64), V, 40).numpy()
+        assert np.array_equal(np.array(got), want), (got, want)
+        decided = 0
+        for beam in (8, 10):
+            for b in range(2):
+                with torch.no_grad():
+                    enc = ref.encode(torch.from_numpy(x[b:b + 1]))
+                hyp, score, info = R.beam_search(R.torch_step_fn(ref, enc), V + 1, V, beam, 40)
+                if info["min_margin"] < 2e-5:
+                    continue
+                decided += 1
+                got_h = model.beam_search(((x[b],), (labels[b],)), beam_size=beam, max_len=40)[0]
+                assert got_h == hyp, (beam, b, got_h, hyp, info)
+                assert abs(model.last_beam_score - score) < 2e-4 * max(1.0, abs(score))
+                assert list(model.last_beam_info) == [info["steps"], info["n_complete"]]
+        assert decided >= 2
+    finally:
+        torch.set_num_threads(prev)
