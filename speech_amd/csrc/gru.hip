@@ -882,6 +882,8 @@ struct PBwdJobs {
                                   // the exchange is 4 slots that live in the XCD's L2 instead of T slots that the host pre-fills
                                   // and HBM writes back (0.39 GB per S-LIBRI step)
     SaDrop drop;                  // gru_bwd_fused_kernel: inter-layer dropout -- d h_out[l-1] = mask * (dai[l] W_ih[l])
+    int w_rowmajor;               // gru_bwd_fused_kernel: w_hh_t / w_ih_t point at the weights AS STORED ((3H, H) row-major) and
+                                  // the block's fragments are read with a stride, once per launch -- no transpose launches
     long pk_kb;                   // gru_bwd_fused_kernel<.., PACKG>: k-tiles of the packed operands, T * B / 16
     int kpk_kb;                   // gru_bwd_fused_kernel<.., PACKK>: k-tiles per row block of the kpk operand (3H / 16, or
                                   // 6H / 16 when the two directions of a layer share one operand, side by side along k)
@@ -1147,10 +1149,19 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int k = (it / IPG) * H + kw + 16 * (it % IPG);
+        if (P.w_rowmajor) {  // W[k + c][u0 + i], c = 0 .. 3: four strided loads (16 lanes x 4 B contiguous each), once per launch
+            const float* wq = J.w_hh_t + (long)k * H + u0 + i;
+            wr[it] = make_float4(wq[0], wq[H], wq[2 * H], wq[3 * H]);
+            if constexpr (FUSE) {
+                const float* xq = fuse ? J.w_ih_t + (long)k * H + u0 + i : wq;
+                wx[it] = fuse ? make_float4(xq[0], xq[H], xq[2 * H], xq[3 * H]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
         wr[it] = *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + i) * H3 + k);
         if constexpr (FUSE)
             wx[it] = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     // Every address inside the loop is a per-thread base (formed here, once) plus t times a scalar stride.  The job's
     // fields are read out of the kernel-argument segment HERE: left alone, hipcc re-loads them inside the loop (an
@@ -2742,10 +2753,12 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     };
     auto mid_of = [&](int l) { return (float*)(ws + (size_t)L * D * per_dir + (size_t)l * mid_bytes); };  // l < L-1
     const long DH = (long)D * H;
-    for (int l = 0; l < L; ++l)
-        for (int d = 0; d < D; ++d)
-            hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream,
-                               w_hh[l * D + d], wt_of(l, d), 3 * H, H);
+    auto transpose_whh = [&]() {   // W_hh^T per (layer, direction): what every kernel but the one-launch fused one reads
+        for (int l = 0; l < L; ++l)
+            for (int d = 0; d < D; ++d)
+                hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream,
+                                   w_hh[l * D + d], wt_of(l, d), 3 * H, H);
+    };
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     BwdJobs P;
     P.B = B; P.H = H; P.rb = 1; P.rt = B; P.bt0 = 0; P.tile_rows = 16; P.stamp = nullptr;
@@ -2762,6 +2775,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     };
 
     if (D == 2) {
+        transpose_whh();
         const int bi_nbt = (B + 15) / 16, bi_tpp = tiles_per_pass(2, H);
         unsigned bi_launches = 0;
         const size_t bi_lds = xcd_lds((size_t)2 * 4 * 256 * sizeof(float));
@@ -2806,7 +2820,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                            bi_tiled_fn ? (size_t)(xring_enabled() ? min(T, kXRing) : T) * bi_nbt * 16 * 3 * H
                                                        : (size_t)T * B * 3 * H, stream))
                             return CTC_STATUS_MEMOPS_FAILED;
-                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = (bi_tiled_fn && xring_enabled()) ? 2 : 1; Q.reg = sync + kSyncReg;
+                Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = (bi_tiled_fn && xring_enabled()) ? 2 : 1; Q.reg = sync + kSyncReg; Q.w_rowmajor = 0;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
                 Q.pk_kb = bi_packg ? (long)T * B / 16 : 0;
                 Q.kpk_kb = 6 * H / 16;
@@ -2973,7 +2987,12 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                                tiled ? (size_t)(xring == 2 ? min(T, kXRing) : T) * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
                                stream))
                 return CTC_STATUS_MEMOPS_FAILED;
-    if (fused) {
+    // the one-launch kernel reads its weight fragments from the matrices as stored (PBwdJobs::w_rowmajor): 2 L - 1 transpose
+    // launches less per step; SA_GRU_WT=1: transposed copies as before
+    const char* wt_e = getenv("SA_GRU_WT");
+    const bool rowmajor = one_launch && !(wt_e && wt_e[0] == '1');
+    if (!rowmajor) transpose_whh();
+    if (fused && !rowmajor) {
         for (int l = 1; l < L; ++l)
             hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream, w_ih[l],
                                wih_t_of(l), 3 * H, H);
@@ -2996,14 +3015,14 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr; Q.drop = dc.drop;
         Q.pk_kb = packg ? (long)T * B / 16 : 0; Q.kpk_kb = 0;
-        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg;
+        Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg; Q.w_rowmajor = rowmajor ? 1 : 0;
         if (packg) { issuer.gates_prepacked = true; issuer.gsum_parts = nbt; }
         for (int l = L - 1, n = 0; l >= 0; --l, ++n) {
             PBwdJob& J = Q.j[n];
             J.dh_out = (l == L - 1) ? dh_top : mid_of(l); J.ds_b = DH; J.ds_t = (long)B * DH;
-            J.stash = stash[l]; J.w_hh_t = wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
+            J.stash = stash[l]; J.w_hh_t = rowmajor ? w_hh[l] : wt_of(l, 0); J.dai = dai[l]; J.dah = dah[l];
             J.dh_state = dh_buf(l, 0, 0); J.counters = sync + l * nbt;
-            J.w_ih_t = l > 0 ? wih_t_of(l) : nullptr; J.dx_out = l > 0 ? mid_of(l - 1) : nullptr;
+            J.w_ih_t = l > 0 ? (rowmajor ? w_ih[l] : wih_t_of(l)) : nullptr; J.dx_out = l > 0 ? mid_of(l - 1) : nullptr;
             J.xs_b = DH; J.xs_t = (long)B * DH; J.xch = xch_of(l); J.dump = (float*)(ws + dump_off);
             J.dx_drop_stream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
             J.gpk = packg ? wws + spl.g_off + (size_t)l * spl.g_each : nullptr;
@@ -3062,7 +3081,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
             Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
             Q.pk_kb = 0; Q.kpk_kb = 0;
             Q.drop = dc.drop;
-            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg;
+            Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg; Q.w_rowmajor = 0;
             int n = 0;
             for (int l = L - 1; l >= 0; --l) {
                 const int cc = w - (L - 1 - l);
