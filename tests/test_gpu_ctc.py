@@ -301,3 +301,13 @@ def test_wide_full_size_rows_and_default_switch(monkeypatch):
     assert np.abs(gw.sum(axis=2)).max() < 1e-4
     for b in range(0, 640, 97):
         assert np.all(gw[b, al[b]:] == 0)
+
+
+def test_rows_softmax_tile_kernel_on_ragged_batches():
+    # B * T >= 256 K rows selects the tile form of the log-softmax (ctc_logsoftmax2_rows_kernel: 64 rows per one-wave
+    # workgroup, one lane per row).  B = 301, ragged lengths (tiles that end inside an utterance), both memory orders:
+    # every cost and gradient against the fp64 oracle.
+    acts, labs, al, ll = make(31, 301, 900, 29, 5, 60, ragged_T=True)
+    assert acts.shape[0] * acts.shape[1] >= 256 * 1024
+    compare(acts, labs, al, ll)
+    compare(np.ascontiguousarray(acts.transpose(1, 0, 2)), labs, al, ll, batch_first=False)

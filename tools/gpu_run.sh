@@ -8,7 +8,8 @@
 #   configs[:ONLY]   tools/bench_configs.py [--only ONLY] -> configs.json
 #   py:SCRIPT ARGS   python SCRIPT ARGS -> SCRIPT-basename.log         (tools/*.py experiments)
 #   profpy:SCRIPT ARGS  rocprofv3 --kernel-trace --stats of python SCRIPT ARGS -> SCRIPT-basename_kernel_stats.csv
-#   trace:SCRIPT ARGS  rocprofv3 --kernel-trace of python SCRIPT ARGS -> SCRIPT-basename_timeline.txt (the last step's kernels in time)
+#   trace:SCRIPT ARGS  rocprofv3 --kernel-trace of python SCRIPT ARGS -> SCRIPT-basename_timeline.txt (the last step's kernels in time;
+#                    TRACE_MIN_US=0 lists every kernel, default: those of >= 25 us)
 #   pmc:COUNTERS:ARGS  rocprofv3 --pmc COUNTERS --kernel-trace of bench.py ARGS -> pmc_<first counter>.csv
 # Example: gpurun --timeout 1500 -- 'bash tools/gpu_run.sh r3a tests:dropout bench "configs:M-STEP,M-TIMIT"'
 set -u
@@ -65,7 +66,7 @@ PY
       base=$(basename ${script%.py})
       ( cd /tmp && rm -rf /tmp/tr_${TAG}_$base && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_${TAG}_$base -o p -- python $ROOT/$script $rest > $ROOT/$O/${base}_trace.log 2>&1 )
       f=$(find /tmp/tr_${TAG}_$base -name "*kernel_trace.csv" | head -1)
-      python tools/trace_timeline.py $f clip_sgd_kernel 25 > $O/${base}_timeline.txt 2>&1; head -150 $O/${base}_timeline.txt ;;
+      python tools/trace_timeline.py $f clip_sgd_kernel ${TRACE_MIN_US:-25} > $O/${base}_timeline.txt 2>&1; head -150 $O/${base}_timeline.txt ;;
     *) echo "unknown stage $name" ;;
   esac
 done
