@@ -37,15 +37,17 @@ constexpr int kU = 8;          // steps per hand-off batch (producer lead, emiss
 constexpr int kRenorm = 4;     // renormalise every kRenorm batches (32 steps): states drift <~ 200 log2 units between
 constexpr int kMaxChunks = 8;  // chunks per direction: labels up to 64 * 8 - 1 = 511 per utterance
 constexpr int kWideMinBatch = 512;  // from this many utterances per call the one-wave-per-utterance kernel (K_W) runs
+constexpr int kDirectMinBatch = 1024;  // ... and from this many its probability-domain pass reads the activations itself
 
 // ---------------------------------------------------------------------------------------------------------- K_A
 // grid (row blocks, B).  G lanes cooperate on one row (G = 16, 32 or 64); a wave handles 64 / G rows at a time.
 template <int G>
 __global__ __launch_bounds__(256) void ctc_logsoftmax2_kernel(const float* __restrict__ acts, long st, long sb,
                                                               const int* __restrict__ in_lens, int K, long ly_sb,
-                                                              float* __restrict__ ly2) {
+                                                              float* __restrict__ ly2, const int* __restrict__ only) {
     constexpr int RPW = 64 / G;
     const int b = blockIdx.y;
+    if (only && !only[b]) return;  // (the pass behind ctc_wave_p_kernel: flagged utterances only)
     const int T = in_lens[b];
     const int lane = threadIdx.x & 63;
     const int sub = lane / G, gl = lane % G;
@@ -77,11 +79,12 @@ constexpr int kRowTile = 64;  // rows (= lanes) per workgroup: one wave, so its 
                               // a CU interleaves ~20 independent tiles
 __global__ __launch_bounds__(kRowTile) void ctc_logsoftmax2_rows_kernel(const float* __restrict__ acts, long st, long sb,
                                                                    const int* __restrict__ in_lens, int K, long ly_sb,
-                                                                   float* __restrict__ ly2) {
+                                                                   float* __restrict__ ly2, const int* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* tile = reinterpret_cast<float*>(smem_raw);  // [kRowTile][KS]
     const int KS = K | 1;
     const int b = blockIdx.y;
+    if (only && !only[b]) return;
     const int T = in_lens[b];
     const int t0 = blockIdx.x * kRowTile;
     const int nrows = min(kRowTile, T - t0);
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(AbArgs A, float* __restri
 // traffic a full alpha stash costs.  Emission rows are staged KU rows at a time into a per-wave LDS ring with
 // coalesced loads issued a batch ahead.  ~4.5 KB of LDS per wave at K = 29: occupancy is VGPR-bound (4 waves / SIMD).
 struct WaveArgs {
+    const float* acts;  // ctc_wave_p_kernel: the activations themselves (strides st / sb below), normalised while staged
     const float* ly2;
     const int* labels;
     const int* label_lens;
@@ -1340,26 +1344,72 @@ __device__ __forceinline__ void wavep_fast_step(float (&Bst)[R], float (&Lst)[R]
     for (int r = 0; r < R; ++r) { Bst[r] = nB[r]; Lst[r] = nL[r]; }
 }
 
-// Emission rows -> registers -> the LDS ring AS PROBABILITIES (SMALLK staging of RowStager, with the exp2 at the commit).
-template <int R>
+// Emission rows -> registers -> the LDS ring AS PROBABILITIES, straight from the ACTIVATIONS (round 4: no log-softmax
+// pass in front of this kernel, no 2 x |acts| round trip through the workspace).  A batch is KU = 8 rows; eight lanes
+// share a row (lane = 8 row + j holds classes j, j + 8, ...: NU = 8 registers cover K <= 64), the row's max and
+// normaliser are two 3-step DPP butterflies inside the 8-lane group, and the probability is formed exactly as the
+// log-softmax kernels + the old commit formed it: exp2(max((x - m) log2 e - log2 z, SA_NEG)).  The alpha pass and the
+// beta pass stage a row with the same instructions on the same inputs, so the replayed alpha states are bit-identical.
+__device__ __forceinline__ float sa_group8_max(float v) {
+    v = fmaxf(v, SA_DPP_F(v, v, 0xB1, 0xf));   // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, SA_DPP_F(v, v, 0x4E, 0xf));   // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, SA_DPP_F(v, v, 0x141, 0xf));  // row_half_mirror: the other quad of the group
+    return v;
+}
+__device__ __forceinline__ float sa_group8_sum(float v) {
+    v += SA_DPP_F(v, v, 0xB1, 0xf);
+    v += SA_DPP_F(v, v, 0x4E, 0xf);
+    v += SA_DPP_F(v, v, 0x141, 0xf);
+    return v;
+}
+template <int R, bool NORM>
 struct RowStagerP {
     static constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
-    const float* ly;
+    static_assert(KU == 8 && NU == 8, "eight lanes per row, eight classes per lane");
+    static constexpr bool norm = NORM;
+    const float* x;  // the utterance's row 0 -- of the activations, or (norm = false) of the log-softmax K_A left
+    long st;         // floats between its consecutive rows
     int K, lane;
     float pv[NU];
     __device__ __forceinline__ void issue(int tlo, int nrows) {
-        const int n = nrows * K;
-        const float* src = ly + (long)tlo * K;
+        if constexpr (!NORM) {  // K_A's rows: contiguous, element order = memory order
+            const int n = nrows * K;
+            const float* src = x + (long)tlo * K;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) pv[u] = src[min(lane + 64 * u, n - 1)];
+            for (int u = 0; u < NU; ++u) pv[u] = src[min(lane + 64 * u, n - 1)];
+        } else {
+            const int r = lane >> 3, j = lane & 7;
+            const float* src = x + (long)(tlo + min(r, nrows - 1)) * st;  // (rows past the batch: a copy of its last row, unused)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) pv[u] = src[min(j + 8 * u, K - 1)];
+        }
     }
     __device__ __forceinline__ void commit(float* dst) {
+        if constexpr (!NORM) {  // log2-probabilities
 #pragma unroll
-        for (int u = 0; u < NU; ++u) dst[lane + 64 * u] = sa_exp2(pv[u]);
+            for (int u = 0; u < NU; ++u) dst[lane + 64 * u] = sa_exp2(pv[u]);
+            return;
+        }
+        const int r = lane >> 3, j = lane & 7;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) m = j + 8 * u < K ? fmaxf(m, pv[u]) : m;
+        m = sa_group8_max(m);
+        float z = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            pv[u] = (pv[u] - m) * SA_LOG2E;
+            z += j + 8 * u < K ? sa_exp2(pv[u]) : 0.f;
+        }
+        const float lz = sa_log2(sa_group8_sum(z));
+        float* row = dst + r * K + j;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (j + 8 * u < K) row[8 * u] = sa_exp2(fmaxf(pv[u] - lz, SA_NEG));
     }
 };
 
-template <int R>
+template <int R, bool NORM>
 __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU, P = 64 * R;
@@ -1403,8 +1453,10 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
         nrep_f += (j >= 1 && j <= L - 1 && skipf[r] == 0.f) ? 1.f : 0.f;
     }
     const int nslow = (L + 1 + (int)sa_wave_sum_dpp(nrep_f) + 2 * KU) / KU;
-    RowStagerP<R> stage;
-    stage.ly = A.ly2 + (long)b * A.ly_sb; stage.K = K; stage.lane = lane;
+    RowStagerP<R, NORM> stage;
+    stage.x = NORM ? A.acts + (long)b * A.sb : A.ly2 + (long)b * A.ly_sb;
+    stage.st = NORM ? A.st : (long)K;
+    stage.K = K; stage.lane = lane;
     if (T > 0) { stage.issue(0, min(KU, T)); stage.commit(ring); }
     __builtin_amdgcn_s_waitcnt(0);
     bool suspect = false;
@@ -1630,13 +1682,13 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
 }
 
 // R <= 2: four waves per SIMD (<= 128 registers) -- the kernel lives off the latency hiding of its neighbours
-template <int R>
+template <int R, bool NORM>
 __global__ __launch_bounds__(256, 4) void ctc_wave_p_kernel(WaveArgs A, int* __restrict__ flags) {
-    ctc_wave_p_body<R>(A, flags);
+    ctc_wave_p_body<R, NORM>(A, flags);
 }
-template <int R>
+template <int R, bool NORM>
 __global__ __launch_bounds__(256) void ctc_wave_p_wide_kernel(WaveArgs A, int* __restrict__ flags) {
-    ctc_wave_p_body<R>(A, flags);
+    ctc_wave_p_body<R, NORM>(A, flags);
 }
 
 template <int R, bool WITH_GRAD, bool SMALLK>
@@ -1831,28 +1883,32 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
     A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b; A.gscale = grad_scale;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
 
-    if (K <= 64 && (long)B * max_T >= 256 * 1024) {  // K_A, one lane per row out of an LDS tile: the
-        // throughput form; with fewer than ~4 workgroups per CU its serial 3 * K-step row loop is the slower one
-        dim3 grid((max_T + kRowTile - 1) / kRowTile, B);
-        hipLaunchKernelGGL(ctc_logsoftmax2_rows_kernel, grid, dim3(kRowTile), (size_t)kRowTile * (K | 1) * sizeof(float), stream,
-                           acts, stride_t, stride_b, d_input_lengths, K, A.ly_sb, (float*)(ws + o_ly2));
-        SA_CHECK_LAUNCH();
-    } else {  // K_A, a lane group per row
-        const int G = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
-        const int rows_per_block = 4 * (64 / G);
-        dim3 grid((max_T + rows_per_block - 1) / rows_per_block, B);
-        float* ly2 = (float*)(ws + o_ly2);
-        if (G == 16)
-            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<16>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
-                               d_input_lengths, K, A.ly_sb, ly2);
-        else if (G == 32)
-            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<32>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
-                               d_input_lengths, K, A.ly_sb, ly2);
-        else
-            hipLaunchKernelGGL(ctc_logsoftmax2_kernel<64>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
-                               d_input_lengths, K, A.ly_sb, ly2);
-        SA_CHECK_LAUNCH();
-    }
+    // K_A (log-softmax into the workspace); only != null: the utterances whose flag is set
+    auto launch_ka = [&](const int* only) -> ctcStatus_t {
+        if (K <= 64 && (long)B * max_T >= 256 * 1024) {  // K_A, one lane per row out of an LDS tile: the
+            // throughput form; with fewer than ~4 workgroups per CU its serial 3 * K-step row loop is the slower one
+            dim3 grid((max_T + kRowTile - 1) / kRowTile, B);
+            hipLaunchKernelGGL(ctc_logsoftmax2_rows_kernel, grid, dim3(kRowTile), (size_t)kRowTile * (K | 1) * sizeof(float), stream,
+                               acts, stride_t, stride_b, d_input_lengths, K, A.ly_sb, (float*)(ws + o_ly2), only);
+            SA_CHECK_LAUNCH();
+        } else {  // K_A, a lane group per row
+            const int G = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
+            const int rows_per_block = 4 * (64 / G);
+            dim3 grid((max_T + rows_per_block - 1) / rows_per_block, B);
+            float* ly2 = (float*)(ws + o_ly2);
+            if (G == 16)
+                hipLaunchKernelGGL(ctc_logsoftmax2_kernel<16>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
+                                   d_input_lengths, K, A.ly_sb, ly2, only);
+            else if (G == 32)
+                hipLaunchKernelGGL(ctc_logsoftmax2_kernel<32>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
+                                   d_input_lengths, K, A.ly_sb, ly2, only);
+            else
+                hipLaunchKernelGGL(ctc_logsoftmax2_kernel<64>, grid, dim3(256), 0, stream, acts, stride_t, stride_b,
+                                   d_input_lengths, K, A.ly_sb, ly2, only);
+            SA_CHECK_LAUNCH();
+        }
+        return CTC_STATUS_SUCCESS;
+    };
     // K_W: the throughput-regime kernel (one wave per utterance) once every CU holds several utterances
     {
         int R = 1;
@@ -1864,22 +1920,35 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
         const size_t wave_bytes = wave_floats * sizeof(float);
         const char* env = getenv("SA_CTC_WIDE");
         const bool want = env ? (env[0] == '1') : (B >= kWideMinBatch);
-        if (want && wave_bytes <= 150 * 1024) {
+        const bool wide = want && wave_bytes <= 150 * 1024;
+        // probability-domain pass first (gradient calls, K <= 64, R <= 4), the log-domain kernel behind it for flagged
+        // utterances; SA_CTC_PROB=0: log domain only, =2: everything flagged (tests), =3: probability pass alone
+        const char* pe = getenv("SA_CTC_PROB");
+        const int prob = (wide && grads && smallk && R <= 4) ? (pe ? atoi(pe) : 1) : 0;
+        // ... and that pass normalises the activations itself while it stages them (RowStagerP): K_A then runs BEHIND it, for
+        // the flagged utterances only (normally none: ~65 K workgroups that read one word and leave)
+        // Measured (tools/ctc_b4096_time.py, one box): B = 4096 1.53 - 1.65 -> 1.37 - 1.49 ms per call, B = 1024 level, B = 512
+        // 0.59 -> 0.62 (too few waves to hide the longer staging) -- from kDirectMinBatch utterances; SA_CTC_DIRECT=1 / 0 forces.
+        const char* de = getenv("SA_CTC_DIRECT");
+        const bool direct = prob != 0 && grads != acts && (de ? de[0] == '1' : B >= kDirectMinBatch);
+        if (!direct) {
+            ctcStatus_t ks = launch_ka(nullptr);
+            if (ks != CTC_STATUS_SUCCESS) return ks;
+        }
+        if (wide) {
             const int waves = 4 * wave_bytes <= 64 * 1024 ? 4 : 1;
             WaveArgs W;
-            W.ly2 = A.ly2; W.labels = d_flat_labels; W.label_lens = d_label_lengths; W.in_lens = d_input_lengths;
+            W.acts = direct ? acts : nullptr; W.ly2 = A.ly2; W.labels = d_flat_labels; W.label_lens = d_label_lengths; W.in_lens = d_input_lengths;
             W.K = K; W.T_max = max_T; W.blank = blank_label; W.B = B; W.nren = nren; W.nq = (max_T + KU - 1) / KU;
             W.wave_lds_floats = (int)wave_floats;
             W.ly_sb = A.ly_sb; W.stash = A.stash; W.costs = d_costs; W.grads = grads;
             W.st = stride_t; W.sb = stride_b; W.only = nullptr; W.gscale = grad_scale;
             const size_t smem = waves * wave_bytes;
             const dim3 grid((B + waves - 1) / waves), block(64 * waves);
-            // probability-domain pass first (gradient calls, K <= 64, R <= 4), the log-domain kernel behind it for flagged
-            // utterances; SA_CTC_PROB=0: log domain only, =2: everything flagged (tests), =3: probability pass alone
-            const char* pe = getenv("SA_CTC_PROB");
-            const int prob = (grads && smallk && R <= 4) ? (pe ? atoi(pe) : 1) : 0;
             if (prob) {
-                void (*pf)(WaveArgs, int*) = R == 1 ? ctc_wave_p_kernel<1> : R == 2 ? ctc_wave_p_kernel<2> : ctc_wave_p_wide_kernel<4>;
+                void (*pf)(WaveArgs, int*) =
+                    direct ? (R == 1 ? ctc_wave_p_kernel<1, true> : R == 2 ? ctc_wave_p_kernel<2, true> : ctc_wave_p_wide_kernel<4, true>)
+                           : (R == 1 ? ctc_wave_p_kernel<1, false> : R == 2 ? ctc_wave_p_kernel<2, false> : ctc_wave_p_wide_kernel<4, false>);
                 if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)pf, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)smem) != hipSuccess)
                     return CTC_STATUS_EXECUTION_FAILED;
@@ -1889,6 +1958,10 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
                     return CTC_STATUS_MEMOPS_FAILED;
                 if (prob == 3) return CTC_STATUS_SUCCESS;
                 W.only = A.flags;
+                if (direct) {
+                    ctcStatus_t ks = launch_ka(A.flags);
+                    if (ks != CTC_STATUS_SUCCESS) return ks;
+                }
             }
 #define SA_WIDE_LAUNCH(R_)                                                                                        \
     do {                                                                                                          \

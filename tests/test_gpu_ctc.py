@@ -241,9 +241,12 @@ def test_warpctc_shaped_entry_point():
 
 
 # ---- K_W, the one-wave-per-utterance kernel of the throughput regime (default from B >= 512; forced here) ----------
-@pytest.fixture
-def wide(monkeypatch):
+@pytest.fixture(params=["direct", "staged"])
+def wide(request, monkeypatch):
+    """K_W forced; its probability-domain pass either normalises the activations itself while it stages them (the default
+    from 1024 utterances per call) or reads the log-softmax K_A wrote into the workspace (below that)."""
     monkeypatch.setenv("SA_CTC_WIDE", "1")
+    monkeypatch.setenv("SA_CTC_DIRECT", "1" if request.param == "direct" else "0")
 
 
 @pytest.mark.parametrize("B,T,K,Lmin,Lmax", [
@@ -301,6 +304,17 @@ def test_wide_full_size_rows_and_default_switch(monkeypatch):
     assert np.abs(gw.sum(axis=2)).max() < 1e-4
     for b in range(0, 640, 97):
         assert np.all(gw[b, al[b]:] == 0)
+    # ... and past 1024 utterances K_W's probability-domain pass normalises the activations itself (no K_A in front), by
+    # default: time-major, ragged, against the latency kernel again
+    monkeypatch.delenv("SA_CTC_WIDE")
+    acts, labs, al, ll = make(29, 1100, 90, 29, 5, 40, ragged_T=True)
+    acts = np.ascontiguousarray(acts.transpose(1, 0, 2))
+    cw, gw = run_hip(acts, labs, al, ll, batch_first=False)
+    monkeypatch.setenv("SA_CTC_WIDE", "0")
+    cn, gn = run_hip(acts, labs, al, ll, batch_first=False)
+    np.testing.assert_allclose(cw, cn, rtol=COST_RTOL)
+    assert np.abs(gw - gn).max() < grad_atol(cn)
+    assert np.abs(gw.sum(axis=2)).max() < 1e-4
 
 
 def test_rows_softmax_tile_kernel_on_ragged_batches():
