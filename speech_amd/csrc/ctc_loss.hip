@@ -1604,10 +1604,25 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
             // (1) replay this batch's alpha states from its checkpoint
             alpha_batch(Yes(), q, nrows, cur);
             // (2) beta steps, backwards in time, with the occupancies and the gradient row of each step
-            auto beta_batch_t = [&](auto fast_c, auto full_c) {
-                constexpr bool FAST = decltype(fast_c)::value, FULL = decltype(full_c)::value;
+            auto beta_batch_t = [&](auto fast_c, auto full_c, auto both_c) {
+                // BOTH: the replayed alpha batch ran on frozen exponents too -- one scale per pair serves the batch's rows
+                constexpr bool FAST = decltype(fast_c)::value, FULL = decltype(full_c)::value, BOTH = decltype(both_c)::value;
                 float pdx[R], pdy[R];
                 if (FAST) suspect = wavep_refresh<R, 1>(bB, bL, be, skipf, pdx, pdy) || suspect;
+                float scb[R], scl[R];
+                if constexpr (BOTH) {
+                    const int aee = __builtin_bit_cast(int, sa_wave_shr1(__builtin_bit_cast(float, rE[0][R - 1]), __builtin_bit_cast(float, kNoExp)));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int eb_ = be[r] == kNoExp ? 0 : be[r];
+                        const int ea_b = rE[0][r] == kNoExp ? 0 : rE[0][r];
+                        const int eal = r == 0 ? aee : rE[0][r - 1];
+                        // (an occupancy is <= 1 and the hats are held near 2^kFTarget: an exponent above 0 belongs to a pair
+                        // whose hats are zero -- clamped, so that 0 x scale stays 0)
+                        scb[r] = __builtin_amdgcn_ldexpf(rcp, min(ea_b + eb_ - pe, 64));
+                        scl[r] = b_ok[r] ? __builtin_amdgcn_ldexpf(rcp, min((eal == kNoExp ? 0 : eal) + eb_ - pe, 64)) : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int k = KU - 1; k >= 0; --k) {
                     if (FULL || k < nrows) {
@@ -1632,17 +1647,26 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         }
                         // occupancy = alpha_t(s) * sum_beta_t(s) / p; alpha's label state of pair j-1 comes across the lane edge
                         const float aedge = sa_wave_shr1(rL[k][R - 1], 0.f);
-                        const int aeedge = __builtin_bit_cast(int, sa_wave_shr1(__builtin_bit_cast(float, rE[k][R - 1]), __builtin_bit_cast(float, kNoExp)));
                         float gb = 0.f;
+                        if constexpr (BOTH) {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const int eb_ = es[r] == kNoExp ? 0 : es[r];
-                            const int ea_b = rE[k][r] == kNoExp ? 0 : rE[k][r];
-                            gb += __builtin_amdgcn_ldexpf(rB[k][r] * sB[r] * rcp, ea_b + eb_ - pe);
-                            const float al = r == 0 ? aedge : rL[k][r - 1];
-                            const int eal = r == 0 ? aeedge : rE[k][r - 1];
-                            // (a pair without a label state drops a zero into its slot past the sorted labels)
-                            occ[pos[r]] = b_ok[r] ? __builtin_amdgcn_ldexpf(al * sL[r] * rcp, (eal == kNoExp ? 0 : eal) + eb_ - pe) : 0.f;
+                            for (int r = 0; r < R; ++r) {
+                                gb += rB[k][r] * sB[r] * scb[r];
+                                const float al = r == 0 ? aedge : rL[k][r - 1];
+                                occ[pos[r]] = al * sL[r] * scl[r];
+                            }
+                        } else {
+                            const int aeedge = __builtin_bit_cast(int, sa_wave_shr1(__builtin_bit_cast(float, rE[k][R - 1]), __builtin_bit_cast(float, kNoExp)));
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const int eb_ = es[r] == kNoExp ? 0 : es[r];
+                                const int ea_b = rE[k][r] == kNoExp ? 0 : rE[k][r];
+                                gb += __builtin_amdgcn_ldexpf(rB[k][r] * sB[r] * rcp, ea_b + eb_ - pe);
+                                const float al = r == 0 ? aedge : rL[k][r - 1];
+                                const int eal = r == 0 ? aeedge : rE[k][r - 1];
+                                // (a pair without a label state drops a zero into its slot past the sorted labels)
+                                occ[pos[r]] = b_ok[r] ? __builtin_amdgcn_ldexpf(al * sL[r] * rcp, (eal == kNoExp ? 0 : eal) + eb_ - pe) : 0.f;
+                            }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         float sv[R];
@@ -1667,9 +1691,10 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
             };
             {
                 const bool fast = bi >= nslow, full = nrows == KU;
-                if (fast && full) beta_batch_t(Yes(), Yes());
-                else if (fast) beta_batch_t(Yes(), No());
-                else beta_batch_t(No(), No());
+                if (fast && full && q >= nslow) beta_batch_t(Yes(), Yes(), Yes());
+                else if (fast && full) beta_batch_t(Yes(), Yes(), No());
+                else if (fast) beta_batch_t(Yes(), No(), No());
+                else beta_batch_t(No(), No(), No());
             }
             if (q > 0) stage.commit(nxt);
         }
