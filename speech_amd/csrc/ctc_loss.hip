@@ -1347,8 +1347,7 @@ __device__ __forceinline__ void wavep_fast_step(float (&Bst)[R], float (&Lst)[R]
 // Emission rows -> registers -> the LDS ring AS PROBABILITIES, straight from the ACTIVATIONS (round 4: no log-softmax
 // pass in front of this kernel, no 2 x |acts| round trip through the workspace).  A batch is KU = 8 rows; eight lanes
 // share a row (lane = 8 row + j holds classes j, j + 8, ...: NU = 8 registers cover K <= 64), the row's max and
-// normaliser are two 3-step DPP butterflies inside the 8-lane group, and the probability is formed exactly as the
-// log-softmax kernels + the old commit formed it: exp2(max((x - m) log2 e - log2 z, SA_NEG)).  The alpha pass and the
+// normaliser are two 3-step DPP butterflies inside the 8-lane group, p = 2^((x - m) log2 e) / z.  The alpha pass and the
 // beta pass stage a row with the same instructions on the same inputs, so the replayed alpha states are bit-identical.
 __device__ __forceinline__ float sa_group8_max(float v) {
     v = fmaxf(v, SA_DPP_F(v, v, 0xB1, 0xf));   // quad_perm [1, 0, 3, 2]
@@ -1362,65 +1361,63 @@ __device__ __forceinline__ float sa_group8_sum(float v) {
     v += SA_DPP_F(v, v, 0x141, 0xf);
     return v;
 }
-template <int R, bool NORM>
+constexpr int kRingPitch = 9;                 // floats per class in the probability ring: [class][row of the batch], odd pitch
+constexpr int kRingP = 64 * kRingPitch;       // one batch: K <= 64 classes x 8 rows
+template <int R, bool NORM, int NUE>
 struct RowStagerP {
-    static constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU;
-    static_assert(KU == 8 && NU == 8, "eight lanes per row, eight classes per lane");
-    static constexpr bool norm = NORM;
-    const float* x;  // the utterance's row 0 -- of the activations, or (norm = false) of the log-softmax K_A left
+    static constexpr int KU = WaveCfg<R>::KU;
+    static_assert(KU == 8 && (NUE == 4 || NUE == 8), "eight lanes per row, NUE classes per lane (K <= 8 NUE)");
+    const float* x;  // the utterance's row 0 -- of the activations (NORM), or of the log-softmax K_A left in the workspace
     long st;         // floats between its consecutive rows
     int K, lane;
-    float pv[NU];
+    float pv[NUE];
     __device__ __forceinline__ void issue(int tlo, int nrows) {
-        if constexpr (!NORM) {  // K_A's rows: contiguous, element order = memory order
-            const int n = nrows * K;
-            const float* src = x + (long)tlo * K;
+        const int r = lane >> 3, j = lane & 7;
+        const float* src = x + (long)(tlo + min(r, nrows - 1)) * st;  // (rows past the batch: a copy of its last row, unused)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) pv[u] = src[min(lane + 64 * u, n - 1)];
-        } else {
-            const int r = lane >> 3, j = lane & 7;
-            const float* src = x + (long)(tlo + min(r, nrows - 1)) * st;  // (rows past the batch: a copy of its last row, unused)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) pv[u] = src[min(j + 8 * u, K - 1)];
-        }
+        for (int u = 0; u < NUE; ++u) pv[u] = src[min(j + 8 * u, K - 1)];
     }
+    // The ring holds the batch TRANSPOSED: class c of row k at c * kRingPitch + k -- a state's emission for the 8 rows of a
+    // batch sits at one register address plus an immediate (no address arithmetic per step), and distinct classes fall
+    // on distinct banks (pitch 9, K <= 32; two-way from there).
     __device__ __forceinline__ void commit(float* dst) {
+        const int r = lane >> 3, j = lane & 7;
+        float* out = dst + j * kRingPitch + r;
         if constexpr (!NORM) {  // log2-probabilities
 #pragma unroll
-            for (int u = 0; u < NU; ++u) dst[lane + 64 * u] = sa_exp2(pv[u]);
-            return;
+            for (int u = 0; u < NUE; ++u)
+                if (j + 8 * u < K) out[8 * u * kRingPitch] = sa_exp2(pv[u]);
+        } else {  // p = 2^((x - m) log2 e) / z: one exp2 per class, the normaliser by two 8-lane butterflies
+            float m = -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < NUE; ++u) m = j + 8 * u < K ? fmaxf(m, pv[u]) : m;
+            m = sa_group8_max(m);
+            float z = 0.f;
+#pragma unroll
+            for (int u = 0; u < NUE; ++u) {
+                pv[u] = sa_exp2((pv[u] - m) * SA_LOG2E);
+                z += j + 8 * u < K ? pv[u] : 0.f;
+            }
+            const float rz = 1.0f / sa_group8_sum(z);
+#pragma unroll
+            for (int u = 0; u < NUE; ++u)
+                if (j + 8 * u < K) out[8 * u * kRingPitch] = pv[u] * rz;
         }
-        const int r = lane >> 3, j = lane & 7;
-        float m = -3.0e38f;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) m = j + 8 * u < K ? fmaxf(m, pv[u]) : m;
-        m = sa_group8_max(m);
-        float z = 0.f;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            pv[u] = (pv[u] - m) * SA_LOG2E;
-            z += j + 8 * u < K ? sa_exp2(pv[u]) : 0.f;
-        }
-        const float lz = sa_log2(sa_group8_sum(z));
-        float* row = dst + r * K + j;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-            if (j + 8 * u < K) row[8 * u] = sa_exp2(fmaxf(pv[u] - lz, SA_NEG));
     }
 };
 
-template <int R, bool NORM>
+template <int R, bool NORM, int NUE>
 __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int KU = WaveCfg<R>::KU, NU = WaveCfg<R>::NU, P = 64 * R;
+    constexpr int KU = WaveCfg<R>::KU, P = 64 * R;
     constexpr int kNoExp = -(1 << 28);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;
     if (b >= A.B) return;  // waves are independent: no workgroup barrier anywhere in this kernel
     float* base = reinterpret_cast<float*>(smem_raw) + (long)wave * A.wave_lds_floats;
-    float* ring = base;                 // [2][64 * NU]
-    float* occ = ring + 2 * 64 * NU;    // sorted occupancies [64 R + 1]
+    float* ring = base;                 // [2][kRingP]: two batches of emission probabilities, [class][row] (RowStagerP)
+    float* occ = ring + 2 * kRingP;     // sorted occupancies [64 R + 1]
     const int K = A.K, L = A.label_lens[b], T = A.in_lens[b];
     int loff = 0;
     for (int i = lane; i < b; i += 64) loff += A.label_lens[i];
@@ -1429,7 +1426,8 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
     float* ckb = A.stash + (long)b * A.nq * 3 * P + lane * R;  // checkpoints [nq][3][P]
 
     // ------------------------------------------------------------------------------------------------ alpha
-    int a_lab[R];
+    int a_lab[R], a_off[R];  // a_off: the label's column of the probability ring
+    const int bl_off = A.blank * kRingPitch;
     bool a_ok[R];
     float skipf[R];
     float aB[R], aL[R];
@@ -1439,6 +1437,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
         const int j = lane * R + r;
         a_ok[r] = j < L;
         a_lab[r] = a_ok[r] ? lab[j] : A.blank;
+        a_off[r] = a_lab[r] * kRingPitch;
         skipf[r] = (j >= 1 && j <= L - 1 && lab[j] != lab[j - 1]) ? 1.f : 0.f;
         aB[r] = j == 0 ? 1.0f : 0.f;
         aL[r] = 0.f;
@@ -1453,7 +1452,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
         nrep_f += (j >= 1 && j <= L - 1 && skipf[r] == 0.f) ? 1.f : 0.f;
     }
     const int nslow = (L + 1 + (int)sa_wave_sum_dpp(nrep_f) + 2 * KU) / KU;
-    RowStagerP<R, NORM> stage;
+    RowStagerP<R, NORM, NUE> stage;
     stage.x = NORM ? A.acts + (long)b * A.sb : A.ly2 + (long)b * A.ly_sb;
     stage.st = NORM ? A.st : (long)K;
     stage.K = K; stage.lane = lane;
@@ -1472,12 +1471,11 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
 #pragma unroll
         for (int k = 0; k < KU; ++k) {
             if (FULL || k < nrows) {
-                const float* rowp = cur + k * K;
-                const float yb = rowp[A.blank];
+                const float yb = cur[bl_off + k];
                 float yl[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float v = rowp[a_lab[r]];
+                    const float v = cur[a_off[r] + k];
                     yl[r] = a_ok[r] ? v : 0.f;
                 }
                 if (FAST) wavep_fast_step<R, 0>(aB, aL, yl, yb, pdx, pdy, sB, sL);
@@ -1500,8 +1498,8 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
     {
         int q = 0;
         for (int r0 = 0; r0 < T; r0 += KU, ++q) {
-            const float* cur = ring + (q & 1) * 64 * NU;
-            float* nxt = ring + ((q + 1) & 1) * 64 * NU;
+            const float* cur = ring + (q & 1) * kRingP;
+            float* nxt = ring + ((q + 1) & 1) * kRingP;
             float* ck = ckb + (long)q * 3 * P;
 #pragma unroll
             for (int r = 0; r < R; ++r) { ck[r] = aB[r]; ck[P + r] = aL[r]; ck[2 * P + r] = __builtin_bit_cast(float, ae[r]); }
@@ -1535,7 +1533,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
     if (T_live > 0) {
         // ------------------------------------------------------------------------------------------------- beta
         const float rcp = 1.0f / ph;
-        int b_lab[R];
+        int b_lab[R], b_off[R];
         bool b_ok[R];
         float bB[R], bL[R];
         int be[R];
@@ -1544,6 +1542,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
             const int j = lane * R + r;
             b_ok[r] = j >= 1 && j - 1 < L;
             b_lab[r] = b_ok[r] ? lab[j - 1] : A.blank;
+            b_off[r] = b_lab[r] * kRingPitch;
             bB[r] = j == L ? 1.0f : 0.f;
             bL[r] = 0.f;
             be[r] = j == L ? 0 : kNoExp;
@@ -1591,8 +1590,8 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
         for (int q = q_last; q >= 0; --q, ++bi) {
             const int tlo = q * KU;
             const int nrows = min(KU, T - tlo);
-            const float* cur = ring + (bi & 1) * 64 * NU;
-            float* nxt = ring + ((bi + 1) & 1) * 64 * NU;
+            const float* cur = ring + (bi & 1) * kRingP;
+            float* nxt = ring + ((bi + 1) & 1) * kRingP;
 #pragma unroll
             for (int r = 0; r < R; ++r) { aB[r] = cB[r]; aL[r] = cL[r]; ae[r] = cE[r]; }
             if (q > 0) {  // the previous batch in time: rows and checkpoint, a batch ahead of their use
@@ -1627,12 +1626,11 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                 for (int k = KU - 1; k >= 0; --k) {
                     if (FULL || k < nrows) {
                         const int t = tlo + k;
-                        const float* rowp = cur + k * K;
-                        const float yb = rowp[A.blank];
+                        const float yb = cur[bl_off + k];
                         float yl[R], sB[R], sL[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            const float v = rowp[b_lab[r]];
+                            const float v = cur[b_off[r] + k];
                             yl[r] = b_ok[r] ? v : 0.f;
                         }
                         int es[R];  // the exponent the pre-emission sums sB, sL are expressed in
@@ -1685,7 +1683,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         const int c = min(lane, K - 1);  // K <= 64: lanes past K repeat lane K-1's store
                         const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
                         float* g = A.grads + (long)b * A.sb + (long)t * A.st;
-                        g[c] = (rowp[c] - o) * A.gscale;
+                        g[c] = (cur[c * kRingPitch + k] - o) * A.gscale;
                     }
                 }
             };
@@ -1707,13 +1705,14 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
 }
 
 // R <= 2: four waves per SIMD (<= 128 registers) -- the kernel lives off the latency hiding of its neighbours
-template <int R, bool NORM>
+// NUE: classes per staging lane (4: K <= 32, every character-level model; 8: K <= 64)
+template <int R, bool NORM, int NUE>
 __global__ __launch_bounds__(256, 4) void ctc_wave_p_kernel(WaveArgs A, int* __restrict__ flags) {
-    ctc_wave_p_body<R, NORM>(A, flags);
+    ctc_wave_p_body<R, NORM, NUE>(A, flags);
 }
-template <int R, bool NORM>
+template <int R, bool NORM, int NUE>
 __global__ __launch_bounds__(256) void ctc_wave_p_wide_kernel(WaveArgs A, int* __restrict__ flags) {
-    ctc_wave_p_body<R, NORM>(A, flags);
+    ctc_wave_p_body<R, NORM, NUE>(A, flags);
 }
 
 template <int R, bool WITH_GRAD, bool SMALLK>
@@ -1941,7 +1940,9 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
         const int KU = R <= 4 ? 8 : 4;
         const int nren = max_T / 32 + 2;
         const bool smallk = KU * K <= 512 && K <= 64;  // a batch of emission rows fits the 8 staging registers
-        const size_t wave_floats = sa_align_up((size_t)2 * (smallk ? 512 : KU * K) + (smallk ? 64 * R + 1 : K) + nren, 4);
+        // (smallk: two batches of emissions -- 2 x 512 floats row-major in the log-domain kernel, 2 x kRingP class-major in
+        // the probability-domain one -- and the sorted occupancies)
+        const size_t wave_floats = sa_align_up((size_t)2 * (smallk ? kRingP : KU * K) + (smallk ? 64 * R + 1 : K) + nren, 4);
         const size_t wave_bytes = wave_floats * sizeof(float);
         const char* env = getenv("SA_CTC_WIDE");
         const bool want = env ? (env[0] == '1') : (B >= kWideMinBatch);
@@ -1971,9 +1972,11 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
             const size_t smem = waves * wave_bytes;
             const dim3 grid((B + waves - 1) / waves), block(64 * waves);
             if (prob) {
-                void (*pf)(WaveArgs, int*) =
-                    direct ? (R == 1 ? ctc_wave_p_kernel<1, true> : R == 2 ? ctc_wave_p_kernel<2, true> : ctc_wave_p_wide_kernel<4, true>)
-                           : (R == 1 ? ctc_wave_p_kernel<1, false> : R == 2 ? ctc_wave_p_kernel<2, false> : ctc_wave_p_wide_kernel<4, false>);
+                void (*pf)(WaveArgs, int*) = nullptr;
+#define SA_PF(N_, U_) (R == 1 ? ctc_wave_p_kernel<1, N_, U_> : R == 2 ? ctc_wave_p_kernel<2, N_, U_> : ctc_wave_p_wide_kernel<4, N_, U_>)
+                if (direct) pf = K <= 32 ? SA_PF(true, 4) : SA_PF(true, 8);
+                else pf = K <= 32 ? SA_PF(false, 4) : SA_PF(false, 8);
+#undef SA_PF
                 if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)pf, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)smem) != hipSuccess)
                     return CTC_STATUS_EXECUTION_FAILED;
