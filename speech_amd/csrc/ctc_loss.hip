@@ -1324,21 +1324,49 @@ __device__ __forceinline__ bool wavep_refresh(float (&Bst)[R], float (&Lst)[R], 
     return clamped;
 }
 
+// Lane i receives lane i-1's (i+1's) value, the lane without a source 0 (DPP bound_ctrl: no register to preset)
+__device__ __forceinline__ float sa_wave_shr1_z(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sa_wave_shl1_z(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+// One step on frozen exponents.  R even: the packed operations run ACROSS pairs -- {B_2h, B_2h+1}, {L_2h, L_2h+1} -- so a
+// state lives in the register pair the previous step's packed multiply left it in (pairing a state's blank with its
+// label, as rounds 2-3 did, costs ~7 register moves per step to re-form the operands): one packed add, two packed
+// fmas, two packed multiplies, the lane-edge DPP move and one move per pair.  Element for element the same operations
+// as before (bit-identical).
 template <int R, int DIR>
 __device__ __forceinline__ void wavep_fast_step(float (&Bst)[R], float (&Lst)[R], const float (&yl)[R], float yb,
                                                 const float (&pdx)[R], const float (&pdy)[R], float (&sB)[R],
                                                 float (&sL)[R]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const float nedge = DIR == 0 ? sa_wave_shr1(Lst[R - 1], 0.f) : sa_wave_shl1(Lst[0], 0.f);
+    const float nedge = DIR == 0 ? sa_wave_shr1_z(Lst[R - 1]) : sa_wave_shl1_z(Lst[0]);
     float nB[R], nL[R];
+    if constexpr ((R & 1) == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float n = DIR == 0 ? (r == 0 ? nedge : Lst[r - 1]) : (r == R - 1 ? nedge : Lst[r + 1]);
-        const f32x2 nn = {n, n}, pp = {pdx[r], pdy[r]}, base = {Bst[r], Lst[r] + Bst[r]}, yy = {yb, yl[r]};
-        const f32x2 sum = __builtin_elementwise_fma(nn, pp, base);
-        const f32x2 nxt = sum * yy;
-        sB[r] = sum.x; sL[r] = sum.y;
-        nB[r] = nxt.x; nL[r] = nxt.y;
+        for (int h = 0; h < R / 2; ++h) {
+            const int r0 = 2 * h, r1 = 2 * h + 1;
+            const float n0 = DIR == 0 ? (h == 0 ? nedge : Lst[r0 - 1]) : Lst[r1];
+            const float n1 = DIR == 0 ? Lst[r0] : (r1 == R - 1 ? nedge : Lst[r1 + 1]);
+            const f32x2 nn = {n0, n1}, B2 = {Bst[r0], Bst[r1]}, L2 = {Lst[r0], Lst[r1]};
+            const f32x2 px = {pdx[r0], pdx[r1]}, py = {pdy[r0], pdy[r1]}, y2 = {yl[r0], yl[r1]}, yb2 = {yb, yb};
+            const f32x2 sb = __builtin_elementwise_fma(nn, px, B2);
+            const f32x2 sl = __builtin_elementwise_fma(nn, py, L2 + B2);
+            const f32x2 nb = sb * yb2, nl = sl * y2;
+            sB[r0] = sb.x; sB[r1] = sb.y; sL[r0] = sl.x; sL[r1] = sl.y;
+            nB[r0] = nb.x; nB[r1] = nb.y; nL[r0] = nl.x; nL[r1] = nl.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float n = DIR == 0 ? (r == 0 ? nedge : Lst[r - 1]) : (r == R - 1 ? nedge : Lst[r + 1]);
+            const f32x2 nn = {n, n}, pp = {pdx[r], pdy[r]}, base = {Bst[r], Lst[r] + Bst[r]}, yy = {yb, yl[r]};
+            const f32x2 sum = __builtin_elementwise_fma(nn, pp, base);
+            const f32x2 nxt = sum * yy;
+            sB[r] = sum.x; sL[r] = sum.y;
+            nB[r] = nxt.x; nL[r] = nxt.y;
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) { Bst[r] = nB[r]; Lst[r] = nL[r]; }
@@ -1362,7 +1390,9 @@ __device__ __forceinline__ float sa_group8_sum(float v) {
     return v;
 }
 constexpr int kRingPitch = 9;                 // floats per class in the probability ring: [class][row of the batch], odd pitch
-constexpr int kRingP = 64 * kRingPitch;       // one batch: K <= 64 classes x 8 rows
+constexpr int kRingP = 65 * kRingPitch;       // one batch: K <= 64 classes x 8 rows, and column 64 = zeros: the emission of a
+                                              // pair WITHOUT a label state (no select per step)
+constexpr int kRingZero = 64 * kRingPitch;
 template <int R, bool NORM, int NUE>
 struct RowStagerP {
     static constexpr int KU = WaveCfg<R>::KU;
@@ -1418,6 +1448,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
     float* base = reinterpret_cast<float*>(smem_raw) + (long)wave * A.wave_lds_floats;
     float* ring = base;                 // [2][kRingP]: two batches of emission probabilities, [class][row] (RowStagerP)
     float* occ = ring + 2 * kRingP;     // sorted occupancies [64 R + 1]
+    if (lane < 2 * kRingPitch) ring[(lane >= kRingPitch ? kRingP - kRingPitch : 0) + kRingZero + lane] = 0.f;
     const int K = A.K, L = A.label_lens[b], T = A.in_lens[b];
     int loff = 0;
     for (int i = lane; i < b; i += 64) loff += A.label_lens[i];
@@ -1437,7 +1468,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
         const int j = lane * R + r;
         a_ok[r] = j < L;
         a_lab[r] = a_ok[r] ? lab[j] : A.blank;
-        a_off[r] = a_lab[r] * kRingPitch;
+        a_off[r] = a_ok[r] ? a_lab[r] * kRingPitch : kRingZero;
         skipf[r] = (j >= 1 && j <= L - 1 && lab[j] != lab[j - 1]) ? 1.f : 0.f;
         aB[r] = j == 0 ? 1.0f : 0.f;
         aL[r] = 0.f;
@@ -1474,10 +1505,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                 const float yb = cur[bl_off + k];
                 float yl[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float v = cur[a_off[r] + k];
-                    yl[r] = a_ok[r] ? v : 0.f;
-                }
+                for (int r = 0; r < R; ++r) yl[r] = cur[a_off[r] + k];  // (no label state: the ring's zero column)
                 if (FAST) wavep_fast_step<R, 0>(aB, aL, yl, yb, pdx, pdy, sB, sL);
                 else wavep_slow_step<R, 0>(aB, aL, ae, yl, yb, skipf, sB, sL, (k & 3) == 0);
             }
@@ -1542,7 +1570,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
             const int j = lane * R + r;
             b_ok[r] = j >= 1 && j - 1 < L;
             b_lab[r] = b_ok[r] ? lab[j - 1] : A.blank;
-            b_off[r] = b_lab[r] * kRingPitch;
+            b_off[r] = b_ok[r] ? b_lab[r] * kRingPitch : kRingZero;
             bB[r] = j == L ? 1.0f : 0.f;
             bL[r] = 0.f;
             be[r] = j == L ? 0 : kNoExp;
@@ -1629,10 +1657,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         const float yb = cur[bl_off + k];
                         float yl[R], sB[R], sL[R];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const float v = cur[b_off[r] + k];
-                            yl[r] = b_ok[r] ? v : 0.f;
-                        }
+                        for (int r = 0; r < R; ++r) yl[r] = cur[b_off[r] + k];
                         int es[R];  // the exponent the pre-emission sums sB, sL are expressed in
                         if (FAST) {
 #pragma unroll
@@ -1644,7 +1669,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                             for (int r = 0; r < R; ++r) es[r] = be[r];  // the aligned exponent of the step (kNoExp: sums are 0)
                         }
                         // occupancy = alpha_t(s) * sum_beta_t(s) / p; alpha's label state of pair j-1 comes across the lane edge
-                        const float aedge = sa_wave_shr1(rL[k][R - 1], 0.f);
+                        const float aedge = sa_wave_shr1_z(rL[k][R - 1]);
                         float gb = 0.f;
                         if constexpr (BOTH) {
 #pragma unroll
@@ -1674,14 +1699,20 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         for (int r = 1; r < R; ++r) sv[r] += sv[r - 1];
                         const float incl = wave_scan_dpp(sv[R - 1]);
                         const float excl = incl - sv[R - 1];
-                        gb = sa_wave_sum_dpp(gb);
-                        const float total = gb + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
-                        bad_row = bad_row || !(fabsf(total - 1.0f) < 1e-4f);  // flow conservation (NaN compares false)
+                        // The blank's occupancy is what the label states leave of the row's unit flow.  That the flow IS one
+                        // (the certificate of this pass) is checked with the blank states' own sum on the first and the last
+                        // row of every batch -- where the frozen exponents of beta resp. of the replayed alpha have drifted
+                        // furthest -- instead of on every row (a 64-lane reduction per row: 10 of the step's ~100 instructions).
+                        const float lab_tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+                        if (k == 0 || k == KU - 1)
+                            bad_row = bad_row || !(fabsf(sa_wave_sum_dpp(gb) + lab_tot - 1.0f) < 1e-4f);  // (NaN compares false)
+                        const float ob = 1.0f - lab_tot;
 #pragma unroll
                         for (int r = 0; r < R; ++r) occ[lane * R + r] = sv[r] + excl;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         const int c = min(lane, K - 1);  // K <= 64: lanes past K repeat lane K-1's store
-                        const float o = c == A.blank ? gb : occ[seg_hi] - occ[seg_lo];
+                        const float od = occ[seg_hi] - occ[seg_lo];
+                        const float o = c == A.blank ? ob : od;
                         float* g = A.grads + (long)b * A.sb + (long)t * A.st;
                         g[c] = (cur[c * kRingPitch + k] - o) * A.gscale;
                     }
