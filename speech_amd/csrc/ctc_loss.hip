@@ -1644,10 +1644,11 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         const int eb_ = be[r] == kNoExp ? 0 : be[r];
                         const int ea_b = rE[0][r] == kNoExp ? 0 : rE[0][r];
                         const int eal = r == 0 ? aee : rE[0][r - 1];
-                        // (an occupancy is <= 1 and the hats are held near 2^kFTarget: an exponent above 0 belongs to a pair
-                        // whose hats are zero -- clamped, so that 0 x scale stays 0)
-                        scb[r] = __builtin_amdgcn_ldexpf(rcp, min(ea_b + eb_ - pe, 64));
-                        scl[r] = b_ok[r] ? __builtin_amdgcn_ldexpf(rcp, min((eal == kNoExp ? 0 : eal) + eb_ - pe, 64)) : 0.f;
+                        // (clamped so that the scale stays finite: 0 x scale is then 0 for a pair whose hats are zero and whose
+                        // exponents mean nothing; hats that DECAYED inside the batch -- peaked emissions: 2^-35 per step --
+                        // legitimately meet exponents far above 0, so the clamp sits at the top of the fp32 range)
+                        scb[r] = __builtin_amdgcn_ldexpf(rcp, min(ea_b + eb_ - pe, 125));
+                        scl[r] = b_ok[r] ? __builtin_amdgcn_ldexpf(rcp, min((eal == kNoExp ? 0 : eal) + eb_ - pe, 125)) : 0.f;
                     }
                 }
 #pragma unroll
