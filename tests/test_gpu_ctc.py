@@ -6,6 +6,7 @@ Tolerances (fp32 log-space kernels vs an fp64 oracle):
   fp32, so its absolute error is a few ulp(|log2 p|): atol = max(2e-5, 4 * 2^-24 * |log2 p|max) -- the same error
   class as any fp32 log-space implementation (oracle/ctc_ref.c's own float port shows it, test_oracle_ctc.py)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -334,3 +335,24 @@ def test_wide_results_repeat(wide):
     c2, g2 = run_hip(acts, labs, al, ll)
     assert np.array_equal(c1, c2) and np.array_equal(g1, g2)
     compare(acts, labs, al, ll)
+
+
+def test_wide_peaked_logits_stay_in_the_probability_domain(monkeypatch):
+    # Logits of the kind a trained model emits (noise + a margin of 10 on the class of one monotonic alignment) must not be
+    # flagged by K_W's probability-domain pass -- a flagged utterance costs a whole log-domain pass -- and the results hold
+    # against the oracle either way.  (tools/ctc_flags_probe.py measures the same at B = 1024 ... 4096.)
+    monkeypatch.setenv("SA_CTC_WIDE", "1")
+    rng = np.random.RandomState(5)
+    B, T, K, L = 24, 600, 29, 60
+    labs = rng.randint(0, K - 1, B * L).astype(np.int32)
+    acts = rng.randn(B, T, K).astype(np.float32)
+    for b in range(B):
+        starts = np.sort(rng.choice(T // 4, L, replace=False)) * 4
+        cls = np.full(T, K - 1)
+        for i, t0 in enumerate(starts):
+            cls[t0:t0 + rng.randint(1, 4)] = labs[b * L + i]
+        acts[b, np.arange(T), cls] += 10.0
+    al, ll = np.full(B, T, np.int32), np.full(B, L, np.int32)
+    compare(acts, labs, al, ll)
+    if os.environ.get("SA_CTC_PROB") is None:  # the default mode: nothing handed over
+        assert not flags_of(B, T, K, L).any()
