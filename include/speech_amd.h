@@ -296,11 +296,12 @@ int sa_gru_profile_steps_per_launch(int kind);
  *     appends that float to its gradient message and hands it to sa_clip_sgd_step() as d_skip_flag, so the optimiser
  *     skips the update ON THE DEVICE (no host round trip between a failure and the update it must stop; summed by the
  *     data-parallel all-reduce, one rank's failure stops every rank's update);
- *   - every sa_gru_stack_* call copies the word to a ring of pinned host words; once a later call finds a non-zero
- *     copy the persistent path is off for the process (every stack call from then on runs the step kernels).  The
+ *   - the failing workgroup also ORs its code into a word of mapped host memory (no copy is queued: a healthy call costs
+ *     the host nothing); every sa_gru_stack_* call looks at that word, and once one finds it non-zero the persistent
+ *     path is off for the process (every stack call from then on runs the step kernels).  The
  *     calls themselves keep returning success -- data-parallel ranks must stay in lock-step, so the failure travels
  *     through the gate above, not through one rank's return code; forward-only users call sa_gru_persist_status();
- *   - sa_gru_persist_status() waits for every outstanding copy and returns the OR of the codes seen (0 = fine;
+ *   - sa_gru_persist_status() waits for the device to drain and returns the OR of the codes seen (0 = fine;
  *     1 = a hand-off timed out, 2 = more than 32 workgroups landed on one XCD, 4 = an XCD-filtered side-stream GEMM
  *     launch -- the weight gradients / input projections that run beside a bidirectional layer's recurrence on the XCDs
  *     it leaves idle -- did not draw all of its tiles because the dispatcher placed too few of its blocks there);

@@ -30,6 +30,16 @@ static inline size_t sa_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 __device__ __forceinline__ float sa_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float sa_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 
+// The sticky health word of the persistent kernels (PersistHealth, gru.hip): err[0] is the device-side word the optimiser
+// gates on; err[2 .. 3] hold the device address of a word in MAPPED HOST memory (or 0).  A failing block ORs its code into
+// both -- the host sees a failure the moment it happens, and a healthy call costs the host nothing (rounds 1-3 copied the
+// word to a pinned ring after every stack call: two 4-byte copies and ~20 us of launch gaps per train step).
+__device__ __forceinline__ void sa_raise(unsigned* err, unsigned code) {
+    atomicOr(err, code);
+    unsigned* hp = *reinterpret_cast<unsigned* const*>(err + 2);
+    if (hp) __hip_atomic_fetch_or(hp, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Whole-wave shift by one lane (gfx9 DPP wave_shr / wave_shl): lane i receives lane i-1 (resp. i+1);
 // the lane with no source keeps `edge`.
 __device__ __forceinline__ float sa_wave_shr1(float v, float edge) {

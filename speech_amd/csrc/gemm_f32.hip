@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_filtered_kernel(GemmArgs g) {
 // sequential; blocks that drew a tile have finished it by the time this kernel runs on the same stream).
 __global__ void gemm_filtered_check_kernel(const unsigned* __restrict__ tile_counter, unsigned total,
                                            unsigned* __restrict__ err_word) {
-    if (__hip_atomic_load(tile_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) atomicOr(err_word, 4u);
+    if (__hip_atomic_load(tile_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) sa_raise(err_word, 4u);
 }
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int splits) {

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
         }
         __syncthreads();
         if (s_role[1] < 0 || s_role[1] >= 32) {  // more than 32 workgroups landed on this XCD
-            if (threadIdx.x == 0) atomicOr(P.err, 2u);
+            if (threadIdx.x == 0) sa_raise(P.err, 2u);
             return;
         }
         // an XCD hosts 32 / ntile_u groups (narrower layers: 16 or 8 unit tiles per group)
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                 int spins = 0;
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 4 * P.spin_limit) { dead = true; atomicOr(P.err, 1u); break; }
+                    if (++spins > 4 * P.spin_limit) { dead = true; sa_raise(P.err, 1u); break; }
                 }
             }
             __syncthreads();
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
                     for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;  // wave-uniform: the MFMAs below stay convergent
                     // budget: a wave-uniform scalar; after one timeout it is 0, so a lost call drains quickly
-                    if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
+                    if (spins > budget) { if (lane == 0) sa_raise(P.err, 1u); budget = 0; break; }
                 }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     }
     __syncthreads();
     if (s_role[1] < 0 || s_role[1] >= 32) {
-        if (threadIdx.x == 0) atomicOr(P.err, 2u);
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
         unsigned c;
         while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
                (unsigned)P.ntile_u * (unsigned)(tt + 1)) {
-            if (++spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
+            if (++spins > budget) { if (lane == 0) sa_raise(P.err, 1u); budget = 0; break; }
         }
         avail = c / (unsigned)P.ntile_u;
     };
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
 #pragma unroll
                     for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
+                    if (spins > budget) { if (lane == 0) sa_raise(P.err, 1u); budget = 0; break; }
                 }
                 SA_TICK(1)
                 if (prefetch) {  // the slow loads go out only now, behind the poll (H <= 512: this loop runs once)
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
     }
     __syncthreads();
     if (s_role[1] < 0 || s_role[1] >= 32) {
-        if (threadIdx.x == 0) atomicOr(P.err, 2u);
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                 const unsigned need = J.base + (unsigned)P.ntile_u * (unsigned)s;
                 int spins = 0;
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                    if (++spins > 4 * P.spin_limit) { dead = true; atomicOr(P.err, 1u); break; }
+                    if (++spins > 4 * P.spin_limit) { dead = true; sa_raise(P.err, 1u); break; }
                 }
             }
             __syncthreads();
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
                     for (int it = 0; it < 24; ++it) stale |= has_sentinel(a[it]);
                     if (timed) ++tacc[4];
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > budget) { if (lane == 0) atomicOr(P.err, 1u); budget = 0; break; }
+                    if (spins > budget) { if (lane == 0) sa_raise(P.err, 1u); budget = 0; break; }
                     if (POLL == 0 && SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
                 }
                 SA_TICK(0)
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     }
     __syncthreads();
     if (s_role[1] < 0 || s_role[1] >= 32) {
-        if (threadIdx.x == 0) atomicOr(P.err, 2u);
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
         return;
     }
     const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             for (int it = 0; it < NITG; ++it) stale |= has_sentinel(a[it]);
             if (timed) ++tacc[4];
             if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-            if (spins > budget) { if (lane == 0) atomicOr(errp, 1u); budget = 0; break; }
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
         }
     };
     auto second = [&](int par) {  // a[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15)
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             for (int spins = 0; __builtin_amdgcn_ballot_w64(live && __builtin_bit_cast(unsigned, dh) == kSentinel) != 0; ++spins) {
                 if (__builtin_bit_cast(unsigned, dh) == kSentinel)
                     dh = __hip_atomic_load(p_dh + (long)t * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (spins > budget) { if (lane == 0) atomicOr(errp, 1u); budget = 0; break; }
+                if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
             }
         }
         float dpr = 0.f, dpz = 0.f, dpn = 0.f, dqn = 0.f;
@@ -1745,60 +1745,44 @@ struct StepProfiler {
 //   * the optimiser gates on it ON THE DEVICE: sa_gru_health_flag() turns the word into a float the caller appends to
 //     its gradient message, sa_clip_sgd_step() skips the update when that float is non-zero (and, summed by the
 //     gradient all-reduce, when ANY rank's is).  No host round trip sits between a failure and the update it must stop.
-//   * the host learns about it without a sync: every stack call copies the word into the next slot of a small ring of
-//     pinned words (one event each); a later call looks at whichever copies have landed.  sa_gru_persist_status()
-//     waits for all of them.
+//   * the host learns about it without a sync and without a copy: the failing block also ORs its code into a word of
+//     mapped host memory (sa_raise); every stack call looks at that word, sa_gru_persist_status() first waits for the
+//     device to drain.
 struct PersistHealth {
-    static constexpr int kSlots = 8;
-    unsigned* dev = nullptr;
-    unsigned* host = nullptr;
-    hipEvent_t ev[kSlots];
-    bool pending[kSlots];
-    int next = 0;
+    unsigned* dev = nullptr;            // [0] the sticky word, [1] spare, [2 .. 3] the device address of `host` (sa_raise, common.h)
+    volatile unsigned* host = nullptr;  // one word of mapped, coherent host memory: failing blocks OR their code in
     unsigned code = 0;      // OR of every failure code seen since the last reset
     bool disabled = false;  // a failure was seen at some point: the persistent path stays off for the process
     bool ready = false;
     bool init() {
         if (ready) return true;
-        if (hipMalloc((void**)&dev, 2 * sizeof(unsigned)) != hipSuccess) { dev = nullptr; return false; }
-        if (hipMemset(dev, 0, 2 * sizeof(unsigned)) != hipSuccess) return false;
-        if (hipHostMalloc((void**)&host, kSlots * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { host = nullptr; return false; }
-        for (int i = 0; i < kSlots; ++i) {
-            host[i] = 0; pending[i] = false;
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
-        }
+        if (hipMalloc((void**)&dev, 4 * sizeof(unsigned)) != hipSuccess) { dev = nullptr; return false; }
+        if (hipMemset(dev, 0, 4 * sizeof(unsigned)) != hipSuccess) return false;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return false;
+        host = (volatile unsigned*)h;
+        host[0] = 0;
+        void* hd = nullptr;
+        if (hipHostGetDevicePointer(&hd, h, 0) != hipSuccess) return false;
+        if (hipMemcpy(dev + 2, &hd, sizeof(void*), hipMemcpyHostToDevice) != hipSuccess) return false;
         ready = true;
         return true;
     }
-    void harvest(int i) {
-        pending[i] = false;
-        if (host[i]) { code |= host[i]; disabled = true; }
-    }
-    void submit(hipStream_t stream) {
-        if (!init()) return;
-        const int i = next;
-        next = (next + 1) % kSlots;
-        if (pending[i]) { if (hipEventSynchronize(ev[i]) == hipSuccess) harvest(i); }  // kSlots calls old: long done
-        if (hipMemcpyAsync(host + i, dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-            hipEventRecord(ev[i], stream) == hipSuccess)
-            pending[i] = true;
-    }
-    // 0 = fine (or nothing has been reported yet)
+    // (rounds 1-3 queued a copy of the word here; the kernels report to the host word themselves now)
+    void submit(hipStream_t) { (void)init(); }
+    // 0 = fine (or nothing has been reported yet); wait: everything queued on the device so far has run
     unsigned poll(bool wait) {
         if (!ready) return 0;
-        for (int i = 0; i < kSlots; ++i) {
-            if (!pending[i]) continue;
-            if (wait) { if (hipEventSynchronize(ev[i]) != hipSuccess) continue; }
-            else if (hipEventQuery(ev[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
-            harvest(i);
-        }
+        if (wait) (void)hipDeviceSynchronize();
+        const unsigned c = host[0];
+        if (c) { code |= c; disabled = true; }
         return code;
     }
     void reset() {
         if (!ready) return;
-        (void)hipDeviceSynchronize();
-        for (int i = 0; i < kSlots; ++i) if (pending[i]) harvest(i);
+        (void)poll(true);
         (void)hipMemset(dev, 0, 2 * sizeof(unsigned));
+        host[0] = 0;
         code = 0;  // `disabled` stays
     }
 };
