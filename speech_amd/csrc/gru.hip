@@ -1898,6 +1898,41 @@ static int fault_injection() {  // tests only: SA_GRU_FAULT=1 makes one workgrou
 static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
     return hipMemsetD32Async((hipDeviceptr_t)p, (int)kSentinel, n, stream) == hipSuccess;
 }
+// The pre-fills of one stack call as ONE launch (round 4): the one-launch forward issues five fills (the layers' h_out with the
+// sentinel, the sync words with 0), the one-launch backward eight -- 35 + 45 us of 5 - 8 us launches for 130 + 98 MB; one
+// kernel writes the same bytes at the same rate without the seven launch tails in between.
+struct FillList { unsigned* p[8]; unsigned long long n[8]; unsigned v[8]; int count; };
+__global__ __launch_bounds__(256) void fill_many_kernel(FillList f) {
+    const size_t stride = (size_t)gridDim.x * 256, first = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (int k = 0; k < f.count; ++k) {
+        const unsigned v = f.v[k];
+        const uint4 v4 = make_uint4(v, v, v, v);
+        uint4* d4 = reinterpret_cast<uint4*>(f.p[k]);   // 16-byte aligned (workspace offsets, torch allocations)
+        const size_t n4 = f.n[k] >> 2;
+        for (size_t i = first; i < n4; i += stride) d4[i] = v4;
+        if (first < (f.n[k] & 3)) f.p[k][4 * n4 + first] = v;
+    }
+}
+struct FillBatch {
+    FillList f;
+    hipStream_t stream;
+    bool batched, ok = true;
+    FillBatch(hipStream_t s, bool on) : stream(s), batched(on) { f.count = 0; }
+    void add(void* p, size_t nwords, unsigned value) {
+        if (!batched || ((uintptr_t)p & 15) != 0) {
+            ok = ok && hipMemsetD32Async((hipDeviceptr_t)p, (int)value, nwords, stream) == hipSuccess;
+            return;
+        }
+        if (f.count == 8) flush();
+        f.p[f.count] = (unsigned*)p; f.n[f.count] = nwords; f.v[f.count] = value; ++f.count;
+    }
+    void flush() {
+        if (f.count == 0) return;
+        hipLaunchKernelGGL(fill_many_kernel, dim3(2048), dim3(256), 0, stream, f);
+        ok = ok && hipGetLastError() == hipSuccess;
+        f.count = 0;
+    }
+};
 
 // shapes the XCD-local persistent kernels take: 8 XCDs x 32 CUs; a sync group = one (concurrent job, batch tile) with
 // H / 16 = 32, 16 or 8 unit tiles, so an XCD hosts 1, 2 or 4 groups.  jobs = layers in flight (unidirectional layer
@@ -1928,6 +1963,10 @@ static int fwd_chunks(int T) {  // bidirectional forward: time chunks per layer 
 }
 static bool fuse_dx_enabled() {  // SA_GRU_FUSE_DX=0: the per-wave grouped GEMM computes d h_out of the lower layers
     const char* e = getenv("SA_GRU_FUSE_DX");
+    return !(e && e[0] == '0');
+}
+static bool fill_batch_enabled() {  // SA_GRU_FILL_BATCH=0: one hipMemsetD32Async per buffer (rounds 1-3)
+    const char* e = getenv("SA_GRU_FILL_BATCH");
     return !(e && e[0] == '0');
 }
 static bool xring_enabled() {  // SA_GRU_XRING=0: the backward exchange as T pre-filled time slots (rounds 2-3)
@@ -2187,14 +2226,19 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     if (xcd) plds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
     unsigned persist_launches = 0;
     const bool flagless = xcd && flagless_mode();
+    const char* fe = getenv("SA_GRU_FUSED");
+    const size_t flds = xcd_lds((size_t)2 * 4 * 4 * 256 * sizeof(float));
+    const bool fused_fwd = !(fe && fe[0] == '0') && flagless && flds <= 160 * 1024 && L * nbt <= kSyncErr;
+    FillBatch fills(stream, fused_fwd && fill_batch_enabled());
     if (flagless)
-        for (int l = 0; l < L; ++l)
-            if (!sentinel_fill(h_out[l], (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+        for (int l = 0; l < L; ++l) fills.add(h_out[l], (size_t)T * B * H, kSentinel);
+    if (!fused_fwd) fills.flush();
+    if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
     {   // the whole stack as ONE launch with in-kernel input projections (gru_fwd_fused_kernel); SA_GRU_FUSED=0: off
-        const char* fe = getenv("SA_GRU_FUSED");
-        const size_t flds = xcd_lds((size_t)2 * 4 * 4 * 256 * sizeof(float));
-        if (!(fe && fe[0] == '0') && flagless && flds <= 160 * 1024 && L * nbt <= kSyncErr) {
-            if (hipMemsetAsync(sync, 0, 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+        if (fused_fwd) {
+            fills.add(sync, 1024 / 4, 0u);
+            fills.flush();
+            if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
             if (hipFuncSetAttribute((const void*)gru_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)flds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
@@ -2965,12 +3009,13 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
     const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed
+    FillBatch fills(stream, one_launch && fill_batch_enabled());
     if (flagless)
         for (int l = 0; l < L; ++l)  // the exchanged values are their own flags (ring: kXRing time slots, re-armed in the kernel)
-            if (!sentinel_fill(tiled ? xch_of(l) : dah[l],
-                               tiled ? (size_t)(xring == 2 ? min(T, kXRing) : T) * nbt * 16 * 3 * H : (size_t)T * B * 3 * H,
-                               stream))
-                return CTC_STATUS_MEMOPS_FAILED;
+            fills.add(tiled ? xch_of(l) : dah[l],
+                      tiled ? (size_t)(xring == 2 ? min(T, kXRing) : T) * nbt * 16 * 3 * H : (size_t)T * B * 3 * H, kSentinel);
+    if (!one_launch) fills.flush();
+    if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
     // the one-launch kernel reads its weight fragments from the matrices as stored (PBwdJobs::w_rowmajor): 2 L - 1 transpose
     // launches less per step; SA_GRU_WT=1: transposed copies as before
     const char* wt_e = getenv("SA_GRU_WT");
@@ -2987,14 +3032,17 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // per step in round 2, profiles/r02_overlap_experiments.txt -- and that side-stream path is retired; the products
     // run behind the recurrence, wgrad_rest below)
     if (xcd) {
-        if (hipMemsetAsync(sync, 0, getenv("SA_GRU_TIMING") ? kSyncBytes : 1024, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+        fills.add(sync, (getenv("SA_GRU_TIMING") ? kSyncBytes : 1024) / 4, 0u);
+        if (!one_launch) fills.flush();
+        if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)plds) != hipSuccess)
             return CTC_STATUS_EXECUTION_FAILED;
     }
     if (one_launch) {
-        for (int l = 0; l + 1 < L; ++l)
-            if (!sentinel_fill(mid_of(l), (size_t)T * B * H, stream)) return CTC_STATUS_MEMOPS_FAILED;
+        for (int l = 0; l + 1 < L; ++l) fills.add(mid_of(l), (size_t)T * B * H, kSentinel);
+        fills.flush();
+        if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
         Q.timing = nullptr; Q.drop = dc.drop;
