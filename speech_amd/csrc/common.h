@@ -36,7 +36,11 @@ __device__ __forceinline__ float sa_log2(float x) { return __builtin_amdgcn_logf
 // word to a pinned ring after every stack call: two 4-byte copies and ~20 us of launch gaps per train step).
 __device__ __forceinline__ void sa_raise(unsigned* err, unsigned code) {
     atomicOr(err, code);
-    unsigned* hp = *reinterpret_cast<unsigned* const*>(err + 2);
+    // a GLOBAL-address-space pointer: through a generic one this is a flat_atomic_or, and a FLAT instruction that may be
+    // pending makes hipcc's wait-count pass turn every later vmcnt wait into vmcnt(0) -- in the recurrence kernels that
+    // was the top of every time step (round 5: the raise sits in their polling loops)
+    typedef __attribute__((address_space(1))) unsigned sa_global_u32;
+    sa_global_u32* hp = (sa_global_u32*)*reinterpret_cast<unsigned* const*>(err + 2);
     if (hp) __hip_atomic_fetch_or(hp, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -1702,10 +1702,10 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         const float excl = incl - sv[R - 1];
                         // The blank's occupancy is what the label states leave of the row's unit flow.  That the flow IS one
                         // (the certificate of this pass) is checked with the blank states' own sum on the first and the last
-                        // row of every batch -- where the frozen exponents of beta resp. of the replayed alpha have drifted
+                        // LIVE row of every batch -- where the frozen exponents of beta resp. of the replayed alpha have drifted
                         // furthest -- instead of on every row (a 64-lane reduction per row: 10 of the step's ~100 instructions).
                         const float lab_tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
-                        if (k == 0 || k == KU - 1)
+                        if (k == 0 || k == nrows - 1)  // (a partial last batch ends at row nrows - 1, not KU - 1)
                             bad_row = bad_row || !(fabsf(sa_wave_sum_dpp(gb) + lab_tot - 1.0f) < 1e-4f);  // (NaN compares false)
                         const float ob = 1.0f - lab_tot;
 #pragma unroll

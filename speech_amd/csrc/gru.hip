@@ -479,9 +479,10 @@ struct PFusedFwd {
     int spin_limit, fault, prio; // see PFwdJobs
     unsigned long long* stamp;
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
+    float* dump;                 // 256 x 256 floats nobody reads: where the stores of rows beyond the batch go
 };
 
-__global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
+__global__ __launch_bounds__(256) void gru_fwd_fused_r4_kernel(PFusedFwd P) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
     SA_PERSIST_EXCLUSIVE(P.prio);
@@ -734,6 +735,305 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     }
     if (timed) {
         unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
+        for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
+    }
+#undef SA_TICK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
+}
+
+// ------------------------------------------------------------------- fused forward layer wavefront, round 5
+// The same algorithm as gru_fwd_fused_r4_kernel with everything the compiler needs to know at compile time known:
+//   * H = 64 IPG is a template parameter.  With a run-time width every k-group of every product sat under its own
+//     uniform branch (`16 it < kslice`), and hipcc's wait-count insertion has to assume the path on which NONE of the
+//     younger loads was issued: the ISA of rounds 1-4 waits vmcnt(0) at the top of every step (i.e. for the
+//     acknowledgement of the step's own write-through stores) and again right after the lower layer's rows of step t+1
+//     have been requested (i.e. for a memory round trip to another XCD) -- the software pipeline of the comment above
+//     existed in the source only.  Now the wave waits for exactly the loads it is about to use.
+//   * no branch around a vector-memory instruction inside the loop: t = 0 is peeled, the prefetch of the last step is
+//     clamped, layer 0 and the upper layers run two separate loop bodies (LOWER), rows beyond the batch store to a dump
+//     slot, stash / dropout are template parameters.
+//   * POLL_AT (eighths of the step's input MFMAs): the first polling trip for the own layer's h[t-1] is issued after
+//     that share of the input product and examined after all of it -- its L2 round trip runs under the remaining input
+//     MFMAs instead of behind them (8: issued after the product, rounds 1-4).
+//   * layer 0's three input-projection values are requested during the PREVIOUS step, behind its poll (they came from
+//     HBM at the top of their own step, in front of the poll, in the in-order vector-memory queue).
+template <int IPG, int POLL_AT, bool STASH, bool DROP, bool TIMED>
+__global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
+    constexpr int H = 64 * IPG, NTU = H / 16, KS = 16 * IPG;
+    constexpr int kPollIt = POLL_AT >= 8 ? IPG : (IPG * POLL_AT) / 8;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE(P.prio);
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / NTU, grp = s_role[0] * (32 / NTU) + sub;
+    if (sub >= 32 / NTU) return;
+    const int role_x = s_role[1] - sub * NTU, l = grp / P.nbt, role_y = grp - l * P.nbt + P.bt0;
+    if (l >= P.L) return;
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
+    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
+    const int B = P.B, T = P.T;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    float* red = psm;             // [2][4 waves][4 sums][256]  (the weights live in registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    const float e_br = P.b_hh[l][u], e_bz = P.b_hh[l][H + u], e_bn = P.b_hh[l][2 * H + u];
+    float* h_out = P.h_out[l];
+    const long hs_t = (long)B * H;
+    const int kbeg = wave * KS;
+    const int brow = min(b0 + i, B - 1);
+    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)h_out, 0, 0x7fffffff, 0x00020000);
+    unsigned* my_prog = P.prog + l * P.nbt_all + role_y;
+    unsigned* errp = P.err;
+    // per-thread store targets: base + t * stride (a row beyond the batch keeps hitting its dump slot)
+    float* dump = P.dump + blockIdx.x * 256 + tid;
+    float* p_h = live ? h_out + (long)b * H + u : dump;
+    const long s_h = live ? hs_t : 0;
+    float* p_hd = (DROP && live && P.h_drop[l]) ? P.h_drop[l] + (long)b * H + u : dump;
+    const long s_hd = (DROP && live && P.h_drop[l]) ? hs_t : 0;
+    float* p_st = (STASH && live) ? P.stash[l] + (long)b * P.rb * 5 * H + u : dump;
+    const long s_st = (STASH && live) ? (long)P.rt * 5 * H : 0;
+    const int so = (STASH && live) ? H : 0;  // distance between a row's stashed gates
+    const SaDrop drop = P.drop;
+    const unsigned drop_stream = P.drop_stream0 + (unsigned)l;
+    const long drop_idx0 = (long)(live ? b : 0) * H + u;
+    float hp = 0.f;
+    // the W_hh fragments this lane feeds to its MFMAs: resident in registers for the whole launch
+    float4 wh[IPG][3];
+#pragma unroll
+    for (int it = 0; it < IPG; ++it)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            wh[it][n] = *reinterpret_cast<const float4*>(P.w_hh[l] + (long)(n * H + u0 + i) * H + kbeg + 16 * it + 4 * g);
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;  // TIMED: input / poll / recurrent MFMA / rest
+    const bool timed = TIMED && P.timing != nullptr && tid == 0;
+    if (timed) tprev = wall_clock64();
+#define SA_TICK(k) if (TIMED && timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
+    __syncthreads();
+
+    f32x4v a[IPG];  // the gathered k-slice of the own layer's h[t-1]
+    auto issue_poll = [&](int tprev_idx) {
+        const int abase = (int)((((long)tprev_idx * B + brow) * H + kbeg + 4 * g) * 4);
+#pragma unroll
+        for (int it = 0; it < IPG; ++it)
+            a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 64 * it, 0, 16));
+    };
+    auto poll_until_fresh = [&](int tprev_idx, bool first_trip_issued) {  // flag-less hand-off inside the XCD
+        for (int spins = 0;; ++spins) {
+            if (!(first_trip_issued && spins == 0)) {
+                asm volatile("" ::: "memory");  // every trip re-issues its loads
+                issue_poll(tprev_idx);
+            }
+            bool stale = false;
+#pragma unroll
+            for (int it = 0; it < IPG; ++it) stale |= has_sentinel(a[it]);
+            if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+        }
+    };
+    auto recurrent = [&](f32x4 (&acc)[3], f32x4& acc_hn) {  // r and z share accumulators with the input product
+#pragma unroll
+        for (int it = 0; it < IPG; ++it)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const float4 w = wh[it][n];
+                f32x4& dst = n == 2 ? acc_hn : acc[n];
+                dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, dst, 0, 0, 0);
+            }
+    };
+    // reduce over the four waves, gates, publish: everything after the step's MFMAs.  `report`: tell the layer above
+    // that the PREVIOUS step is out (every thread of the block has consumed loads it issued after those stores: they
+    // are acknowledged -- vmcnt is one in-order queue)
+    auto finish = [&](int t, const f32x4 (&acc)[3], const f32x4& acc_hn, float e_ai_r, float e_ai_z, float e_ai_n,
+                      bool report) {
+        float* rd = red + (t & 1) * 4096;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (g * 4 + r) * 16 + i;
+            rd[(wave * 4 + 0) * 256 + o] = acc[0][r];
+            rd[(wave * 4 + 1) * 256 + o] = acc[1][r];
+            rd[(wave * 4 + 2) * 256 + o] = acc[2][r];
+            rd[(wave * 4 + 3) * 256 + o] = acc_hn[r];
+        }
+        __syncthreads();
+        if (report && tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float sr = 0.f, sz = 0.f, sin_ = 0.f, shn = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sr += rd[(w * 4 + 0) * 256 + tid];
+            sz += rd[(w * 4 + 1) * 256 + tid];
+            sin_ += rd[(w * 4 + 2) * 256 + tid];
+            shn += rd[(w * 4 + 3) * 256 + tid];
+        }
+        const float r = sigmoidf_(e_ai_r + sr + e_br);
+        const float z = sigmoidf_(e_ai_z + sz + e_bz);
+        const float q = shn + e_bn;
+        const float n = tanhf(e_ai_n + sin_ + r * q);
+        const float h = (1.0f - z) * n + z * hp;
+        __hip_atomic_store(p_h + (long)t * s_h, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+        if (DROP)  // what the layer above reads, written through like h and AFTER it (the own layer's next step waits for h)
+            __hip_atomic_store(p_hd + (long)t * s_hd,
+                               h * sa_drop_factor(drop, drop_stream, (uint64_t)((long)t * hs_t + drop_idx0)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (STASH) {  // streaming stores: the stash must not push anything out of the XCD's L2
+            float* st = p_st + (long)t * s_st;
+            __builtin_nontemporal_store(r, st);
+            __builtin_nontemporal_store(z, st + so);
+            __builtin_nontemporal_store(n, st + 2 * so);
+            __builtin_nontemporal_store(q, st + 3 * so);
+            __builtin_nontemporal_store(hp, st + 4 * so);
+        }
+        hp = h;
+    };
+
+    if (l == 0) {
+        // ---- layer 0: its input projection is one GEMM before the launch (ai0)
+        const float* p_ai = P.ai0 + (long)(live ? b : 0) * P.rb * 3 * H + u;
+        const long s_ai = (long)P.rt * 3 * H;
+        float nx_r, nx_z, nx_n;  // the values of the step about to be processed, requested a step ago
+        auto fetch_ai = [&](int tt) { const float* q = p_ai + (long)tt * s_ai; nx_r = q[0]; nx_z = q[H]; nx_n = q[2 * H]; };
+        fetch_ai(0);
+        if (T > 0) {  // t = 0 (peeled: no recurrent phase, nobody to wait for)
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+            finish(0, acc, acc_hn, e_r, e_z, e_n, false);
+            fetch_ai(T > 1 ? 1 : 0);
+            SA_TICK(3)
+        }
+        for (int t = 1; t < T; ++t) {
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+            SA_TICK(0)
+            poll_until_fresh(t - 1, false);
+            SA_TICK(1)
+            // the next step's values (HBM): requested behind the poll -- in front of it they would hold the poll's data
+            // back (one in-order queue), at the end of the step they would hold the NEXT poll's back
+            fetch_ai(t + 1 < T ? t + 1 : t);  // (the last step re-reads its own: unused)
+            __builtin_amdgcn_sched_barrier(0);
+            recurrent(acc, acc_hn);
+            SA_TICK(2)
+            finish(t, acc, acc_hn, e_r, e_z, e_n, true);
+            SA_TICK(3)
+        }
+    } else {
+        // ---- layers >= 1: the input projection W_ih h_{l-1}[t] is formed in the kernel, on rows fetched a step ago
+        const float bi_r = P.b_ih[l][u], bi_z = P.b_ih[l][H + u], bi_n = P.b_ih[l][2 * H + u];
+        const float* lower = (DROP && P.h_drop[l - 1]) ? P.h_drop[l - 1] : P.h_out[l - 1];
+        __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)lower, 0, 0x7fffffff, 0x00020000);
+        const unsigned* lower_prog = P.prog + (l - 1) * P.nbt_all + role_y;
+        unsigned avail = 0;        // steps of the lower layer known to be published
+        unsigned cnt_pending = 0;  // the arrival counter as requested a step ago
+        float4 wn[IPG][3];         // W_ih fragments, resident like W_hh
+#pragma unroll
+        for (int it = 0; it < IPG; ++it)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                wn[it][n] = *reinterpret_cast<const float4*>(P.w_ih[l] + (long)(n * H + u0 + i) * H + kbeg + 16 * it + 4 * g);
+        f32x4v an[IPG];            // the lower layer's rows of the step about to be processed
+        auto wait_lower = [&](int tt) {  // the lower layer has published step tt (every wave polls for itself)
+            if (avail >= (unsigned)(tt + 1)) return;
+            int spins = 0;
+            unsigned c;
+            while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NTU * (unsigned)(tt + 1)) {
+                if (++spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+            }
+            avail = c / (unsigned)NTU;
+        };
+        auto issue_rows = [&](int tt) {  // from memory (another XCD wrote them through): slow, read once
+            const int abase = (int)((((long)tt * B + brow) * H + kbeg + 4 * g) * 4);
+#pragma unroll
+            for (int it = 0; it < IPG; ++it)
+                an[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(lres, abase + 64 * it, 0, 16 | 2));  // sc1 + nt
+        };
+        auto mfma_input = [&](f32x4 (&acc)[3], int lo, int hi) {
+#pragma unroll
+            for (int it = 0; it < IPG; ++it)
+                if (it >= lo && it < hi)
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].x, wn[it][n].x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].y, wn[it][n].y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].z, wn[it][n].z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].w, wn[it][n].w, acc[n], 0, 0, 0);
+                    }
+        };
+        if (T > 0) {
+            wait_lower(0);
+            issue_rows(0);
+            // t = 0 (peeled: no recurrent phase)
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mfma_input(acc, 0, IPG);
+            SA_TICK(0)
+            const int t1 = T > 1 ? 1 : 0;
+            wait_lower(t1);
+            issue_rows(t1);
+            cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            SA_TICK(2)
+            finish(0, acc, acc_hn, bi_r, bi_z, bi_n, false);
+            SA_TICK(3)
+        }
+        // Order of the vector-memory operations of a step (one in-order queue): [input MFMAs on rows fetched a step ago,
+        // the first polling trip issued part-way through] -> [trip examined; re-polled until fresh] -> [the counter value
+        // requested a step ago is consumed, the rows of step t+1 and the counter are requested: the slow loads go out
+        // only now, behind the poll] -> [recurrent MFMAs, reduce, gates, publish].
+        for (int t = 1; t < T; ++t) {
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mfma_input(acc, 0, kPollIt);
+            if (kPollIt < IPG) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_poll(t - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_input(acc, kPollIt, IPG);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            SA_TICK(0)
+            poll_until_fresh(t - 1, kPollIt < IPG);
+            SA_TICK(1)
+            {
+                asm volatile("" : "+v"(cnt_pending) :: "memory");  // consumed HERE, not where it was loaded
+                const unsigned got = cnt_pending / (unsigned)NTU;
+                if (got > avail) avail = got;
+                const int tn = t + 1 < T ? t + 1 : t;  // (the last step re-reads its own rows: unused)
+                wait_lower(tn);  // almost always satisfied by the value requested a step ago
+                issue_rows(tn);
+                cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_sched_barrier(0);  // requested BEFORE the recurrent MFMAs (hipcc sinks them below otherwise)
+            }
+            recurrent(acc, acc_hn);
+            SA_TICK(2)
+            finish(t, acc, acc_hn, bi_r, bi_z, bi_n, true);
+            SA_TICK(3)
+        }
+    }
+    if (TIMED && timed) {
+        unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y - P.bt0) * NTU + role_x);
         for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
     }
 #undef SA_TICK
@@ -1360,13 +1660,9 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             // holes a reader could wait on).  Consecutive threads, consecutive addresses: 1 KB per store instruction.
             float* xp = p_xs + (long)(ring ? (t & (kXRing - 1)) : t) * s_x;
             const float third = FUSE ? dpn : dqn;
-            if (packed) {  // plain stores: the XCD's own L2 is where the group meets, nothing needs to reach memory
-                xp[0] = dpr; xp[(H / 16) * 256] = dpz; xp[2 * (H / 16) * 256] = third;
-            } else {
-                __hip_atomic_store(xp, dpr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
-                __hip_atomic_store(xp + (H / 16) * 256, dpz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(xp + 2 * (H / 16) * 256, third, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // plain stores: the XCD's own L2 is where the group meets, nothing needs to reach memory (a write-through
+            // variant behind `if (!packed)` was dead code since round 3 -- and its join cost a vmcnt(0) here)
+            xp[0] = dpr; xp[(H / 16) * 256] = dpz; xp[2 * (H / 16) * 256] = third;
         }
         {
             // ring: this step's gather found every block's tile of time t - dt, so every block had finished gathering time
@@ -1861,6 +2157,7 @@ extern "C" ctcStatus_t sa_gru_health_flag(float* d_flag, void* stream_) {
 }
 
 constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
+constexpr size_t kFwdDumpBytes = (size_t)256 * 256 * sizeof(float);  // gru_fwd_fused_kernel: where predicated-off stores go
 
 static int device_cus() {
     static int cus_of[kMaxDevices] = {0};
@@ -1997,6 +2294,33 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg
 }
 // the backward kernel has a form that packs the weight gradients' operands itself (PACKG / PACKK) for these widths
 static bool packg_available(int H, bool fuse) { return H == 512 || H == 256 || (fuse && H == 128); }
+typedef void (*FusedFwdFn)(PFusedFwd);
+// gru_fwd_fused_kernel<IPG, POLL_AT, STASH, DROP, TIMED> for H = 64 IPG (null: no such instance)
+template <int IPG, int POLL_AT>
+static FusedFwdFn fused_fwd_pick(bool stash, bool drop, bool timed) {
+    if (timed) return stash && !drop ? gru_fwd_fused_kernel<IPG, POLL_AT, true, false, true> : nullptr;
+    if (stash) return drop ? gru_fwd_fused_kernel<IPG, POLL_AT, true, true, false> : gru_fwd_fused_kernel<IPG, POLL_AT, true, false, false>;
+    return drop ? gru_fwd_fused_kernel<IPG, POLL_AT, false, true, false> : gru_fwd_fused_kernel<IPG, POLL_AT, false, false, false>;
+}
+static FusedFwdFn fused_fwd_fn(int H, int poll_at, bool stash, bool drop, bool timed) {
+    if (H == 512) {
+        if (poll_at == 6) return fused_fwd_pick<8, 6>(stash, drop, timed);
+        if (poll_at == 5) return fused_fwd_pick<8, 5>(stash, drop, timed);
+        if (poll_at == 4) return fused_fwd_pick<8, 4>(stash, drop, timed);
+        if (poll_at == 3) return fused_fwd_pick<8, 3>(stash, drop, timed);
+        if (poll_at == 2) return fused_fwd_pick<8, 2>(stash, drop, timed);
+        return fused_fwd_pick<8, 8>(stash, drop, timed);
+    }
+    switch (H / 64) {
+        case 7: return fused_fwd_pick<7, 8>(stash, drop, timed);
+        case 6: return fused_fwd_pick<6, 8>(stash, drop, timed);
+        case 5: return fused_fwd_pick<5, 8>(stash, drop, timed);
+        case 4: return fused_fwd_pick<4, 8>(stash, drop, timed);
+        case 3: return fused_fwd_pick<3, 8>(stash, drop, timed);
+        case 2: return fused_fwd_pick<2, 8>(stash, drop, timed);
+    }
+    return nullptr;
+}
 static int persist_prio() { return 1; }  // the recurrence waves issue at raised priority (s_setprio 3)
 
 static int clamp_chunk(int chunk, int T) {
@@ -2024,23 +2348,36 @@ static int persistent_chunk(int L, int B, int T, int H) {
     return best > T ? T : best;
 }
 static size_t stack_gemm_ws(int L, int B, int T, int H, int chunk, bool fwd) {
-    // split-K workspace of the grouped per-chunk projections (up to L-1 problems per launch)
+    // workspace of the grouped per-chunk projections.  A launch carries 1 .. L-1 problems (fill / drain of the layer
+    // wavefront, a ragged last chunk on its own) and the split-K factor -- hence the bytes -- is NOT monotone in the
+    // problem count, so every count is priced (a split-bf16 product without room for its operands is an error
+    // now, not a silent fall-back to the exact kernel).
     const int c = clamp_chunk(chunk, T);
-    const size_t w = fwd ? sa_gemm_group_workspace_bytes(L > 1 ? L - 1 : 1, c * B, 3 * H, H)
-                         : sa_gemm_group_workspace_bytes(L > 1 ? L - 1 : 1, c * B, H, 3 * H);
+    size_t w = 0;
+    for (int np = 1; np <= (L > 1 ? L - 1 : 1); ++np) {
+        const size_t v = fwd ? sa_gemm_group_workspace_bytes(np, c * B, 3 * H, H)
+                             : sa_gemm_group_workspace_bytes(np, c * B, H, 3 * H);
+        if (v > w) w = v;
+    }
     return sa_align_up(w, 256);
+}
+// ... over every chunk length a call can use (the default is 24 .. 40 steps, callers may pass 1 .. 64, the last chunk of
+// a sequence is whatever is left)
+static size_t stack_gemm_ws_max(int L, int B, int T, int H, bool fwd) {
+    size_t gw = 0;
+    for (int c = 1; c <= 64; ++c) { const size_t w = stack_gemm_ws(L, B, T, H, c, fwd); if (w > gw) gw = w; }
+    return gw;
 }
 
 extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, int H, int I0) {
     if (L <= 0 || D <= 0 || B <= 0 || T <= 0 || H <= 0 || I0 <= 0) return 0;
-    size_t gw = 0;
-    for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, true); if (w > gw) gw = w; }
+    size_t gw = stack_gemm_ws_max(L, B, T, H, true);
     // the whole-layer input projections (layer 0 of a unidirectional stack; every layer of a bidirectional one, both
     // directions grouped): the packed split-bf16 copies of their operands live here (gemm_f32.hip)
     const int Imax = I0 > D * H ? I0 : D * H;
     const size_t pw = sa_align_up(sa_gemm_group_workspace_bytes(D, T * B, 3 * H, D == 1 ? I0 : Imax), 256);
     if (pw > gw) gw = pw;
-    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + kSyncBytes;
+    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + kFwdDumpBytes + kSyncBytes;
 }
 
 namespace {
@@ -2080,7 +2417,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
-    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kSyncBytes;
+    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kFwdDumpBytes - kSyncBytes;
     unsigned* sync = (unsigned*)((char*)workspace + workspace_bytes - kSyncBytes);
     const long DH = (long)D * H;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -2239,15 +2576,25 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             fills.add(sync, 1024 / 4, 0u);
             fills.flush();
             if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
-            if (hipFuncSetAttribute((const void*)gru_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            const bool timing_on = getenv("SA_GRU_TIMING") != nullptr;
+            FusedFwdFn fused_fn = nullptr;
+            {
+                const char* r4 = getenv("SA_GRU_FWD_R4");  // round-5 A/B: the run-time-width kernel of rounds 1-4
+                const char* pa = getenv("SA_GRU_FWD_POLLAT");
+                if (r4 && r4[0] == '1') fused_fn = gru_fwd_fused_r4_kernel;
+                else fused_fn = fused_fwd_fn(H, pa ? atoi(pa) : 8, stash != nullptr, drop_on, timing_on);
+                if (!fused_fn) fused_fn = gru_fwd_fused_r4_kernel;
+            }
+            if (hipFuncSetAttribute((const void*)fused_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)flds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
             PFusedFwd Q;
             Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
             Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
             Q.stamp = g_prof.slot(0, true, false, T);
-            Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;
+            Q.timing = timing_on ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
             Q.drop = dc.drop; Q.drop_stream0 = dc.stream0;
             for (int l = 0; l < kMaxJobs; ++l) Q.h_drop[l] = nullptr;
             for (int l = 0; l < L; ++l) {
@@ -2261,7 +2608,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
                 Q.reg_base = launches++ * 32u;
                 if (bt0 > 0) Q.stamp = nullptr;
-                hipLaunchKernelGGL(gru_fwd_fused_kernel, dim3(256), dim3(256), flds, stream, Q);
+                hipLaunchKernelGGL(fused_fn, dim3(256), dim3(256), flds, stream, Q);
             }
             SA_CHECK_LAUNCH();
             g_health.submit(stream);
@@ -2475,8 +2822,7 @@ extern "C" size_t sa_gru_stack_bwd_workspace_bytes(int L, int D, int B, int T, i
                            sa_align_up((size_t)3 * H * H * sizeof(float), 256);       // W_hh^T
     const size_t mid = sa_align_up(((size_t)T * B + 128) * D * H * sizeof(float), 256);  // d h_out of a lower layer (+ one
                                                                                           // row block: chunked products end on whole blocks)
-    size_t gw = 0;
-    for (int c = 1; c <= 64; c *= 2) { const size_t w = stack_gemm_ws(L, B, T, H, c, false); if (w > gw) gw = w; }
+    size_t gw = stack_gemm_ws_max(L, B, T, H, false);
     {   // the whole-sequence input-gradient products (d x of layer 0; every layer of a bidirectional stack): packed copies
         const size_t a = sa_align_up(sa_gemm_group_workspace_bytes(1, T * B, I0, 3 * H), 256);
         const size_t b = D == 2 ? sa_align_up(sa_gemm_group_workspace_bytes(1, T * B, 2 * H, 3 * H), 256) : 0;

@@ -1087,8 +1087,10 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
 // =====================================================================================================================
 namespace {
 
-constexpr int kBeamMaxW = 32;       // beam_size limit (reference default 10)
-constexpr int kBeamMaxCand = 8192;  // beam_size * K limit: the candidates' scores sit in LDS as doubles (64 KB)
+constexpr int kBeamMaxW = 64;       // beam_size limit: the selection kernel gives every live hypothesis one lane of a
+                                    // wave (the reference's default is 10; it takes any width)
+constexpr int kBeamLdsCand = 8192;  // up to this many candidates (beam_size * classes) their scores sit in LDS as doubles
+                                    // (64 KB); beyond it -- a word-piece vocabulary -- in the workspace
 
 struct BeamState {
     int done, n_live, n_complete, steps;
@@ -1111,6 +1113,7 @@ struct BeamBufs {
     float* ix;            // (W, E) next token's GRU input: embedding + context
     const float* emb;     // (V, E)
     int W, K, T, H, E, end_tok, step, max_len;
+    double* cand_mem;     // (W, K) candidate scores when they do not fit the LDS budget, else null
 };
 
 __global__ void s2s_beam_init_kernel(BeamState* st, float* ix, float* h_prev, const float* __restrict__ emb, int start_tok,
@@ -1128,10 +1131,11 @@ __global__ void s2s_beam_init_kernel(BeamState* st, float* ix, float* h_prev, co
 // does candidate (s, i) come before candidate (e, ei) in the reference's sorted list?
 __device__ __forceinline__ bool beam_precedes(double s, int i, double e, int ei) { return s > e || (s == e && i < ei); }
 
-// one workgroup of 256 threads; dynamic LDS: cand[W * K] doubles
+// one workgroup of 256 threads; dynamic LDS: cand[W * K] doubles (or none, and the scores live in Q.cand_mem: one
+// workgroup reads back what it wrote before a barrier, so plain global memory does)
 __global__ __launch_bounds__(256) void s2s_beam_select_kernel(BeamBufs Q) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* cand = reinterpret_cast<double*>(smem_raw);
+    double* cand = Q.cand_mem ? Q.cand_mem : reinterpret_cast<double*>(smem_raw);
     __shared__ double ends[kBeamMaxW], sel_s[kBeamMaxW], comp_s[kBeamMaxW];
     __shared__ int sel_i[kBeamMaxW], comp_r[kBeamMaxW];
     __shared__ int n_new_s;
@@ -1277,7 +1281,7 @@ __global__ void s2s_beam_final_kernel(const BeamState* st, const int* __restrict
     info[1] = st->n_complete;
 }
 
-struct BeamLayout { size_t st, tok, par, ix, hprev, axprev, hx, ax, sx, oin, gi, gh, logits, score, done_host, total; };
+struct BeamLayout { size_t st, tok, par, ix, hprev, axprev, hx, ax, sx, oin, gi, gh, logits, score, cand, done_host, total; };
 
 BeamLayout beam_layout(int T, int H, int E, int K, int W, int max_len) {
     BeamLayout L;
@@ -1290,13 +1294,14 @@ BeamLayout beam_layout(int T, int H, int E, int K, int W, int max_len) {
     L.hx = take((size_t)W * H * f); L.ax = take((size_t)W * T * f); L.sx = take((size_t)W * H * f);
     L.oin = take((size_t)W * H * f); L.gi = take((size_t)W * 3 * H * f); L.gh = take((size_t)W * 3 * H * f);
     L.logits = take((size_t)W * K * f); L.score = take((size_t)W * T * f);
+    L.cand = take((long)W * K > kBeamLdsCand ? (size_t)W * K * sizeof(double) : 0);
     L.total = p;
     return L;
 }
 
 bool beam_ok(int T, int H, int E, int KS, int K, int W, int max_len) {
     S2SDims d{W, T, 1, H, E, KS, K};
-    return s2s_ok(d) && W >= 1 && W <= kBeamMaxW && (long)W * K <= kBeamMaxCand && max_len >= 1;
+    return s2s_ok(d) && W >= 1 && W <= kBeamMaxW && (long)W * K < (1L << 30) && max_len >= 1;
 }
 
 }  // namespace
@@ -1334,7 +1339,9 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
     const float* const* P = params;
     const size_t smem1 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + (size_t)H) * sizeof(float);
     const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
-    const size_t smem3 = (size_t)W * K * sizeof(double);
+    const bool cand_in_lds = (long)W * K <= kBeamLdsCand;
+    const size_t smem3 = cand_in_lds ? (size_t)W * K * sizeof(double) : 0;
+    double* cand_mem = cand_in_lds ? nullptr : (double*)(ws + L.cand);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2) ||
         !att_smem((const void*)s2s_beam_select_kernel, smem3))
         return CTC_STATUS_INVALID_VALUE;
@@ -1351,7 +1358,7 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
         skinny_launch(&q, 1, W, stream);
         BeamBufs Q{st, (int*)(ws + L.tok), (int*)(ws + L.par), logits, hx, ax, sx, hprev, axprev, ix, P[P_EMB],
-                   W, K, T, H, E, end_tok, t, max_len};
+                   W, K, T, H, E, end_tok, t, max_len, cand_mem};
         hipLaunchKernelGGL(s2s_beam_select_kernel, dim3(1), dim3(256), smem3, stream, Q);
         if (check_every > 0 && (t + 1) % check_every == 0 && t + 1 < max_len) {
             int done = 0;
@@ -1398,6 +1405,9 @@ __global__ __launch_bounds__(64) void s2s_greedy_pick_kernel(GreedyState* st, co
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
+    // a row without a finite maximum (all NaN / all -inf: nothing ever compared greater) picks class 0, a valid index
+    // like the one torch.max returns there, rather than reading the embedding 2^31 rows out of bounds
+    if ((unsigned)bi >= (unsigned)K) bi = 0;
     for (int e = lane; e < E; e += 64) ix[(long)b * E + e] = emb[(long)bi * E + e] + sx[(long)b * E + e];  // the next token's input
     if (lane == 0) {
         tokens[(long)b * ncol + step + 1] = bi;

@@ -21,8 +21,6 @@ Deviations from the reference, all supersets:
   * `.volatile` is a dead torch-0.3 flag; set_eval()/infer() run under torch.no_grad() instead.
   * loss() returns a 1-element tensor, so both `loss.data[0]` (train.py:33) and `loss.item()` work.
 """
-import math
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -34,24 +32,28 @@ from .encoder import EncoderFunction, EncoderPlan
 class Model(nn.Module):
 
     def __init__(self, input_dim, config):
+        """model.py:12-42.  The modules built here are PARAMETER CONTAINERS (module docstring): what must match the
+        reference is their order of construction (the initial values under one torch seed) and their positions inside
+        `self.conv` -- [Conv2d, ReLU] per layer, plus a Dropout slot when the config has dropout -- because those
+        positions are the state-dict keys (conv.0.weight, conv.2.weight / conv.3.weight, ..., rnn.weight_ih_l0)."""
         super().__init__()
         self.input_dim = input_dim
         self._ctor_args = (input_dim, config)
-        encoder_cfg = config["encoder"]
-        convs = []
-        in_c = 1
-        for out_c, h, w, s in encoder_cfg["conv"]:
-            convs.extend([nn.Conv2d(in_c, out_c, (h, w), stride=(s, s), padding=0), nn.ReLU()])
-            if config["dropout"] != 0:
-                convs.append(nn.Dropout(p=config["dropout"]))
-            in_c = out_c
-        self.conv = nn.Sequential(*convs)
-        conv_out = out_c * self.conv_out_size(input_dim, 1)
-        assert conv_out > 0, "Convolutional ouptut frequency dimension is negative."
-        rnn_cfg = encoder_cfg["rnn"]
-        self.rnn = nn.GRU(input_size=conv_out, hidden_size=rnn_cfg["dim"], num_layers=rnn_cfg["layers"],
-                          batch_first=True, dropout=config["dropout"], bidirectional=rnn_cfg["bidirectional"])
-        self._encoder_dim = rnn_cfg["dim"]
+        enc, p_drop = config["encoder"], config["dropout"]
+        slots, channels = [], 1
+        for n_filters, k_time, k_freq, stride in enc["conv"]:
+            slots.append(nn.Conv2d(channels, n_filters, (k_time, k_freq), stride=(stride, stride), padding=0))
+            slots.append(nn.ReLU())
+            if p_drop != 0:
+                slots.append(nn.Dropout(p=p_drop))
+            channels = n_filters
+        self.conv = nn.Sequential(*slots)
+        features = channels * self.conv_out_size(input_dim, 1)  # what one frame of the conv output hands to the GRU
+        assert features > 0, "input_dim %d leaves no frequency bins after the conv stack %s" % (input_dim, enc["conv"])
+        rnn = enc["rnn"]
+        self.rnn = nn.GRU(input_size=features, hidden_size=rnn["dim"], num_layers=rnn["layers"], batch_first=True,
+                          dropout=p_drop, bidirectional=rnn["bidirectional"])
+        self._encoder_dim = rnn["dim"]
         self._plan = EncoderPlan(input_dim, config)
         self.volatile = False
         # data-parallel training (speech_amd.dist) describes the GLOBAL batch here so that a rank's shard is padded
@@ -63,12 +65,12 @@ class Model(nn.Module):
 
     # ---- reference API -------------------------------------------------------------------------------------------
     def conv_out_size(self, n, dim):
-        """model.py:44-52"""
-        for c in self.conv.children():
-            if type(c) == nn.Conv2d:
-                k = c.kernel_size[dim]
-                s = c.stride[dim]
-                n = int(math.ceil((n - k + 1) / s))
+        """Length left of `n` input positions along axis `dim` (0 = time, 1 = frequency) after the un-padded conv stack:
+        every layer maps n -> ceil((n - kernel + 1) / stride)  (model.py:44-52)."""
+        for layer in self.conv:
+            if isinstance(layer, nn.Conv2d):
+                span = n - layer.kernel_size[dim] + 1
+                n = -(-span // layer.stride[dim])  # integer ceiling, also for span <= 0
         return n
 
     def forward(self, batch):

@@ -135,7 +135,7 @@ def beam_search(eh, P, log_t, start_tok, end_tok, beam_size, max_len, check_ever
     nbytes = L.sa_s2s_beam_workspace_bytes(T, H, E, KS, K, beam_size, max_len)
     if nbytes == 0:
         raise _lib.SpeechAmdError("Seq2Seq beam search: unsupported shape (embedding_dim == rnn dim, dims % 4 == 0, odd "
-                                  "location kernel <= 15 taps, beam_size <= 32, beam_size * classes <= 8192)")
+                                  "location kernel <= 15 taps, beam_size <= 64)")
     ws = _lib.WORKSPACE.get(nbytes, eh.device, "s2s_beam")
     # one result record: [hyp (max_len + 1) int64 | score double | len, steps, n_complete, pad int32]
     rec = torch.empty(max_len + 1 + 1 + 2, dtype=torch.int64, device=eh.device)

@@ -179,6 +179,43 @@ def test_device_beam_search_equals_restatement_on_other_shapes():
             assert abs(m.last_beam_score - score) < 1e-4 and list(m.last_beam_info) == [info["steps"], info["n_complete"]]
 
 
+def test_device_beam_search_takes_wide_beams_and_word_piece_vocabularies():
+    """the reference's beam_search takes any beam width and vocabulary (seq2seq.py:180); the device search
+    kept the candidates' scores in 64 KB of LDS and refused beam_size > 32 or beam_size * classes > 8192 -- a word-piece
+    vocabulary of 1000 with the default beam of 10 raised.  Now: a lane per live hypothesis (beam_size <= 64) and the
+    candidate scores in the workspace beyond the LDS budget.  Against oracle/seq2seq_beam_ref.py."""
+    from oracle import seq2seq_beam_ref as R
+    from speech_amd.models import Seq2Seq
+    for seed, dim, vocab, beams, fc_scale in ((11, 32, 1000, (10, 12), 40.0), (12, 32, 40, (33, 40, 64), 25.0)):
+        cfg = {"dropout": 0.0, "encoder": {"conv": [[4, 5, 9, 2]], "rnn": {"dim": dim, "bidirectional": False, "layers": 1}},
+               "decoder": {"embedding_dim": dim, "layers": 1, "log_t": True}}
+        torch.manual_seed(seed)
+        ref = torch_ref.TorchRefSeq2Seq(20, vocab + 1, cfg)
+        with torch.no_grad():
+            ref.fc.fc.weight.mul_(fc_scale)
+            ref.fc.fc.bias.mul_(fc_scale)
+        ref.eval()
+        m = Seq2Seq(20, vocab + 1, cfg)
+        m.load_state_dict(ref.state_dict())
+        m = m.cuda()
+        m.set_eval()
+        x = np.random.RandomState(seed).randn(90, 20).astype(np.float32)
+        with torch.no_grad():
+            enc = ref.encode(torch.from_numpy(x)[None])
+        checked = 0
+        for beam in beams:
+            want, score, info = R.beam_search(R.torch_step_fn(ref, enc), vocab, vocab - 1, beam, 12)
+            got = m.beam_search(((x,), ([vocab, 0, vocab - 1],)), beam_size=beam, max_len=12)[0]
+            if info["min_margin"] < 2e-5:
+                continue   # a cut inside fp32 noise: the winner is not defined at this precision
+            checked += 1
+            assert got == want, (seed, beam, got, want, info)
+            assert abs(m.last_beam_score - score) < 1e-4 and list(m.last_beam_info) == [info["steps"], info["n_complete"]]
+        assert checked > 0, (seed, "every case fell inside fp32 noise: pick another seed")
+    with pytest.raises(Exception):  # beyond a wave's 64 lanes: a clear error, not a wrong search
+        m.beam_search(((x,), ([vocab, 0, vocab - 1],)), beam_size=65, max_len=4)
+
+
 def test_scheduled_sampling_consumes_the_rng_like_the_reference_and_trains():
     g = fixture()
     cfg = dict(CFG, decoder=dict(CFG["decoder"], sample_prob=0.5))
