@@ -480,286 +480,34 @@ struct PFusedFwd {
     unsigned long long* stamp;
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
     float* dump;                 // 256 x 256 floats nobody reads: where the stores of rows beyond the batch go
+    int report_every;            // a layer's blocks report progress to the layer above every so many steps (power of two)
 };
 
-__global__ __launch_bounds__(256) void gru_fwd_fused_r4_kernel(PFusedFwd P) {
-    extern __shared__ __attribute__((aligned(16))) float psm[];
-    __shared__ int s_role[2];
-    SA_PERSIST_EXCLUSIVE(P.prio);
-    if (threadIdx.x == 0) {
-        const int x = xcc_id();
-        s_role[0] = x;
-        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
-    }
-    __syncthreads();
-    if (s_role[1] < 0 || s_role[1] >= 32) {
-        if (threadIdx.x == 0) sa_raise(P.err, 2u);
-        return;
-    }
-    const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
-    if (sub >= 32 / P.ntile_u) return;
-    const int role_x = s_role[1] - sub * P.ntile_u, l = grp / P.nbt, role_y = grp - l * P.nbt + P.bt0;
-    if (l >= P.L) return;
-    if ((P.fault & 1) && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
-    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
-    const int H = P.H, B = P.B, T = P.T;
-    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
-    if (stamper) P.stamp[0] = wall_clock64();
-    float* red = psm;             // [2][4 waves][4 sums][256]  (the weights live in registers)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 15, g = lane >> 4;
-    const int u0 = role_x * 16, b0 = role_y * 16;
-    const float* w_hh = P.w_hh[l];
-    const int bi = tid >> 4, uj = tid & 15;
-    const int b = b0 + bi, u = u0 + uj;
-    const bool live = b < B;
-    const float e_br = P.b_hh[l][u], e_bz = P.b_hh[l][H + u], e_bn = P.b_hh[l][2 * H + u];
-    float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;
-    if (l > 0) { bi_r = P.b_ih[l][u]; bi_z = P.b_ih[l][H + u]; bi_n = P.b_ih[l][2 * H + u]; }
-    float* h_out = P.h_out[l];
-    float* stash = P.stash[l];
-    const long hs_t = (long)B * H;
-    const int kslice = H / 4, kbeg = wave * kslice;
-    const int brow = min(b0 + i, B - 1);
-    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)h_out, 0, 0x7fffffff, 0x00020000);
-    // the layer below as THIS layer sees it: its dropped copy when inter-layer dropout is on
-    const float* lower = l > 0 ? (P.h_drop[l - 1] ? P.h_drop[l - 1] : P.h_out[l - 1]) : h_out;
-    __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)lower, 0, 0x7fffffff, 0x00020000);
-    float* h_drop = P.h_drop[l];  // null: the top layer, or no dropout
-    const SaDrop drop = P.drop;
-    const unsigned drop_stream = P.drop_stream0 + (unsigned)l;
-    unsigned* my_prog = P.prog + l * P.nbt_all + role_y;
-    const unsigned* lower_prog = P.prog + (l > 0 ? l - 1 : 0) * P.nbt_all + role_y;
-    const float* w_ih = l > 0 ? P.w_ih[l] : nullptr;
-    unsigned avail = 0;  // steps of the lower layer known to be published
-    float hp = 0.f;
-    __syncthreads();
-
-    // (a) is software-pipelined one step ahead: the loads of step t+1's input (the lower layer's rows out of memory,
-    // the W_ih rows out of L2) are issued BEFORE the recurrent phase of step t and their MFMAs run AFTER step t's h has
-    // been published, i.e. inside the store -> L2 -> load hop every block waits out anyway.
-    f32x4 accg[3];  // input projection of the step about to be processed
-    f32x4v an[8];
-    float4 wn[8][3];
-#pragma unroll
-    for (int n = 0; n < 3; ++n) accg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto wait_lower = [&](int tt) {  // the lower layer has published step tt (every wave polls for itself)
-        if (avail >= (unsigned)(tt + 1)) return;
-        int spins = 0;
-        unsigned c;
-        while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <
-               (unsigned)P.ntile_u * (unsigned)(tt + 1)) {
-            if (++spins > budget) { if (lane == 0) sa_raise(P.err, 1u); budget = 0; break; }
-        }
-        avail = c / (unsigned)P.ntile_u;
-    };
-    // H <= 512: the wave's k-slice is at most 8 iterations of 16
-    auto issue_rows = [&](int tt) {  // the lower layer's rows of step tt: from memory (another XCD wrote them), slow
-        const int abase = (int)((((long)tt * B + brow) * H) * 4);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int k = kbeg + 16 * it + 4 * g;
-            an[it] = 16 * it < kslice
-                         ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(lres, abase + 4 * k, 0, 16 | 2))  // sc1 + nt: read once
-                         : f32x4v{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto issue_weights = [&]() {  // this block's W_ih rows: read-only, resident in the XCD's L2
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int k = kbeg + 16 * it + 4 * g;
-#pragma unroll
-            for (int n = 0; n < 3; ++n)
-                wn[it][n] = 16 * it < kslice ? *reinterpret_cast<const float4*>(w_ih + (long)(n * H + u0 + i) * H + k)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto mfma_input = [&]() {
-#pragma unroll
-        for (int n = 0; n < 3; ++n) accg[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            if (16 * it < kslice) {
-#pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].x, wn[it][n].x, accg[n], 0, 0, 0);
-                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].y, wn[it][n].y, accg[n], 0, 0, 0);
-                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].z, wn[it][n].z, accg[n], 0, 0, 0);
-                    accg[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[it].w, wn[it][n].w, accg[n], 0, 0, 0);
-                }
-            }
-        }
-    };
-    // Order of the VMEM operations matters: vmcnt is one in-order queue, so a slow load (the lower layer's rows, the
-    // arrival counter: both come from memory) issued BEFORE the polling loads of phase (b) would put its latency on
-    // the critical path.  Per step: [W_ih loads, input MFMAs of step t on rows fetched a step ago] -> [(b) poll]
-    // -> [consume the counter value requested a step ago, issue the rows of step t+1, request the counter again]
-    // -> [(b) MFMAs, reduce, gates, publish].
-    unsigned cnt_pending = 0;
-    // The W_ih fragments a lane feeds to its MFMAs are the same every step (3 gates x 8 k-groups x 4 floats = 96
-    // registers): they are loaded ONCE and stay in the register file -- streaming the block's 96 KB slice from L2 every
-    // step measured 3 us per step (32 blocks x 96 KB = 3 MB per step saturate the XCD's L2 read path).
-    if (l > 0) issue_weights();
-    // ... and so are the W_hh fragments (another 96 registers; the file holds 512 per lane at one wave per SIMD), which
-    // takes the 24 LDS reads per step out of the recurrent phase.  LDS keeps only the reduction scratch.
-    float4 wh[8][3];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int k = kbeg + 16 * it + 4 * g;
-#pragma unroll
-        for (int n = 0; n < 3; ++n)
-            wh[it][n] = 16 * it < kslice ? *reinterpret_cast<const float4*>(w_hh + (long)(n * H + u0 + i) * H + k)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (l > 0 && T > 0) { wait_lower(0); issue_rows(0); }
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;  // debug (SA_GRU_TIMING): input / poll / recurrent MFMA / rest
-    const bool timed = P.timing != nullptr && tid == 0;
-    if (timed) tprev = wall_clock64();
-#define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
-
-    for (int t = 0; t < T; ++t) {
-        const long row = (long)(live ? b : 0) * P.rb + (long)t * P.rt;
-        float e_ai_r = bi_r, e_ai_z = bi_z, e_ai_n = bi_n;
-        f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (l == 0) {
-            if (live) {
-                const float* ai = P.ai0 + row * 3 * H;
-                e_ai_r = ai[u]; e_ai_z = ai[H + u]; e_ai_n = ai[2 * H + u];
-            }
-        }
-        if (l > 0) {  // (a) input projection of THIS step: fills the wait for the neighbours' h[t-1]
-            mfma_input();
-#pragma unroll
-            for (int n = 0; n < 3; ++n) acc[n] = accg[n];
-        }
-        SA_TICK(0)
-        const bool prefetch = l > 0 && t + 1 < T;
-        if (t == 0 && prefetch) {  // no recurrent phase at t = 0: do the prefetch bookkeeping here
-            wait_lower(1);
-            issue_rows(1);
-            cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (t > 0) {
-            // (b) own layer's h[t-1]: flag-less poll inside the XCD, W_hh out of LDS; r and z share accumulators with (a)
-            const int abase = (int)((((long)(t - 1) * B + brow) * H) * 4);
-            for (int kk0 = kbeg; kk0 < kbeg + kslice; kk0 += 128) {
-                f32x4v a[8];
-                for (int spins = 0;; ++spins) {
-                    bool stale = false;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int k = kk0 + 16 * it + 4 * g;
-                        a[it] = kk0 + 16 * it < kbeg + kslice
-                                    ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 4 * k, 0, 16))
-                                    : f32x4v{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) stale |= has_sentinel(a[it]);
-                    if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
-                    if (spins > budget) { if (lane == 0) sa_raise(P.err, 1u); budget = 0; break; }
-                }
-                SA_TICK(1)
-                if (prefetch) {  // the slow loads go out only now, behind the poll (H <= 512: this loop runs once)
-                    const unsigned got = cnt_pending / (unsigned)P.ntile_u;
-                    if (got > avail) avail = got;
-                    wait_lower(t + 1);  // almost always satisfied by the value requested a step ago
-                    issue_rows(t + 1);
-                    cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    if (kk0 + 16 * it < kbeg + kslice) {
-#pragma unroll
-                        for (int n = 0; n < 3; ++n) {
-                            const float4 w = wh[it][n];
-                            f32x4& dst = n == 2 ? acc_hn : acc[n];
-                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, dst, 0, 0, 0);
-                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, dst, 0, 0, 0);
-                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, dst, 0, 0, 0);
-                            dst = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, dst, 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        SA_TICK(2)
-        float* rd = red + (t & 1) * 4096;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = (g * 4 + r) * 16 + i;
-            rd[(wave * 4 + 0) * 256 + o] = acc[0][r];
-            rd[(wave * 4 + 1) * 256 + o] = acc[1][r];
-            rd[(wave * 4 + 2) * 256 + o] = acc[2][r];
-            rd[(wave * 4 + 3) * 256 + o] = acc_hn[r];
-        }
-        // vmcnt is one in-order queue for loads and stores on gfx9: every thread has just consumed loads it issued
-        // AFTER its stores of step t-1 (the poll of phase (b)), so those stores are acknowledged; after the barrier
-        // that holds for the whole block, which can report step t-1 to the layer above without waiting for anything.
-        __syncthreads();
-        if (t > 0 && tid == 0)
-            __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float sr = 0.f, sz = 0.f, sin_ = 0.f, shn = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            sr += rd[(w * 4 + 0) * 256 + tid];
-            sz += rd[(w * 4 + 1) * 256 + tid];
-            sin_ += rd[(w * 4 + 2) * 256 + tid];
-            shn += rd[(w * 4 + 3) * 256 + tid];
-        }
-        if (live) {
-            const float r = sigmoidf_(e_ai_r + sr + e_br);
-            const float z = sigmoidf_(e_ai_z + sz + e_bz);
-            const float q = shn + e_bn;
-            const float n = tanhf(e_ai_n + sin_ + r * q);
-            const float h = (1.0f - z) * n + z * hp;
-            __hip_atomic_store(h_out + (long)t * hs_t + (long)b * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // what the layer above reads: written through like h (another XCD picks it up once `prog` says so), AFTER
-            // h -- the own layer's next step waits for h, the layer above trails a step behind anyway
-            if (h_drop)
-                __hip_atomic_store(h_drop + (long)t * hs_t + (long)b * H + u,
-                                   h * sa_drop_factor(drop, drop_stream, (uint64_t)((long)t * hs_t + (long)b * H + u)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (stash) {  // streaming stores: the stash must not push the W_ih rows out of the XCD's L2
-                float* st = stash + row * 5 * H;
-                __builtin_nontemporal_store(r, st + u);
-                __builtin_nontemporal_store(z, st + H + u);
-                __builtin_nontemporal_store(n, st + 2 * H + u);
-                __builtin_nontemporal_store(q, st + 3 * H + u);
-                __builtin_nontemporal_store(hp, st + 4 * H + u);
-            }
-            hp = h;
-        }
-        SA_TICK(3)
-    }
-    if (timed) {
-        unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y - P.bt0) * P.ntile_u + role_x);
-        for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
-    }
-#undef SA_TICK
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
-}
-
-// ------------------------------------------------------------------- fused forward layer wavefront, round 5
-// The same algorithm as gru_fwd_fused_r4_kernel with everything the compiler needs to know at compile time known:
+// Round 5: what the comment above describes is now also what the ISA does.
 //   * H = 64 IPG is a template parameter.  With a run-time width every k-group of every product sat under its own
 //     uniform branch (`16 it < kslice`), and hipcc's wait-count insertion has to assume the path on which NONE of the
-//     younger loads was issued: the ISA of rounds 1-4 waits vmcnt(0) at the top of every step (i.e. for the
+//     younger loads was issued: the kernel of rounds 1-4 waited vmcnt(0) at the top of every step (i.e. for the
 //     acknowledgement of the step's own write-through stores) and again right after the lower layer's rows of step t+1
-//     have been requested (i.e. for a memory round trip to another XCD) -- the software pipeline of the comment above
-//     existed in the source only.  Now the wave waits for exactly the loads it is about to use.
+//     had been requested (a memory round trip to another XCD) -- the software pipeline existed in the source only.
+//     (A second cause, found on the way: sa_raise's host-visible word was reached through a generic pointer, a
+//     flat_atomic_or, and ONE possibly-pending FLAT instruction in a loop turns every vmcnt wait behind it into
+//     vmcnt(0); common.h now casts to the global address space.)
 //   * no branch around a vector-memory instruction inside the loop: t = 0 is peeled, the prefetch of the last step is
-//     clamped, layer 0 and the upper layers run two separate loop bodies (LOWER), rows beyond the batch store to a dump
-//     slot, stash / dropout are template parameters.
+//     clamped, layer 0 and the upper layers run two separate loop bodies, rows beyond the batch store to a dump slot,
+//     stash / dropout are template parameters.
 //   * POLL_AT (eighths of the step's input MFMAs): the first polling trip for the own layer's h[t-1] is issued after
 //     that share of the input product and examined after all of it -- its L2 round trip runs under the remaining input
-//     MFMAs instead of behind them (8: issued after the product, rounds 1-4).
+//     MFMAs instead of behind them.  4 measured best at S-LIBRI (3 / 4 / 5 / 6 / 8: 2.21 / 2.22 / 2.30 / 2.39 / 2.60 ms
+//     per stack forward); earlier and the trip comes back stale, later and its latency is exposed.
 //   * layer 0's three input-projection values are requested during the PREVIOUS step, behind its poll (they came from
 //     HBM at the top of their own step, in front of the poll, in the in-order vector-memory queue).
+//   * progress is reported to the layer above every `report_every` steps (4), that many at a time.  THIS was the
+//     cross-layer coupling rounds 3-4 could not find (they thinned out the READS of the counter; the cost is the 32
+//     memory-side read-modify-writes per layer and step on a line that 128 waves of the layer above poll): with a
+//     report every step the issue of the next vector-memory instruction of the reporting wave stalls ~0.8 us per step
+//     at L = 4 (in-kernel clocks, tools/gru_fused_timing.py) -- 1 / 2 / 4 / 8 / 16 steps per report: 2.69 / 2.18 / 2.22 /
+//     2.27 / 2.37 ms per stack forward (the consumer trails by up to that many steps more: (L - 1) reports of fill).
+// Bit-identical to the kernel of rounds 1-4 (same products in the same order), 2.93 -> 2.22 ms per S-LIBRI stack forward.
 template <int IPG, int POLL_AT, bool STASH, bool DROP, bool TIMED>
 __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     constexpr int H = 64 * IPG, NTU = H / 16, KS = 16 * IPG;
@@ -813,6 +561,8 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     const SaDrop drop = P.drop;
     const unsigned drop_stream = P.drop_stream0 + (unsigned)l;
     const long drop_idx0 = (long)(live ? b : 0) * H + u;
+    const int rep_tid = 0;
+    const int exp_every = P.report_every;  // a power of two
     float hp = 0.f;
     // the W_hh fragments this lane feeds to its MFMAs: resident in registers for the whole launch
     float4 wh[IPG][3];
@@ -821,9 +571,11 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
 #pragma unroll
         for (int n = 0; n < 3; ++n)
             wh[it][n] = *reinterpret_cast<const float4*>(P.w_hh[l] + (long)(n * H + u0 + i) * H + kbeg + 16 * it + 4 * g);
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;  // TIMED: input / poll / recurrent MFMA / rest
+    // TIMED: input / poll / recurrent MFMA / rest in 10 ns ticks, then shader-clock cycles and wall ticks of the whole loop
+    // (their ratio is the clock the XCD actually ran at), polling trips beyond the first, and blocked waits for the lower layer
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool timed = TIMED && P.timing != nullptr && tid == 0;
-    if (timed) tprev = wall_clock64();
+    if (timed) { tprev = wall_clock64(); tacc[4] = clock64(); tacc[5] = tprev; }
 #define SA_TICK(k) if (TIMED && timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
     __syncthreads();
 
@@ -875,7 +627,12 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
             rd[(wave * 4 + 3) * 256 + o] = acc_hn[r];
         }
         __syncthreads();
-        if (report && tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (exp_every == 1) {
+            if (report && tid == rep_tid) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (report && tid == rep_tid && (t & (exp_every - 1)) == 0)
+                __hip_atomic_fetch_add(my_prog, (unsigned)exp_every, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         float sr = 0.f, sz = 0.f, sin_ = 0.f, shn = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -1008,12 +765,16 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
             mfma_input(acc, 0, kPollIt);
             if (kPollIt < IPG) {
                 __builtin_amdgcn_sched_barrier(0);
+                SA_TICK(0)
                 issue_poll(t - 1);
                 __builtin_amdgcn_sched_barrier(0);
+                SA_TICK(6)
                 mfma_input(acc, kPollIt, IPG);
                 __builtin_amdgcn_sched_barrier(0);
+                SA_TICK(7)
+            } else {
+                SA_TICK(0)
             }
-            SA_TICK(0)
             poll_until_fresh(t - 1, kPollIt < IPG);
             SA_TICK(1)
             {
@@ -1033,13 +794,20 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
         }
     }
     if (TIMED && timed) {
-        unsigned long long* o = P.timing + 4 * ((l * P.nbt + role_y - P.bt0) * NTU + role_x);
-        for (int k = 0; k < 4; ++k) atomicAdd(&o[k], tacc[k]);
+        tacc[4] = clock64() - tacc[4]; tacc[5] = wall_clock64() - tacc[5];
+        unsigned long long* o = P.timing + 8 * ((l * P.nbt + role_y - P.bt0) * NTU + role_x);
+        for (int k = 0; k < 8; ++k) atomicAdd(&o[k], tacc[k]);
     }
 #undef SA_TICK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        // reports so far: steps 1 .. T-1 one each (or, batched, exp_every at every multiple of exp_every below T); the
+        // block ends having reported T steps
+        unsigned done = T > 1 ? (unsigned)(T - 1) : 0u;
+        if (exp_every > 1) done = T > 1 ? (unsigned)(((T - 1) / exp_every) * exp_every) : 0u;
+        __hip_atomic_fetch_add(my_prog, (unsigned)T - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
 
@@ -1397,8 +1165,15 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // consecutive k = the block's 16 units of one gate -- the A operand of the layer's input-gradient product
 // d in = sum over directions of dai W_ih, which runs between this layer's recurrence and the next one's.  Waves 0 .. 2 take
 // {dpr, dpz, dpn} out of the same LDS staging; no row-major copy of dai is left.
-template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false>
+// EARLY (with FUSE; round 5): the gather of the NEXT step is issued half-way through this step's second product, into a
+// second set of fragment registers, and examined at the top of the next step -- its L2 round trip (0.8 - 1.6 us, which used
+// to follow the tail) runs under the tail's remaining MFMAs, as the forward kernel's polling trip does under its input
+// product.  The 96 registers the second set costs are paid for by the W_ih^T fragments: they move to LDS (96 KB at H = 512,
+// every lane reads back exactly the 16 bytes it wrote: conflict-free ds_read_b128, off the critical path) -- 416 + 96 would
+// have been the whole 512-register file.  The loop runs two steps per trip (the two fragment sets swap roles).
+template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false, bool EARLY = false>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
+    static_assert(!EARLY || FUSE, "EARLY overlaps the gather with the second product: FUSE only");
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
     // multiplies.  With it they are {dpr, dpz, dpn} (what W_ih multiplies) and a wave forms dqn = dpn * r itself from
@@ -1433,6 +1208,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     float* red = psm;          // [2][4][256]: the four waves' partial sums of the recurrent product, per step parity
     float* red2 = psm + 2048;  // [2][4][256]: the same for the input-gradient product
     float* pks = psm + 4096;   // PACKG: [2][4 gates][16 units][20]: a step's gate gradients, unit-major (16 used of 20)
+    float4* wxl = reinterpret_cast<float4*>(psm + 4096 + (PACKG ? 2560 : 0));  // EARLY: [3 IPG][256] the lanes' W_ih^T fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int u0 = role_x * 16, b0 = role_y * 16;
@@ -1445,7 +1221,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const int kw = wave * (H / 4) + 4 * g;  // the lane's column offset inside a gate; fragment `it` adds 16 (it % IPG)
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
     // Resident in the register file for the whole launch: the lane's fragments of rows u0 + i of W_hh^T and W_ih^T.
-    float4 wr[NIT], wx[FUSE ? NIT : 1];
+    float4 wr[NIT], wx[(FUSE && !EARLY) ? NIT : 1];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int k = (it / IPG) * H + kw + 16 * (it % IPG);
@@ -1454,13 +1230,16 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             wr[it] = make_float4(wq[0], wq[H], wq[2 * H], wq[3 * H]);
             if constexpr (FUSE) {
                 const float* xq = fuse ? J.w_ih_t + (long)k * H + u0 + i : wq;
-                wx[it] = fuse ? make_float4(xq[0], xq[H], xq[2 * H], xq[3 * H]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 wv = fuse ? make_float4(xq[0], xq[H], xq[2 * H], xq[3 * H]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EARLY) wxl[it * 256 + tid] = wv; else wx[it] = wv;
             }
         } else {
         wr[it] = *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + i) * H3 + k);
-        if constexpr (FUSE)
-            wx[it] = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FUSE) {
+            const float4 wv = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EARLY) wxl[it * 256 + tid] = wv; else wx[it] = wv;
+        }
         }
     }
     // Every address inside the loop is a per-thread base (formed here, once) plus t times a scalar stride.  The job's
@@ -1492,35 +1271,48 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     if (timed) tprev = wall_clock64();
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
     f32x4v a[NITG];  // the gathered row block: rows = the batch tile, this wave's fragments of every exchanged gate
+    f32x4v a2[EARLY ? NITG : 1];  // EARLY: the second set (the next step's rows arrive while this step's are still in use)
     const bool ring = packed >= 2;
-    auto gather = [&](int trow) {  // returns once no fragment holds the sentinel (or the call is lost)
+    auto gather_issue = [&](auto& buf, int trow) {
         const int abase = a0 + (ring ? (trow & (kXRing - 1)) : trow) * (int)(s_x * 4);
-        for (int spins = 0;; ++spins) {
-            asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
 #pragma unroll
-            for (int it = 0; it < NITG; ++it)
-                a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
+        for (int it = 0; it < NITG; ++it)
+            buf[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
+    };
+    auto gather = [&](auto& buf, int trow, bool issued) {  // returns once no fragment holds the sentinel (or the call is lost)
+        for (int spins = 0;; ++spins) {
+            if (!(issued && spins == 0)) {
+                asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
+                gather_issue(buf, trow);
+            }
             bool stale = false;
 #pragma unroll
-            for (int it = 0; it < NITG; ++it) stale |= has_sentinel(a[it]);
+            for (int it = 0; it < NITG; ++it) stale |= has_sentinel(buf[it]);
             if (timed) ++tacc[4];
             if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
             if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
         }
     };
-    auto second = [&](int par) {  // a[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15)
-        // four chains (one per k within a fragment): wherever the scheduler cuts the sequence to slip a memory
-        // instruction in, neighbouring MFMAs stay independent
-        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    // buf[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15), fragments [lo, hi) of the 3 IPG; four
+    // chains (one per k within a fragment): wherever the scheduler cuts the sequence to slip a memory instruction in,
+    // neighbouring MFMAs stay independent
+    f32x4 c0, c1, c2, c3;
+    auto second_part = [&](auto& buf, int lo, int hi) {
+        if (lo == 0) { c0 = f32x4{0.f, 0.f, 0.f, 0.f}; c1 = c0; c2 = c0; c3 = c0; }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const float4 w = wx[FUSE ? it : 0];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, c3, 0, 0, 0);
+            if (it >= lo && it < hi) {
+                float4 w;
+                if constexpr (EARLY) w = wxl[it * 256 + tid]; else w = wx[FUSE ? it : 0];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].x, w.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].y, w.y, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].z, w.z, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].w, w.w, c3, 0, 0, 0);
+            }
         }
+    };
+    auto second_store = [&](int par) {
         float* rd = red2 + par * 1024;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = (c0[rr] + c1[rr]) + (c2[rr] + c3[rr]);
@@ -1612,11 +1404,11 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     }
     fetch(t0);
     int pend_t = -1;  // time index of the input-gradient row whose partial sums wait in red2[(s - 1) & 1]
-    for (int s = 0; s < nsteps; ++s) {
+    auto step = [&](int s, auto& a, auto& nxt) {  // a: this step's gathered rows; nxt (EARLY): where the next step's land
         const int t = t0 + s * dt;
         const bool have_next = t != t_first;
         if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
-            gather(t - dt);
+            gather(a, t - dt, EARLY && s > 0);
             SA_TICK(0)
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // even / odd fragments
 #pragma unroll
@@ -1706,8 +1498,9 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             z_next = z;
         }
         fetch(s + 1 < nsteps ? t + dt : t);  // the next step's operands (the last step re-reads its own: unused)
-        if constexpr (FUSE) {
-            second(s & 1);
+        if constexpr (FUSE && !EARLY) {
+            second_part(a, 0, NIT);
+            second_store(s & 1);
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
@@ -1715,7 +1508,37 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             }
             pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
         }
+        if constexpr (EARLY) {
+            // first half of the second product with the tail's 21 vector-memory instructions dealt out between its
+            // MFMAs; then the NEXT step's gather goes out (the row every block has just published: time t), its 3 IPG
+            // loads dealt out between the second half's MFMAs.  (The last step's early gather serves the product behind
+            // the loop.)
+            second_part(a, 0, NIT / 2);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 vector-memory instruction
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gather_issue(nxt, t);
+            second_part(a, NIT / 2, NIT);
+            second_store(s & 1);
+#pragma unroll
+            for (int k = 0; k < NITG; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 vector-memory READ
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
+        }
         SA_TICK(3)
+    };
+    if constexpr (EARLY) {
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) { step(s, a, a2); step(s + 1, a2, a); }
+        if (s < nsteps) step(s, a, a2);
+    } else {
+        for (int s = 0; s < nsteps; ++s) step(s, a, a);
     }
 #undef SA_TICK
     if (timed) {
@@ -1724,8 +1547,14 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     }
     if (FUSE && fuse) {  // the chunk's last row, published by the step that just ended
         const int tl = t0 + (nsteps - 1) * dt;
-        gather(tl);
-        second(nsteps & 1);
+        if constexpr (EARLY) {  // (requested by the last step, into the set that step did not use)
+            if (nsteps & 1) { gather(a2, tl, nsteps > 0); second_part(a2, 0, NIT); }
+            else { gather(a, tl, nsteps > 0); second_part(a, 0, NIT); }
+        } else {
+            gather(a, tl, false);
+            second_part(a, 0, NIT);
+        }
+        second_store(nsteps & 1);
         __syncthreads();
         flush2((nsteps - 1) & 1, pend_t >= 0, pend_t);
         flush2(nsteps & 1, true, tl);
@@ -2156,7 +1985,7 @@ extern "C" ctcStatus_t sa_gru_health_flag(float* d_flag, void* stream_) {
     return CTC_STATUS_SUCCESS;
 }
 
-constexpr size_t kSyncBytes = 16384;  // hand-off counters of the persistent kernels (+ an error word)
+constexpr size_t kSyncBytes = 32768;  // hand-off counters of the persistent kernels (+ an error word)
 constexpr size_t kFwdDumpBytes = (size_t)256 * 256 * sizeof(float);  // gru_fwd_fused_kernel: where predicated-off stores go
 
 static int device_cus() {
@@ -2274,8 +2103,17 @@ static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels
     const char* e = getenv("SA_GRU_TILED");
     return !(e && e[0] == '0');
 }
+static bool bwd_early_enabled() {  // round 5: the next step's gather issued inside the second product (EARLY instances)
+    const char* e = getenv("SA_GRU_BWD_EARLY");
+    return !(e && e[0] == '0');
+}
+static bool bwd_early_available(int H, bool fuse) { return fuse && H == 512 && bwd_early_enabled(); }
 static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
     if (!tiled_enabled()) return nullptr;
+    if (bwd_early_available(H, fuse)) {
+        if (packg) return drop ? gru_bwd_fused_kernel<8, true, true, true, false, true> : gru_bwd_fused_kernel<8, true, false, true, false, true>;
+        return drop ? gru_bwd_fused_kernel<8, true, true, false, false, true> : gru_bwd_fused_kernel<8, true, false, false, false, true>;
+    }
     if (packg && !fuse) {  // bidirectional layers: gate operands and the input-gradient operand
         if (H == 512) return gru_bwd_fused_kernel<8, false, false, true, true>;
         if (H == 256) return gru_bwd_fused_kernel<4, false, false, true, true>;
@@ -2298,26 +2136,20 @@ typedef void (*FusedFwdFn)(PFusedFwd);
 // gru_fwd_fused_kernel<IPG, POLL_AT, STASH, DROP, TIMED> for H = 64 IPG (null: no such instance)
 template <int IPG, int POLL_AT>
 static FusedFwdFn fused_fwd_pick(bool stash, bool drop, bool timed) {
-    if (timed) return stash && !drop ? gru_fwd_fused_kernel<IPG, POLL_AT, true, false, true> : nullptr;
+    if (timed && !drop)  // (the phase clocks exist without dropout only: with it the call runs un-instrumented)
+        return stash ? gru_fwd_fused_kernel<IPG, POLL_AT, true, false, true> : gru_fwd_fused_kernel<IPG, POLL_AT, false, false, true>;
     if (stash) return drop ? gru_fwd_fused_kernel<IPG, POLL_AT, true, true, false> : gru_fwd_fused_kernel<IPG, POLL_AT, true, false, false>;
     return drop ? gru_fwd_fused_kernel<IPG, POLL_AT, false, true, false> : gru_fwd_fused_kernel<IPG, POLL_AT, false, false, false>;
 }
-static FusedFwdFn fused_fwd_fn(int H, int poll_at, bool stash, bool drop, bool timed) {
-    if (H == 512) {
-        if (poll_at == 6) return fused_fwd_pick<8, 6>(stash, drop, timed);
-        if (poll_at == 5) return fused_fwd_pick<8, 5>(stash, drop, timed);
-        if (poll_at == 4) return fused_fwd_pick<8, 4>(stash, drop, timed);
-        if (poll_at == 3) return fused_fwd_pick<8, 3>(stash, drop, timed);
-        if (poll_at == 2) return fused_fwd_pick<8, 2>(stash, drop, timed);
-        return fused_fwd_pick<8, 8>(stash, drop, timed);
-    }
+static FusedFwdFn fused_fwd_fn(int H, bool stash, bool drop, bool timed) {
     switch (H / 64) {
-        case 7: return fused_fwd_pick<7, 8>(stash, drop, timed);
-        case 6: return fused_fwd_pick<6, 8>(stash, drop, timed);
-        case 5: return fused_fwd_pick<5, 8>(stash, drop, timed);
-        case 4: return fused_fwd_pick<4, 8>(stash, drop, timed);
-        case 3: return fused_fwd_pick<3, 8>(stash, drop, timed);
-        case 2: return fused_fwd_pick<2, 8>(stash, drop, timed);
+        case 8: return fused_fwd_pick<8, 4>(stash, drop, timed);
+        case 7: return fused_fwd_pick<7, 4>(stash, drop, timed);
+        case 6: return fused_fwd_pick<6, 4>(stash, drop, timed);
+        case 5: return fused_fwd_pick<5, 4>(stash, drop, timed);
+        case 4: return fused_fwd_pick<4, 4>(stash, drop, timed);
+        case 3: return fused_fwd_pick<3, 4>(stash, drop, timed);
+        case 2: return fused_fwd_pick<2, 4>(stash, drop, timed);
     }
     return nullptr;
 }
@@ -2577,14 +2409,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             fills.flush();
             if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
             const bool timing_on = getenv("SA_GRU_TIMING") != nullptr;
-            FusedFwdFn fused_fn = nullptr;
-            {
-                const char* r4 = getenv("SA_GRU_FWD_R4");  // round-5 A/B: the run-time-width kernel of rounds 1-4
-                const char* pa = getenv("SA_GRU_FWD_POLLAT");
-                if (r4 && r4[0] == '1') fused_fn = gru_fwd_fused_r4_kernel;
-                else fused_fn = fused_fwd_fn(H, pa ? atoi(pa) : 8, stash != nullptr, drop_on, timing_on);
-                if (!fused_fn) fused_fn = gru_fwd_fused_r4_kernel;
-            }
+            FusedFwdFn fused_fn = fused_fwd_fn(H, stash != nullptr, drop_on, timing_on);
+            if (!fused_fn) return CTC_STATUS_INVALID_VALUE;  // (xcd_shape_ok admits H = 128 .. 512 in steps of 64 only)
             if (hipFuncSetAttribute((const void*)fused_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)flds) != hipSuccess)
                 return CTC_STATUS_EXECUTION_FAILED;
@@ -2592,9 +2418,10 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             Q.L = L; Q.B = B; Q.H = H; Q.T = T; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B;
             Q.ai0 = ai_of(0, 0); Q.prog = sync; Q.reg = sync + kSyncReg; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio();
             Q.stamp = g_prof.slot(0, true, false, T);
-            Q.timing = timing_on ? (unsigned long long*)(sync + 256) : nullptr;
-            if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 4 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
+            Q.timing = timing_on && !drop_on ? (unsigned long long*)(sync + 256) : nullptr;
+            if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 8 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;  // (r4 kernel: 4 words per block)
             Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
+            { const char* re = getenv("SA_GRU_FWD_REPORT"); int r = re ? atoi(re) : 4; Q.report_every = (r >= 1 && r <= 64 && (r & (r - 1)) == 0) ? r : 4; }
             Q.drop = dc.drop; Q.drop_stream0 = dc.stream0;
             for (int l = 0; l < kMaxJobs; ++l) Q.h_drop[l] = nullptr;
             for (int l = 0; l < L; ++l) {
@@ -3351,7 +3178,9 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const bool packg = one_launch && wg && (B % 16) == 0 && !(pg_e && pg_e[0] == '0') && packg_available(H, true) &&
                        issuer.shared_ok(spl);
     const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
-    const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
+    // (EARLY instances keep the lanes' W_ih^T fragments in LDS: 3 H / 64 x 256 x 16 bytes behind the PACKG staging slot)
+    const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + 2 * 4 * 16 * 20) * sizeof(float) +
+                                (bwd_early_available(H, fused) ? (size_t)(3 * H / 64) * 256 * 16 : 0));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
     const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed

@@ -20,7 +20,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 ws = _lib.WORKSPACE._bufs[(str(x.device), "gru_stack_bwd")]
 nbytes = _lib.lib().sa_gru_stack_bwd_workspace_bytes(L, D, B, T, H, I0)
-sync = ws[ws.numel() - 16384: ws.numel()].cpu().numpy().view(np.uint64)
+sync = ws[ws.numel() - 32768: ws.numel()].cpu().numpy().view(np.uint64)
 tim = sync[256:256 + 5 * 256].reshape(-1, 5).astype(np.float64)   # sync + 512 uints = 256 u64
 steps = T
 us = tim[:, :4] * 0.01 / steps

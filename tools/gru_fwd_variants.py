@@ -1,6 +1,8 @@
-"""Round-5 A/B of the fused forward recurrence inside ONE process / one box: the run-time-width kernel of rounds 1-4
-(SA_GRU_FWD_R4=1) against gru_fwd_fused_kernel<IPG, POLL_AT, ..> for several POLL_AT, round robin, HIP events over 10
-stack-forward calls each; outputs compared with the r4 kernel's.   python tools/gru_fwd_variants.py [L] [rounds]"""
+"""A/B of the fused forward recurrence inside ONE process / one box: how often a layer reports its progress to the layer
+above (SA_GRU_FWD_REPORT = 1 / 2 / 4 / 8 / 16 steps; 4 is the default), round robin, HIP events over 10 stack-forward calls
+each; outputs compared with the default's bit for bit.   python tools/gru_fwd_variants.py [L] [rounds]
+(The round-5 sweep that also covered the kernel of rounds 1-4 and the position of the first polling trip is recorded in
+profiles/r05_forward_recurrence_experiments.txt.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,11 +16,10 @@ k = 1.0 / H ** 0.5
 w_ih = [torch.empty(3 * H, I0 if l == 0 else H, device="cuda").uniform_(-k, k) for l in range(L)]
 w_hh = [torch.empty(3 * H, H, device="cuda").uniform_(-k, k) for l in range(L)]
 b = [torch.empty(3 * H, device="cuda").uniform_(-k, k) for l in range(L)]
-VARIANTS = [("r4", {"SA_GRU_FWD_R4": "1"})] + [("pollat%d" % p, {"SA_GRU_FWD_POLLAT": str(p)}) for p in (8, 6, 5, 4, 3, 2)]
-
+VARIANTS = [("report%d" % r, {"SA_GRU_FWD_REPORT": str(r)}) for r in (4, 1, 2, 8, 16)]
 
 def run(env, n):
-    for kk in ("SA_GRU_FWD_R4", "SA_GRU_FWD_POLLAT"):
+    for kk in ("SA_GRU_FWD_REPORT",):
         os.environ.pop(kk, None)
     os.environ.update(env)
     out = None
@@ -40,13 +41,13 @@ for r in range(ROUNDS):
     for name, env in VARIANTS:
         ms, (h, st) = run(env, 10)
         times[name].append(ms)
-        if name == "r4" and ref is None:
+        if ref is None:
             ref = ([t.clone() for t in h], [t.clone() for t in st])
         elif r == 0:
             dh = max(float((a - c).abs().max()) for a, c in zip(h, ref[0]))
             ds = max(float((a - c).abs().max()) for a, c in zip(st, ref[1]))
-            print("%-8s max|h - h_r4| = %.3g  max|stash - stash_r4| = %.3g  status %d" % (name, dh, ds, ops.persist_status()), flush=True)
+            print("%-16s max|h - h_ref| = %.3g  max|stash - stash_ref| = %.3g  status %d" % (name, dh, ds, ops.persist_status()), flush=True)
 for name, _ in VARIANTS:
     v = times[name]
-    print("L=%d %-8s %s  min %.3f ms  (%.2f us per time step incl. the layer-0 projection and fills)"
+    print("L=%d %-16s %s  min %.3f ms  (%.2f us per time step incl. the layer-0 projection and fills)"
           % (L, name, " ".join("%.3f" % t for t in v), min(v), min(v) * 1e3 / (T + L - 1)), flush=True)

@@ -15,7 +15,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 ws = _lib.WORKSPACE._bufs[(str(x.device), "gru_stack")]
 nbytes = _lib.lib().sa_gru_stack_fwd_workspace_bytes(L, D, B, T, H, I0)
-sync = ws[ws.numel() - 16384: ws.numel()].cpu().numpy().view(np.uint64)
+sync = ws[ws.numel() - 32768: ws.numel()].cpu().numpy().view(np.uint64)
 tim = sync[128:128 + 4 * 256].reshape(-1, 4).astype(np.float64) * 0.01   # us, 10 ns ticks (sync + 256 uints = 128 u64)
 steps = T  # each block saw ~T steps of its layer in the last call (accumulated over the call's chunks)
 print("per-step us (mean over blocks): wait %.2f  load+mfma %.2f  epilogue %.2f  drain+publish %.2f  | total %.2f" % tuple(list(tim.mean(0) / steps) + [tim.sum(1).mean() / steps]))
