@@ -275,6 +275,14 @@ ctcStatus_t sa_gru_stack_bwd_wgrad_dropout(const float* dh_top, const float* con
                                            void* workspace, size_t workspace_bytes, float p, unsigned long long seed,
                                            unsigned int mask_stream0, void* stream);
 
+/* Opt-in profiler of the CTC loss's serial part (bench.py's `ctc_chain_*` fields): after sa_ctc_profile_configure(1) every
+ * latency-regime call (minibatch < 512: one workgroup per utterance) stamps the device-clock span of its alpha / beta
+ * kernel -- earliest workgroup entry to latest workgroup exit -- into one of 256 slots; sa_ctc_profile_read(i, &us, &T, &B)
+ * copies slot i back (SYNC).  Process-wide state, one device.  Returns 0 / -1. */
+int sa_ctc_profile_configure(int enable);
+int sa_ctc_profile_count(void);
+int sa_ctc_profile_read(int i, double* chain_us, int* T, int* B);
+
 /* Opt-in launch profiler for the stack entry points (bench.py): after sa_gru_profile_configure(1), block 0 of every
  * step launch stamps the 100 MHz wall clock at entry and exit into a device ring (16 K launches).
  * sa_gru_profile_read(kind, &interval_us, &kernel_us) (kind 0 = forward, 1 = backward step kernel; SYNC) returns the

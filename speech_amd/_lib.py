@@ -79,6 +79,9 @@ SIGNATURES = {
     "sa_gru_stack_bwd_workspace_bytes": (c_size_t, [c_int] * 6),
     "sa_gru_stack_bwd": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "sa_gru_stack_bwd_wgrad": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "sa_ctc_profile_configure": (c_int, [c_int]),
+    "sa_ctc_profile_count": (c_int, []),
+    "sa_ctc_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sa_gru_profile_configure": (None, [c_int]),
     "sa_gru_profile_read": (c_int, [c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "sa_gru_profile_steps_per_launch": (c_int, [c_int]),

@@ -179,6 +179,7 @@ struct AbArgs {
     long g_st, g_sb;
     float gscale;         // every gradient element is multiplied by this (the caller's 1 / batch size)
     unsigned long long* dbg;  // debug (SA_CTC_DBG): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
+    unsigned long long* prof; // sa_ctc_profile_*: {earliest workgroup entry, latest workgroup exit} of this launch (100 MHz ticks) or null
 };
 
 // One (direction, chunk) wave over all T steps.  DIR 0 = alpha (time forward), 1 = beta (time backward).
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
 
     const int b = blockIdx.x;
     if (A.gate && A.flags[b] == 0) return;  // the log-domain pass behind a probability-domain one: flagged utterances only
+    if (A.prof && threadIdx.x == 0) atomicMin(A.prof, (unsigned long long)wall_clock64());
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dir = wave / A.nchunks;
@@ -788,6 +790,8 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         if (PROB) A.flags[b] = (dead || sh->suspect) ? 1 : 0;  // every utterance writes its flag (no memset between calls); "infeasible" is
                                               // the log-domain kernels' call
     }
+    if (A.prof && threadIdx.x == 0) atomicMax(A.prof + 1, (unsigned long long)wall_clock64());  // (the chains are done: the
+                                                                                                // hand-over rows below are not chain time)
     if (!PROB && WITH_BETA && A.gate) {  // the hand-over pass: this block also writes the utterance's gradient rows
         __threadfence();                 // the stash, costs and log2 p written above are read back through memory
         __syncthreads();
@@ -1898,6 +1902,43 @@ extern "C" ctcStatus_t sa_scale_by_device_scalar(float* y, size_t n, const float
     return CTC_STATUS_SUCCESS;
 }
 
+// ---- opt-in chain profiler (bench.py): device-clock span of the alpha / beta kernel of every latency-regime call ----
+// After sa_ctc_profile_configure(1) every sa_ctc_loss* call that runs ctc_alphabeta_kernel (B < 512) hands it a slot
+// {earliest workgroup entry, latest workgroup exit} in 100 MHz ticks (atomic min / max: the span of the LAUNCH, not of one
+// workgroup); sa_ctc_profile_read(i, ..) copies slot i back (SYNC) together with the call's T and B.  At most
+// kCtcProfSlots calls are recorded per configure.  Process-wide state, one device (like sa_gru_profile_*).
+namespace {
+constexpr int kCtcProfSlots = 256;
+struct CtcProf {
+    unsigned long long* dev = nullptr;
+    int n = 0, on = 0;
+    int T[kCtcProfSlots], B[kCtcProfSlots];
+} g_ctc_prof;
+}  // namespace
+extern "C" int sa_ctc_profile_configure(int enable) {
+    CtcProf& P = g_ctc_prof;
+    P.on = 0; P.n = 0;
+    if (!enable) return 0;
+    if (!P.dev && hipMalloc((void**)&P.dev, (size_t)kCtcProfSlots * 2 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long init[2 * kCtcProfSlots];
+    for (int i = 0; i < kCtcProfSlots; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    if (hipMemcpy(P.dev, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    P.on = 1;
+    return 0;
+}
+extern "C" int sa_ctc_profile_count(void) { return g_ctc_prof.n; }
+extern "C" int sa_ctc_profile_read(int i, double* chain_us, int* T, int* B) {
+    CtcProf& P = g_ctc_prof;
+    if (!P.dev || i < 0 || i >= P.n || !chain_us) return -1;
+    unsigned long long v[2];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(v, P.dev + 2 * i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    *chain_us = v[1] > v[0] ? (double)(v[1] - v[0]) * 0.01 : 0.0;
+    if (T) *T = P.T[i];
+    if (B) *B = P.B[i];
+    return 0;
+}
+
 namespace {
 ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long stride_b, const int* d_flat_labels,
                           const int* d_label_lengths, const int* d_input_lengths, int alphabet_size, int minibatch,
@@ -1938,6 +1979,7 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
     { const char* fe = getenv("SA_CTC_PROB_FAST"); A.no_fast = fe && fe[0] == '0'; }
     A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b; A.gscale = grad_scale;
     A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
+    A.prof = nullptr;
 
     // K_A (log-softmax into the workspace); only != null: the utterances whose flag is set
     auto launch_ka = [&](const int* only) -> ctcStatus_t {
@@ -2066,9 +2108,14 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
         ctcStatus_t s;
         const dim3 ggrid((max_T + 3) / 4, B);
         const size_t gsmem = 4 * (size_t)(A.Ppad + 1) * sizeof(float);
+        if (g_ctc_prof.on && g_ctc_prof.n < kCtcProfSlots) {  // the first alpha / beta launch of this call is the one stamped
+            CtcProf& Q = g_ctc_prof;
+            A.prof = Q.dev + 2 * Q.n; Q.T[Q.n] = max_T; Q.B[Q.n] = B; ++Q.n;
+        }
         if (prob) {
             if (ab_smem(true) > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
             s = launch_ab_any<true>(A, B, threads, ab_smem(true), true, ab_lds_em(true), stream);
+            A.prof = nullptr;
             if (s != CTC_STATUS_SUCCESS) return s;
             hipLaunchKernelGGL(ctc_grad_kernel<true>, ggrid, dim3(256), gsmem, stream, A, grads, stride_t, stride_b);
             SA_CHECK_LAUNCH();
