@@ -1165,15 +1165,8 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // consecutive k = the block's 16 units of one gate -- the A operand of the layer's input-gradient product
 // d in = sum over directions of dai W_ih, which runs between this layer's recurrence and the next one's.  Waves 0 .. 2 take
 // {dpr, dpz, dpn} out of the same LDS staging; no row-major copy of dai is left.
-// EARLY (with FUSE; round 5): the gather of the NEXT step is issued half-way through this step's second product, into a
-// second set of fragment registers, and examined at the top of the next step -- its L2 round trip (0.8 - 1.6 us, which used
-// to follow the tail) runs under the tail's remaining MFMAs, as the forward kernel's polling trip does under its input
-// product.  The 96 registers the second set costs are paid for by the W_ih^T fragments: they move to LDS (96 KB at H = 512,
-// every lane reads back exactly the 16 bytes it wrote: conflict-free ds_read_b128, off the critical path) -- 416 + 96 would
-// have been the whole 512-register file.  The loop runs two steps per trip (the two fragment sets swap roles).
-template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false, bool EARLY = false>
+template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
-    static_assert(!EARLY || FUSE, "EARLY overlaps the gather with the second product: FUSE only");
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
     // multiplies.  With it they are {dpr, dpz, dpn} (what W_ih multiplies) and a wave forms dqn = dpn * r itself from
@@ -1208,7 +1201,6 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     float* red = psm;          // [2][4][256]: the four waves' partial sums of the recurrent product, per step parity
     float* red2 = psm + 2048;  // [2][4][256]: the same for the input-gradient product
     float* pks = psm + 4096;   // PACKG: [2][4 gates][16 units][20]: a step's gate gradients, unit-major (16 used of 20)
-    float4* wxl = reinterpret_cast<float4*>(psm + 4096 + (PACKG ? 2560 : 0));  // EARLY: [3 IPG][256] the lanes' W_ih^T fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int u0 = role_x * 16, b0 = role_y * 16;
@@ -1221,7 +1213,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     const int kw = wave * (H / 4) + 4 * g;  // the lane's column offset inside a gate; fragment `it` adds 16 (it % IPG)
     __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
     // Resident in the register file for the whole launch: the lane's fragments of rows u0 + i of W_hh^T and W_ih^T.
-    float4 wr[NIT], wx[(FUSE && !EARLY) ? NIT : 1];
+    float4 wr[NIT], wx[FUSE ? NIT : 1];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int k = (it / IPG) * H + kw + 16 * (it % IPG);
@@ -1230,16 +1222,13 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             wr[it] = make_float4(wq[0], wq[H], wq[2 * H], wq[3 * H]);
             if constexpr (FUSE) {
                 const float* xq = fuse ? J.w_ih_t + (long)k * H + u0 + i : wq;
-                const float4 wv = fuse ? make_float4(xq[0], xq[H], xq[2 * H], xq[3 * H]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (EARLY) wxl[it * 256 + tid] = wv; else wx[it] = wv;
+                wx[it] = fuse ? make_float4(xq[0], xq[H], xq[2 * H], xq[3 * H]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
         wr[it] = *reinterpret_cast<const float4*>(J.w_hh_t + (long)(u0 + i) * H3 + k);
-        if constexpr (FUSE) {
-            const float4 wv = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EARLY) wxl[it * 256 + tid] = wv; else wx[it] = wv;
-        }
+        if constexpr (FUSE)
+            wx[it] = fuse ? *reinterpret_cast<const float4*>(J.w_ih_t + (long)(u0 + i) * H3 + k)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // Every address inside the loop is a per-thread base (formed here, once) plus t times a scalar stride.  The job's
@@ -1271,48 +1260,35 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     if (timed) tprev = wall_clock64();
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
     f32x4v a[NITG];  // the gathered row block: rows = the batch tile, this wave's fragments of every exchanged gate
-    f32x4v a2[EARLY ? NITG : 1];  // EARLY: the second set (the next step's rows arrive while this step's are still in use)
     const bool ring = packed >= 2;
-    auto gather_issue = [&](auto& buf, int trow) {
+    auto gather = [&](int trow) {  // returns once no fragment holds the sentinel (or the call is lost)
         const int abase = a0 + (ring ? (trow & (kXRing - 1)) : trow) * (int)(s_x * 4);
-#pragma unroll
-        for (int it = 0; it < NITG; ++it)
-            buf[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
-    };
-    auto gather = [&](auto& buf, int trow, bool issued) {  // returns once no fragment holds the sentinel (or the call is lost)
         for (int spins = 0;; ++spins) {
-            if (!(issued && spins == 0)) {
-                asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
-                gather_issue(buf, trow);
-            }
+            asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
+#pragma unroll
+            for (int it = 0; it < NITG; ++it)
+                a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
             bool stale = false;
 #pragma unroll
-            for (int it = 0; it < NITG; ++it) stale |= has_sentinel(buf[it]);
+            for (int it = 0; it < NITG; ++it) stale |= has_sentinel(a[it]);
             if (timed) ++tacc[4];
             if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
             if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
         }
     };
-    // buf[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15), fragments [lo, hi) of the 3 IPG; four
-    // chains (one per k within a fragment): wherever the scheduler cuts the sequence to slip a memory instruction in,
-    // neighbouring MFMAs stay independent
-    f32x4 c0, c1, c2, c3;
-    auto second_part = [&](auto& buf, int lo, int hi) {
-        if (lo == 0) { c0 = f32x4{0.f, 0.f, 0.f, 0.f}; c1 = c0; c2 = c0; c3 = c0; }
+    auto second = [&](int par) {  // a[] W_ih -> this wave's partial sums of d h_out[l-1] (columns u0 .. u0+15)
+        // four chains (one per k within a fragment): wherever the scheduler cuts the sequence to slip a memory
+        // instruction in, neighbouring MFMAs stay independent
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            if (it >= lo && it < hi) {
-                float4 w;
-                if constexpr (EARLY) w = wxl[it * 256 + tid]; else w = wx[FUSE ? it : 0];
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].x, w.x, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].y, w.y, c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].z, w.z, c2, 0, 0, 0);
-                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[it].w, w.w, c3, 0, 0, 0);
-            }
+            const float4 w = wx[FUSE ? it : 0];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, c3, 0, 0, 0);
         }
-    };
-    auto second_store = [&](int par) {
         float* rd = red2 + par * 1024;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = (c0[rr] + c1[rr]) + (c2[rr] + c3[rr]);
@@ -1404,11 +1380,11 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     }
     fetch(t0);
     int pend_t = -1;  // time index of the input-gradient row whose partial sums wait in red2[(s - 1) & 1]
-    auto step = [&](int s, auto& a, auto& nxt) {  // a: this step's gathered rows; nxt (EARLY): where the next step's land
+    for (int s = 0; s < nsteps; ++s) {
         const int t = t0 + s * dt;
         const bool have_next = t != t_first;
         if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
-            gather(a, t - dt, EARLY && s > 0);
+            gather(t - dt);
             SA_TICK(0)
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // even / odd fragments
 #pragma unroll
@@ -1498,9 +1474,8 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             z_next = z;
         }
         fetch(s + 1 < nsteps ? t + dt : t);  // the next step's operands (the last step re-reads its own: unused)
-        if constexpr (FUSE && !EARLY) {
-            second_part(a, 0, NIT);
-            second_store(s & 1);
+        if constexpr (FUSE) {
+            second(s & 1);
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
@@ -1508,37 +1483,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
             }
             pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
         }
-        if constexpr (EARLY) {
-            // first half of the second product with the tail's 21 vector-memory instructions dealt out between its
-            // MFMAs; then the NEXT step's gather goes out (the row every block has just published: time t), its 3 IPG
-            // loads dealt out between the second half's MFMAs.  (The last step's early gather serves the product behind
-            // the loop.)
-            second_part(a, 0, NIT / 2);
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 vector-memory instruction
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            gather_issue(nxt, t);
-            second_part(a, NIT / 2, NIT);
-            second_store(s & 1);
-#pragma unroll
-            for (int k = 0; k < NITG; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 vector-memory READ
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            pend_t = fuse && have_next && s > 0 ? t - dt : -1;  // s = 0: that row belongs to the previous launch
-        }
         SA_TICK(3)
-    };
-    if constexpr (EARLY) {
-        int s = 0;
-        for (; s + 1 < nsteps; s += 2) { step(s, a, a2); step(s + 1, a2, a); }
-        if (s < nsteps) step(s, a, a2);
-    } else {
-        for (int s = 0; s < nsteps; ++s) step(s, a, a);
     }
 #undef SA_TICK
     if (timed) {
@@ -1547,14 +1492,8 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     }
     if (FUSE && fuse) {  // the chunk's last row, published by the step that just ended
         const int tl = t0 + (nsteps - 1) * dt;
-        if constexpr (EARLY) {  // (requested by the last step, into the set that step did not use)
-            if (nsteps & 1) { gather(a2, tl, nsteps > 0); second_part(a2, 0, NIT); }
-            else { gather(a, tl, nsteps > 0); second_part(a, 0, NIT); }
-        } else {
-            gather(a, tl, false);
-            second_part(a, 0, NIT);
-        }
-        second_store(nsteps & 1);
+        gather(tl);
+        second(nsteps & 1);
         __syncthreads();
         flush2((nsteps - 1) & 1, pend_t >= 0, pend_t);
         flush2(nsteps & 1, true, tl);
@@ -2103,17 +2042,8 @@ static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels
     const char* e = getenv("SA_GRU_TILED");
     return !(e && e[0] == '0');
 }
-static bool bwd_early_enabled() {  // round 5: the next step's gather issued inside the second product (EARLY instances)
-    const char* e = getenv("SA_GRU_BWD_EARLY");
-    return !(e && e[0] == '0');
-}
-static bool bwd_early_available(int H, bool fuse) { return fuse && H == 512 && bwd_early_enabled(); }
 static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
     if (!tiled_enabled()) return nullptr;
-    if (bwd_early_available(H, fuse)) {
-        if (packg) return drop ? gru_bwd_fused_kernel<8, true, true, true, false, true> : gru_bwd_fused_kernel<8, true, false, true, false, true>;
-        return drop ? gru_bwd_fused_kernel<8, true, true, false, false, true> : gru_bwd_fused_kernel<8, true, false, false, false, true>;
-    }
     if (packg && !fuse) {  // bidirectional layers: gate operands and the input-gradient operand
         if (H == 512) return gru_bwd_fused_kernel<8, false, false, true, true>;
         if (H == 256) return gru_bwd_fused_kernel<4, false, false, true, true>;
@@ -3178,9 +3108,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const bool packg = one_launch && wg && (B % 16) == 0 && !(pg_e && pg_e[0] == '0') && packg_available(H, true) &&
                        issuer.shared_ok(spl);
     const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
-    // (EARLY instances keep the lanes' W_ih^T fragments in LDS: 3 H / 64 x 256 x 16 bytes behind the PACKG staging slot)
-    const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + 2 * 4 * 16 * 20) * sizeof(float) +
-                                (bwd_early_available(H, fused) ? (size_t)(3 * H / 64) * 256 * 16 : 0));
+    const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
     const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed
