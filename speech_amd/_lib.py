@@ -79,6 +79,12 @@ SIGNATURES = {
     "sa_gru_stack_bwd_workspace_bytes": (c_size_t, [c_int] * 6),
     "sa_gru_stack_bwd": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "sa_gru_stack_bwd_wgrad": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "sa_set_option": (c_int, [ctypes.c_char_p, c_long]),
+    "sa_get_option": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_long)]),
+    "sa_reset_options": (None, []),
+    "sa_option_count": (c_int, []),
+    "sa_option_name": (ctypes.c_char_p, [c_int]),
+    "sa_option_help": (ctypes.c_char_p, [c_int]),
     "sa_ctc_profile_configure": (c_int, [c_int]),
     "sa_ctc_profile_count": (c_int, []),
     "sa_ctc_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -158,7 +164,58 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _LIB = L
+        options_from_env()
+    elif ENV_SYNC:
+        options_from_env()
     return _LIB
+
+
+# ---- run-time options (include/speech_amd.h: sa_set_option) -------------------------------------------------------------
+# The C library never reads the environment.  This host does, ONCE, when it loads the library: SA_<NAME> sets the option
+# <name> (SA_GRU_FUSED=0 -> "gru.fused" = 0), so `SA_GRU_TIMING=1 python tools/gru_fused_timing.py` keeps working.
+# ENV_SYNC = True (tests/conftest.py) re-applies the environment whenever it changed since the last library access, which is
+# what lets a test switch a kernel path with monkeypatch.setenv between two calls.
+ENV_SYNC = False
+_ENV_SEEN = None
+
+
+def option_names():
+    L = _LIB
+    return [L.sa_option_name(i).decode() for i in range(L.sa_option_count())]
+
+
+def _env_name(option):
+    return "SA_" + option.replace(".", "_").upper()
+
+
+def options_from_env():
+    global _ENV_SEEN
+    seen = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SA_")))
+    if seen == _ENV_SEEN:
+        return
+    _ENV_SEEN = seen
+    _LIB.sa_reset_options()
+    env = dict(seen)
+    for name in option_names():
+        v = env.get(_env_name(name))
+        if v is not None and v.lstrip("-").isdigit():
+            _LIB.sa_set_option(name.encode(), int(v))
+
+
+def set_option(name, value):
+    """Set a library option (see sa_option_help); returns the previous value."""
+    L = lib()
+    old = c_long(0)
+    if L.sa_get_option(name.encode(), ctypes.byref(old)) != 0 or L.sa_set_option(name.encode(), int(value)) != 0:
+        raise SpeechAmdError("unknown library option %r (known: %s)" % (name, ", ".join(option_names())))
+    return old.value
+
+
+def get_option(name):
+    v = c_long(0)
+    if lib().sa_get_option(name.encode(), ctypes.byref(v)) != 0:
+        raise SpeechAmdError("unknown library option %r" % name)
+    return v.value
 
 
 def check(status, what):

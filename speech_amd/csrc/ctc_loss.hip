@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -172,13 +173,13 @@ struct AbArgs {
                           // that ctc_grad_kernel folds the occupancies of a class with a prefix sum (no atomics)
     int* flags;           // [B]: nonzero = the probability-domain pass may have lost mass for this utterance (see
                           // ctc_chain_p): the log-domain kernels, launched behind it with gate = 1, redo exactly those
-    int no_fast;          // debug / tests (SA_CTC_PROB_FAST=0): keep ctc_chain_p in its per-step alignment (phase 1) throughout
+    int no_fast;          // debug / tests ((retired switch)): keep ctc_chain_p in its per-step alignment (phase 1) throughout
     int gate;             // 1: process only the utterances whose flag is set -- and finish them here, gradient rows
                           // included (ONE launch behind the probability-domain pass, returning at once when nothing is flagged)
     float* grads;         // gate only: where ctc_grad_row writes
     long g_st, g_sb;
     float gscale;         // every gradient element is multiplied by this (the caller's 1 / batch size)
-    unsigned long long* dbg;  // debug (SA_CTC_DBG): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
+    unsigned long long* dbg;  // debug (option ctc.dbg): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
     unsigned long long* prof; // sa_ctc_profile_*: {earliest workgroup entry, latest workgroup exit} of this launch (100 MHz ticks) or null
 };
 
@@ -349,7 +350,7 @@ __device__ __forceinline__ void ctc_chain(const AbArgs& A, AbShared* sh, float* 
     }
 }
 
-// ---- the same chain in the PROBABILITY domain (the default; SA_CTC_PROB=0 keeps the log-domain chain above) ----
+// ---- the same chain in the PROBABILITY domain (the default; option ctc.prob = 0 keeps the log-domain chain above) ----
 // alpha_t(s) = (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) y_t(s): adds and multiplies, no exp2 / log2
 // on the 1000-step dependent chain (the log-domain step above is ~27 mostly dependent instructions, ~240 cycles).  The
 // emissions are converted once (exp2 while they are staged in LDS).
@@ -1976,9 +1977,9 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
     A.flags = (int*)(ws + o_flags);
     A.lsort = (int*)(ws + o_lsort);
     A.gate = 0;
-    { const char* fe = getenv("SA_CTC_PROB_FAST"); A.no_fast = fe && fe[0] == '0'; }
+    A.no_fast = 0;
     A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b; A.gscale = grad_scale;
-    A.dbg = getenv("SA_CTC_DBG") ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
+    A.dbg = sa_opt(SA_OPT_CTC_DBG) ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
     A.prof = nullptr;
 
     // K_A (log-softmax into the workspace); only != null: the utterances whose flag is set
@@ -2018,19 +2019,19 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
         // the probability-domain one -- and the sorted occupancies)
         const size_t wave_floats = sa_align_up((size_t)2 * (smallk ? kRingP : KU * K) + (smallk ? 64 * R + 1 : K) + nren, 4);
         const size_t wave_bytes = wave_floats * sizeof(float);
-        const char* env = getenv("SA_CTC_WIDE");
-        const bool want = env ? (env[0] == '1') : (B >= kWideMinBatch);
+        const long wide_opt = sa_opt(SA_OPT_CTC_WIDE);
+        const bool want = wide_opt >= 0 ? wide_opt == 1 : (B >= kWideMinBatch);
         const bool wide = want && wave_bytes <= 150 * 1024;
         // probability-domain pass first (gradient calls, K <= 64, R <= 4), the log-domain kernel behind it for flagged
-        // utterances; SA_CTC_PROB=0: log domain only, =2: everything flagged (tests), =3: probability pass alone
-        const char* pe = getenv("SA_CTC_PROB");
-        const int prob = (wide && grads && smallk && R <= 4) ? (pe ? atoi(pe) : 1) : 0;
+        // utterances; option ctc.prob = 0: log domain only, =2: everything flagged (tests), =3: probability pass alone
+        const long prob_opt = sa_opt(SA_OPT_CTC_PROB);
+        const int prob = (wide && grads && smallk && R <= 4) ? (prob_opt >= 0 ? (int)prob_opt : 1) : 0;
         // ... and that pass normalises the activations itself while it stages them (RowStagerP): K_A then runs BEHIND it, for
         // the flagged utterances only (normally none: ~65 K workgroups that read one word and leave)
         // Measured (tools/ctc_b4096_time.py, one box): B = 4096 1.53 - 1.65 -> 1.37 - 1.49 ms per call, B = 1024 level, B = 512
-        // 0.59 -> 0.62 (too few waves to hide the longer staging) -- from kDirectMinBatch utterances; SA_CTC_DIRECT=1 / 0 forces.
-        const char* de = getenv("SA_CTC_DIRECT");
-        const bool direct = prob != 0 && grads != acts && (de ? de[0] == '1' : B >= kDirectMinBatch);
+        // 0.59 -> 0.62 (too few waves to hide the longer staging) -- from kDirectMinBatch utterances; option ctc.direct = 1 / 0 forces.
+        const long direct_opt = sa_opt(SA_OPT_CTC_DIRECT);
+        const bool direct = prob != 0 && grads != acts && (direct_opt >= 0 ? direct_opt == 1 : B >= kDirectMinBatch);
         if (!direct) {
             ctcStatus_t ks = launch_ka(nullptr);
             if (ks != CTC_STATUS_SUCCESS) return ks;
@@ -2097,14 +2098,14 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
         auto ab_smem = [&](bool prob) { return ab_fixed_lds(prob) + (ab_lds_em(prob) ? em_bytes : 0); };
         if (ab_smem(false) > 160 * 1024) return CTC_STATUS_INVALID_VALUE;
         const int threads = 64 * nch * (grads ? 2 : 1);
-        // probability-domain chain first (SA_CTC_PROB=0: log domain only; =2: flag every utterance, which exercises the
+        // probability-domain chain first (option ctc.prob = 0: log domain only; =2: flag every utterance, which exercises the
         // hand-over in tests), then the log-domain kernels for whatever it flagged (see ctc_chain_p).  A score-only call
         // has no rows to check: it stays in the log domain.
-        const char* pe = getenv("SA_CTC_PROB");
-        int prob = !grads ? 0 : (pe ? atoi(pe) : 1);
+        const long prob_opt = sa_opt(SA_OPT_CTC_PROB);
+        int prob = !grads ? 0 : (prob_opt >= 0 ? (int)prob_opt : 1);
         // the probability-domain chain needs its emissions in LDS to pay (its hand-off arrays are twice the log domain's:
         // from three chunks at T = 1000 they do not fit beside them) -- then the log-domain kernels run alone
-        if (prob && (!ab_lds_em(true) || ab_smem(true) > 160 * 1024) && !(pe && atoi(pe) >= 2)) prob = 0;
+        if (prob && (!ab_lds_em(true) || ab_smem(true) > 160 * 1024) && !(prob_opt >= 2)) prob = 0;
         ctcStatus_t s;
         const dim3 ggrid((max_T + 3) / 4, B);
         const size_t gsmem = 4 * (size_t)(A.Ppad + 1) * sizeof(float);

@@ -393,7 +393,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
 // v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 192 instead of
 // 512 matrix-pipe cycles per 16 k.  Accumulation is fp32 throughout, as in the exact kernel (measured against an fp64
 // product the split kernel's error is the exact kernel's: tools/gemm_bench.py, tests/test_gpu_blocks.py).
-// SA_GEMM_EXACT=1 selects the f32-input MFMA kernel everywhere; small products, the XCD-filtered launches, the direct
+// option gemm.exact = 1 selects the f32-input MFMA kernel everywhere; small products, the XCD-filtered launches, the direct
 // convolutions and the recurrence kernels always use f32-input MFMAs.
 //
 // Splitting costs ~5.5 VALU instructions per element.  Done while a tile is staged (first version of this kernel) every
@@ -927,11 +927,11 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
 }
 
 // Products big enough that two pack launches (and a pass over both operands) pay: >= 8 GFLOP per launch, a reduction of
-// at least 256, and an output at least half a tile wide in both directions.  SA_GEMM_EXACT=1 switches the path off,
-// SA_GEMM_EXACT=0 forces it for every unfiltered product.
+// at least 256, and an output at least half a tile wide in both directions.  option gemm.exact = 1 switches the path off,
+// gemm.exact = 0 forces it for every unfiltered product.
 bool pk_worth_it(int M, int N, int K, int nprob) {
-    const char* e = getenv("SA_GEMM_EXACT");  // "1": never; "0": always (tests: small shapes through the packed path)
-    if (e && (e[0] == '1' || e[0] == '0')) return e[0] == '0';
+    const long e = sa_opt(SA_OPT_GEMM_EXACT);  // 1: never; 0: always (tests: small shapes through the packed path)
+    if (e == 0 || e == 1) return e == 0;
     return 2.0 * M * N * K * nprob >= 8.0e9 && K >= 256 && M >= 64 && N >= 64;
 }
 
@@ -963,7 +963,6 @@ int choose_splits(int M, int N, int K, int nprob = 1) {
 // 256 x 256 block tiles (half the LDS traffic per flop, one block per CU) when they fill the chip: no split-K and >= 85 %
 // of whole rounds of 256 CUs; else 128 x 128 tiles, two blocks per CU (measured, tools/gemm_bench.py: 4096^3 191 vs 182
 // TFLOP/s, d x of layer 0 132 vs 130; but the layer-0 projection 136 vs 156 and the weight gradients 89 vs 122).
-// SA_GEMM_TILE=128 / 256 forces either (experiments).
 ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsigned* err_word = nullptr) {
     static bool pk_attr_dev[48] = {false};
     int devid = 0;
@@ -988,9 +987,7 @@ ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsign
         return CTC_STATUS_SUCCESS;
     }
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
-    const char* tile_e = getenv("SA_GEMM_TILE");
-    const bool big_tile = tile_e ? atoi(tile_e) == 256
-                                 : (splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85);
+    const bool big_tile = splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85;
     if (big_tile) {
         if (!pk_attr_dev[devid + 16]) {
             if (hipFuncSetAttribute((const void*)gemm_pk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1177,8 +1174,7 @@ __global__ __launch_bounds__(256) void thin_tn_fold_kernel(const float* __restri
 
 // which thin kernel (0 = none) a single plain product takes; a function of the shape and the strides only
 int thin_kind(int trans_a, int trans_b, int M, int N, int K, long lda, long ldb) {
-    const char* e = getenv("SA_GEMM_THIN");
-    if (e && e[0] == '0') return 0;
+    if (sa_opt(SA_OPT_GEMM_THIN) == 0) return 0;
     if (!trans_a && trans_b && N <= 32 && M >= 2048 && K >= 16 && K <= 1024 && (K % 16) == 0 && (lda & 3) == 0 && (ldb & 3) == 0)
         return 1;
     if (!trans_a && !trans_b && K <= 32 && M >= 2048 && N >= 16 && N <= 1024 && (N % 16) == 0) return 2;
@@ -1253,10 +1249,8 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.col_stride = ep ? ep->col_stride : 1;
     g.relu = ep ? ep->relu : 0;
     // The split-bf16 kernel on packed operands for every product that is worth two pack launches, when the caller's
-    // workspace has room for the packed copies; SA_GEMM_EXACT=1 (read per call): the f32-input MFMA kernel everywhere.
-    const bool filtered = opts && opts->xcc_mask && opts->tile_counter;
-    const char* fpk_e = getenv("SA_GEMM_FILTERED_PK");
-    bool use_pk = !(opts && opts->exact) && pk_worth_it(M, N, K, nprob) && (!filtered || !(fpk_e && fpk_e[0] == '0'));
+    // workspace has room for the packed copies; option gemm.exact = 1: the f32-input MFMA kernel everywhere.
+    bool use_pk = !(opts && opts->exact) && pk_worth_it(M, N, K, nprob);
     const size_t pkA = sa_align_up(pk_bytes(M, K), 256), pkB = sa_align_up(pk_bytes(N, K), 256);
     const int pk_kt = 8, pk_parts = 2 * ((((K + PK_K - 1) / PK_K) + pk_kt - 1) / pk_kt);
     const int Mpad = (M + BM - 1) / BM * BM;

@@ -1705,10 +1705,7 @@ __global__ void side_delay_kernel(unsigned long long ticks) {
 // With all three: bidirectional S-LIBRI 36.3 -> 30.9 ms per step (backward stack 22.2 -> 17.7 ms: the 2.9 ms of weight-
 // gradient products of a layer run entirely inside the next layer's 2.96 ms recurrence).  ON for bidirectional stacks;
 // SA_GRU_OVERLAP=0 switches it off (A/B runs).
-bool overlap_enabled() {
-    const char* e = getenv("SA_GRU_OVERLAP");
-    return !(e && e[0] == '0');
-}
+bool overlap_enabled() { return true; }
 
 
 // A whole-sequence product (input projection / input gradient: tall M, short K) with room for the packed split-bf16
@@ -1943,22 +1940,20 @@ static int device_cus() {
 // (Round 1's chip-wide persistent groups -- SA_GRU_PERSIST=1: one sync group spanning XCDs, an in-kernel step of ~10 us
 // against a 9 us kernel boundary -- are retired; the finding is in DESIGN.md 3.3.)
 static int persist_mode() {  // 2: XCD-local groups (default where eligible); 0: off (SA_GRU_PERSIST=0, or after a failure)
-    const char* e = getenv("SA_GRU_PERSIST");
-    const int m = e ? ((e[0] == '2' || e[0] == '3') ? 2 : 0) : 2;
+    const long e = sa_opt(SA_OPT_GRU_PERSIST);  // -1 auto; 0 off; 2 arrival counters; 3 flag-less (= auto)
+    const int m = e < 0 ? 2 : ((e == 2 || e == 3) ? 2 : 0);
     return (m == 2 && g_health.disabled) ? 0 : m;
 }
 static bool flagless_mode() {  // the flag-less (sentinel) hand-off is the default; SA_GRU_PERSIST=2 keeps the counters
-    const char* e = getenv("SA_GRU_PERSIST");
-    return !e || e[0] == '3';
+    const long e = sa_opt(SA_OPT_GRU_PERSIST);
+    return e < 0 || e == 3;
 }
 static int spin_limit() {
-    const char* e = getenv("SA_GRU_SPIN_LIMIT");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : (1 << 20);
+    const long v = sa_opt(SA_OPT_GRU_SPIN_LIMIT);
+    return v > 0 ? (int)v : (1 << 20);
 }
 static int fault_injection() {  // tests only: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave early
-    const char* e = getenv("SA_GRU_FAULT");
-    return (e && e[0] == '1') ? 1 : 0;
+    return sa_opt(SA_OPT_GRU_FAULT) == 1 ? 1 : 0;
 }
 static bool sentinel_fill(float* p, size_t n, hipStream_t stream) {
     return hipMemsetD32Async((hipDeviceptr_t)p, (int)kSentinel, n, stream) == hipSuccess;
@@ -2020,27 +2015,18 @@ static size_t xcd_lds(size_t need) { return need; }
 typedef void (*BwdPersistFn)(PBwdJobs);
 static BwdPersistFn bwd_persist_fn() { return gru_bwd_persist_kernel; }
 static int fwd_chunks(int T) {  // bidirectional forward: time chunks per layer for the projection / recurrence overlap
-    const char* e = getenv("SA_GRU_FWD_CHUNKS");
-    const int v = e ? atoi(e) : 0;
+    const int v = (int)sa_opt(SA_OPT_GRU_FWD_CHUNKS);
     // measured (S-LIBRI T' = 498 / TIMIT T' = 144, ms per step): 1 chunk 30.9 / 6.26, 2: 29.5 / 6.15, 4: 29.5 / 6.27,
     // 6: 29.7 / 6.55, 8: 32.0 / 6.78 -- a chunk launch costs a ramp and an event
     return v > 0 ? (v > 15 ? 15 : v) : (T >= 256 ? 4 : 2);
 }
 static bool fuse_dx_enabled() {  // SA_GRU_FUSE_DX=0: the per-wave grouped GEMM computes d h_out of the lower layers
-    const char* e = getenv("SA_GRU_FUSE_DX");
-    return !(e && e[0] == '0');
+    return sa_opt(SA_OPT_GRU_FUSE_DX) != 0;
 }
-static bool fill_batch_enabled() {  // SA_GRU_FILL_BATCH=0: one hipMemsetD32Async per buffer (rounds 1-3)
-    const char* e = getenv("SA_GRU_FILL_BATCH");
-    return !(e && e[0] == '0');
-}
-static bool xring_enabled() {  // SA_GRU_XRING=0: the backward exchange as T pre-filled time slots (rounds 2-3)
-    const char* e = getenv("SA_GRU_XRING");
-    return !(e && e[0] == '0');
-}
+static bool fill_batch_enabled() { return true; }  // (one hipMemsetD32Async per buffer was rounds 1-3)
+static bool xring_enabled() { return true; }  // (the backward exchange as T pre-filled time slots was rounds 2-3)
 static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels (row-major exchange; bit-identical to the step kernels)
-    const char* e = getenv("SA_GRU_TILED");
-    return !(e && e[0] == '0');
+    return sa_opt(SA_OPT_GRU_TILED) != 0;
 }
 static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
     if (!tiled_enabled()) return nullptr;
@@ -2325,9 +2311,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     if (xcd) plds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
     unsigned persist_launches = 0;
     const bool flagless = xcd && flagless_mode();
-    const char* fe = getenv("SA_GRU_FUSED");
     const size_t flds = xcd_lds((size_t)2 * 4 * 4 * 256 * sizeof(float));
-    const bool fused_fwd = !(fe && fe[0] == '0') && flagless && flds <= 160 * 1024 && L * nbt <= kSyncErr;
+    const bool fused_fwd = sa_opt(SA_OPT_GRU_FUSED) != 0 && flagless && flds <= 160 * 1024 && L * nbt <= kSyncErr;
     FillBatch fills(stream, fused_fwd && fill_batch_enabled());
     if (flagless)
         for (int l = 0; l < L; ++l) fills.add(h_out[l], (size_t)T * B * H, kSentinel);
@@ -2338,7 +2323,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             fills.add(sync, 1024 / 4, 0u);
             fills.flush();
             if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
-            const bool timing_on = getenv("SA_GRU_TIMING") != nullptr;
+            const bool timing_on = sa_opt(SA_OPT_GRU_TIMING) != 0;
             FusedFwdFn fused_fn = fused_fwd_fn(H, stash != nullptr, drop_on, timing_on);
             if (!fused_fn) return CTC_STATUS_INVALID_VALUE;  // (xcd_shape_ok admits H = 128 .. 512 in steps of 64 only)
             if (hipFuncSetAttribute((const void*)fused_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2351,7 +2336,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             Q.timing = timing_on && !drop_on ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 8 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;  // (r4 kernel: 4 words per block)
             Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
-            { const char* re = getenv("SA_GRU_FWD_REPORT"); int r = re ? atoi(re) : 4; Q.report_every = (r >= 1 && r <= 64 && (r & (r - 1)) == 0) ? r : 4; }
+            { const long r = sa_opt(SA_OPT_GRU_FWD_REPORT); Q.report_every = (r >= 1 && r <= 64 && (r & (r - 1)) == 0) ? (int)r : 4; }
             Q.drop = dc.drop; Q.drop_stream0 = dc.stream0;
             for (int l = 0; l < kMaxJobs; ++l) Q.h_drop[l] = nullptr;
             for (int l = 0; l < L; ++l) {
@@ -2415,7 +2400,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             Q.xcd_mode = xcd ? 1 : 0; Q.nbt = nbt; Q.nbt_all = nbt; Q.bt0 = 0; Q.ntile_u = ntile_u; Q.reg = sync + kSyncReg;
             Q.flagless = flagless ? 1 : 0;
             Q.stamp = nullptr;
-            Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 256) : nullptr;  // 3 KB of the sync page
+            Q.timing = sa_opt(SA_OPT_GRU_TIMING) ? (unsigned long long*)(sync + 256) : nullptr;  // 3 KB of the sync page
             int n = 0;
             for (int l = 0; l < L; ++l) {
                 const int c = w - l;
@@ -2493,8 +2478,7 @@ extern "C" ctcStatus_t sa_gru_stack_fwd_dropout(const float* x, int I0, const fl
 // three gates, then dah's third: dah's first two ARE dai's), which dW_ih reads as rows [0, 3H) and dW_hh as rows [0, 2H) +
 // [3H, 4H).  0 = the shape does not take this path.
 static bool shared_pack_enabled() {
-    const char* e = getenv("SA_GRU_SHARED_PACK");
-    return !(e && e[0] == '0');
+    return sa_opt(SA_OPT_GRU_SHARED_PACK) != 0;
 }
 struct SharedPackLayout { size_t g_each, h_each, x_bytes, cs_bytes, g_off, hp_off, lo_off, x_off, cs_off, sk_off, total; int parts; };
 static bool shared_pack_layout(int L, int D, int B, int T, int H, int I0, SharedPackLayout& y) {
@@ -2923,8 +2907,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         // ... which also writes the weight gradients' gate operands, packed (gru_bwd_fused_kernel<.., PACKG>); the products
         // of a layer then run on shared operands (issue_shared_bi), filtered beside the next layer or plain on `stream`
         SharedPackLayoutBi spb;
-        const char* bpg_e = getenv("SA_GRU_PACK_IN_KERNEL");
-        const bool bi_packg = bi_tiled && wg && !(bpg_e && bpg_e[0] == '0') && bi_nbt <= bi_tpp && issuer.shared_ok_bi(spb) &&
+        const bool bi_packg = bi_tiled && wg && sa_opt(SA_OPT_GRU_PACK_IN_KERNEL) != 0 && bi_nbt <= bi_tpp && issuer.shared_ok_bi(spb) &&
                               bwd_fused_fn(H, false, false, true) != nullptr;
         const BwdPersistFn bi_tiled_fn = bi_tiled ? bwd_fused_fn(H, false, false, bi_packg) : nullptr;
         const size_t bi_lds_run = bi_packg ? xcd_lds((size_t)(4 * 4 * 256 + 2 * 4 * 16 * 20) * sizeof(float)) : bi_lds;
@@ -2994,19 +2977,17 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 const int RB = (T * B + 127) / 128;
                 const SaDrop* dmask = (drop_on && l > 0) ? &dc.drop : nullptr;   // the mask of h_out[l-1], in the epilogue
                 const unsigned dstream = dc.stream0 + (unsigned)(l > 0 ? l - 1 : 0);
-                const char* sx_e = getenv("SA_GRU_STREAM_DX");
                 // Streamed (layers above the bottom one, side stream available): the next layer's two chains start at the two
                 // ENDS of the sequence, so only the end rows have to exist before its recurrence is launched; the rest arrives
                 // chunk by chunk from the side stream (XCD-filtered, beside that recurrence, ahead of this layer's weight
                 // gradients) while the chains work inwards -- the consumer polls the sentinel this buffer is filled with
                 // (gru_bwd_fused_kernel<.., PACKK>).  Chunk 0 = a quarter of the rows on the whole chip.
-                const char* nc_e = getenv("SA_GRU_DX_CHUNKS");
-                const char* f0_e = getenv("SA_GRU_DX_FIRST");
-                const int nchunk = nc_e && atoi(nc_e) > 1 ? min(atoi(nc_e), 12) : 4, per_end = (RB / 2 + nchunk - 1) / nchunk;
-                if (l > 0 && bi_side && RB >= 16 && !(sx_e && sx_e[0] == '0') && issuer.next_counter + nchunk + 4 <= issuer.max_counters) {
+                // (more, smaller chunks lose: 6 +0.6 ms, 8 +1.4; first chunks of 8 - 28 row blocks per end are within noise: round 3)
+                const int nchunk = 4, per_end = (RB / 2 + nchunk - 1) / nchunk;
+                if (l > 0 && bi_side && RB >= 16 && issuer.next_counter + nchunk + 4 <= issuer.max_counters) {
                     if (!sentinel_fill(din, ((size_t)T * B + 128) * I, stream)) return CTC_STATUS_MEMOPS_FAILED;
                     int lo = 0, hi = RB;  // row blocks [lo, hi) still owed
-                    const int n0 = min(f0_e && atoi(f0_e) > 0 ? atoi(f0_e) : per_end, (hi - lo) / 2);
+                    const int n0 = min(per_end, (hi - lo) / 2);
                     int ends[2] = {lo, hi - n0};
                     st = issuer.input_grad_bi_rows(spb, l, din, 2, ends, n0, stream, 0u, dmask, dstream);
                     if (st != CTC_STATUS_SUCCESS) return st;
@@ -3100,12 +3081,10 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // ONE launch for the whole backward recurrence of the stack (fused kernel only): every layer runs all T steps, a
     // lower layer picks each row of its d h_out up as the layer above stores it (sentinel pre-fill, see the kernel) --
     // T + a few steps per layer of lag instead of (T / chunk + L - 1) chunks, and no launch ramps in between.
-    const char* one_e = getenv("SA_GRU_BWD_ONE");
-    const bool one_launch = fused && !(one_e && one_e[0] == '0') && !getenv("SA_GRU_TIMING");
+    const bool one_launch = fused && sa_opt(SA_OPT_GRU_BWD_ONE) != 0 && !sa_opt(SA_OPT_GRU_TIMING);
     // ... and that launch writes the weight-gradient products' gate operand itself, packed (gru_bwd_fused_kernel<PACKG>)
     SharedPackLayout spl;
-    const char* pg_e = getenv("SA_GRU_PACK_IN_KERNEL");
-    const bool packg = one_launch && wg && (B % 16) == 0 && !(pg_e && pg_e[0] == '0') && packg_available(H, true) &&
+    const bool packg = one_launch && wg && (B % 16) == 0 && sa_opt(SA_OPT_GRU_PACK_IN_KERNEL) != 0 && packg_available(H, true) &&
                        issuer.shared_ok(spl);
     const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
     const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
@@ -3120,9 +3099,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     if (!one_launch) fills.flush();
     if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
     // the one-launch kernel reads its weight fragments from the matrices as stored (PBwdJobs::w_rowmajor): 2 L - 1 transpose
-    // launches less per step; SA_GRU_WT=1: transposed copies as before
-    const char* wt_e = getenv("SA_GRU_WT");
-    const bool rowmajor = one_launch && !(wt_e && wt_e[0] == '1');
+    // launches less per step
+    const bool rowmajor = one_launch;
     if (!rowmajor) transpose_whh();
     if (fused && !rowmajor) {
         for (int l = 1; l < L; ++l)
@@ -3135,7 +3113,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // per step in round 2, profiles/r02_overlap_experiments.txt -- and that side-stream path is retired; the products
     // run behind the recurrence, wgrad_rest below)
     if (xcd) {
-        fills.add(sync, (getenv("SA_GRU_TIMING") ? kSyncBytes : 1024) / 4, 0u);
+        fills.add(sync, (sa_opt(SA_OPT_GRU_TIMING) ? kSyncBytes : 1024) / 4, 0u);
         if (!one_launch) fills.flush();
         if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
         if (hipFuncSetAttribute((const void*)bwd_persist_fn(), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3213,7 +3191,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         if (xcd) {  // ONE launch unwinds the whole chunk of every active layer
             PBwdJobs Q;
             Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = flagless ? 1 : 0;
-            Q.timing = getenv("SA_GRU_TIMING") ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
+            Q.timing = sa_opt(SA_OPT_GRU_TIMING) ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
             Q.pk_kb = 0; Q.kpk_kb = 0;
             Q.drop = dc.drop;
             Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg; Q.w_rowmajor = 0;

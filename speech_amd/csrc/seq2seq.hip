@@ -856,8 +856,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
     // (r4) three launches per token instead of six: the projections; the score network, which forms the GRUCell gates itself;
     // softmax + context, which also forms the NEXT token's index and embedding + context row when that token is teacher
     // forced.  SA_S2S_FUSE=0: the six-launch loop.
-    const char* fuse_e = getenv("SA_S2S_FUSE");
-    const bool fuse = !(fuse_e && fuse_e[0] == '0');
+    const bool fuse = true;  // (the GRUCell gates inside the score kernel; the unfused launches were SA_S2S_FUSE=0, retired in round 5)
     const size_t smem1f = smem1 + (fuse ? (size_t)H * sizeof(float) : 0);
     if (fuse && !att_smem((const void*)attention_score_kernel, smem1f)) return CTC_STATUS_INVALID_VALUE;
     bool have_ix = false;   // token t's idx / ix were produced by token t-1's context kernel
@@ -1006,8 +1005,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     char* aws = ws + L.att;
     const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * (H + 1)) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
-    const char* fuse_e = getenv("SA_S2S_FUSE");
-    const bool fuse_b = !(fuse_e && fuse_e[0] == '0');
+    const bool fuse_b = true;
     for (int t = U1 - 1; t >= 0; --t) {
         const bool has_next = t + 1 < U1;
         const float* hx = HX + (long)t * B * H;

@@ -118,21 +118,23 @@ class _CTCFunction(torch.autograd.Function):
         g = ctx.grads
         if g is None:
             return (None,) * 8
-        # d loss arrives as a device scalar (1 for loss.backward()): one early-out launch, no pass over the gradient
-        go = grad_out.reshape(-1)[:1].contiguous()
         first = getattr(ctx, "applied", None)
         if first is None:
-            # the saved buffer is scaled IN PLACE (it is dense in the logits' own layout: numel() consecutive floats from
-            # its data pointer) and handed on; the factor is remembered so that a second backward over a retained graph
-            # does not apply its own factor on top of this one
-            _lib.check(_lib.lib().sa_scale_by_device_scalar(_lib.ptr(g), g.numel(), _lib.ptr(go), _lib.cur_stream()),
-                       "sa_scale_by_device_scalar")
-            ctx.applied = go.clone()
+            ctx.applied = grad_out  # (a reference, not a copy: the factor the saved buffer now carries)
+            from .ops import unit_gradient
+            if grad_out.data_ptr() != unit_gradient(g.device).data_ptr():
+                # d loss arrives as a device scalar: the saved buffer is scaled IN PLACE (it is dense in the logits' own
+                # layout: numel() consecutive floats from its data pointer) by one launch that returns without touching
+                # memory when the scalar is exactly 1 (plain loss.backward()); ops.backward(loss) hands autograd the
+                # cached unit gradient and takes the branch above: no launch at all
+                go = grad_out.reshape(-1)[:1].contiguous()
+                _lib.check(_lib.lib().sa_scale_by_device_scalar(_lib.ptr(g), g.numel(), _lib.ptr(go), _lib.cur_stream()),
+                           "sa_scale_by_device_scalar")
             return (g,) + (None,) * 7
         # a retained graph, walked again (rare: off the hot path): a FRESH tensor carrying the new factor instead of the
         # first one -- the saved buffer stays what the first walk made of it (a first factor of 0 has erased the gradient:
         # inf / nan then says so rather than a silent 0)
-        return (g * (go / first),) + (None,) * 7
+        return (g * (grad_out.reshape(-1)[:1] / first.reshape(-1)[:1]),) + (None,) * 7
 
 
 class CTCLoss(torch.nn.Module):

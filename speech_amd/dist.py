@@ -166,3 +166,11 @@ def max_over_ranks(value, device):
         td.all_reduce(t, op=td.ReduceOp.MAX)
         return float(t.item())
     return value
+
+
+def sum_over_ranks(value, device):
+    if active():
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return float(t.item())
+    return value

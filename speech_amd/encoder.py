@@ -15,7 +15,6 @@ layers) happens INSIDE those kernels: each forward pass draws one 64-bit Philox 
 recurrence kernels evaluate the mask of the element they write (or whose gradient they route) from (key, tensor, index)
 -- no mask tensor, no extra pass, and the GRU stack stays one launch per direction of time (csrc/dropout.h).
 """
-import os
 
 import torch
 
@@ -39,7 +38,7 @@ class EncoderPlan:
             f = ops.conv_out_size(f, w, s)
         self.conv_out_dim = self.conv_cfg[-1][0] * f
         self.input_dim = input_dim
-        self.chunk = int(os.environ.get("SA_GRU_CHUNK", "0"))  # time steps per wavefront chunk (0: library default)
+        self.chunk = 0  # time steps per wavefront chunk of the non-fused paths (0: the library's default)
 
         # Model.flatten_parameters_() opts in to by-reference gradient hand-over (see EncoderFunction.backward)
         self.grad_by_reference = True

@@ -446,3 +446,25 @@ class ScalarPipe:
 
     def drain(self):
         return self._collect(wait=True)
+
+
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """The (1,) float32 tensor holding 1.0 on `device`, created once: what backward(loss) seeds autograd with."""
+    key = str(device)
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones(1, dtype=torch.float32, device=device)
+    return _UNIT[key]
+
+
+def backward(loss):
+    """loss.backward() (/root/reference/train.py:30) without autograd's own launches: torch seeds the walk with
+    ones_like(loss) -- a fill kernel per step -- and the CTC node then multiplies its gradient by that 1 (a second launch);
+    seeded with the cached unit gradient the walk starts with no launch and the node recognises the seed.  Plain
+    loss.backward() keeps working (and keeps those two launches)."""
+    if loss.numel() == 1 and loss.dtype == torch.float32:
+        loss.backward(gradient=unit_gradient(loss.device).view_as(loss))
+    else:
+        loss.backward()

@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _library_options_follow_the_environment():
+    """The C library reads no environment variables (include/speech_amd.h: sa_set_option); speech_amd._lib applies SA_<NAME>
+    variables once, at load.  Tests switch kernel paths with monkeypatch.setenv BETWEEN calls, so here the host re-applies the
+    environment whenever it changed since the last library access."""
+    from speech_amd import _lib
+    _lib.ENV_SYNC = True
+    yield
+    _lib.ENV_SYNC = False

@@ -124,3 +124,41 @@ def test_product_path_never_touches_the_oracle():
             if "oracle" in open(os.path.join(dp, f), errors="ignore").read():
                 offenders.append(os.path.join(dp, f))
     assert not offenders, offenders
+
+
+def test_options_are_a_table_not_the_environment(monkeypatch):
+    """the library read 28 SA_* environment variables with getenv() on every call.  Now it reads none
+    (no getenv in csrc/ at all); the surviving switches are named integer options behind sa_set_option / sa_get_option, and
+    the Python host applies SA_<NAME> variables to them (once at load; under tests whenever the environment changed)."""
+    import ctypes
+    import glob
+    for src in glob.glob(os.path.join(ROOT, "speech_amd", "csrc", "*.h*")):
+        code = re.sub(r"//.*", "", open(src).read())
+        assert "getenv" not in code, src
+    L = _lib.lib()
+    names = _lib.option_names()
+    assert len(names) == L.sa_option_count() >= 10 and len(set(names)) == len(names)
+    for i, n in enumerate(names):
+        assert re.fullmatch(r"[a-z0-9]+\.[a-z0-9_]+", n) and L.sa_option_help(i)
+    assert L.sa_option_name(-1) is None and L.sa_option_name(len(names)) is None
+    L.sa_reset_options()
+    defaults = {n: _lib.get_option(n) for n in names}
+    assert defaults["gru.fused"] == 1 and defaults["ctc.prob"] == -1 and defaults["gru.fwd_report"] == 4
+    assert _lib.set_option("gru.fused", 0) == 1 and _lib.get_option("gru.fused") == 0
+    v = ctypes.c_long(0)
+    assert L.sa_set_option(b"no.such_option", 1) == 2 and L.sa_get_option(b"no.such_option", ctypes.byref(v)) == 2
+    assert L.sa_set_option(None, 1) == 2
+    with pytest.raises(_lib.SpeechAmdError):
+        _lib.set_option("no.such_option", 1)
+    L.sa_reset_options()
+    assert {n: _lib.get_option(n) for n in names} == defaults
+    # the host's bridge: SA_GRU_FUSED=0 -> gru.fused = 0, removed again -> the default is back
+    monkeypatch.setenv("SA_GRU_FUSED", "0")
+    monkeypatch.setenv("SA_CTC_PROB", "2")
+    monkeypatch.setenv("SA_NOT_AN_OPTION", "7")
+    _lib.lib()
+    assert _lib.get_option("gru.fused") == 0 and _lib.get_option("ctc.prob") == 2
+    monkeypatch.delenv("SA_GRU_FUSED")
+    monkeypatch.delenv("SA_CTC_PROB")
+    _lib.lib()
+    assert {n: _lib.get_option(n) for n in names} == defaults

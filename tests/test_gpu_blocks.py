@@ -537,6 +537,30 @@ def test_bidirectional_forward_projection_overlap():
                 assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max())), shape
 
 
+def test_fused_forward_is_bit_identical_for_every_progress_report_period(monkeypatch):
+    """Round 5: a layer of the one-launch forward reports its progress to the layer above every `gru.fwd_report` steps (the
+    per-step memory-side fetch_add was what coupled the layers: 2.69 -> 2.22 ms per S-LIBRI stack forward at 4).  The period
+    only changes WHEN the layer above may read a row, never what it reads: every period gives the same bits -- also with
+    T not a multiple of the period, T smaller than it, ragged batch tiles and inter-layer dropout."""
+    from speech_amd import ops, _lib
+    for (L, B, T, I0, H), drop in (((4, 32, 61, 40, 512), None), ((3, 20, 7, 24, 256), None), ((4, 32, 45, 40, 512), (0.3, 11, 64)),
+                                   ((2, 48, 19, 24, 128), None)):
+        x, w_ih, b_ih, w_hh, b_hh = _stack_case(L, B, T, I0, H)
+        ref = None
+        for period in (4, 1, 2, 8, 16):
+            monkeypatch.setenv("SA_GRU_FWD_REPORT", str(period))
+            out = ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 1, H, want_stash=True, drop=drop)
+            torch.cuda.synchronize()
+            assert _lib.lib().sa_gru_persist_status() == 0
+            got = [t.clone() for t in out[0] + out[1] + (out[2] if drop else [])]
+            if ref is None:
+                ref = got
+            else:
+                for a, b in zip(ref, got):
+                    assert torch.equal(a, b), (L, B, T, H, period)
+        monkeypatch.delenv("SA_GRU_FWD_REPORT")
+
+
 def test_fused_forward_wavefront_matches_oracle_and_default():
     """gru_fwd_fused_kernel (the default forward of eligible unidirectional stacks: one launch, in-kernel input
     projections, weights resident in registers) against the NumPy oracle and against the chunked path; its stash feeds

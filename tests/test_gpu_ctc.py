@@ -356,3 +356,30 @@ def test_wide_peaked_logits_stay_in_the_probability_domain(monkeypatch):
     compare(acts, labs, al, ll)
     if os.environ.get("SA_CTC_PROB") is None:  # the default mode: nothing handed over
         assert not flags_of(B, T, K, L).any()
+
+
+def aligned_case(seed, B, T, K, L, margin):
+    """Alignment-shaped logits (tools/ctc_flags_probe.py, bench.py's *_aligned20 legs): N(0, 1) noise plus `margin` on the class
+    of one monotonic alignment per utterance -- what a TRAINED CTC model emits."""
+    rng = np.random.RandomState(seed)
+    labs = rng.randint(0, K - 1, B * L).astype(np.int32)
+    acts = rng.randn(B, T, K).astype(np.float32)
+    for b in range(B):
+        starts = np.sort(rng.choice(T // 4, L, replace=False)) * 4
+        cls = np.full(T, K - 1)
+        for i, t0 in enumerate(starts):
+            cls[t0:t0 + rng.randint(1, 4)] = labs[b * L + i]
+        acts[b, np.arange(T), cls] += margin
+    return acts, labs, np.full(B, T, np.int32), np.full(B, L, np.int32)
+
+
+@pytest.mark.parametrize("margin", [5.0, 10.0, 20.0])
+@pytest.mark.parametrize("regime", ["latency", "throughput"])
+def test_alignment_shaped_logits_match_the_oracle(regime, margin, monkeypatch):
+    """M-CTC-shaped lattices (T = 1000, 29 classes, 100 labels) on the logits a trained model emits, in both
+    regimes (one workgroup per utterance / one wave per utterance, forced), in all three kernel modes of the fixture above:
+    cost and gradient against the fp64 oracle whether or not the probability-domain pass keeps the utterance (at margin 20 it
+    hands most of them to the log-domain kernels: the flag count is in bench.py's `ctc_flagged`)."""
+    monkeypatch.setenv("SA_CTC_WIDE", "1" if regime == "throughput" else "0")
+    B, T, K, L = 6, 1000, 29, 100
+    compare(*aligned_case(int(margin) * 7 + (regime == "throughput"), B, T, K, L, margin))

@@ -1,12 +1,12 @@
 """A/B of the fused forward recurrence inside ONE process / one box: how often a layer reports its progress to the layer
-above (SA_GRU_FWD_REPORT = 1 / 2 / 4 / 8 / 16 steps; 4 is the default), round robin, HIP events over 10 stack-forward calls
+above (library option gru.fwd_report = 1 / 2 / 4 / 8 / 16 steps; 4 is the default), round robin, HIP events over 10 stack-forward calls
 each; outputs compared with the default's bit for bit.   python tools/gru_fwd_variants.py [L] [rounds]
 (The round-5 sweep that also covered the kernel of rounds 1-4 and the position of the first polling trip is recorded in
 profiles/r05_forward_recurrence_experiments.txt.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from speech_amd import ops
+from speech_amd import ops, _lib
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 D, B, T, H, I0 = 1, 32, 498, 512, 800
@@ -16,12 +16,11 @@ k = 1.0 / H ** 0.5
 w_ih = [torch.empty(3 * H, I0 if l == 0 else H, device="cuda").uniform_(-k, k) for l in range(L)]
 w_hh = [torch.empty(3 * H, H, device="cuda").uniform_(-k, k) for l in range(L)]
 b = [torch.empty(3 * H, device="cuda").uniform_(-k, k) for l in range(L)]
-VARIANTS = [("report%d" % r, {"SA_GRU_FWD_REPORT": str(r)}) for r in (4, 1, 2, 8, 16)]
+VARIANTS = [("report%d" % r, {"gru.fwd_report": r}) for r in (4, 1, 2, 8, 16)]
 
 def run(env, n):
-    for kk in ("SA_GRU_FWD_REPORT",):
-        os.environ.pop(kk, None)
-    os.environ.update(env)
+    for name, value in env.items():
+        _lib.set_option(name, value)
     out = None
     for _ in range(2):
         out = ops.gru_stack_fwd(x, w_ih, b, w_hh, b, L, D, H, want_stash=True)

@@ -48,7 +48,7 @@ def train_step(model, flat, opt_cfg, batch, shape=None):
         model.skipped_step()  # ... and keeps its random generator in step with the ranks that did run a forward pass
     else:
         loss = model.loss(batch)
-        loss.backward()
+        ops.backward(loss)
     ops.stamp_health(flat_g)
     dist.allreduce_gradients(flat_g)
     norm = ops.clip_sgd_step(flat_p, flat_g, mom, opt_cfg["learning_rate"], opt_cfg["momentum"], 200.0)
