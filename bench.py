@@ -368,7 +368,7 @@ def train_loop_leg(model, flat_p, flat_g, world, rank, dev, steps):
             yield host[k % len(host)]
 
     t0 = None
-    for k, (batch, shape) in enumerate(dist.with_global_shapes(batches())):
+    for k, (batch, shape) in enumerate(dist.with_global_shapes(batches(), model)):
         if k == warm:
             torch.cuda.synchronize()
             dist.barrier()

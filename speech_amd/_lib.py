@@ -266,14 +266,20 @@ class PinnedRing:
     slot), so the host fills batch k+1's slot while batch k's copy and kernels are still in flight."""
 
     def __init__(self, dtype, depth=4):
+        import threading
         self._dtype = dtype
         self._bufs = [None] * depth
         self._events = [None] * depth
         self._next = 0
         self._by_ptr = {}
+        self._lock = threading.Lock()  # (a model's collate-ahead thread takes slots while the loop marks copies)
 
     def get(self, shape):
         """A pinned tensor of `shape` (contents undefined)."""
+        with self._lock:
+            return self._get(shape)
+
+    def _get(self, shape):
         i = self._next
         self._next = (i + 1) % len(self._bufs)
         n = 1
@@ -293,11 +299,12 @@ class PinnedRing:
 
     def copied(self, host_tensor, stream=None):
         """Call right after enqueueing (on `stream`, default the current one) the H2D copy of a tensor from get()."""
-        i = self._by_ptr.get(host_tensor.data_ptr())
-        if i is not None:
-            ev = torch.cuda.Event()
-            ev.record(stream if stream is not None else torch.cuda.current_stream())
-            self._events[i] = ev
+        with self._lock:
+            i = self._by_ptr.get(host_tensor.data_ptr())
+            if i is not None:
+                ev = torch.cuda.Event()
+                ev.record(stream if stream is not None else torch.cuda.current_stream())
+                self._events[i] = ev
 
 
 _INT_RING = None

@@ -151,6 +151,39 @@ __device__ __forceinline__ float wave_scan_dpp(float v) {
     return v;
 }
 
+// Exclusive prefix (suffix) maximum over the 64 lanes of an int: lane i receives max(v[0 .. i-1]) (max(v[i+1 .. 63])), the
+// lane without a source `none`.  In-row scans on the DPP network (row_shr / row_shl 1, 2, 4, 8), the three row totals through
+// SGPRs (v_readlane), one wave shift: ~20 instructions, once per frozen batch (ctc_chain_p / wavep_refresh: exponent lifting).
+#define sa_dpp_i(old_, src_, ctrl_) __builtin_amdgcn_update_dpp((old_), (src_), (ctrl_), 0xf, 0xf, false)
+__device__ __forceinline__ int wave_prefix_max_excl(int v, int none, int lane) {
+    int x = v;
+    x = max(x, sa_dpp_i(none, x, 0x111));
+    x = max(x, sa_dpp_i(none, x, 0x112));
+    x = max(x, sa_dpp_i(none, x, 0x114));
+    x = max(x, sa_dpp_i(none, x, 0x118));
+    const int t0 = __builtin_amdgcn_readlane(x, 15);
+    const int t1 = max(t0, __builtin_amdgcn_readlane(x, 31));
+    const int t2 = max(t1, __builtin_amdgcn_readlane(x, 47));
+    const int row = lane >> 4;
+    const int before = row == 0 ? none : (row == 1 ? t0 : (row == 2 ? t1 : t2));
+    x = max(x, before);  // inclusive
+    return __builtin_amdgcn_update_dpp(none, x, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ int wave_suffix_max_excl(int v, int none, int lane) {
+    int x = v;
+    x = max(x, sa_dpp_i(none, x, 0x101));
+    x = max(x, sa_dpp_i(none, x, 0x102));
+    x = max(x, sa_dpp_i(none, x, 0x104));
+    x = max(x, sa_dpp_i(none, x, 0x108));
+    const int t3 = __builtin_amdgcn_readlane(x, 48);
+    const int t2 = max(t3, __builtin_amdgcn_readlane(x, 32));
+    const int t1 = max(t2, __builtin_amdgcn_readlane(x, 16));
+    const int row = lane >> 4;
+    const int after = row == 3 ? none : (row == 2 ? t3 : (row == 1 ? t2 : t1));
+    x = max(x, after);  // inclusive
+    return __builtin_amdgcn_update_dpp(none, x, 0x130, 0xf, 0xf, false);  // wave_shl:1
+}
+
 // Hand-off arrays exist only for the chunks that HAVE a consumer: alpha chunks 0 .. n-2, beta chunks 1 .. n-1 -- n - 1 per
 // direction (none for a one-chunk lattice): with all 2n of them the emission copy stopped fitting LDS from three chunks.
 __device__ __forceinline__ int ctc_hand_slot(int dir, int chunk, int nchunks) {
@@ -377,6 +410,11 @@ constexpr int kPTarget = 100;
 constexpr int kPRenorm = 4;
 constexpr int kFTarget = 10;    // phase 2: a pair is re-normalised to 2^kFTarget at every batch ...
 constexpr int kFMaxShift = 90;  // ... and may sit up to 2^kFMaxShift below its neighbour (2^(10 + 13 + 90) < 2^127)
+constexpr int kFLift = 32;      // ... but is LIFTED to 2^kFLift below it when the batch starts (round 5): on the logits a trained
+                                // model emits consecutive pairs ahead of the alignment differ by 2^29 per frame, mass that moves two
+                                // pairs inside one frozen batch then multiplies two such shifts -- 2^(10 + 90 + 90) overflowed,
+                                // UNNOTICED (-inf / garbage costs on 4 of 6 margin-20 utterances, tests/test_gpu_ctc.py) -- and a pair
+                                // whose own mass is 2^-32 of what is about to arrive can drop it (fp32 resolves 2^-24)
 
 template <int DIR, bool WITH_BETA, bool LDS_EM, bool HAS_PROD, bool HAS_CONS>  // a chunk before / after this one in the pipeline
 __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float* hand_all, float* hdummy,
@@ -527,10 +565,32 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
     float hs[kU];
     auto refresh = [&]() {
         const float mx = fmaxf(Bst, Lst);
+        if (!(mx < 3.0e38f)) atomicOr(&sh->suspect, 1);  // a state overflowed inside the last batch (inf, or NaN behind it)
         const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kFTarget : 0;
         Bst = __builtin_amdgcn_ldexpf(Bst, -f);
         Lst = __builtin_amdgcn_ldexpf(Lst, -f);
         e += f;
+        // lift (see wavep_refresh): the max-plus scan along this chunk's 64 pairs, seeded with the neighbour chunk's scale --
+        // its hand-off values carry their own (post-lift) exponents -- as the pair in front of the edge lane
+        {
+            constexpr int kNone = -(1 << 29);
+            int hmax = kNone;
+#pragma unroll
+            for (int k = 0; k < kU; ++k) hmax = max(hmax, hv[k] > 0.f ? hx[k] + __builtin_amdgcn_frexp_expf(hv[k]) - kFTarget : kNone);
+            if (!has_prod) hmax = kNone;
+            int m;
+            if (DIR == 0) {
+                const int v = e + lane * kFLift;
+                m = max(max(v, wave_prefix_max_excl(v, kNone, lane)), hmax - kFLift) - lane * kFLift;   // seed = pair -1
+            } else {
+                const int v = e - lane * kFLift;
+                m = max(max(v, wave_suffix_max_excl(v, kNone, lane)), hmax - 64 * kFLift) + lane * kFLift;  // seed = pair 64
+            }
+            const int up = e != kNoExp ? min(m - e, 300) : 0;
+            Bst = __builtin_amdgcn_ldexpf(Bst, -up);
+            Lst = __builtin_amdgcn_ldexpf(Lst, -up);
+            e += up;
+        }
         const int e_edge = __builtin_amdgcn_readlane(e, DIR == 0 ? 0 : 63);
 #pragma unroll
         for (int k = 0; k < kU; ++k)
@@ -538,7 +598,7 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
         const int en = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, e))
                                                        : sa_wave_shl1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, e)));
         const bool valid = e != kNoExp && en != kNoExp;
-        const int d = valid ? en - e : 0;
+        const int d = valid ? en - e : 0;  // (the neighbour's own lift can leave more than kFLift between the two)
         if (d > kFMaxShift) atomicOr(&sh->suspect, 1);
         const float pd = valid ? __builtin_amdgcn_ldexpf(1.0f, min(d, kFMaxShift)) : 0.f;
         pdx = pd;
@@ -788,7 +848,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         float c = dead ? __builtin_inff() : (float)(-((double)lp + (double)o0) * 0.6931471805599453);
         if (sh->timeout) c = __builtin_bit_cast(float, 0x7fc00000);  // NaN marks a hand-off timeout (never expected)
         A.costs[b] = c;
-        if (PROB) A.flags[b] = (dead || sh->suspect) ? 1 : 0;  // every utterance writes its flag (no memset between calls); "infeasible" is
+        if (PROB) A.flags[b] = (dead || sh->suspect || !(lp < 3.0e38f)) ? 1 : 0;  // (inf / NaN: an overflow inside the last batch)  // every utterance writes its flag (no memset between calls); "infeasible" is
                                               // the log-domain kernels' call
     }
     if (A.prof && threadIdx.x == 0) atomicMax(A.prof + 1, (unsigned long long)wall_clock64());  // (the chains are done: the
@@ -1305,17 +1365,64 @@ template <int R, int DIR>
 __device__ __forceinline__ bool wavep_refresh(float (&Bst)[R], float (&Lst)[R], int (&e)[R], const float (&skipf)[R],
                                               float (&pdx)[R], float (&pdy)[R]) {
     constexpr int kNoExp = -(1 << 28);
+    bool clamped = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float mx = fmaxf(Bst[r], Lst[r]);
+        clamped = clamped || !(mx < 3.0e38f);  // a state overflowed inside the last batch (inf, or NaN behind it)
         const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kFTarget : 0;
         Bst[r] = __builtin_amdgcn_ldexpf(Bst[r], -f);
         Lst[r] = __builtin_amdgcn_ldexpf(Lst[r], -f);
         e[r] += f;
     }
-    const int eedge = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e[R - 1]), __builtin_bit_cast(float, kNoExp))
-                                                       : sa_wave_shl1(__builtin_bit_cast(float, e[0]), __builtin_bit_cast(float, kNoExp)));
-    bool clamped = false;
+    // Exponent lifting (kFLift), only when some pair IS further below its predecessor than 2^kFLift: on flat distributions
+    // none is, and the batch starts with one DPP and a ballot.
+    int eedge = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e[R - 1]), __builtin_bit_cast(float, kNoExp))
+                                                 : sa_wave_shl1(__builtin_bit_cast(float, e[0]), __builtin_bit_cast(float, kNoExp)));
+    bool deep = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int en = DIR == 0 ? (r == 0 ? eedge : e[r - 1]) : (r == R - 1 ? eedge : e[r + 1]);
+        deep = deep || (e[r] != kNoExp && en != kNoExp && en - e[r] > kFLift);
+    }
+    if (__builtin_amdgcn_ballot_w64(deep) != 0) {
+        // lift: e'[j] = max over the pairs k that mass reaches j from (k <= j for alpha, k >= j for beta) of
+        // e[k] - |j - k| kFLift -- a max-plus prefix (suffix) scan along the lattice: afterwards NO pair sits more than
+        // 2^kFLift below its predecessor, and nothing was lifted that a predecessor's own lift would have pushed further (a
+        // one-hop lift leaves a cliff at the end of the lifted run: measured, it flagged MORE utterances than none)
+        const int lane = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+        constexpr int kNone = -(1 << 29);
+        int m[R];
+        if (DIR == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int v = e[r] + (lane * R + r) * kFLift;
+                m[r] = r == 0 ? v : max(m[r - 1], v);
+            }
+            const int before = wave_prefix_max_excl(m[R - 1], kNone, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] = max(m[r], before) - (lane * R + r) * kFLift;
+        } else {
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                const int v = e[r] - (lane * R + r) * kFLift;
+                m[r] = r == R - 1 ? v : max(m[r + 1], v);
+            }
+            const int after = wave_suffix_max_excl(m[0], kNone, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] = max(m[r], after) + (lane * R + r) * kFLift;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int up = e[r] != kNoExp ? min(m[r] - e[r], 300) : 0;  // (>= 0; 2^-300 of an fp32 hat is 0 anyway)
+            Bst[r] = __builtin_amdgcn_ldexpf(Bst[r], -up);
+            Lst[r] = __builtin_amdgcn_ldexpf(Lst[r], -up);
+            e[r] += up;
+        }
+        eedge = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e[R - 1]), __builtin_bit_cast(float, kNoExp))
+                                                 : sa_wave_shl1(__builtin_bit_cast(float, e[0]), __builtin_bit_cast(float, kNoExp)));
+    }
+    // ... then the shifts, on the exponents both sides will really use during the batch
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int en = DIR == 0 ? (r == 0 ? eedge : e[r - 1]) : (r == R - 1 ? eedge : e[r + 1]);
@@ -1555,7 +1662,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
     e0 = (int)sa_wave_max_dpp((float)e0); e1 = (int)sa_wave_max_dpp((float)e1);  // |exponents| < 2^24 ... kNoExp is exact too
     const int em = max(f0 > 0.f ? e0 : kNoExp, f1 > 0.f ? e1 : kNoExp);
     const float psum = (f0 > 0.f ? __builtin_amdgcn_ldexpf(f0, e0 - em) : 0.f) + (f1 > 0.f ? __builtin_amdgcn_ldexpf(f1, e1 - em) : 0.f);
-    const bool dead = !(psum > 0.f);
+    const bool dead = !(psum > 0.f) || !(psum < 3.0e38f);  // no mass, NaN -- or an overflow in the last batch: all redone in the log domain
     const int pe = dead ? 0 : em + __builtin_amdgcn_frexp_expf(psum);
     const float ph = dead ? 1.f : __builtin_amdgcn_frexp_mantf(psum);
     if (lane == 0) {
@@ -1712,6 +1819,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                         const float lab_tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
                         if (k == 0 || k == nrows - 1)  // (a partial last batch ends at row nrows - 1, not KU - 1)
                             bad_row = bad_row || !(fabsf(sa_wave_sum_dpp(gb) + lab_tot - 1.0f) < 1e-4f);  // (NaN compares false)
+                        bad_row = bad_row || !(lab_tot > -1e-4f && lab_tot < 1.0001f);  // every row: NaN / inf / a sum outside [0, 1]
                         const float ob = 1.0f - lab_tot;
 #pragma unroll
                         for (int r = 0; r < R; ++r) occ[lane * R + r] = sv[r] + excl;

@@ -221,6 +221,7 @@ struct PFwdJobs {
     int spin_limit;      // polls before a hand-off counts as failed (SA_GRU_SPIN_LIMIT; default 1 << 20)
     int fault;           // fault injection (SA_GRU_FAULT=1, tests only): unit tile 1 of group 0 leaves before its first step
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
+    float* dump;         // gru_fwd_chunk_kernel: 256 x 256 floats nobody reads (stores of rows beyond the batch)
     PFwdJob j[kMaxJobs];
 };
 
@@ -442,6 +443,159 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(PFwdJobs P) {
     }
     if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 #undef SA_TICK
+}
+
+// ------------------------------------------------------------------ persistent forward chunk, flag-less, round 5 form
+// gru_fwd_persist_kernel<true> with its flag-less XCD-local hand-off, rebuilt like gru_fwd_fused_kernel (see there): the
+// width is a template parameter and no branch surrounds a vector-memory instruction inside the loop -- the run-time-width
+// kernel waits vmcnt(0) in front of every polling trip (for the step's HBM operands and for the acknowledgement of its own
+// stores) and in front of every group of twelve MFMAs.  Serves the two directions of a bidirectional layer (one launch for
+// all T steps, or chunk by chunk beside the side-stream projections) and the chunked layer wavefront (option gru.fused = 0).
+// Bit-identical to gru_fwd_persist_kernel (same products in the same order).
+template <int IPG, bool STASH>
+__global__ __launch_bounds__(256) void gru_fwd_chunk_kernel(PFwdJobs P) {
+    constexpr int H = 64 * IPG, NTU = H / 16, KS = 16 * IPG;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE(P.prio);
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {  // more than 32 workgroups landed on this XCD
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / NTU, grp = s_role[0] * (32 / NTU) + sub;
+    if (sub >= 32 / NTU) return;
+    const int role_x = s_role[1] - sub * NTU, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
+    if (role_z >= P.n) return;  // idle group: fill / drain of the layer wavefront, or fewer groups than slots
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+    const PFwdJob& J = P.j[role_z];
+    const int B = P.B;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    float* red = psm;  // [2][4 waves][3 sums][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    const float e_br = J.b_hh[u], e_bz = J.b_hh[H + u], e_bn = J.b_hh[2 * H + u];
+    const int kbeg = wave * KS;
+    const int brow = min(b0 + i, B - 1);
+    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
+    unsigned* errp = P.err;
+    const int t0 = J.t0, nsteps = J.nsteps, dt = J.dt, t_first = J.t_first;
+    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)J.h_out, 0, 0x7fffffff, 0x00020000);
+    const long hrow = ((long)brow * J.hs_b + kbeg + 4 * g) * 4;  // byte offset of this lane's first fragment in row brow, t = 0
+    const long hstep = J.hs_t * 4;
+    // per-thread operand / store addresses: base + t * stride (a row beyond the batch loads row 0 and stores to its dump slot)
+    const float* p_ai = J.ai + (long)(live ? b : 0) * P.rb * 3 * H + u;
+    const long s_ai = (long)P.rt * 3 * H;
+    float* dump = P.dump + blockIdx.x * 256 + tid;
+    float* p_h = live ? J.h_out + (long)b * J.hs_b + u : dump;
+    const long s_h = live ? J.hs_t : 0;
+    float* p_st = (STASH && live) ? J.stash + (long)b * P.rb * 5 * H + u : dump;
+    const long s_st = (STASH && live) ? (long)P.rt * 5 * H : 0;
+    const int so = (STASH && live) ? H : 0;
+    float hp = 0.f;
+    if (live && t0 != t_first) hp = J.h_out[(long)b * J.hs_b + (long)(t0 - dt) * J.hs_t + u];
+    float4 wh[IPG][3];  // the W_hh fragments this lane feeds to its MFMAs: resident in registers
+#pragma unroll
+    for (int it = 0; it < IPG; ++it)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            wh[it][n] = *reinterpret_cast<const float4*>(J.w_hh + (long)(n * H + u0 + i) * H + kbeg + 16 * it + 4 * g);
+    __syncthreads();
+
+    f32x4v a[IPG];
+    auto poll_until_fresh = [&](int tprev) {  // flag-less hand-off inside the XCD: the row block of time tprev
+        const int abase = (int)(hrow + (long)tprev * hstep);
+        for (int spins = 0;; ++spins) {
+            asm volatile("" ::: "memory");  // every trip re-issues its loads
+#pragma unroll
+            for (int it = 0; it < IPG; ++it)
+                a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hres, abase + 64 * it, 0, 16));
+            bool stale = false;
+#pragma unroll
+            for (int it = 0; it < IPG; ++it) stale |= has_sentinel(a[it]);
+            if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+        }
+    };
+    float nx_r, nx_z, nx_n;  // the input projection of the step about to be processed, requested a step ago
+    auto fetch_ai = [&](int tt) { const float* q = p_ai + (long)tt * s_ai; nx_r = q[0]; nx_z = q[H]; nx_n = q[2 * H]; };
+    auto finish = [&](int s, int t, const f32x4 (&acc)[3], float e_r, float e_z, float e_n) {
+        float* rd = red + (s & 1) * 3072;
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rd[(wave * 3 + n) * 256 + (g * 4 + r) * 16 + i] = acc[n][r];
+        __syncthreads();
+        float sr = 0.f, sz = 0.f, sn = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sr += rd[(w * 3 + 0) * 256 + tid];
+            sz += rd[(w * 3 + 1) * 256 + tid];
+            sn += rd[(w * 3 + 2) * 256 + tid];
+        }
+        const float r = sigmoidf_(e_r + sr + e_br);
+        const float z = sigmoidf_(e_z + sz + e_bz);
+        const float q = sn + e_bn;
+        const float n = tanhf(e_n + r * q);
+        const float h = (1.0f - z) * n + z * hp;
+        __hip_atomic_store(p_h + (long)t * s_h, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+        if (STASH) {
+            float* st = p_st + (long)t * s_st;
+            st[0] = r; st[so] = z; st[2 * so] = n; st[3 * so] = q; st[4 * so] = hp;
+        }
+        hp = h;
+    };
+    fetch_ai(t0);
+    int s = 0;
+    if (t0 == t_first && nsteps > 0) {  // the sequence's first step (peeled: no recurrent term, nobody to wait for)
+        f32x4 acc[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+        fetch_ai(nsteps > 1 ? t0 + dt : t0);
+        finish(0, t0, acc, e_r, e_z, e_n);
+        s = 1;
+    }
+    for (; s < nsteps; ++s) {
+        const int t = t0 + s * dt;
+        f32x4 acc[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+        // Pacing: the first polling trip goes out once this step's own stores are acknowledged -- about when the other
+        // blocks' rows land too (they published at the same moment).  Issued straight behind the stores the trip comes back
+        // stale and is repeated: three trips of 1 MB per group and step instead of one, in L2 bandwidth that the stores
+        // compete for -- 5.0 instead of 3.7 us per step on a bidirectional S-LIBRI layer (the run-time-width kernel was paced
+        // by accident: hipcc's vmcnt(0) in front of its polling loads).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        poll_until_fresh(t - dt);
+        // the next step's operands (HBM): requested behind the poll -- in front of it they hold the poll's data back (one
+        // in-order queue), at the end of the step they hold the NEXT poll's back
+        fetch_ai(s + 1 < nsteps ? t + dt : t);  // (the last step re-reads its own row: unused)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < IPG; ++it)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const float4 w = wh[it][n];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, acc[n], 0, 0, 0);
+            }
+        finish(s, t, acc, e_r, e_z, e_n);
+    }
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
 
 // ------------------------------------------------------------------------------------- fused forward layer wavefront
@@ -684,6 +838,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
             for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
             SA_TICK(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pacing of the first polling trip (see gru_fwd_chunk_kernel)
             poll_until_fresh(t - 1, false);
             SA_TICK(1)
             // the next step's values (HBM): requested behind the poll -- in front of it they would hold the poll's data
@@ -2069,6 +2224,16 @@ static FusedFwdFn fused_fwd_fn(int H, bool stash, bool drop, bool timed) {
     }
     return nullptr;
 }
+typedef void (*FwdChunkFn)(PFwdJobs);
+// gru_fwd_chunk_kernel<IPG, STASH> for H = 64 IPG (the flag-less XCD-local persistent forward; null: no such instance)
+static FwdChunkFn fwd_chunk_fn(int H, bool stash) {
+    switch (H / 64) {
+#define SA_FWD_CHUNK(I_) case I_: return stash ? gru_fwd_chunk_kernel<I_, true> : gru_fwd_chunk_kernel<I_, false>;
+        SA_FWD_CHUNK(8) SA_FWD_CHUNK(7) SA_FWD_CHUNK(6) SA_FWD_CHUNK(5) SA_FWD_CHUNK(4) SA_FWD_CHUNK(3) SA_FWD_CHUNK(2)
+#undef SA_FWD_CHUNK
+    }
+    return nullptr;
+}
 static int persist_prio() { return 1; }  // the recurrence waves issue at raised priority (s_setprio 3)
 
 static int clamp_chunk(int chunk, int T) {
@@ -2271,7 +2436,10 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                     for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
                         Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
                         Q.reg_base = bi_launches++ * 32u;
-                        hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
+                        Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
+                        FwdChunkFn cfn = Q.flagless ? fwd_chunk_fn(H, Q.j[0].stash != nullptr) : nullptr;  // (arrival counters: option gru.persist = 2)
+                        if (cfn) hipLaunchKernelGGL(cfn, dim3(256), dim3(256), bi_lds, stream, Q);
+                        else hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
                     }
                 }
                 st = finish_layer();
@@ -2420,7 +2588,10 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                     Q.bt0 = bt0; Q.nbt = min(tpp, nbt - bt0);
                     Q.reg_base = persist_launches++ * 32u;
                     if (bt0 > 0) Q.stamp = nullptr;
-                    hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), plds, stream, Q);
+                    Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
+                    FwdChunkFn cfn = (Q.flagless && !Q.timing) ? fwd_chunk_fn(H, stash != nullptr) : nullptr;
+                    if (cfn) hipLaunchKernelGGL(cfn, dim3(256), dim3(256), plds, stream, Q);
+                    else hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), plds, stream, Q);
                 }
             }
             continue;

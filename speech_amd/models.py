@@ -129,10 +129,38 @@ class Model(nn.Module):
 
     def _pad_inputs(self, inputs):
         if self.is_cuda and getattr(self, "_staged", False) and not torch.is_tensor(inputs[0]):
+            ahead, self._ahead = getattr(self, "_ahead", None), None
+            if ahead is not None and ahead[0] is inputs:  # stage_ahead() padded exactly this batch on its worker thread
+                staged = ahead[1].result()
+                want_t = max(max(int(i.shape[0]) for i in inputs), int(self.pad_frames or 0))
+                if staged is not None and staged.shape[1] == want_t:
+                    return staged
             if self._stage is None:
                 self._stage = _PinnedStage()
             return zero_pad_concat(inputs, self.pad_frames, stage=self._stage)
         return _as_tensor(zero_pad_concat(inputs, self.pad_frames))
+
+    def stage_ahead(self, batch, shape=None):
+        """Start padding the NEXT batch into pinned memory on a worker thread (numpy releases the interpreter lock for the
+        copy), while the caller enqueues the current step: dist.with_global_shapes(loader, model) calls this for batch k+1 as
+        it hands out batch k.  `shape`: the batch's global-shape handle under data parallelism (its frames are what
+        set_global_batch() will put into pad_frames before loss(batch)); None = the batch is whole.  loss() / forward() /
+        infer() on exactly this batch object then find the padded tensor ready; anything else is padded as usual."""
+        inputs = batch[0]
+        if not self.is_cuda or len(inputs) == 0 or torch.is_tensor(inputs[0]):
+            return
+        if self._stage is None:
+            self._stage = _PinnedStage()
+        if getattr(self, "_ahead_pool", None) is None:
+            import concurrent.futures
+            self._ahead_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="speech_amd-pad")
+        def work():
+            try:  # (the shape handle's frames are what set_global_batch() will put into pad_frames before loss(batch))
+                frames = int(shape.result()[1]) if shape is not None and hasattr(shape, "result") else 0
+                return zero_pad_concat(inputs, frames, stage=self._stage)
+            except Exception:  # never fatal: the batch is then padded on the launch path, as before
+                return None
+        self._ahead = (inputs, self._ahead_pool.submit(work))
 
     def _healthy(self, fn):
         """Forward-only use (infer, dev-set loss): there is no optimiser whose device-side gate would catch a failed

@@ -605,7 +605,7 @@ def test_fused_forward_wavefront_matches_oracle_and_default():
 
 def test_gemm_arithmetic_is_a_function_of_the_shape_not_of_the_workspace(monkeypatch):
     """include/speech_amd.h section 4: a product runs the split-bf16 path iff sa_gemm_is_split_bf16(M, N, K) (>= 8 GFLOP,
-    K >= 256, M, N >= 64; SA_GEMM_EXACT forces either way) -- a split-path product handed less workspace than
+    K >= 256, M, N >= 64; option gemm.exact forces either way) -- a split-path product handed less workspace than
     sa_gemm_workspace_bytes returns CTC_STATUS_INVALID_VALUE instead of quietly running the other kernel; an exact-path
     product accepts no workspace at all (K is then simply not split)."""
     from speech_amd import _lib
@@ -626,6 +626,7 @@ def test_gemm_arithmetic_is_a_function_of_the_shape_not_of_the_workspace(monkeyp
     split = c.clone()
     assert call(need // 2) == 2 and call(0) == 2          # CTC_STATUS_INVALID_VALUE: never a silent change of arithmetic
     monkeypatch.setenv("SA_GEMM_EXACT", "1")
+    L = _lib.lib()  # (the host applies the changed environment to the library's option table on its next access)
     assert L.sa_gemm_is_split_bf16(M, N, K) == 0
     assert call(0) == 0                                    # the exact path needs no workspace
     ref = a.double() @ b.double().t()

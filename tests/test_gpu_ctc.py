@@ -68,12 +68,12 @@ def run_hip(acts, labs, al, ll, blank=None, batch_first=True, want_grad=True):
     return costs.cpu().numpy(), (grads.cpu().numpy() if grads is not None else None)
 
 
-def compare(acts, labs, al, ll, blank=None, batch_first=True):
+def compare(acts, labs, al, ll, blank=None, batch_first=True, cost_atol=0.0):
     c, g = run_hip(acts, labs, al, ll, blank, batch_first)
     co, go = ctc_ref.ctc_loss(acts, labs, al, ll, blank=blank, batch_first=batch_first)
     finite = np.isfinite(co)
     assert np.array_equal(np.isinf(c), ~finite), (c, co)
-    np.testing.assert_allclose(c[finite], co[finite], rtol=COST_RTOL)
+    np.testing.assert_allclose(c[finite], co[finite], rtol=COST_RTOL, atol=cost_atol)
     assert np.isfinite(g).all()
     err = np.abs(g - go).max()
     assert err < grad_atol(co), (err, grad_atol(co))
@@ -382,4 +382,7 @@ def test_alignment_shaped_logits_match_the_oracle(regime, margin, monkeypatch):
     hands most of them to the log-domain kernels: the flag count is in bench.py's `ctc_flagged`)."""
     monkeypatch.setenv("SA_CTC_WIDE", "1" if regime == "throughput" else "0")
     B, T, K, L = 6, 1000, 29, 100
-    compare(*aligned_case(int(margin) * 7 + (regime == "throughput"), B, T, K, L, margin))
+    # At margin 20 the alignment carries p = 0.9998: the cost is 1.5e-4 nats, and an fp32 recurrence rounds a probability
+    # near one once per lattice step -- T * 2^-24 = 6e-5 nats of systematic error that no fp32 CTC (warp-ctc's included)
+    # avoids and rtol 1e-5 of a near-zero cost cannot absorb: the absolute floor is two such roundings per step.
+    compare(*aligned_case(int(margin) * 7 + (regime == "throughput"), B, T, K, L, margin), cost_atol=2 * T * 2.0 ** -24)

@@ -174,3 +174,44 @@ def test_flat_buffer_gradients_accumulate_without_zero_grad():
     model.zero_grad(set_to_none=True)
     model.loss(batch).backward()
     torch.testing.assert_close(flat_g[:-1], once, rtol=0, atol=0)  # and a fresh step is exactly the single gradient
+
+
+def test_padding_a_batch_ahead_changes_nothing_but_where_it_runs():
+    """Round 5: dist.with_global_shapes(loader, model) has the model pad batch k+1 into pinned memory on a worker thread while
+    step k is being enqueued (Model.stage_ahead; the 10 MB host copy of an S-LIBRI batch had become the launch path's longest
+    item once the step itself took 6.9 ms).  The loss of a batch is the same bits whether it was padded ahead or in place;
+    a batch padded ahead and never used, a different batch object, a changed pad_frames and ops.backward() all fall back
+    to / agree with the plain path."""
+    from speech_amd import dist, ops
+    from speech_amd.models import CTC
+    cfg = {"dropout": 0.0, "encoder": {"conv": [[8, 5, 11, 2]], "rnn": {"dim": 16, "bidirectional": True, "layers": 2}}}
+    rng = np.random.RandomState(3)
+    batches = [make_batch(rng, 3, 40 + 7 * k, 40, 10, 5) for k in range(5)]
+    torch.manual_seed(0)
+    model = CTC(40, 10, cfg).cuda()
+    model.set_train()
+    plain = [float(model.loss(b).item()) for b in batches]
+    seen = []
+    for batch, shape in dist.with_global_shapes(iter(batches), model):
+        model.set_global_batch(*shape)
+        seen.append(float(model.loss(batch).item()))
+    assert seen == plain
+    model.set_global_batch()
+    model.stage_ahead(batches[1])                 # padded ahead, then another batch is used: the stale copy is ignored
+    assert float(model.loss(batches[2]).item()) == plain[2]
+    model.stage_ahead(batches[3])
+    model.set_global_batch(3, 200, 5)             # padded ahead to its own length, consumed with a longer pad: re-padded
+    longer = float(model.loss(batches[3]).item())
+    model.set_global_batch()
+    assert longer != plain[3] and float(model.loss(batches[3]).item()) == plain[3]
+    # ops.backward(loss) == loss.backward(): the cached unit gradient instead of autograd's fill launch
+    model.zero_grad(set_to_none=True)
+    model.loss(batches[0]).backward()
+    want = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    ops.backward(model.loss(batches[0]))
+    assert all(torch.equal(a, p.grad) for a, p in zip(want, model.parameters()))
+    model.zero_grad(set_to_none=True)
+    (2.0 * model.loss(batches[0])).backward()     # a non-unit seed still scales the saved gradient
+    for a, p in zip(want, model.parameters()):
+        torch.testing.assert_close(p.grad, 2.0 * a, rtol=1e-6, atol=1e-7)

@@ -109,7 +109,7 @@ def run_epoch(model, flat, opt_cfg, train_ldr, it, avg_loss, world, rank, step_f
             raise RuntimeError("update of iteration %d skipped again after the reset (step kernels): giving up" % bad)
 
     # (batch, global shape) pairs: the shape exchange of batch k+1 runs while step k is being enqueued
-    for batch, shape in dist.with_global_shapes(tq):
+    for batch, shape in dist.with_global_shapes(tq, model):
         start_t = time.time()
         recent.append((it, (batch, shape)))
         loss, norm = step_fn(batch, shape)
