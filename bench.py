@@ -296,11 +296,11 @@ def infer_legs(dev):
         rng = np.random.RandomState(11)
         for bs in (1, 8):
             batch = (tuple(rng.randn(frames, freq).astype(np.float32) for _ in range(bs)), tuple([0, 1] for _ in range(bs)))
-            for _ in range(3):
+            for _ in range(10):  # (the pinned rings of the host path grow slot by slot: eight calls until every slot exists)
                 model.infer(batch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n = 10
+            n = 20
             for _ in range(n):
                 model.infer(batch)
             torch.cuda.synchronize()

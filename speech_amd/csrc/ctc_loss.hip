@@ -410,7 +410,10 @@ constexpr int kPTarget = 100;
 constexpr int kPRenorm = 4;
 constexpr int kFTarget = 10;    // phase 2: a pair is re-normalised to 2^kFTarget at every batch ...
 constexpr int kFMaxShift = 90;  // ... and may sit up to 2^kFMaxShift below its neighbour (2^(10 + 13 + 90) < 2^127)
-constexpr int kFLift = 32;      // ... but is LIFTED to 2^kFLift below it when the batch starts (round 5): on the logits a trained
+#ifndef SA_KFLIFT
+#define SA_KFLIFT 32
+#endif
+constexpr int kFLift = SA_KFLIFT;  // ... but is LIFTED to 2^kFLift below it when the batch starts (round 5): on the logits a trained
                                 // model emits consecutive pairs ahead of the alignment differ by 2^29 per frame, mass that moves two
                                 // pairs inside one frozen batch then multiplies two such shifts -- 2^(10 + 90 + 90) overflowed,
                                 // UNNOTICED (-inf / garbage costs on 4 of 6 margin-20 utterances, tests/test_gpu_ctc.py) -- and a pair
@@ -565,31 +568,39 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
     float hs[kU];
     auto refresh = [&]() {
         const float mx = fmaxf(Bst, Lst);
-        if (!(mx < 3.0e38f)) atomicOr(&sh->suspect, 1);  // a state overflowed inside the last batch (inf, or NaN behind it)
+        const bool blown = !(mx < 3.0e38f);  // a state overflowed inside the last batch (inf, or NaN behind it): flagged below
         const int f = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - kFTarget : 0;
         Bst = __builtin_amdgcn_ldexpf(Bst, -f);
         Lst = __builtin_amdgcn_ldexpf(Lst, -f);
         e += f;
         // lift (see wavep_refresh): the max-plus scan along this chunk's 64 pairs, seeded with the neighbour chunk's scale --
-        // its hand-off values carry their own (post-lift) exponents -- as the pair in front of the edge lane
+        // its hand-off values carry their own (post-lift) exponents -- as the pair in front of the edge lane.  Only when
+        // some pair IS more than 2^kFLift below its predecessor (flat distributions: never; one DPP and a ballot then).
         {
             constexpr int kNone = -(1 << 29);
-            int hmax = kNone;
+            // (the test looks at the gaps INSIDE the chunk only: the hand-off values of the neighbour chunk are still on their
+            // way out of LDS here, and waiting for them would put an LDS round trip on every batch of the chain -- measured:
+            // 89 -> 105 ns per step; an edge pair that alone sits too deep overflows its shift and is flagged a batch later)
+            const int en0 = __builtin_bit_cast(int, DIR == 0 ? sa_wave_shr1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, kNoExp))
+                                                            : sa_wave_shl1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, kNoExp)));
+            if (__builtin_amdgcn_ballot_w64(e != kNoExp && en0 != kNoExp && en0 - e > kFLift) != 0) {
+                int hmax = kNone;
 #pragma unroll
-            for (int k = 0; k < kU; ++k) hmax = max(hmax, hv[k] > 0.f ? hx[k] + __builtin_amdgcn_frexp_expf(hv[k]) - kFTarget : kNone);
-            if (!has_prod) hmax = kNone;
-            int m;
-            if (DIR == 0) {
-                const int v = e + lane * kFLift;
-                m = max(max(v, wave_prefix_max_excl(v, kNone, lane)), hmax - kFLift) - lane * kFLift;   // seed = pair -1
-            } else {
-                const int v = e - lane * kFLift;
-                m = max(max(v, wave_suffix_max_excl(v, kNone, lane)), hmax - 64 * kFLift) + lane * kFLift;  // seed = pair 64
+                for (int k = 0; k < kU; ++k) hmax = max(hmax, hv[k] > 0.f ? hx[k] + __builtin_amdgcn_frexp_expf(hv[k]) - kFTarget : kNone);
+                if (!has_prod) hmax = kNone;
+                int m;
+                if (DIR == 0) {
+                    const int v = e + lane * kFLift;
+                    m = max(max(v, wave_prefix_max_excl(v, kNone, lane)), hmax - kFLift) - lane * kFLift;   // seed = pair -1
+                } else {
+                    const int v = e - lane * kFLift;
+                    m = max(max(v, wave_suffix_max_excl(v, kNone, lane)), hmax - 64 * kFLift) + lane * kFLift;  // seed = pair 64
+                }
+                const int up = e != kNoExp ? min(m - e, 300) : 0;
+                Bst = __builtin_amdgcn_ldexpf(Bst, -up);
+                Lst = __builtin_amdgcn_ldexpf(Lst, -up);
+                e += up;
             }
-            const int up = e != kNoExp ? min(m - e, 300) : 0;
-            Bst = __builtin_amdgcn_ldexpf(Bst, -up);
-            Lst = __builtin_amdgcn_ldexpf(Lst, -up);
-            e += up;
         }
         const int e_edge = __builtin_amdgcn_readlane(e, DIR == 0 ? 0 : 63);
 #pragma unroll
@@ -599,7 +610,7 @@ __device__ __forceinline__ void ctc_chain_p(const AbArgs& A, AbShared* sh, float
                                                        : sa_wave_shl1(__builtin_bit_cast(float, e), __builtin_bit_cast(float, e)));
         const bool valid = e != kNoExp && en != kNoExp;
         const int d = valid ? en - e : 0;  // (the neighbour's own lift can leave more than kFLift between the two)
-        if (d > kFMaxShift) atomicOr(&sh->suspect, 1);
+        if (d > kFMaxShift || blown) atomicOr(&sh->suspect, 1);
         const float pd = valid ? __builtin_amdgcn_ldexpf(1.0f, min(d, kFMaxShift)) : 0.f;
         pdx = pd;
         pdy = pd * skipf;

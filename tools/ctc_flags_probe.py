@@ -45,4 +45,4 @@ for B in (int(a) for a in (sys.argv[1:] or ["4096"])):
             ctc_loss_raw(acts, lab)
         e1.record()
         torch.cuda.synchronize()
-        print("B", B, ("random logits x %g" % scale) if scale > 0 else ("aligned logits, margin %g" % -scale), "flagged", int((fl != 0).sum()), "of", B, "ms", round(e0.elapsed_time(e1) / 3, 4), flush=True)
+        print("B", B, ("random logits x %g" % scale) if scale > 0 else ("aligned logits, margin %g" % -scale), "flagged", int((fl != 0).sum()), "(alpha-dead %d, beta %d)" % (int((fl == 1).sum()), int((fl == 2).sum())), "of", B, "ms", round(e0.elapsed_time(e1) / 3, 4), flush=True)
