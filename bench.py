@@ -146,8 +146,9 @@ def gpu_leg(args, world, rank, local):
     pipe = ops.ScalarPipe()
     with torch.no_grad():  # the loss of the initial weights on this batch, before any update
         loss_step0 = float(loss_fn(model.forward_impl(x), labels, None, None).item())
-        if strong:  # (a shard's loss is its share of the global mean: the global loss is the sum over ranks)
-            loss_step0 = dist.sum_over_ranks(loss_step0, dev)
+        # (a rank's loss is its shard's share of the global mean: the GLOBAL loss is the sum over ranks -- what a single
+        # process computes on the whole global batch, tests/test_gpu_rccl_two_gpus.py)
+        loss_step0 = dist.sum_over_ranks(loss_step0, dev)
     step = make_step(model, flat_p, flat_g, x, labels, loss_fn, norm, pipe, last)
 
     for _ in range(args.warmup):
@@ -198,7 +199,10 @@ def gpu_leg(args, world, rank, local):
            "params": int(flat_p.numel()), "Tp": Tp, "per_gpu_batch": Bl,
            "ctc_chain_in_step_us": float(np.mean(chain_in_step)) if chain_in_step else None}
     if args.scaling == "both" and world > 1:  # the weak-scaling headline above; the same global batch sharded, beside it
-        res["strong"] = strong_scaling_leg(args, model, flat_p, flat_g, world, rank, dev)
+        try:
+            res["strong"] = strong_scaling_leg(args, model, flat_p, flat_g, world, rank, dev)
+        except Exception as exc:  # (an extra leg must never cost the headline line)
+            res["strong"] = {"error": repr(exc)}
 
     if args.headline_only:  # A/B experiments (tools/ab_env.sh): the timed region and the device clocks, nothing else
         res.update({"train_loop_dt": 1.0, "train_loop_steps": 0})

@@ -75,9 +75,26 @@ def _worker(rank, world, port, out, lens, sharded_loader):
     flat, loss = _grad_of(shard, shape)
     dist.allreduce_gradients(flat)
     total_loss = dist.allreduce_sum_host([loss])[0]
+    # the scalar reductions bench.py's multi-GPU legs use, and the look-ahead iterator with a model's stage_ahead hook
+    cpu = torch.device("cpu")
+    ssum, smax = dist.sum_over_ranks(float(rank + 1), cpu), dist.max_over_ranks(float(rank + 1), cpu)
+
+    class Recorder:  # stands in for Model.stage_ahead: resolves the batch's global shape on ANOTHER thread
+        def __init__(self):
+            import concurrent.futures
+            self.pool, self.seen = concurrent.futures.ThreadPoolExecutor(1), []
+
+        def stage_ahead(self, batch, handle):
+            self.seen.append(self.pool.submit(handle.result))
+    rec = Recorder()
+    lo, hi = dist.shard_bounds(len(lens), world, rank)
+    mine = (whole[0][lo:hi], whole[1][lo:hi])
+    shapes = [sh for _, sh in dist.with_global_shapes(iter([mine, mine, mine]), rec)]
+    ahead = [f.result() for f in rec.seen]
     dist.barrier()
     if rank == 0:
-        torch.save({"flat": flat, "n": len(shard[0]), "shape": shape, "loss": total_loss}, out)
+        torch.save({"flat": flat, "n": len(shard[0]), "shape": shape, "loss": total_loss, "ssum": ssum, "smax": smax,
+                    "shapes": shapes, "ahead": ahead}, out)
 
 
 def test_shard_bounds_cover_batch_exactly():
@@ -100,6 +117,9 @@ def test_two_rank_allreduce_equals_single_process_on_a_ragged_batch(tmp_path, sh
     assert got["n"] == 3 and tuple(got["shape"]) == (5, 52, 4)  # rank 0 takes the remainder utterance
     torch.testing.assert_close(got["flat"], want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))  # fp32 sum order
     assert abs(got["loss"] - want_loss) <= 1e-5 * abs(want_loss)
+    assert got["ssum"] == 3.0 and got["smax"] == 2.0
+    # the look-ahead iterator: every batch's global shape, also as the collate-ahead thread saw it (one wait, two readers)
+    assert got["shapes"] == [(5, 52, 4)] * 3 and got["ahead"] == [(5, 52, 4)] * 3
     # the round-1 behaviour -- each shard padded to its OWN longest utterance -- is a different function
     s1 = (whole[0][3:], whole[1][3:])
     local, _ = _grad_of(s1, (5, max(LENS[3:]), 4))

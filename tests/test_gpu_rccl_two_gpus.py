@@ -47,6 +47,39 @@ def test_bench_two_gpus_over_rccl_reports_the_world():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
     assert line["persist_status"] == 0
     assert abs(line["value"] - 64 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    # SURVEY 8(e) "report both": the strong-scaling leg rides in the same line -- the global batch of 32 sharded 16 + 16
+    strong = line["strong_scaling"]
+    assert strong and "error" not in strong, strong
+    assert strong["global_batch"] == 32 and strong["per_gpu_batch"] == 16 and strong["n_gpus"] == 2
+    assert abs(strong["value"] - 32 * 4 / (strong["ms_per_step"] * 4e-3)) < 1e-6 * strong["value"]
+    # ... and the two-rank loss of the initial weights IS the single-process loss of the same global batch of 64
+    # (rank r trains bench.synthetic(r): the whole batch is their concatenation)
+    sys.path.insert(0, ROOT)
+    import bench
+    from speech_amd.ctc import CTCLabels, CTCLoss
+    from speech_amd.models import CTC
+    torch.manual_seed(2017)
+    model = CTC(bench.F, bench.V, bench.S_LIBRI).cuda()
+    model.set_train()
+    parts = [bench.synthetic(r) for r in range(2)]
+    x = torch.from_numpy(np.concatenate([p[0] for p in parts])).cuda()
+    lab = np.concatenate([p[1] for p in parts])
+    Tp = model.conv_out_size(bench.T, 0)
+    labels = CTCLabels(lab, np.full(64, Tp, np.int32), np.full(64, bench.L, np.int32), x.device)
+    with torch.no_grad():
+        whole = float(CTCLoss(denom=64)(model.forward_impl(x), labels, None, None).item())
+    assert abs(line["loss_step0"] - whole) <= 1e-5 * abs(whole), (line["loss_step0"], whole)
+    # N = 1 for comparison: the same code path, world of one, the loss of rank 0's own batch
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only",
+                         "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert one["n_gpus"] == 1 and one["strong_scaling"] is None and one["scaling"] == "weak"
+    with torch.no_grad():
+        x0 = torch.from_numpy(parts[0][0]).cuda()
+        lab0 = CTCLabels(parts[0][1], np.full(32, Tp, np.int32), np.full(32, bench.L, np.int32), x.device)
+        own = float(CTCLoss(denom=32)(model.forward_impl(x0), lab0, None, None).item())
+    assert abs(one["loss_step0"] - own) <= 1e-5 * abs(own), (one["loss_step0"], own)
 
 
 WORKER = r'''
