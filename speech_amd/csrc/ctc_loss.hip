@@ -1630,7 +1630,11 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
 #pragma unroll
                 for (int r = 0; r < R; ++r) yl[r] = cur[a_off[r] + k];  // (no label state: the ring's zero column)
                 if (FAST) wavep_fast_step<R, 0>(aB, aL, yl, yb, pdx, pdy, sB, sL);
-                else wavep_slow_step<R, 0>(aB, aL, ae, yl, yb, skipf, sB, sL, (k & 3) == 0);
+                // (re-normalised EVERY step while the front crosses: on the logits a trained model emits an off-alignment
+                // state loses 2^-29 per step, four steps between re-normalisations took a 2^10 hat below the smallest fp32, the
+                // pair fell back to "empty" -- and an empty pair cuts the lattice for good once the exponents freeze:
+                // the alignment's mass then never reaches the end, p = 0: the "alpha-dead" quarter of margin-20 batches)
+                else wavep_slow_step<R, 0>(aB, aL, ae, yl, yb, skipf, sB, sL, true);
             }
             if (REC) {
 #pragma unroll
@@ -1788,7 +1792,7 @@ __device__ __forceinline__ void ctc_wave_p_body(const WaveArgs& A, int* __restri
                             for (int r = 0; r < R; ++r) es[r] = be[r];
                             wavep_fast_step<R, 1>(bB, bL, yl, yb, pdx, pdy, sB, sL);
                         } else {
-                            wavep_slow_step<R, 1>(bB, bL, be, yl, yb, skipf, sB, sL, ((KU - 1 - k) & 3) == 0);
+                            wavep_slow_step<R, 1>(bB, bL, be, yl, yb, skipf, sB, sL, true);
 #pragma unroll
                             for (int r = 0; r < R; ++r) es[r] = be[r];  // the aligned exponent of the step (kNoExp: sums are 0)
                         }

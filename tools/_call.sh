@@ -1,11 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-python - <<PY
-import sys, torch
-sys.path.insert(0, ".")
-import bench
-dev = torch.device("cuda", 0)
-torch.cuda.set_device(dev)
-r = bench.ctc_legs(dev)
-print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()})
-PY
+O=gpurun_out/r5c24; mkdir -p $O
+timeout 600 python tools/ctc_flags_probe.py 1024 4096 32 2>&1 | grep -v amdgpu | tee $O/flags.log
 timeout 300 python -m pytest tests/test_gpu_ctc.py -x -q 2>&1 | tail -2
