@@ -1025,43 +1025,62 @@ ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsign
 typedef float tf32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThinSplit = 64;  // K chunks of thin_tn_kernel
 
+// U: 16-byte loads of the streamed operand a lane keeps in flight (K / 16 is a multiple of U): the kernel is a latency chain
+// of load trips, and four in flight left it at 19 us for 32.6 MB (round 5: eight at K = 512 -- 8 KB per wave)
+template <int U>
 __global__ __launch_bounds__(256) void thin_nt_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                       long ldb, const float* __restrict__ bias, float* __restrict__ C,
                                                       long ldc, int M, int N, int K, float beta) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];  // Bs[32][K + 4]
     const int pitch = K + 4;
-    for (int e = threadIdx.x; e < 32 * (K / 4); e += 256) {
-        const int n = e / (K / 4), k4 = e - n * (K / 4);
-        const float4 v = n < N ? *reinterpret_cast<const float4*>(B + (long)n * ldb + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(tsm + n * pitch + 4 * k4) = v;
+    {   // the thin operand into LDS, eight 16-byte loads per thread in flight (unconditional loads on clamped indices: one
+        // load per trip with its own wait was a chain of 16 L2 round trips, 6 of the kernel's 19 us)
+        const int k4n = K / 4, total = 32 * k4n;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = min(e0 + 256 * q, total - 1), n = e / k4n, k4 = e - n * k4n;
+                v[q] = *reinterpret_cast<const float4*>(B + (long)min(n, N - 1) * ldb + 4 * k4);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + 256 * q, n = e / k4n, k4 = e - n * k4n;
+                if (e < total) *reinterpret_cast<float4*>(tsm + n * pitch + 4 * k4) = n < N ? v[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int m0 = (blockIdx.x * 4 + wave) * 16;
-    if (m0 >= M) return;
     const float* a_row = A + (long)min(m0 + i, M - 1) * lda + 4 * g;
+    const int nit = K / 16;
+    float4 a[U];  // the first trip's rows are requested before the barrier: they travel while the block fills its LDS
+#pragma unroll
+    for (int q = 0; q < U; ++q) a[q] = *reinterpret_cast<const float4*>(a_row + 16 * q);
+    __syncthreads();
+    if (m0 >= M) return;
     const float* b0 = tsm + i * pitch + 4 * g;
     const float* b1 = tsm + (16 + i) * pitch + 4 * g;
     tf32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-    const int nit = K / 16;
-    for (int it0 = 0; it0 < nit; it0 += 4) {  // four 16-byte loads of the streamed operand in flight
-        float4 a[4];
+    for (int it0 = 0; it0 < nit; it0 += U) {
+        float4 ac[U];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = it0 + q < nit ? *reinterpret_cast<const float4*>(a_row + 16 * (it0 + q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < U; ++q) ac[q] = a[q];
+        const int itn = it0 + U < nit ? it0 + U : it0;  // the next trip's rows (the last trip re-reads its own: unused)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (it0 + q < nit) {
-                const float4 w0 = *reinterpret_cast<const float4*>(b0 + 16 * (it0 + q));
-                const float4 w1 = *reinterpret_cast<const float4*>(b1 + 16 * (it0 + q));
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, w0.x, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, w1.x, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, w0.y, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, w1.y, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, w0.z, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, w1.z, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, w0.w, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, w1.w, c1, 0, 0, 0);
-            }
+        for (int q = 0; q < U; ++q) a[q] = *reinterpret_cast<const float4*>(a_row + 16 * (itn + q));
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const float4 w0 = *reinterpret_cast<const float4*>(b0 + 16 * (it0 + q));
+            const float4 w1 = *reinterpret_cast<const float4*>(b1 + 16 * (it0 + q));
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].x, w0.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].x, w1.x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].y, w0.y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].y, w1.y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].z, w0.z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].z, w1.z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].w, w0.w, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q].w, w1.w, c1, 0, 0, 0);
         }
     }
     // C / D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -1075,45 +1094,100 @@ __global__ __launch_bounds__(256) void thin_nt_kernel(const float* __restrict__ 
     }
 }
 
+// A wave = 16 rows of C, every column.  The product is formed TRANSPOSED -- the thin operand's 16-column tile as the MFMA's
+// row operand, the streamed rows as its column operand -- so that a lane ends up with four CONSECUTIVE columns of ONE row
+// of C: one 16-byte store per tile (64 bytes contiguous per row and instruction) instead of four 4-byte ones.  BETA is a
+// template parameter and whole row tiles take a loop without a branch: with a load of C (beta) or a branch around the stores
+// inside the loop hipcc waits for vmcnt(0) every trip, i.e. for the previous tile's stores to be ACKNOWLEDGED -- 32 trips x
+// ~1 us, the 33 us this kernel took for a 33 MB result in rounds 4-5 (ISA: s_waitcnt vmcnt(0) at the loop head).
+template <bool BETA>
 __global__ __launch_bounds__(256) void thin_nn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                       long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
                                                       float beta) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];  // Bt[N][36]: the thin operand transposed, k padded to 32
-    for (int e = threadIdx.x; e < N * 32; e += 256) {
-        const int k = e / N, n = e - k * N;  // consecutive threads read consecutive n of one k
-        tsm[n * 36 + k] = k < K ? B[(long)k * ldb + n] : 0.f;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int m0 = (blockIdx.x * 4 + wave) * 16;
-    if (m0 >= M) return;
     const float* a_row = A + (long)min(m0 + i, M - 1) * lda;
-    float a[2][4];
+    float a[2][4];  // unconditional loads on clamped indices, requested before the LDS fill
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 16 * it + 4 * g + j;
-            a[it][j] = k < K ? a_row[k] : 0.f;
+            const float v = a_row[min(k, K - 1)];
+            a[it][j] = k < K ? v : 0.f;
         }
-    for (int c = 0; c < N / 16; ++c) {
+    {   // the thin operand, transposed, into LDS: eight 16-byte loads per thread in flight (one 4-byte load per trip with
+        // its own wait was a chain of 64 L2 round trips -- most of the 33 us this kernel took in rounds 4-5)
+        const int n4n = N / 4, total = 32 * n4n;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = min(e0 + 256 * q, total - 1), k = e / n4n, n4 = e - k * n4n;
+                v[q] = *reinterpret_cast<const float4*>(B + (long)min(k, K - 1) * ldb + 4 * n4);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + 256 * q, k = e / n4n, n4 = e - k * n4n;
+                if (e < total) {
+                    const bool on = k < K;
+                    float* t = tsm + (4 * n4) * 36 + k;
+                    t[0] = on ? v[q].x : 0.f; t[36] = on ? v[q].y : 0.f; t[72] = on ? v[q].z : 0.f; t[108] = on ? v[q].w : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (m0 >= M) return;
+    // lane (i, g): row m0 + i of C, columns 16 c + 4 g .. + 3 of tile c
+    auto tile = [&](int c) {
         const float* bt = tsm + (16 * c + i) * 36 + 4 * g;
         const float4 w0 = *reinterpret_cast<const float4*>(bt), w1 = *reinterpret_cast<const float4*>(bt + 16);
         tf32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][0], w0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][1], w0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][2], w0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][3], w0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][0], w1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][1], w1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][2], w1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][3], w1.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, a[0][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, a[0][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, a[0][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, a[0][3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, a[1][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, a[1][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, a[1][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, a[1][3], acc, 0, 0, 0);
+        return acc;
+    };
+    const int nc = N / 16;
+    if (m0 + 16 <= M) {
+        float* crow = C + (long)(m0 + i) * ldc + 4 * g;
+        int c = 0;
+        for (; c + 4 <= nc; c += 4) {  // four independent MFMA chains per trip
+            tf32x4 acc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * g + r;
-            if (m < M) {
-                float* cp = C + (long)m * ldc + 16 * c + i;
-                *cp = beta != 0.f ? acc[r] + beta * *cp : acc[r];
+            for (int q = 0; q < 4; ++q) acc[q] = tile(c + q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4* cp = reinterpret_cast<float4*>(crow + 16 * (c + q));
+                float4 v = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+                if constexpr (BETA) { const float4 o = *cp; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
+                *cp = v;
+            }
+        }
+        for (; c < nc; ++c) {
+            const tf32x4 acc = tile(c);
+            float4* cp = reinterpret_cast<float4*>(crow + 16 * c);
+            float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if constexpr (BETA) { const float4 o = *cp; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
+            *cp = v;
+        }
+    } else {  // the last, ragged row tile of the matrix (one wave of the launch)
+        const bool ok = m0 + i < M;
+        float* crow = C + (long)min(m0 + i, M - 1) * ldc + 4 * g;
+        for (int c = 0; c < nc; ++c) {
+            const tf32x4 acc = tile(c);
+            if (ok) {
+                float4* cp = reinterpret_cast<float4*>(crow + 16 * c);
+                float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if constexpr (BETA) { const float4 o = *cp; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
+                *cp = v;
             }
         }
     }
@@ -1201,19 +1275,23 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         const float* bs = bias ? bias[0] : nullptr;
         if (kind == 1) {
             const size_t smem = (size_t)32 * (K + 4) * sizeof(float);
-            if (smem <= 48 * 1024 || hipFuncSetAttribute((const void*)thin_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            const int nit = K / 16;
+            auto nt_fn = (nit % 8) == 0 ? thin_nt_kernel<8> : (nit % 4) == 0 ? thin_nt_kernel<4> : (nit % 2) == 0 ? thin_nt_kernel<2>
+                                                                                                              : thin_nt_kernel<1>;
+            if (smem <= 48 * 1024 || hipFuncSetAttribute((const void*)nt_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          (int)smem) == hipSuccess) {
-                hipLaunchKernelGGL(thin_nt_kernel, dim3((M + 63) / 64), dim3(256), smem, stream, A[0], lda, B[0], ldb, bs, C[0],
+                hipLaunchKernelGGL(nt_fn, dim3((M + 63) / 64), dim3(256), smem, stream, A[0], lda, B[0], ldb, bs, C[0],
                                    ldc, M, N, K, beta);
                 SA_CHECK_LAUNCH();
                 return CTC_STATUS_SUCCESS;
             }
             (void)hipGetLastError();
-        } else if (kind == 2 && !bs) {
+        } else if (kind == 2 && !bs && ((ldc | ldb) & 3) == 0 && ((uintptr_t)C[0] & 15) == 0) {  // (16-byte accesses)
             const size_t smem = (size_t)N * 36 * sizeof(float);
-            if (smem <= 48 * 1024 || hipFuncSetAttribute((const void*)thin_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            auto nn_fn = beta != 0.f ? thin_nn_kernel<true> : thin_nn_kernel<false>;
+            if (smem <= 48 * 1024 || hipFuncSetAttribute((const void*)nn_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          (int)smem) == hipSuccess) {
-                hipLaunchKernelGGL(thin_nn_kernel, dim3((M + 63) / 64), dim3(256), smem, stream, A[0], lda, B[0], ldb, C[0], ldc,
+                hipLaunchKernelGGL(nn_fn, dim3((M + 63) / 64), dim3(256), smem, stream, A[0], lda, B[0], ldb, C[0], ldc,
                                    M, N, K, beta);
                 SA_CHECK_LAUNCH();
                 return CTC_STATUS_SUCCESS;
