@@ -342,6 +342,14 @@ size_t sa_colsum_workspace_bytes(int M, int N);
 ctcStatus_t sa_colsum_f32(const float* a, long lda, int M, int N, float* out, int accumulate, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Weight and bias gradient of a linear layer in one call (LinearND, model.py:118-133, under loss.backward(), train.py:30):
+ * C (M, N) = A^T B for A stored (K, M) -- the gradient of the layer's output, rows x classes -- and B (K, N) the layer's
+ * input; colsum (M) = the column sums of A.  Both are OVERWRITTEN.  With M <= 32 (the 29 classes of the CTC model) one pass
+ * over the operands forms both (thin_tn_kernel<CS>); other shapes take the tiled kernel with its column-sum epilogue.
+ * Deterministic (fixed summation order).  workspace: sa_gemm_workspace_bytes(M, N, K). */
+ctcStatus_t sa_gemm_tn_colsum_f32(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                                  long ldc, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
+
 /* y[i] = a[i] + b[i] (bidirectional sum, model.py:75-77, and gradient fan-in); strided rows. */
 ctcStatus_t sa_add_rows_f32(const float* a, long lda, const float* b, long ldb, float* y, long ldy, int rows,
                             int cols, void* stream);

@@ -94,6 +94,8 @@ SIGNATURES = {
     "sa_gru_persist_status": (c_int, []),
     "sa_gru_persist_reset": (c_int, []),
     "sa_gru_health_flag": (c_int, [c_void_p, c_void_p]),
+    "sa_gemm_tn_colsum_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
     "sa_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sa_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sa_add_rows_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),

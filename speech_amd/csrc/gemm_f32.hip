@@ -1193,52 +1193,125 @@ __global__ __launch_bounds__(256) void thin_nn_kernel(const float* __restrict__ 
     }
 }
 
-// grid (N / 16, kThinSplit): a wave = one 16-column tile of C, both 16-row tiles, a quarter of the block's K chunk
+// grid (ceil(N / 64), kThinSplit): a wave = a 64-column group of C, both 16-row tiles, a quarter of the block's K chunk.
+// A lane reads 16 bytes of a row of B -- columns n0 + 4 i .. + 3, one for each of four MFMA column tiles (tile q <-> columns
+// n0 + 4 i + q) -- so an instruction of the wave covers four rows of k x 256 contiguous bytes (round 4: 4-byte loads, 64
+// bytes per row, one 16-column tile per wave, 15.7 us for the 33 MB operand), and the next trip's loads are in flight during
+// a trip's 32 MFMAs.  Loads are unconditional on clamped indices; what lies beyond K, M or N is zeroed by selects.
+// CS: the column sums of A (the bias gradient of the layer, db = dlogits^T 1: ctc_model.py:29) ride along as one more MFMA per
+// k step against a column of ones, in the blocks of column group 0 -- two launches less than a separate column-sum pass.
+template <bool CS>
 __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
-                                                      long ldb, float* __restrict__ part, int M, int N, int K) {
-    __shared__ float red[4][2][256];
+                                                      long ldb, float* __restrict__ part, float* __restrict__ cs_part, int M,
+                                                      int N, int K) {
+    __shared__ __attribute__((aligned(16))) float red[4][32][64];  // [wave][slot = 16 t + 4 r + q][lane]
+    __shared__ float red_cs[4][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-    const int c = blockIdx.x;
+    const int n0 = blockIdx.x * 64;
+    const bool do_cs = CS && blockIdx.x == 0;
     const int per = (((K + kThinSplit - 1) / kThinSplit) + 63) / 64 * 64;  // rows of K per block: four waves x whole 16-k trips
     const int kb = blockIdx.y * per + wave * (per / 4);
     const int kend = min(K, kb + per / 4);
-    tf32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-    const bool r0 = i < M, r1 = 16 + i < M;
-    for (int k0 = kb; k0 < kend; k0 += 16) {
-        float a0[4], a1[4], b[4];
+    tf32x4 c[2][4], cs[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // (a wave's four lane groups read four different k: a 16-k slab per trip)
-            const int k = k0 + g + 4 * j;
-            const bool ok = k < kend;
-            const int kc = ok ? k : 0;
-            a0[j] = ok && r0 ? A[(long)kc * lda + i] : 0.f;
-            a1[j] = ok && r1 ? A[(long)kc * lda + 16 + i] : 0.f;
-            b[j] = ok ? B[(long)kc * ldb + 16 * c + i] : 0.f;
-        }
+    for (int t = 0; t < 2; ++t) {
+        cs[t] = tf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[t][q] = tf32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool r0 = i < M, r1 = 16 + i < M, cn = n0 + 4 * i < N;  // (N is a multiple of 16: a lane's four columns are in or out)
+    const float* pa0 = A + min(i, M - 1);
+    const float* pa1 = A + min(16 + i, M - 1);
+    const float* pb = B + min(n0 + 4 * i, N - 4);
+    float a0[4], a1[4];
+    float4 b[4];
+    auto fetch = [&](int k0) {  // (a wave's four lane groups read four different k: a 16-k slab per trip)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[j], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[j], c1, 0, 0, 0);
+            const int k = k0 + g + 4 * j;
+            const bool ok = k < kend;
+            const long kc = ok ? k : (K - 1);
+            const float v0 = pa0[kc * lda], v1 = pa1[kc * lda];
+            const float4 vb = *reinterpret_cast<const float4*>(pb + kc * ldb);
+            // masked by a PRODUCT, not a select: hipcc sinks a load whose value only one arm of a select uses under that
+            // arm's condition -- a branch around every load and a wait behind each (the clamped rows are rows of the matrix)
+            const float f0 = ok && r0 ? 1.f : 0.f, f1 = ok && r1 ? 1.f : 0.f, fb = ok && cn ? 1.f : 0.f;
+            a0[j] = v0 * f0;
+            a1[j] = v1 * f1;
+            b[j] = make_float4(vb.x * fb, vb.y * fb, vb.z * fb, vb.w * fb);
+        }
+    };
+    if (kb < kend) fetch(kb);
+    for (int k0 = kb; k0 < kend; k0 += 16) {
+        float x0[4], x1[4];
+        float4 y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x0[j] = a0[j]; x1[j] = a1[j]; y[j] = b[j]; }
+        fetch(k0 + 16 < kend ? k0 + 16 : k0);  // the next trip's slab (the last trip re-reads its own: unused)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], y[j].x, c[0][0], 0, 0, 0);
+            c[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], y[j].x, c[1][0], 0, 0, 0);
+            c[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], y[j].y, c[0][1], 0, 0, 0);
+            c[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], y[j].y, c[1][1], 0, 0, 0);
+            c[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], y[j].z, c[0][2], 0, 0, 0);
+            c[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], y[j].z, c[1][2], 0, 0, 0);
+            c[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], y[j].w, c[0][3], 0, 0, 0);
+            c[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], y[j].w, c[1][3], 0, 0, 0);
+            if (do_cs) {
+                cs[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], 1.f, cs[0], 0, 0, 0);
+                cs[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], 1.f, cs[1], 0, 0, 0);
+            }
         }
     }
+    // C / D layout: lane (i, g), register r <-> row 16 t + 4 g + r, column n0 + 4 i + q of tile q
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        red[wave][0][(4 * g + r) * 16 + i] = c0[r];
-        red[wave][1][(4 * g + r) * 16 + i] = c1[r];
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][16 * t + 4 * r + q][lane] = c[t][q][r];
+    if (do_cs && i == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red_cs[wave][16 * t + 4 * g + r] = cs[t][r];
     }
     __syncthreads();
-    // part[split][32][N]
-    for (int e = threadIdx.x; e < 512; e += 256) {
-        const int t = e >> 8, o = e & 255, row = 16 * t + (o >> 4), col = 16 * c + (o & 15);
-        const float v = (red[0][t][o] + red[1][t][o]) + (red[2][t][o] + red[3][t][o]);
-        part[((long)blockIdx.y * 32 + row) * N + col] = v;
+    // part[split][32][N]: thread (wave w, lane) folds slots 8 w .. 8 w + 7 = row tile t = w / 2, registers r = 2 (w % 2) + {0, 1},
+    // the four column tiles: two 16-byte stores of four consecutive columns each; the four waves' sums in a fixed order
+    {
+        const int t = wave >> 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * (wave & 1) + rr, slot = 16 * t + 4 * r;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[q] = (red[0][slot + q][lane] + red[1][slot + q][lane]) + (red[2][slot + q][lane] + red[3][slot + q][lane]);
+            const int row = 16 * t + 4 * g + r;
+            if (cn) *reinterpret_cast<float4*>(part + ((long)blockIdx.y * 32 + row) * N + n0 + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
+    if (do_cs && threadIdx.x < 32)
+        cs_part[blockIdx.y * 32 + threadIdx.x] = (red_cs[0][threadIdx.x] + red_cs[1][threadIdx.x]) + (red_cs[2][threadIdx.x] + red_cs[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void thin_tn_fold_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc,
-                                                           int M, int N, float beta) {
+// C = the sum of the kThinSplit partial products (in a fixed order: deterministic); elements [M N, M N + M) of the grid: the
+// column sums of A likewise (cs_part != null)
+__global__ __launch_bounds__(256) void thin_tn_fold_kernel(const float* __restrict__ part, const float* __restrict__ cs_part,
+                                                           float* __restrict__ C, long ldc, float* __restrict__ colsum, int M,
+                                                           int N, float beta) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)M * N) return;
+    const long mn = (long)M * N;
+    if (e >= mn) {
+        const int m = (int)(e - mn);
+        if (!cs_part || m >= M) return;
+        float v = 0.f;
+        for (int sblk = 0; sblk < kThinSplit; ++sblk) v += cs_part[sblk * 32 + m];
+        colsum[m] = v;
+        return;
+    }
     const int row = (int)(e / N), col = (int)(e - (long)row * N);
     float v = 0.f;
     for (int sblk = 0; sblk < kThinSplit; ++sblk) v += part[((long)sblk * 32 + row) * N + col];
@@ -1257,7 +1330,7 @@ int thin_kind(int trans_a, int trans_b, int M, int N, int K, long lda, long ldb)
 }
 size_t thin_workspace_bytes(int trans_a, int trans_b, int M, int N, int K) {
     // (the strides of a contiguous operand; a caller with other strides that misses the kernel simply takes the tiled path)
-    return thin_kind(trans_a, trans_b, M, N, K, 4, 4) == 3 ? (size_t)kThinSplit * 32 * N * sizeof(float) : 0;
+    return thin_kind(trans_a, trans_b, M, N, K, 4, 4) == 3 ? (size_t)kThinSplit * 32 * (N + 1) * sizeof(float) : 0;  // (+ column sums)
 }
 
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
@@ -1269,9 +1342,10 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     if (opts && opts->colsum && (!trans_a || alpha != 1.f)) return CTC_STATUS_INVALID_VALUE;
     if (M < 0 || N < 0 || K < 0 || nprob < 1 || nprob > kMaxGroup) return CTC_STATUS_INVALID_VALUE;
     if (M == 0 || N == 0) return CTC_STATUS_SUCCESS;
-    if (nprob == 1 && alpha == 1.f && !ep && !(opts && (opts->colsum || opts->xcc_mask || opts->drop)) && A[0] && B[0] && C[0] &&
+    if (nprob == 1 && alpha == 1.f && !ep && !(opts && (opts->xcc_mask || opts->drop)) && A[0] && B[0] && C[0] &&
         (((uintptr_t)A[0] | (uintptr_t)B[0]) & 15) == 0) {
-        const int kind = thin_kind(trans_a, trans_b, M, N, K, lda, ldb);
+        int kind = thin_kind(trans_a, trans_b, M, N, K, lda, ldb);
+        if (opts && opts->colsum && (kind != 3 || beta != 0.f || !opts->colsum[0])) kind = 0;  // column sums: the weight-gradient form only
         const float* bs = bias ? bias[0] : nullptr;
         if (kind == 1) {
             const size_t smem = (size_t)32 * (K + 4) * sizeof(float);
@@ -1297,11 +1371,16 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
                 return CTC_STATUS_SUCCESS;
             }
             (void)hipGetLastError();
-        } else if (kind == 3 && !bs && workspace && workspace_bytes >= (size_t)kThinSplit * 32 * N * sizeof(float)) {
+        } else if (kind == 3 && !bs && (ldb & 3) == 0 && workspace &&
+                   workspace_bytes >= (size_t)kThinSplit * 32 * (N + 1) * sizeof(float)) {
             float* part = (float*)workspace;
-            hipLaunchKernelGGL(thin_tn_kernel, dim3(N / 16, kThinSplit), dim3(256), 0, stream, A[0], lda, B[0], ldb, part, M, N, K);
-            hipLaunchKernelGGL(thin_tn_fold_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, stream,
-                               (const float*)part, C[0], ldc, M, N, beta);
+            float* cs_part = part + (size_t)kThinSplit * 32 * N;
+            float* cs_out = opts && opts->colsum ? opts->colsum[0] : nullptr;  // (beta = 0 semantics: written, not accumulated)
+            const dim3 tgrid((N + 63) / 64, kThinSplit);
+            if (cs_out) hipLaunchKernelGGL(thin_tn_kernel<true>, tgrid, dim3(256), 0, stream, A[0], lda, B[0], ldb, part, cs_part, M, N, K);
+            else hipLaunchKernelGGL(thin_tn_kernel<false>, tgrid, dim3(256), 0, stream, A[0], lda, B[0], ldb, part, cs_part, M, N, K);
+            hipLaunchKernelGGL(thin_tn_fold_kernel, dim3((unsigned)(((long)M * N + (cs_out ? M : 0) + 255) / 256)), dim3(256), 0,
+                               stream, (const float*)part, cs_out ? (const float*)cs_part : nullptr, C[0], ldc, cs_out, M, N, beta);
             SA_CHECK_LAUNCH();
             return CTC_STATUS_SUCCESS;
         }
@@ -1466,6 +1545,22 @@ extern "C" ctcStatus_t sa_gemm_f32(int trans_a, int trans_b, int M, int N, int K
                             workspace_bytes, (hipStream_t)stream);
 }
 
+
+// C (M, N) = A^T B for A stored (K, M), B (K, N), and colsum (M) = the column sums of A, in one call: the weight and bias
+// gradients of a linear layer from the gradient of its output (A = d out (rows, classes), B = the layer's input): what
+// autograd derives for LinearND (/root/reference/speech/models/model.py:118-133; CTC.loss -> loss.backward(), train.py:30).
+// Thin A (M <= 32): thin_tn_kernel<CS> forms both in one pass over the operands; other shapes: the tiled kernel with its
+// column-sum epilogue.  Workspace: sa_gemm_workspace_bytes(M, N, K).
+extern "C" ctcStatus_t sa_gemm_tn_colsum_f32(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                                             long ldc, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+    SA_CLEAR_ERR();
+    if (!A || !B || !C || !colsum) return CTC_STATUS_INVALID_VALUE;
+    SaGemmOpts o;
+    o.no_split = 0; o.colsum = &colsum; o.xcc_mask = 0; o.tile_counter = nullptr;
+    const float* bias = nullptr;
+    return sa_gemm_f32_group_impl(1, 1, 0, M, N, K, 1.f, &A, lda, &B, ldb, 0.f, &C, ldc, &bias, nullptr, workspace, workspace_bytes,
+                                  (hipStream_t)stream, &o);
+}
 
 // ---- packed operands as a caller-visible (library-internal) object: internal.h ----------------------------------------
 size_t sa_pk_operand_bytes(int R, int K) { return sa_align_up(pk_bytes(R, K), 256); }

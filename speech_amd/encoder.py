@@ -126,8 +126,7 @@ class EncoderFunction(torch.autograd.Function):
                  if by_ref and slot is not None and p.grad is not None and p.grad.data_ptr() == slot.data_ptr()]
         fc_i = 2 * nconv + 4 * L * D
         grads = [None] * (fc_i + 2)
-        grads[fc_i] = ops.gemm(dl, ctx.enc, trans_a=True, out=slots[fc_i])
-        grads[fc_i + 1] = ops.colsum(dl, out=slots[fc_i + 1])
+        grads[fc_i], grads[fc_i + 1] = ops.gemm_tn_colsum(dl, ctx.enc, out=slots[fc_i], colsum_out=slots[fc_i + 1])
         denc = ops.gemm(dl, ctx.fc_w)  # (T'*B, H)
         # both directions of the top layer receive denc (model.py:75-77)
         dtop = torch.cat([denc, denc], dim=1).view(Tp, B, 2 * H) if D == 2 else denc.view(Tp, B, H)

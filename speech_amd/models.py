@@ -286,7 +286,8 @@ class _LinearFunction(torch.autograd.Function):
             dw = ops.gemm(dy_t, x_p, out=ctx.slots[0])
             return dx, dw, ops.colsum(dy, out=ctx.slots[1])
         dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
-        return dx, ops.gemm(dy, x, trans_a=True, out=ctx.slots[0]), ops.colsum(dy, out=ctx.slots[1])
+        dw, db = ops.gemm_tn_colsum(dy, x, out=ctx.slots[0], colsum_out=ctx.slots[1])
+        return dx, dw, db
 
 
 def zero_pad_concat(inputs, min_t=0, stage=None):

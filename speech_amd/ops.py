@@ -80,6 +80,28 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, alpha=1.0, bet
     return out
 
 
+def gemm_tn_colsum(a, b, out=None, colsum_out=None):
+    """(a^T @ b, column sums of a) for a (K, M), b (K, N): the weight and the bias gradient of a linear layer from the
+    gradient of its output, in one library call (sa_gemm_tn_colsum_f32).  Both outputs are overwritten."""
+    _f32(a, "a"), _f32(b, "b")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0]
+    K, M = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if colsum_out is None:
+        colsum_out = torch.empty(M, dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and colsum_out.numel() == M and colsum_out.is_contiguous()
+    L = _lib.lib()
+    nbytes = L.sa_gemm_workspace_bytes(M, N, K)
+    ws = WORKSPACE.get(nbytes, a.device, "gemm") if nbytes else None
+    with _span("gemm", 2, 2.0 * M * N * K):
+        check(L.sa_gemm_tn_colsum_f32(M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+                                      ptr(colsum_out), ptr(ws), ws.numel() if ws is not None else 0, cur_stream()),
+              "sa_gemm_tn_colsum_f32")
+    return out, colsum_out
+
+
 def conv_out_size(n, k, s):
     return int(math.ceil((n - k + 1) / s))
 

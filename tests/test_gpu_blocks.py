@@ -663,6 +663,21 @@ def test_thin_products_of_the_classifier(monkeypatch, M, N, K):
         assert float((np.abs(got - ref) / scale).max()) <= bound, (name, float((np.abs(got - ref) / scale).max()), bound)
         assert float(np.linalg.norm(got - tiled) / np.linalg.norm(ref)) < 1e-6, name
     monkeypatch.delenv("SA_GEMM_THIN", raising=False)
+    # weight and bias gradient in ONE call (sa_gemm_tn_colsum_f32: thin_tn_kernel<CS> forms the column sums of dl with one
+    # more MFMA per k step): the product bit for bit the plain call's, the sums within the fp32 bound of the fp64 ones --
+    # also through the tiled kernel's column-sum epilogue (SA_GEMM_THIN=0) and into views of a larger buffer
+    flat = torch.full((N * K + N + 8,), 7.0, device="cuda")
+    dw, db = ops.gemm_tn_colsum(DL, X, out=flat[4:4 + N * K].view(N, K), colsum_out=flat[4 + N * K:4 + N * K + N])
+    assert torch.equal(dw, ops.gemm(DL, X, trans_a=True))
+    cs_ref = dld.sum(0)
+    cs_bound = 2.0 ** -24 * (2.0 + np.sqrt(M)) * np.abs(dld).sum(0)
+    assert np.all(np.abs(db.cpu().numpy().astype(np.float64) - cs_ref) <= cs_bound)
+    assert float(flat[:4].min()) == 7.0 and float(flat[4 + N * K + N:].min()) == 7.0
+    monkeypatch.setenv("SA_GEMM_THIN", "0")
+    dw_t, db_t = ops.gemm_tn_colsum(DL, X)
+    assert float((dw_t - dw).norm() / dw.norm()) < 1e-6
+    assert np.all(np.abs(db_t.cpu().numpy().astype(np.float64) - cs_ref) <= cs_bound)
+    monkeypatch.delenv("SA_GEMM_THIN", raising=False)
     # exact on integers; beta accumulates; the thin dimension's edge columns / rows are left alone
     xi = rng.randint(-4, 5, (M, K)).astype(np.float32)
     wi = rng.randint(-4, 5, (N, K)).astype(np.float32)
