@@ -81,6 +81,7 @@ struct GemmArgs {
     // product that uses rows [0, s) and [s + j, ...) of a packed operand shared with another product (sa_gemm_pk_group)
     int a_rb_split, a_rb_jump;
     unsigned a_jump_probs;  // bit p: problem p of the group uses the jump
+    int b_kb_stride;        // packed kernels only: k-tiles between B's packed row blocks (0: ceil(K / 16), as A's always are)
     // optional dropout on the output (dropout.h): element at address c is multiplied by the mask factor of index
     // c - drop_base (the output is a window of the masked tensor); off when drop.thresh == 0.  Not with split-K.
     SaDrop drop;
@@ -442,6 +443,10 @@ struct PackArgs {
     // tiles per packed row block (KB, or more: several operands interleaved along k -- problem p at k-tile offset
     // p * dst_stride / tile bytes inside each row block, the products' reduction then runs over all of them)
     int kb_stride;
+    // m-contiguous form: the matrix starts kb_lead tiles into each row block, and the tiles in front of it are written as
+    // zeros (zero_lead) -- an operand that a product also reads SHIFTED by kb_lead k-tiles (h_prev of a GRU layer is its
+    // output one time step earlier, zeros at t = 0)
+    int kb_lead, zero_lead;
 };
 
 // X[r][k] = src[r * ld + k] (k-contiguous memory).  grid (ceil(KB / kt), RB, nprob); thread t: rows t/4 and t/4 + 64,
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) void pk_pack_mcontig_kernel(PackArgs a) {
         unsigned p1[8], p2[8], p3[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) split2(v[2 * q], v[2 * q + 1], p1[q], p2[q], p3[q]);
-        char* tile = dst + (size_t)kb * PK_TILE;
+        char* tile = dst + (size_t)(kb + a.kb_lead) * PK_TILE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             char* d = tile + pk_off(0, rl, h);
@@ -516,6 +521,8 @@ __global__ __launch_bounds__(256) void pk_pack_mcontig_kernel(PackArgs a) {
     }
     if (a.cs_part)
         a.cs_part[((size_t)blockIdx.z * (2 * gridDim.x) + 2 * blockIdx.x + (wave >> 1)) * a.Rpad + blockIdx.y * BM + rl] = rsum;
+    if (a.zero_lead && blockIdx.x == 0)  // the kb_lead tiles in front of the matrix: 768 16-byte chunks each
+        for (int e = threadIdx.x; e < a.kb_lead * (PK_TILE / 16); e += 256) reinterpret_cast<uint4*>(dst)[e] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // colsum[p][m] = (beta ? beta * colsum : 0) + sum over the parts: 16 lanes per column add every 16th part in order,
@@ -585,14 +592,14 @@ __device__ __forceinline__ void pk_issue(const char* __restrict__ At, const char
     }
 }
 // k-tiles [kb0, kb1) of row block `by` of A and `bx` of B
-__device__ __forceinline__ void pk_mainloop(const char* __restrict__ Apk, const char* __restrict__ Bpk, int KB, char* smem,
-                                            int by, int bx, int kb0, int kb1, int tid, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void pk_mainloop(const char* __restrict__ Apk, const char* __restrict__ Bpk, int KB, int KBb,
+                                            char* smem, int by, int bx, int kb0, int kb1, int tid, f32x16 (&acc)[2][2]) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int nt = kb1 - kb0;
     if (nt <= 0) return;
     const char* At = Apk + ((size_t)by * KB + kb0) * PK_TILE;
-    const char* Bt = Bpk + ((size_t)bx * KB + kb0) * PK_TILE;
+    const char* Bt = Bpk + ((size_t)bx * KBb + kb0) * PK_TILE;
     const int fa = pk_off(0, wm * 64 + (lane & 31), lane >> 5);
     const int fb = PK_TILE + pk_off(0, wn * 64 + (lane & 31), lane >> 5);
     pk_issue(At, Bt, smem, wave, lane);
@@ -708,7 +715,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, float* smem, int b
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (DEPTH == 0) {  // packed split-bf16 operands: g.Ag / g.Bg hold PACKED tiles (see pk_mainloop), no edge cases
         pk_mainloop(reinterpret_cast<const char*>(gA), reinterpret_cast<const char*>(gB), (g.K + PK_K - 1) / PK_K,
-                    reinterpret_cast<char*>(smem), pk_a_rb(g, prob, by), bx, kbeg / PK_K,
+                    g.b_kb_stride > 0 ? g.b_kb_stride : (g.K + PK_K - 1) / PK_K, reinterpret_cast<char*>(smem),
+                    pk_a_rb(g, prob, by), bx, kbeg / PK_K,
                     (kend + PK_K - 1) / PK_K, tid, acc);
     } else if (DEPTH == 2) {
         if (fast) gemm_mainloop<TA, TB, true>(g, gA, gB, smem, m0, n0, kbeg, kend, tid, acc, do_colsum, csum);
@@ -793,8 +801,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pk256_kernel(GemmArgs g) {
         const int ra0 = pk_a_rb(g, prob, la0), ra1 = pk_a_rb(g, prob, la1);
         const char* A0 = Apk + ((size_t)ra0 * KB + kb0) * PK_TILE;
         const char* A1 = Apk + ((size_t)ra1 * KB + kb0) * PK_TILE;
-        const char* B0 = Bpk + ((size_t)rb0 * KB + kb0) * PK_TILE;
-        const char* B1 = Bpk + ((size_t)rb1 * KB + kb0) * PK_TILE;
+        const int KBb = g.b_kb_stride > 0 ? g.b_kb_stride : KB;
+        const char* B0 = Bpk + ((size_t)rb0 * KBb + kb0) * PK_TILE;
+        const char* B1 = Bpk + ((size_t)rb1 * KBb + kb0) * PK_TILE;
         // this wave's fragments: A rows = row block wm of the stage, B rows = 64 (wn & 1) .. of row block 2 + (wn >> 1)
         const int fa = wm * PK_TILE + pk_off(0, lane & 31, lane >> 5);
         const int fb = (2 + (wn >> 1)) * PK_TILE + pk_off(0, (wn & 1) * 64 + (lane & 31), lane >> 5);
@@ -1437,7 +1446,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
     g.cs_partial = splits > 1 ? (float*)workspace + (size_t)nprob * splits * M * N : nullptr;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nprob * splits);
     g.xcc_mask = 0; g.tile_counter = nullptr;
-    g.a_rb_split = 1 << 30; g.a_rb_jump = 0; g.a_jump_probs = 0u;
+    g.a_rb_split = 1 << 30; g.a_rb_jump = 0; g.a_jump_probs = 0u; g.b_kb_stride = 0;
     g.drop = sa_drop_make(0.f, 0ull); g.drop_stream = 0u; g.drop_base = nullptr;
     g.grid_x = (int)grid.x; g.grid_y = (int)grid.y; g.grid_z = (int)grid.z;
     if (opts && opts->xcc_mask && opts->tile_counter) {
@@ -1464,7 +1473,7 @@ ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, i
         // pack A (logical [M][K]) and B (logical [N][K]) of every problem, then ONE kernel whatever the transposes were
         const int KB = (K + PK_K - 1) / PK_K;
         PackArgs pa;
-        pa.K = K; pa.KB = KB; pa.kb_stride = KB; pa.kt = pk_kt; pa.cs_part = nullptr; pa.Rpad = Mpad;
+        pa.K = K; pa.KB = KB; pa.kb_stride = KB; pa.kb_lead = 0; pa.zero_lead = 0; pa.kt = pk_kt; pa.cs_part = nullptr; pa.Rpad = Mpad;
         for (int p = 0; p < kMaxGroup; ++p) pa.src_hi[p] = nullptr;
         for (int side = 0; side < 2; ++side) {
             const bool kcontig = side == 0 ? !trans_a : (trans_b != 0);
@@ -1568,12 +1577,15 @@ int sa_pk_rowsum_parts(int K) { return 2 * ((((K + PK_K - 1) / PK_K) + 7) / 8); 
 bool sa_pk_enabled(int M, int N, int K, int nprob) { return pk_worth_it(M, N, K, nprob); }
 
 ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* src_hi, int R_lo, long ld, int R, int K,
-                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream, int kb_stride) {
+                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream, int kb_stride, int kb_lead,
+                       int zero_lead) {
     if (nprob < 1 || nprob > kMaxGroup || !dst || R <= 0 || K <= 0) return CTC_STATUS_INVALID_VALUE;
     PackArgs pa;
     const int KB = (K + PK_K - 1) / PK_K;
     pa.K = K; pa.KB = KB; pa.kt = 8; pa.cs_part = cs_part; pa.Rpad = (R + BM - 1) / BM * BM;
     pa.kb_stride = kb_stride > 0 ? kb_stride : KB;
+    pa.kb_lead = kb_lead; pa.zero_lead = zero_lead;
+    if (kb_lead < 0 || (kb_lead > 0 && (kcontig || pa.kb_stride < KB + kb_lead))) return CTC_STATUS_INVALID_VALUE;
     pa.dst = dst; pa.dst_stride = dst_stride; pa.ld = ld; pa.R = R; pa.R_lo = src_hi ? R_lo : R;
     pa.vec = (ld & 3) == 0;
     for (int p = 0; p < kMaxGroup; ++p) { pa.src[p] = nullptr; pa.src_hi[p] = nullptr; }
@@ -1662,6 +1674,7 @@ ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* 
     g.cs_partial = nullptr;
     g.xcc_mask = 0; g.tile_counter = nullptr;
     g.a_rb_split = a_split / BM; g.a_rb_jump = a_jump / BM; g.a_jump_probs = a_jump ? a_jump_probs : 0u;
+    g.b_kb_stride = opts ? opts->b_kb_stride : 0;
     g.grid_x = (N + BN - 1) / BN; g.grid_y = (M + BM - 1) / BM; g.grid_z = nprob * splits;
     if (opts && opts->xcc_mask && opts->tile_counter) { g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter; }
     const ctcStatus_t st = pk_launch(g, splits, stream, opts ? opts->err_word : nullptr);

@@ -2651,13 +2651,21 @@ extern "C" ctcStatus_t sa_gru_stack_fwd_dropout(const float* x, int I0, const fl
 static bool shared_pack_enabled() {
     return sa_opt(SA_OPT_GRU_SHARED_PACK) != 0;
 }
-struct SharedPackLayout { size_t g_each, h_each, x_bytes, cs_bytes, g_off, hp_off, lo_off, x_off, cs_off, sk_off, total; int parts; };
+// (round 5) h_prev of a layer IS its output one time step earlier (zeros at t = 0), and without dropout the layer above
+// reads that same output: with B a multiple of 16 a time step is B / 16 whole k-tiles, so ONE packed copy of h_out[l] --
+// `lead` = B / 16 zero tiles in front of it in every row block -- serves dW_hh[l] (read at its base: the output shifted by one
+// step behind zeros) and dW_ih[l+1] (read `lead` tiles in): L matrices to pack instead of 2 L - 1 (0.05 ms of pack launches
+// per S-LIBRI step), the same values in the same k order, so the products are bit for bit what separate copies gave.  With
+// dropout the layer above read the DROPPED output: those L - 1 copies are still packed (same tile stride, one launch).
+struct SharedPackLayout { size_t g_each, h_each, x_bytes, cs_bytes, g_off, hp_off, lo_off, x_off, cs_off, sk_off, total; int parts;
+                          int lead; };  // lead > 0: h_each counts ceil(K / 16) + lead tiles per row block
 static bool shared_pack_layout(int L, int D, int B, int T, int H, int I0, SharedPackLayout& y) {
     const long K = (long)T * B;
     if (D != 1 || (H % 128) || K > 0x7fffffffL || 2 * L - 1 > 8 || !shared_pack_enabled()) return false;
     if (!sa_pk_enabled(3 * H, H, (int)K, L) || !sa_pk_enabled(3 * H, I0, (int)K, 1)) return false;
+    y.lead = (B % 16) == 0 && K + B <= 0x7fffffffL ? B / 16 : 0;
     y.g_each = sa_pk_operand_bytes(4 * H, (int)K);
-    y.h_each = sa_pk_operand_bytes(H, (int)K);
+    y.h_each = sa_pk_operand_bytes(H, (int)(K + (y.lead ? B : 0)));
     y.x_bytes = sa_pk_operand_bytes(I0, (int)K);
     y.parts = sa_pk_rowsum_parts((int)K);
     y.cs_bytes = sa_align_up((size_t)L * y.parts * 4 * H * sizeof(float), 256);
@@ -2809,13 +2817,28 @@ struct WGradIssuer {
         if (st != CTC_STATUS_SUCCESS) return st;
         st = sa_pk_rowsum_fold(L, cs, parts, 4 * H, 3 * H, 2 * H, H, wg.db_hh, 0.f, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
-        for (int l = 0; l < L; ++l) src[l] = stash[l] + 4 * H;
-        st = sa_pk_pack(L, src, nullptr, 0, 5 * H, H, K, 0, base + y.hp_off, y.h_each, nullptr, stream);
-        if (st != CTC_STATUS_SUCCESS) return st;
-        if (L > 1) {
-            for (int l = 1; l < L; ++l) src[l - 1] = lower[l];
-            st = sa_pk_pack(L - 1, src, nullptr, 0, H, H, K, 0, base + y.lo_off, y.h_each, nullptr, stream);
+        const bool lead = y.lead > 0 && wg.h_out != nullptr;
+        const int kbs = lead ? (K + 15) / 16 + y.lead : 0;  // tiles per row block of the h operands
+        bool dropped = false;  // the upper layers read something else than the layer below's output (its dropped copy)
+        for (int l = 1; l < L; ++l) dropped = dropped || lower[l] != wg.h_out[l - 1];
+        if (lead) {  // one copy of every layer's output, y.lead zero tiles in front (see SharedPackLayout)
+            for (int l = 0; l < L; ++l) src[l] = wg.h_out[l];
+            st = sa_pk_pack(L, src, nullptr, 0, H, H, K, 0, base + y.hp_off, y.h_each, nullptr, stream, kbs, y.lead, 1);
             if (st != CTC_STATUS_SUCCESS) return st;
+            if (dropped) {
+                for (int l = 1; l < L; ++l) src[l - 1] = lower[l];
+                st = sa_pk_pack(L - 1, src, nullptr, 0, H, H, K, 0, base + y.lo_off, y.h_each, nullptr, stream, kbs, y.lead, 0);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
+        } else {
+            for (int l = 0; l < L; ++l) src[l] = stash[l] + 4 * H;
+            st = sa_pk_pack(L, src, nullptr, 0, 5 * H, H, K, 0, base + y.hp_off, y.h_each, nullptr, stream);
+            if (st != CTC_STATUS_SUCCESS) return st;
+            if (L > 1) {
+                for (int l = 1; l < L; ++l) src[l - 1] = lower[l];
+                st = sa_pk_pack(L - 1, src, nullptr, 0, H, H, K, 0, base + y.lo_off, y.h_each, nullptr, stream);
+                if (st != CTC_STATUS_SUCCESS) return st;
+            }
         }
         src[0] = wg.x;
         st = sa_pk_pack(1, src, nullptr, 0, I0, I0, K, 0, base + y.x_off, y.x_bytes, nullptr, stream);
@@ -2824,8 +2847,16 @@ struct WGradIssuer {
         int np = 0;
         for (int l = 0; l < L; ++l, ++np) { pa[np] = base + y.g_off + l * y.g_each; pb[np] = base + y.hp_off + l * y.h_each; pc[np] = wg.dw_hh[l]; }
         const unsigned jump_probs = (1u << L) - 1u;
-        for (int l = 1; l < L; ++l, ++np) { pa[np] = base + y.g_off + l * y.g_each; pb[np] = base + y.lo_off + (l - 1) * y.h_each; pc[np] = wg.dw_ih[l]; }
-        st = sa_gemm_pk_group(np, 3 * H, H, K, pa, 2 * H, H, jump_probs, pb, 0.f, pc, H, base + y.sk_off, ws_bytes - y.sk_off, stream);
+        const size_t in_tiles = lead ? (size_t)y.lead * 12288 : 0;  // the matrix itself starts y.lead tiles into a row block
+        for (int l = 1; l < L; ++l, ++np) {
+            pa[np] = base + y.g_off + l * y.g_each;
+            pb[np] = (lead && !dropped ? base + y.hp_off : base + y.lo_off) + (l - 1) * y.h_each + in_tiles;
+            pc[np] = wg.dw_ih[l];
+        }
+        SaGemmOpts go;
+        go.no_split = 0; go.colsum = nullptr; go.xcc_mask = 0; go.tile_counter = nullptr; go.b_kb_stride = kbs;
+        st = sa_gemm_pk_group(np, 3 * H, H, K, pa, 2 * H, H, jump_probs, pb, 0.f, pc, H, base + y.sk_off, ws_bytes - y.sk_off, stream,
+                              &go);
         if (st != CTC_STATUS_SUCCESS) return st;
         pa[0] = base + y.g_off; pb[0] = base + y.x_off; pc[0] = wg.dw_ih[0];
         st = sa_gemm_pk_group(1, 3 * H, I0, K, pa, 0, 0, 0u, pb, 0.f, pc, I0, base + y.sk_off, ws_bytes - y.sk_off, stream);

@@ -41,6 +41,7 @@ struct SaGemmOpts {
     const SaDrop* drop = nullptr;
     unsigned drop_stream = 0;
     const float* drop_base = nullptr;
+    int b_kb_stride = 0;    // sa_gemm_pk_group only: k-tiles between B's packed row blocks (0: ceil(K / 16))
 };
 ctcStatus_t sa_gemm_f32_group_impl(int nprob, int trans_a, int trans_b, int M, int N, int K, float alpha,
                                    const float* const* A, long lda, const float* const* B, long ldb, float beta,
@@ -66,7 +67,11 @@ bool sa_pk_enabled(int M, int N, int K, int nprob);  // the size / SA_GEMM_EXACT
 // from src_hi[p][k * ld + (r - R_lo)] when src_hi != NULL.  cs_part (m-contiguous form only, or NULL):
 // [nprob][sa_pk_rowsum_parts(K)][ceil128(R)] partial row sums (fold them with sa_pk_rowsum_fold).
 ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* src_hi, int R_lo, long ld, int R, int K,
-                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream, int kb_stride = 0);
+                       int kcontig, char* dst, size_t dst_stride, float* cs_part, hipStream_t stream, int kb_stride = 0,
+                       int kb_lead = 0, int zero_lead = 0);
+// kb_lead > 0 (m-contiguous form): the matrix starts kb_lead tiles into each row block (kb_stride >= ceil(K / 16) + kb_lead);
+// zero_lead: the tiles in front of it are written as zeros.  A product that reads the operand at its base then sees the
+// matrix shifted by kb_lead k-tiles behind zeros, one that reads it at base + kb_lead tiles sees the matrix itself.
 // kb_stride > 0: the packed row blocks are kb_stride k-tiles apart (default ceil(K / 16)) -- with dst_stride = a whole number
 // of tiles, the nprob matrices land side by side along k inside ONE operand whose reduction length is the sum of theirs.
 ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int Rpad, int M, int split, int jump,
@@ -75,4 +80,4 @@ size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K);
 ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* Apk, int a_split, int a_jump,
                              unsigned a_jump_probs, const char* const* Bpk, float beta, float* const* C, long ldc, void* workspace,
                              size_t workspace_bytes, hipStream_t stream, const SaGemmOpts* opts = nullptr);
-// (opts: only xcc_mask / tile_counter / err_word are read -- the XCD-filtered form of the launch)
+// (opts: only xcc_mask / tile_counter / err_word -- the XCD-filtered form of the launch --, drop* and b_kb_stride are read)
