@@ -658,6 +658,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int prob, int b
     const bool splitk = g.partial != nullptr;
     float* __restrict__ gC = g.Cg[prob];
     const float* __restrict__ gbias = g.biasg[prob];
+    // Whole tiles of the two plain forms (split-K partial sums; alpha acc + bias) take a loop without a branch: the general
+    // loop below tests six things per element, and every branch around a store costs the wait for the store before it
+    // (the same arithmetic: bit-identical results).
+    if (row0 + TI * 32 <= g.M && col0 + TJ * 32 <= g.N) {
+        if (splitk) {
+            float* __restrict__ p0 = g.partial + ((long)bz * g.M + row0 + 4 * (lane >> 5)) * g.N + col0 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        p0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.N + j * 32] = acc[i][j][r];
+            return;
+        }
+        if (g.m_inner <= 0 && g.beta == 0.f && !g.relu && !g.drop.thresh) {
+            float* __restrict__ c0 = gC + (long)(row0 + 4 * (lane >> 5)) * g.ldc + col0 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const float bv = gbias ? gbias[col0 + j * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        c0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32] = g.alpha * acc[i][j][r] + bv;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
