@@ -1637,29 +1637,32 @@ ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* s
 
 namespace {
 // out[p][m] = (beta ? beta * out : 0) + sum over the parts of row (m < split ? m : m + jump), in a fixed order
-struct RowsumOut { float* out[kMaxGroup]; };
+// blockIdx.z selects one of up to two row maps (split, jump) with its own outputs: both bias families of a layer stack
+// (db_ih: rows [0, 3H) of the 4H-row gate operand, db_hh: rows [0, 2H) + [3H, 4H)) in one launch
+struct RowsumOut { float* out[2][kMaxGroup]; int split[2], jump[2]; };
 __global__ __launch_bounds__(256) void pk_rowsum_fold_kernel(const float* __restrict__ part, int nparts, int Rpad, int M,
-                                                             int split, int jump, RowsumOut o, float beta) {
-    const int m = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15, prob = blockIdx.y;
-    const int r = m < split ? m : m + jump;
+                                                             RowsumOut o, float beta) {
+    const int m = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15, prob = blockIdx.y, z = blockIdx.z;
+    const int r = m < o.split[z] ? m : m + o.jump[z];
     float t = 0.f;
     if (m < M)
         for (int q = j; q < nparts; q += 16) t += part[((size_t)prob * nparts + q) * Rpad + r];
 #pragma unroll
     for (int sft = 8; sft > 0; sft >>= 1) t += __shfl_xor(t, sft, 64);
-    if (m >= M || j != 0 || !o.out[prob]) return;
-    float* dstp = o.out[prob] + m;
+    if (m >= M || j != 0 || !o.out[z][prob]) return;
+    float* dstp = o.out[z][prob] + m;
     *dstp = beta != 0.f ? beta * *dstp + t : t;
 }
 }  // namespace
 
 ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int Rpad, int M, int split, int jump,
-                              float* const* out, float beta, hipStream_t stream) {
+                              float* const* out, float beta, hipStream_t stream, int split2, int jump2, float* const* out2) {
     if (nprob < 1 || nprob > kMaxGroup || !cs_part || !out) return CTC_STATUS_INVALID_VALUE;
     RowsumOut o;
-    for (int p = 0; p < kMaxGroup; ++p) o.out[p] = p < nprob ? out[p] : nullptr;
-    hipLaunchKernelGGL(pk_rowsum_fold_kernel, dim3((M + 15) / 16, nprob), dim3(256), 0, stream, cs_part, nparts, Rpad, M,
-                       split, jump, o, beta);
+    for (int p = 0; p < kMaxGroup; ++p) { o.out[0][p] = p < nprob ? out[p] : nullptr; o.out[1][p] = p < nprob && out2 ? out2[p] : nullptr; }
+    o.split[0] = split; o.jump[0] = jump; o.split[1] = split2; o.jump[1] = jump2;
+    hipLaunchKernelGGL(pk_rowsum_fold_kernel, dim3((M + 15) / 16, nprob, out2 ? 2 : 1), dim3(256), 0, stream, cs_part, nparts,
+                       Rpad, M, o, beta);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }

@@ -2813,9 +2813,7 @@ struct WGradIssuer {
         if (!gates_prepacked) st = sa_pk_pack(L, src, hi, 3 * H, 3 * H, 4 * H, K, 0, base + y.g_off, y.g_each, cs, stream);
         if (st != CTC_STATUS_SUCCESS) return st;
         const int parts = gates_prepacked ? gsum_parts : y.parts;
-        st = sa_pk_rowsum_fold(L, cs, parts, 4 * H, 3 * H, 3 * H, 0, wg.db_ih, 0.f, stream);
-        if (st != CTC_STATUS_SUCCESS) return st;
-        st = sa_pk_rowsum_fold(L, cs, parts, 4 * H, 3 * H, 2 * H, H, wg.db_hh, 0.f, stream);
+        st = sa_pk_rowsum_fold(L, cs, parts, 4 * H, 3 * H, 3 * H, 0, wg.db_ih, 0.f, stream, 2 * H, H, wg.db_hh);  // both bias families
         if (st != CTC_STATUS_SUCCESS) return st;
         const bool lead = y.lead > 0 && wg.h_out != nullptr;
         const int kbs = lead ? (K + 15) / 16 + y.lead : 0;  // tiles per row block of the h operands
@@ -2924,9 +2922,7 @@ struct WGradIssuer {
         if (st != CTC_STATUS_SUCCESS) return st;
         for (int d = 0; d < 2; ++d) {  // (the two directions' row sums are not one [prob][part][row] array: a fold each)
             float* o_ih[1] = {wg.db_ih[l * 2 + d]}; float* o_hh[1] = {wg.db_hh[l * 2 + d]};
-            st = sa_pk_rowsum_fold(1, bi_gsum(y, l, d), nbt, 4 * H, 3 * H, 3 * H, 0, o_ih, 0.f, stream);
-            if (st != CTC_STATUS_SUCCESS) return st;
-            st = sa_pk_rowsum_fold(1, bi_gsum(y, l, d), nbt, 4 * H, 3 * H, 2 * H, H, o_hh, 0.f, stream);
+            st = sa_pk_rowsum_fold(1, bi_gsum(y, l, d), nbt, 4 * H, 3 * H, 3 * H, 0, o_ih, 0.f, stream, 2 * H, H, o_hh);
             if (st != CTC_STATUS_SUCCESS) return st;
         }
         SaGemmOpts o;

@@ -75,7 +75,8 @@ ctcStatus_t sa_pk_pack(int nprob, const float* const* src, const float* const* s
 // kb_stride > 0: the packed row blocks are kb_stride k-tiles apart (default ceil(K / 16)) -- with dst_stride = a whole number
 // of tiles, the nprob matrices land side by side along k inside ONE operand whose reduction length is the sum of theirs.
 ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int Rpad, int M, int split, int jump,
-                              float* const* out, float beta, hipStream_t stream);
+                              float* const* out, float beta, hipStream_t stream, int split2 = 0, int jump2 = 0,
+                              float* const* out2 = nullptr);  // out2: a second row map of the same M rows, same launch
 size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K);
 ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* Apk, int a_split, int a_jump,
                              unsigned a_jump_probs, const char* const* Bpk, float beta, float* const* C, long ldc, void* workspace,
