@@ -563,44 +563,108 @@ __global__ __launch_bounds__(512) void conv_dw2_kernel(const float* __restrict__
         const int nt = min(g.TT, g.To - t0);
         const int npos = nt * g.Fo;
         __syncthreads();  // the previous slab's readers are done (first trip: the fills above)
+        // Staging (round 5): every loop below loaded one or two values per trip and waited for them before its LDS store --
+        // `#pragma unroll` notwithstanding: hipcc turns a select whose arm is a single-use load into a branch around the
+        // load, with a vmcnt(0) behind it -- so a slab was staged by ~30 dependent memory round trips (25 of them the masked
+        // dy below).  Now eight trips' loads are issued on clamped
+        // indices before the first value is used; SA_PIN gives every loaded value a second use, which keeps the load where
+        // it is.
+#define SA_PIN(v) asm volatile("" : "+v"(v))
         {
             const int valid = max(0, min(rows, g.T - g.s * t0)) * g.F;
             const float* src = x + (((long)b * g.C + CW * blockIdx.y) * g.T + (long)g.s * t0) * g.F;
-#pragma unroll 4
-            for (int i = tid; i < CW * slabsz; i += 512) {
-                const int cc = i / slabsz, o = i - cc * slabsz;
-                const bool on = o < valid && CW * (int)blockIdx.y + cc < g.C;
-                const float v = src[on ? (long)cc * g.T * g.F + o : 0];
-                dsm[i] = on ? v : 0.f;
+            const int total = CW * slabsz;
+            for (int i0 = tid; i0 < total; i0 += 512 * 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = min(i0 + 512 * q, total - 1);
+                    const int cc = i / slabsz, o = i - cc * slabsz;
+                    const bool on = o < valid && CW * (int)blockIdx.y + cc < g.C;
+                    v[q] = src[on ? (long)cc * g.T * g.F + o : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) SA_PIN(v[q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + 512 * q;
+                    const int cc = i / slabsz, o = i - cc * slabsz;
+                    const bool on = o < valid && CW * (int)blockIdx.y + cc < g.C;
+                    if (i < total) dsm[i] = on ? v[q] : 0.f;
+                }
             }
         }
         if (dypg) {  // the slab of the packed masked gradient is contiguous: npos x O floats
             const float* src = dypg + ((long)b * g.To + t0) * g.Fo * g.O;
             if (g.O == 32) {
                 const float4* s4 = reinterpret_cast<const float4*>(src);
-#pragma unroll 4
-                for (int i = tid; i < npos * 8; i += 512) {
-                    const float4 v = s4[i];
-                    float* d = dyp + (i >> 3) * 33 + (i & 7) * 4;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                const int total = npos * 8;
+                for (int i0 = tid; i0 < total; i0 += 512 * 8) {
+                    float4 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = s4[min(i0 + 512 * q, total - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { SA_PIN(v[q].x); SA_PIN(v[q].y); SA_PIN(v[q].z); SA_PIN(v[q].w); }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = i0 + 512 * q;
+                        if (i < total) {
+                            float* d = dyp + (i >> 3) * 33 + (i & 7) * 4;
+                            d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+                        }
+                    }
                 }
             } else {
-#pragma unroll 4
-                for (int i = tid; i < npos * g.O; i += 512) {
-                    const int pp = i / g.O;
-                    dyp[pp * 33 + (i - pp * g.O)] = src[i];
+                const int total = npos * g.O;
+                for (int i0 = tid; i0 < total; i0 += 512 * 8) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = src[min(i0 + 512 * q, total - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) SA_PIN(v[q]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = i0 + 512 * q, pp = i / g.O;
+                        if (i < total) dyp[pp * 33 + (i - pp * g.O)] = v[q];
+                    }
                 }
             }
         } else {  // (channel, frame, f') with f' fastest: the caller's layout is f'-contiguous
-#pragma unroll 4
-            for (int i = tid; i < npos * g.O; i += 512) {
-                const int fo = i % g.Fo, q = i / g.Fo;
-                const int tl = q % nt, o = q / nt;
-                const long off = (long)b * g.ys_b + (long)o * g.ys_c + (long)(t0 + tl) * g.ys_t + fo;
-                const float yv = y[off], dv = dy[off];
-                dyp[(tl * g.Fo + fo) * 33 + o] = yv > 0.f ? dv * g.dscale : 0.f;
+            // element i = (o nt + tl) Fo + fo; a thread walks i = tid, tid + 512, ...: its (fo, tl, o) advance by the digits
+            // of 512 with carries (two integer divisions per element were 56 of the loop's instructions per element)
+            constexpr int UD = 8;  // trips in flight (16: 109 instead of 86 us at S-LIBRI -- 229 registers, a worse MFMA loop)
+            const int total = npos * g.O;
+            const int dq = 512 / g.Fo, dfo = 512 - dq * g.Fo, do_ = dq / nt, dtl = dq - do_ * nt;
+            int fo = tid % g.Fo, qq0 = tid / g.Fo;
+            int tl = qq0 % nt, o = qq0 / nt;
+            const float* yb = y + (long)b * g.ys_b + (long)t0 * g.ys_t;
+            const float* db = dy + (long)b * g.ys_b + (long)t0 * g.ys_t;
+            for (int i0 = tid; i0 < total; i0 += 512 * UD) {
+                float yv[UD], dv[UD];
+                int dst[UD];
+#pragma unroll
+                for (int q = 0; q < UD; ++q) {
+                    const bool in = i0 + 512 * q < total;  // (past the end: element 0 of the slab, not stored)
+                    const long off = in ? (long)o * g.ys_c + (long)tl * g.ys_t + fo : 0;
+                    yv[q] = yb[off];
+                    dv[q] = db[off];
+                    dst[q] = (tl * g.Fo + fo) * 33 + o;
+                    fo += dfo;
+                    const int c1 = fo >= g.Fo ? 1 : 0;
+                    fo -= c1 * g.Fo;
+                    tl += dtl + c1;
+                    const int c2 = tl >= nt ? 1 : 0;
+                    tl -= c2 * nt;
+                    o += do_ + c2;
+                }
+#pragma unroll
+                for (int q = 0; q < UD; ++q) { SA_PIN(yv[q]); SA_PIN(dv[q]); }
+#pragma unroll
+                for (int q = 0; q < UD; ++q)
+                    if (i0 + 512 * q < total) dyp[dst[q]] = yv[q] > 0.f ? dv[q] * g.dscale : 0.f;
             }
         }
+#undef SA_PIN
         __syncthreads();
         if (c < g.C) {
             // operands of the next trip (two position pairs) are read before this trip's products are issued
@@ -622,39 +686,39 @@ __global__ __launch_bounds__(512) void conv_dw2_kernel(const float* __restrict__
             }
         }
     }
-    if (PW == 1) {
-        if (c >= g.C) return;
-        float* out = part + ((long)blockIdx.x * g.C + c) * 32 * (32 * NT);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
-                out[o * (32 * NT) + 32 * n + r] = acc[n][q];
-            }
-        return;
-    }
-    // fold the position ways in a fixed order (deterministic) through [CW][32][32 NT] floats of LDS
-    float* red = dsm + cs * (32 * 32 * NT);
-    for (int pw = 0; pw < PW; ++pw) {
-        __syncthreads();
-        if (pwy == pw) {
+    // Fold the position ways of a channel slot as a TREE through LDS (round 5; a fixed order: deterministic).  The first
+    // version let one wave at a time add its 96 accumulators into an LDS image -- 96 read-modify-writes that hipcc cannot
+    // overlap (each read waits behind the write before it): 7 rounds x 96 LDS round trips = 24 of the kernel's 115 us at
+    // S-LIBRI.  Now the upper half of the ways writes, the lower half reads 96 independent values and adds in registers,
+    // log2(PW) times; way 0 of every slot stores the result itself.
+    constexpr int RS = 16 * NT * 64;  // floats of one wave's accumulator image: [n][q][lane]
+    for (int half = PW / 2; half >= 1; half >>= 1) {
+        __syncthreads();  // (first trip: the last slab's readers are done with the LDS)
+        if (pwy >= half && pwy < 2 * half) {
+            float* w = dsm + (cs * half + (pwy - half)) * RS + lane;
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
-                    float* dst = &red[o * (32 * NT) + 32 * n + r];
-                    *dst = pw == 0 ? acc[n][q] : *dst + acc[n][q];
-                }
+                for (int q = 0; q < 16; ++q) w[(n * 16 + q) * 64] = acc[n][q];
+        }
+        __syncthreads();
+        if (pwy < half) {
+            const float* rd = dsm + (cs * half + pwy) * RS + lane;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[n][q] += rd[(n * 16 + q) * 64];
         }
     }
-    __syncthreads();
-    for (int i = tid; i < CW * 32 * 32 * NT; i += 512) {
-        const int cc = i / (32 * 32 * NT);
-        if (CW * (int)blockIdx.y + cc < g.C)
-            part[((long)blockIdx.x * g.C + CW * blockIdx.y + cc) * 32 * (32 * NT) + (i - cc * (32 * 32 * NT))] = dsm[i];
-    }
+    if (pwy != 0 || c >= g.C) return;
+    float* out = part + ((long)blockIdx.x * g.C + c) * 32 * (32 * NT);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+            out[o * (32 * NT) + 32 * n + r] = acc[n][q];
+        }
 }
 
 constexpr int kDwBlocks = 512;
@@ -715,7 +779,7 @@ static size_t dir_dw2_lds(const ConvGeom& g, int cw) {
     const int TT = conv_direct_tt(g.kh, g.kw, g.s, g.F, g.Fo);
     const size_t maxpos = (size_t)TT * g.Fo + 40;
     const size_t stage = ((size_t)cw * ((TT - 1) * g.s + g.kh) * g.F + 8 + maxpos * 34) * sizeof(float);
-    const size_t fold = cw < 8 ? (size_t)cw * 32 * 32 * dir_nt(g.kh * g.kw) * sizeof(float) : 0;
+    const size_t fold = cw < 8 ? (size_t)4 * 32 * 32 * dir_nt(g.kh * g.kw) * sizeof(float) : 0;  // the fold tree's first round: 4 images
     return stage > fold ? stage : fold;
 }
 static int dir_dw2_cw(const ConvGeom& g) {
