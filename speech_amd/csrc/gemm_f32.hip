@@ -1397,7 +1397,13 @@ __global__ __launch_bounds__(256) void thin_tn_fold_kernel(const float* __restri
     }
     const int row = (int)(e / N), col = (int)(e - (long)row * N);
     float v = 0.f;
-    for (int sblk = 0; sblk < kThinSplit; ++sblk) v += part[((long)sblk * 32 + row) * N + col];
+    for (int s0 = 0; s0 < kThinSplit; s0 += 8) {  // eight partials in flight, added in order
+        float w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = part[((long)(s0 + q) * 32 + row) * N + col];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += w[q];
+    }
     float* cp = C + (long)row * ldc + col;
     *cp = beta != 0.f ? v + beta * *cp : v;
 }
