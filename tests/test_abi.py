@@ -162,3 +162,19 @@ def test_options_are_a_table_not_the_environment(monkeypatch):
     monkeypatch.delenv("SA_CTC_PROB")
     _lib.lib()
     assert {n: _lib.get_option(n) for n in names} == defaults
+
+
+def test_every_library_option_is_documented():
+    """The options table (sa_set_option / sa_get_option, csrc/options.hip) replaced the environment switches of rounds 1-4:
+    every option the library knows has a help string and a row in DESIGN.md section 7, and a name the library does not
+    know is refused."""
+    import ctypes
+    L = _lib.lib()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    names = _lib.option_names()
+    assert len(names) == L.sa_option_count() >= 18 and len(set(names)) == len(names)
+    for i, name in enumerate(names):
+        assert "`%s`" % name in design, name
+        assert len(L.sa_option_help(i)) > 20, name
+    v = ctypes.c_long(0)
+    assert L.sa_get_option(b"no.such.option", ctypes.byref(v)) == 2 and L.sa_set_option(b"no.such.option", 1) == 2
