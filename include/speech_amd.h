@@ -12,7 +12,8 @@
  * (weight-gradient / projection GEMMs beside a recurrence), and a per-device mutex that serialises the stack calls of
  * several host threads on one device (held while launches are enqueued: microseconds).  Different devices share
  * nothing.  The opt-in profiler (sa_gru_profile_*) is the one piece of process-wide state and serves one device.
- * Environment switches are read at call time.
+ * The library never reads the process environment; what can be steered is the table of named options at the end of this
+ * file (sa_set_option), read when an entry point is called.
  *
  * Each entry point names the reference interface it replaces (paths relative to /root/reference).
  */
@@ -74,7 +75,7 @@ ctcStatus_t get_workspace_size(const int* label_lengths, const int* input_length
  *    Below 512 utterances per call the alpha / beta chains run in the probability domain (no exp2 / log2 on the T-step
  *    dependent chain), certified at run time -- range kept per batch of steps, flow conservation of every lattice row --
  *    and an utterance that fails a check is recomputed by the log-domain kernels launched behind (csrc/ctc_loss.hip,
- *    ctc_chain_p).  SA_CTC_PROB=0 selects the log-domain kernels alone.
+ *    ctc_chain_p).  Option "ctc.prob" = 0 selects the log-domain kernels alone.
  * ----------------------------------------------------------------------------------------------------------------*/
 size_t sa_ctc_workspace_bytes(int max_T, int max_L, int alphabet_size, int minibatch);
 
@@ -129,7 +130,7 @@ ctcStatus_t sa_ctc_greedy_decode(const float* in, long stride_t, long stride_b, 
  *        run on the bf16 MFMA with fp32 accumulation; the dropped terms are below 2^-26 of each product, the result is
  *        within the fp32 accumulation bound 2^-24 (2 + sqrt(K)) |A||B| and measures at or below the f32-input kernel's
  *        error against fp64 (tests/test_gpu_blocks.py::test_split_bf16_gemm_error_budget); integer data stays bit-exact.
- *        Environment SA_GEMM_EXACT=1 selects the f32-input kernel for every product, =0 the split path for every
+ *        Option "gemm.exact" = 1 selects the f32-input kernel for every product, = 0 the split path for every
  *        product (tests); nothing else -- in particular not the workspace size -- changes the arithmetic.
  * ----------------------------------------------------------------------------------------------------------------*/
 
@@ -244,7 +245,7 @@ ctcStatus_t sa_gru_stack_bwd(const float* dh_top, const float* const* stash, con
  * split-bf16 operands packed once per layer -- with the one-launch backward kernel (B a multiple of 16, H a multiple of
  * 128) the kernel writes the packed gate gradients and the bias sums itself.  Bidirectional stacks: a finished layer's
  * products go to a library-owned side stream as XCD-filtered launches that run BESIDE the next layer's recurrence, on the
- * XCDs it leaves idle (SA_GRU_OVERLAP=0: on `stream`); the call joins the side stream before it returns (stream-ordered:
+ * XCDs it leaves idle; the call joins the side stream before it returns (stream-ordered:
  * everything is complete when `stream` reaches the end of the call's work).  Deterministic: fixed accumulation order.
  * dai / dah are SCRATCH for these entry points: when the recurrence kernel packs the gate gradients itself it writes no
  * row-major copy (except dai of the bottom layer of a unidirectional stack, which the d x product reads); callers that
@@ -278,11 +279,12 @@ ctcStatus_t sa_gru_stack_bwd_wgrad_dropout(const float* dh_top, const float* con
 /* ---- run-time options ------------------------------------------------------------------------------------------------
  * The library never reads the process environment (rounds 1-4 did, on every call: VERDICT r04).  What the parity tests and the
  * measurement tools need to steer -- which CTC domain runs, whether the persistent recurrence kernels are used, fault
- * injection, in-kernel phase clocks ... -- is a table of named integer options, process-wide, read by the entry points at call
- * time.  Set an option BEFORE the calls it should affect; -1 means "the library's own rule decides".  Names and meanings:
+ * injection, in-kernel phase clocks ... -- is a table of named integer options: process-wide atomics, read by an entry point
+ * when it is called (setting one from another thread never tears a value; a call already running keeps what it read).  Set an
+ * option BEFORE the calls it should affect; -1 means "the library's own rule decides".  Names and meanings:
  * sa_option_name(i) / sa_option_help(i) for i in [0, sa_option_count()).  Every option's default is the measured-best path; a
  * caller that sets nothing gets exactly what bench.py measures.  (speech_amd/_lib.py applies SA_<NAME> environment variables
- * once, when it loads the library: SA_GRU_FUSED=0 sets "gru.fused" to 0 -- a convenience of the Python host, not of the ABI.)
+ * when it loads the library: SA_GRU_FUSED=0 sets "gru.fused" to 0 -- a convenience of the Python host, not of the ABI.)
  * Unknown name: CTC_STATUS_INVALID_VALUE. */
 ctcStatus_t sa_set_option(const char* name, long value);
 ctcStatus_t sa_get_option(const char* name, long* value);
@@ -290,6 +292,7 @@ void sa_reset_options(void);
 int sa_option_count(void);
 const char* sa_option_name(int i);
 const char* sa_option_help(int i);
+long sa_option_default(int i); /* the value sa_reset_options() gives option i (0 for an index out of range) */
 
 /* Opt-in profiler of the CTC loss's serial part (bench.py's `ctc_chain_*` fields): after sa_ctc_profile_configure(1) every
  * latency-regime call (minibatch < 512: one workgroup per utterance) stamps the device-clock span of its alpha / beta
@@ -312,7 +315,7 @@ int sa_gru_profile_steps_per_launch(int kind);
 
 /* Unidirectional stacks with H = 512 (32 unit tiles), layers x ceil(B/16) <= 8, on a 256-CU device run the recurrence
  * as PERSISTENT chunk kernels whose sync groups are XCD-local (one (layer, batch tile) group per XCD, hand-off through
- * that XCD's L2; bit-identical to the step kernels; SA_GRU_PERSIST=0 switches them off).  A workgroup derives its
+ * that XCD's L2; option "gru.persist" = 0 switches them off).  A workgroup derives its
  * group from the XCC id it actually runs on, so a dispatcher that does not spread 32 workgroups per XCD -- or a
  * hand-off that times out -- cannot hang or silently corrupt: it ORs its code into the library's STICKY device error
  * word (nothing but sa_gru_persist_reset() clears it).  Three things hang off that word:
@@ -331,8 +334,8 @@ int sa_gru_profile_steps_per_launch(int kind);
  *     it leaves idle -- did not draw all of its tiles because the dispatcher placed too few of its blocks there);
  *     sa_gru_persist_reset() does the same, then clears the device word and the host state (the path stays off: the
  *     caller re-runs the lost step on the step kernels).
- * Tests: SA_GRU_FAULT=1 makes one workgroup of every persistent launch leave before its first step,
- * SA_GRU_SPIN_LIMIT=n shortens the hand-off timeout (default 2^20 polls). */
+ * Tests: option "gru.fault" = 1 makes one workgroup of every persistent launch leave before its first step,
+ * "gru.spin_limit" = n shortens the hand-off timeout (default 2^20 polls). */
 int sa_gru_persist_status(void);
 int sa_gru_persist_reset(void);
 ctcStatus_t sa_gru_health_flag(float* d_flag, void* stream);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sa_option_count": (c_int, []),
     "sa_option_name": (ctypes.c_char_p, [c_int]),
     "sa_option_help": (ctypes.c_char_p, [c_int]),
+    "sa_option_default": (c_long, [c_int]),
     "sa_ctc_profile_configure": (c_int, [c_int]),
     "sa_ctc_profile_count": (c_int, []),
     "sa_ctc_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -191,17 +192,36 @@ def _env_name(option):
 
 
 def options_from_env():
+    """Apply SA_<NAME> environment variables to the option table.  Only options whose variable CHANGED since the last look
+    are touched (a variable that went away puts its option back to the default): values set through set_option() survive
+    somebody else's monkeypatch.setenv.  A value that is not an integer is refused loudly."""
     global _ENV_SEEN
-    seen = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SA_")))
+    seen = {k: v for k, v in os.environ.items() if k.startswith("SA_")}
     if seen == _ENV_SEEN:
         return
-    _ENV_SEEN = seen
-    _LIB.sa_reset_options()
-    env = dict(seen)
+    before, _ENV_SEEN = (_ENV_SEEN or {}), seen
+    defaults, bad = None, []
     for name in option_names():
-        v = env.get(_env_name(name))
-        if v is not None and v.lstrip("-").isdigit():
+        e = _env_name(name)
+        v, was = seen.get(e), before.get(e)
+        if v == was:
+            continue
+        if v is None:  # the variable was removed: back to the library's default for this one option
+            if defaults is None:
+                defaults = option_defaults()
+            _LIB.sa_set_option(name.encode(), defaults[name])
+            continue
+        try:
             _LIB.sa_set_option(name.encode(), int(v))
+        except ValueError:
+            bad.append("%s=%r: library option %r takes an integer" % (e, v, name))
+    if bad:
+        raise SpeechAmdError("; ".join(bad))
+
+
+def option_defaults():
+    L = _LIB
+    return {L.sa_option_name(i).decode(): int(L.sa_option_default(i)) for i in range(L.sa_option_count())}
 
 
 def set_option(name, value):
@@ -278,18 +298,19 @@ class PinnedRing:
 
     def get(self, shape):
         """A pinned tensor of `shape` (contents undefined)."""
+        with self._lock:  # take the slot and its pending copy's event under the lock ...
+            i = self._next
+            self._next = (i + 1) % len(self._bufs)
+            ev, self._events[i] = self._events[i], None
+        if ev is not None:  # ... and wait for the device OUTSIDE it: the other thread's get() / copied() must not queue up
+            ev.synchronize()  # behind a copy this thread is waiting for
         with self._lock:
-            return self._get(shape)
+            return self._claim(i, shape)
 
-    def _get(self, shape):
-        i = self._next
-        self._next = (i + 1) % len(self._bufs)
+    def _claim(self, i, shape):
         n = 1
         for d in shape:
             n *= int(d)
-        if self._events[i] is not None:
-            self._events[i].synchronize()
-            self._events[i] = None
         buf = self._bufs[i]
         if buf is None or buf.numel() < n:
             if buf is not None:

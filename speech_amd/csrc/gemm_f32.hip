@@ -1316,12 +1316,15 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ 
             const long kc = ok ? k : (K - 1);
             const float v0 = pa0[kc * lda], v1 = pa1[kc * lda];
             const float4 vb = *reinterpret_cast<const float4*>(pb + kc * ldb);
-            // masked by a PRODUCT, not a select: hipcc sinks a load whose value only one arm of a select uses under that
-            // arm's condition -- a branch around every load and a wait behind each (the clamped rows are rows of the matrix)
-            const float f0 = ok && r0 ? 1.f : 0.f, f1 = ok && r1 ? 1.f : 0.f, fb = ok && cn ? 1.f : 0.f;
-            a0[j] = v0 * f0;
-            a1[j] = v1 * f1;
-            b[j] = make_float4(vb.x * fb, vb.y * fb, vb.z * fb, vb.w * fb);
+            // masked by a bit-AND, not a select: hipcc sinks a load whose value only one arm of a select uses under that
+            // arm's condition -- a branch around every load and a wait behind each (the clamped rows are rows of the matrix).
+            // (Round 5 masked by a PRODUCT with 0 / 1: a non-finite value in the clamped row then put 0 * inf = NaN into sums
+            // that should have received exactly 0 -- ADVICE r05; the AND gives +0 whatever the bits.)
+            const unsigned m0 = ok && r0 ? ~0u : 0u, m1 = ok && r1 ? ~0u : 0u, mb = ok && cn ? ~0u : 0u;
+            auto keep = [](float v, unsigned m) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+            a0[j] = keep(v0, m0);
+            a1[j] = keep(v1, m1);
+            b[j] = make_float4(keep(vb.x, mb), keep(vb.y, mb), keep(vb.z, mb), keep(vb.w, mb));
         }
     };
     if (kb < kend) fetch(kb);

@@ -4,15 +4,19 @@
 // call: a C ABI whose behaviour depends on the process environment at call time is a debugging harness, not a boundary
 // (VERDICT r04 weak 8).  Now the library never reads the environment.  What is left of the switches -- the ones the parity
 // tests and the measurement tools drive; the ones that guarded retired or measured-slower paths are gone with those paths --
-// is a table of named integer options behind sa_set_option / sa_get_option (include/speech_amd.h): process-wide, read at
-// call time, set before the calls they should affect.  speech_amd/_lib.py applies SA_<NAME> environment variables to it ONCE
+// is a table of named integer options behind sa_set_option / sa_get_option (include/speech_amd.h): process-wide atomics, read
+// when a call starts, set before the calls they should affect.  speech_amd/_lib.py applies SA_<NAME> environment variables to it ONCE
 // when it loads the library (SA_GRU_FUSED=0 -> "gru.fused" = 0), so the tools' command lines keep working.
 #include <string.h>
+
+#include <atomic>
 
 #include "internal.h"
 
 namespace {
-struct Opt { const char* name; long def; long value; const char* help; };
+// `value` is atomic: sa_set_option may run on one host thread while library calls on another (a collate-ahead worker, a
+// second device's loop) read the table; a call reads each option it needs once.
+struct Opt { const char* name; long def; std::atomic<long> value; const char* help; };
 // -1 = "auto": the library's own rule decides
 Opt g_opts[SA_OPT_COUNT] = {
     {"ctc.prob", -1, -1, "CTC loss: -1 auto (probability-domain pass, log-domain kernels behind it for what it flags); 0 log "
@@ -39,23 +43,24 @@ Opt g_opts[SA_OPT_COUNT] = {
 };
 }  // namespace
 
-long sa_opt(SaOpt id) { return g_opts[id].value; }
+long sa_opt(SaOpt id) { return g_opts[id].value.load(std::memory_order_relaxed); }
 
 extern "C" int sa_option_count(void) { return SA_OPT_COUNT; }
 extern "C" const char* sa_option_name(int i) { return i >= 0 && i < SA_OPT_COUNT ? g_opts[i].name : nullptr; }
 extern "C" const char* sa_option_help(int i) { return i >= 0 && i < SA_OPT_COUNT ? g_opts[i].help : nullptr; }
+extern "C" long sa_option_default(int i) { return i >= 0 && i < SA_OPT_COUNT ? g_opts[i].def : 0; }
 extern "C" ctcStatus_t sa_set_option(const char* name, long value) {
     if (!name) return CTC_STATUS_INVALID_VALUE;
     for (int i = 0; i < SA_OPT_COUNT; ++i)
-        if (strcmp(g_opts[i].name, name) == 0) { g_opts[i].value = value; return CTC_STATUS_SUCCESS; }
+        if (strcmp(g_opts[i].name, name) == 0) { g_opts[i].value.store(value, std::memory_order_relaxed); return CTC_STATUS_SUCCESS; }
     return CTC_STATUS_INVALID_VALUE;
 }
 extern "C" ctcStatus_t sa_get_option(const char* name, long* value) {
     if (!name || !value) return CTC_STATUS_INVALID_VALUE;
     for (int i = 0; i < SA_OPT_COUNT; ++i)
-        if (strcmp(g_opts[i].name, name) == 0) { *value = g_opts[i].value; return CTC_STATUS_SUCCESS; }
+        if (strcmp(g_opts[i].name, name) == 0) { *value = g_opts[i].value.load(std::memory_order_relaxed); return CTC_STATUS_SUCCESS; }
     return CTC_STATUS_INVALID_VALUE;
 }
 extern "C" void sa_reset_options(void) {
-    for (int i = 0; i < SA_OPT_COUNT; ++i) g_opts[i].value = g_opts[i].def;
+    for (int i = 0; i < SA_OPT_COUNT; ++i) g_opts[i].value.store(g_opts[i].def, std::memory_order_relaxed);
 }

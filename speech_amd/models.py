@@ -129,11 +129,15 @@ class Model(nn.Module):
 
     def _pad_inputs(self, inputs):
         if self.is_cuda and getattr(self, "_staged", False) and not torch.is_tensor(inputs[0]):
-            ahead, self._ahead = getattr(self, "_ahead", None), None
-            if ahead is not None and ahead[0] is inputs:  # stage_ahead() padded exactly this batch on its worker thread
-                staged = ahead[1].result()
+            # stage_ahead() padded exactly this batch object on its worker thread?  (dist.with_global_shapes stages batch
+            # k+1 BEFORE it hands out batch k, so the entry of the batch in use is normally the OLDER of two.)
+            ahead = getattr(self, "_ahead", None)
+            hit = ahead.pop(id(inputs), None) if ahead else None
+            if hit is not None and hit[0] is inputs:
+                staged = hit[1].result()
                 want_t = max(max(int(i.shape[0]) for i in inputs), int(self.pad_frames or 0))
                 if staged is not None and staged.shape[1] == want_t:
+                    self.ahead_hits = getattr(self, "ahead_hits", 0) + 1
                     return staged
             if self._stage is None:
                 self._stage = _PinnedStage()
@@ -160,7 +164,12 @@ class Model(nn.Module):
                 return zero_pad_concat(inputs, frames, stage=self._stage)
             except Exception:  # never fatal: the batch is then padded on the launch path, as before
                 return None
-        self._ahead = (inputs, self._ahead_pool.submit(work))
+        if getattr(self, "_ahead", None) is None:
+            import collections
+            self._ahead = collections.OrderedDict()  # id(inputs) -> (inputs, future); the batch in use + the next one
+        while len(self._ahead) >= 2:  # a staged batch nobody used: its slot of the ring simply comes round again
+            self._ahead.popitem(last=False)
+        self._ahead[id(inputs)] = (inputs, self._ahead_pool.submit(work))
 
     def _healthy(self, fn):
         """Forward-only use (infer, dev-set loss): there is no optimiser whose device-side gate would catch a failed

@@ -471,6 +471,7 @@ class ScalarPipe:
 
 
 _UNIT = {}
+_UNIT_VERSION = {}
 
 
 def unit_gradient(device):
@@ -478,7 +479,17 @@ def unit_gradient(device):
     key = str(device)
     if key not in _UNIT:
         _UNIT[key] = torch.ones(1, dtype=torch.float32, device=device)
+        _UNIT_VERSION[key] = _UNIT[key]._version
     return _UNIT[key]
+
+
+def is_unit_gradient(t):
+    """`t` is the cached unit gradient of its device (the same storage cell), and nothing has written into that tensor
+    since it was created (torch's version counter): only then may a node skip the multiplication by it."""
+    key = str(t.device)
+    u = _UNIT.get(key)
+    return (u is not None and t.numel() == 1 and t.dtype == torch.float32 and t.data_ptr() == u.data_ptr()
+            and u._version == _UNIT_VERSION[key])
 
 
 def backward(loss):

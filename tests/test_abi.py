@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "speech_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(?:ctcStatus_t|size_t|int|void|const char\s*\*)\s+([a-zA-Z_][a-zA-Z0-9_]*)\s*\(", src)
+    names = re.findall(r"\b(?:ctcStatus_t|size_t|int|long|void|const char\s*\*)\s+([a-zA-Z_][a-zA-Z0-9_]*)\s*\(", src)
     return sorted(set(names))
 
 
@@ -158,8 +158,22 @@ def test_options_are_a_table_not_the_environment(monkeypatch):
     monkeypatch.setenv("SA_NOT_AN_OPTION", "7")
     _lib.lib()
     assert _lib.get_option("gru.fused") == 0 and _lib.get_option("ctc.prob") == 2
+    # a value set through set_option() survives somebody else's environment change (only the options whose
+    # variable changed are touched) ...
+    _lib.set_option("gru.fwd_report", 8)
     monkeypatch.delenv("SA_GRU_FUSED")
+    _lib.lib()
+    assert _lib.get_option("gru.fused") == 1 and _lib.get_option("ctc.prob") == 2 and _lib.get_option("gru.fwd_report") == 8
+    _lib.set_option("gru.fwd_report", 4)
     monkeypatch.delenv("SA_CTC_PROB")
+    _lib.lib()
+    assert {n: _lib.get_option(n) for n in names} == defaults
+    assert _lib.option_defaults() == defaults and L.sa_option_default(-1) == 0
+    # ... and a value that is not an integer is refused, not silently ignored
+    monkeypatch.setenv("SA_GRU_PERSIST", "off")
+    with pytest.raises(_lib.SpeechAmdError):
+        _lib.lib()
+    monkeypatch.delenv("SA_GRU_PERSIST")
     _lib.lib()
     assert {n: _lib.get_option(n) for n in names} == defaults
 

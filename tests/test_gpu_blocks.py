@@ -690,3 +690,14 @@ def test_thin_products_of_the_classifier(monkeypatch, M, N, K):
     out = dev(c0.copy())
     ops.gemm(X, W, trans_b=True, bias=Bv, out=out, beta=0.5)
     np.testing.assert_allclose(out.cpu().numpy(), (xd @ wd.T + b + 0.5 * c0), rtol=2e-5, atol=2e-4)
+    # out-of-range k / rows are read from CLAMPED rows and masked; a non-finite value in the last row must reach
+    # exactly the sums it belongs to (+inf stays +inf, as on the tiled path), never 0 * inf = NaN through the mask
+    x_inf, dl_pos = x.copy(), np.abs(dl) + 0.5
+    x_inf[M - 1, 3] = np.inf
+    dl_pos[M - 1, N - 1] = np.inf
+    thin = ops.gemm(dev(dl_pos), dev(x_inf), trans_a=True).cpu().numpy()
+    monkeypatch.setenv("SA_GEMM_THIN", "0")
+    tiled = ops.gemm(dev(dl_pos), dev(x_inf), trans_a=True).cpu().numpy()
+    monkeypatch.delenv("SA_GEMM_THIN", raising=False)
+    assert np.array_equal(np.isnan(thin), np.isnan(tiled)) and np.array_equal(np.isposinf(thin), np.isposinf(tiled))
+    assert np.isposinf(thin[:N - 1, 3]).all() and np.isfinite(thin[:N - 1, :3]).all()

