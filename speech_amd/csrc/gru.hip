@@ -635,6 +635,10 @@ struct PFusedFwd {
     unsigned long long* timing;  // debug (SA_GRU_TIMING=1): per block 4 phase accumulators in 10 ns ticks, else null
     float* dump;                 // 256 x 256 floats nobody reads: where the stores of rows beyond the batch go
     int report_every;            // a layer's blocks report progress to the layer above every so many steps (power of two)
+    // gru_fwd_planes_kernel: the exchange copy of a layer's output as three bf16 planes (see there), pre-filled with
+    // kPlaneSentinel; hxd[l]: the same for the DROPPED output (what layer l + 1 reads under inter-layer dropout), or null
+    char* hx[kMaxJobs];
+    char* hxd[kMaxJobs];
 };
 
 // Round 5: what the comment above describes is now also what the ISA does.
@@ -959,6 +963,358 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
     if (tid == 0) {
         // reports so far: steps 1 .. T-1 one each (or, batched, exp_every at every multiple of exp_every below T); the
         // block ends having reported T steps
+        unsigned done = T > 1 ? (unsigned)(T - 1) : 0u;
+        if (exp_every > 1) done = T > 1 ? (unsigned)(((T - 1) / exp_every) * exp_every) : 0u;
+        __hip_atomic_fetch_add(my_prog, (unsigned)T - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
+}
+
+// ------------------------------------------------------------------- fused forward layer wavefront on bf16 planes (r6)
+// gru_fwd_fused_kernel with both of a step's products on the bf16 MFMA.  Rounds 3-5 established that every cycle of the 96
+// f32-input MFMAs of the recurrent product (1.43 us) is on the step's critical path, that the upper layers carry 96 more for
+// their input product (2.9 us of matrix pipe in a 4.2 us step), and that splitting the freshly gathered fp32 rows into bf16
+// pieces on the CONSUMER side (176 VALU instructions per lane and step, on the same path) eats what the faster MFMAs save
+// (profiles/r03_recurrence_split_bf16_experiment.txt).  Here the PRODUCER splits: a thread owns one h value in a register
+// when it is born; it pairs up with its neighbour lane (one DPP move), splits the pair exactly into three bf16 pieces
+// (sa_split2, 11 instructions) and publishes the three packed pairs with two 4-byte stores into the layer's PLANES buffer
+//     hx[t][batch tile][plane 3][k / 32][row 16][k % 32]   bf16  (1 KB per (plane, k / 32) tile: one load instruction of a wave)
+// which is the A operand of v_mfma_f32_16x16x32_bf16 as it lies: lane (row i, k-group g) reads the 16 bytes k = 8 g .. 8 g + 7
+// of row i.  Consumers -- the own layer's next step inside the XCD, the layer above from another XCD -- gather 12 x 16 B per
+// lane instead of 8 (48 KB per block and step instead of 32) and run 72 sixteen-cycle MFMAs per product instead of 96
+// thirty-two-cycle ones (the six piece products that carry an fp32 product down to 2^-26 of it, smallest first: the
+// arithmetic of the split-bf16 GEMMs, gemm_f32.hip): 1152 instead of 3072 matrix-pipe cycles per product.  The weights'
+// fragments are split once at launch (2 x 144 registers).  The data is its own flag as before: the planes are pre-filled
+// with 0xffffffff (a pair of bf16 NaNs no split of a finite number produces), a dword store is atomic, and a consumer folds
+// the 48 dwords of a trip with v_max3_u32 -- one compare per trip.
+// What else changed against gru_fwd_fused_kernel, all on the reduce .. publish path that follows the MFMAs:
+//   * thread (wave w, lane (i, g)) finishes element (row 4 g + w, unit i) -- the element whose partial sums sit in register w
+//     of the SAME lane in every wave (16x16 C/D layout: row = 4 (lane >> 4) + reg, col = lane & 15).  The four waves' partial
+//     sums cross LDS as 16-byte vectors {r, z, n_in, n_h}: 4 ds_write_b128 + 4 ds_read_b128 per thread instead of 16 + 16
+//     four-byte accesses; neighbouring lanes hold neighbouring units, which is what the pair-wise publish wants;
+//   * sigmoid and tanh on v_exp_f32 / v_rcp_f32 (1 ulp each; tanh x = 2 sigmoid(2 x) - 1: absolute error < 2e-7) instead of
+//     expf / IEEE division / tanhf (~100 instructions on the critical path of every step);
+//   * the fp32 h_out (what the classifier, the weight-gradient packs and the caller read) leaves with a plain store behind
+//     the planes and needs no sentinel fill.
+// NOT bit-identical to the step kernels any more (different products, different summation order, different transcendental
+// rounding): tests/test_gpu_blocks.py holds the stack against an fp64 restatement with an error budget instead, and every
+// oracle / golden comparison is unchanged.  Even IPG only (a wave's K slice is whole 32-k steps): H = 128, 256, 384, 512.
+constexpr unsigned kPlaneSentinel = 0xffffffffu;
+__host__ __device__ inline size_t hx_step_bytes(int H) { return (size_t)3 * (H / 32) * 1024; }  // per (t, batch tile)
+
+__device__ __forceinline__ float sa_fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-SA_LOG2E * x));
+}
+__device__ __forceinline__ float sa_fast_tanh(float x) {
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * SA_LOG2E * x)) - 1.0f;
+}
+__device__ __forceinline__ float sa_quad_swap1(float v) {  // lane i <-> lane i ^ 1 (DPP quad_perm [1, 0, 3, 2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+}
+
+template <int IPG, int POLL_AT, bool STASH, bool DROP, bool TIMED>
+__global__ __launch_bounds__(256) void gru_fwd_planes_kernel(PFusedFwd P) {
+    static_assert((IPG & 1) == 0, "a wave's K slice must be whole 32-k MFMA steps");
+    constexpr int H = 64 * IPG, NTU = H / 16, KS = 16 * IPG, NK = IPG / 2, NKT = H / 32;
+    constexpr int kPollIt = POLL_AT >= 8 ? NK : (NK * POLL_AT) / 8;
+    constexpr int kStep = 3 * NKT * 1024;  // bytes of the planes per (t, batch tile)
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE(P.prio);
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / NTU, grp = s_role[0] * (32 / NTU) + sub;
+    if (sub >= 32 / NTU) return;
+    const int role_x = s_role[1] - sub * NTU, l = grp / P.nbt, role_y = grp - l * P.nbt + P.bt0;
+    if (l >= P.L) return;
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && l == 0) return;  // injected fault: a group one member short
+    int budget = P.spin_limit;  // wave-uniform; 0 after the first timeout: the call is lost, drain quickly
+    const int B = P.B, T = P.T;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + l == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    float4* red = reinterpret_cast<float4*>(psm);  // [2][source wave 4][register = destination wave 4][lane 64] {r, z, n_in, n_h}
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const int row = 4 * g + wave;  // the element this thread finishes: (row, unit i) of the block's 16 x 16 tile
+    const int b = b0 + row, u = u0 + i;
+    const bool live = b < B;
+    const float e_br = P.b_hh[l][u], e_bz = P.b_hh[l][H + u], e_bn = P.b_hh[l][2 * H + u];
+    const long hs_t = (long)B * H;
+    const int kbeg = wave * KS;
+    const int s_hx = P.nbt_all * kStep;  // bytes of a layer's planes per time step
+    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)P.hx[l], 0, 0x7fffffff, 0x00020000);
+    const int gather_off = i * 64 + g * 16 + wave * NK * 1024;  // lane part of a gather address (+ plane / k-step / time: scalar)
+    const int tile_off = role_y * kStep;
+    unsigned* my_prog = P.prog + l * P.nbt_all + role_y;
+    unsigned* errp = P.err;
+    // per-thread store targets: base + t * stride (a row beyond the batch keeps hitting its dump slot)
+    float* dump = P.dump + blockIdx.x * 256 + tid;
+    float* p_h = live ? P.h_out[l] + (long)b * H + u : dump;
+    const long s_h = live ? hs_t : 0;
+    float* p_hd = (DROP && live && P.h_drop[l]) ? P.h_drop[l] + (long)b * H + u : dump;
+    const long s_hd = (DROP && live && P.h_drop[l]) ? hs_t : 0;
+    float* p_st = (STASH && live) ? P.stash[l] + (long)b * P.rb * 5 * H + u : dump;
+    const long s_st = (STASH && live) ? (long)P.rt * 5 * H : 0;
+    const int so = (STASH && live) ? H : 0;  // distance between a row's stashed gates
+    // the publish: lanes 2 j and 2 j + 1 hold the same three packed pairs; store A carries plane 0 (even lane) and plane 1
+    // (odd lane), store B plane 2 (both lanes: same address, same value)
+    const bool odd = (i & 1) != 0;
+    const int pub_col = ((role_x & 1) * 16 + (i & ~1)) * 2 + row * 64 + (role_x >> 1) * 1024 + tile_off;
+    const int pub_a = pub_col + (odd ? NKT * 1024 : 0), pub_b = pub_col + 2 * NKT * 1024;
+    char* hx_own = P.hx[l];
+    // DROP: the dropped copy for the layer above; the top layer has none and re-publishes h into its own planes (the same
+    // values at the same addresses: no branch around the stores inside the loop)
+    const bool has_drop = DROP && P.hxd[l] != nullptr;
+    char* hx_drop = has_drop ? P.hxd[l] : P.hx[l];
+    const SaDrop drop = P.drop;
+    const unsigned drop_stream = P.drop_stream0 + (unsigned)l;
+    const long drop_idx0 = (long)(live ? b : 0) * H + u;
+    const int rep_tid = 0;
+    const int exp_every = P.report_every;  // a power of two
+    float hp = 0.f;
+    // Weight fragments: rows n H + u0 + i, this wave's K slice, split once.  The two sets are 288 registers; the first
+    // `pin` k-steps of a set are pinned in the ACCUMULATOR half of the register file ("+a": an MFMA reads its A / B operands
+    // from there directly) -- left alone hipcc keeps the fragments in the vector half's class, parks them in accumulator
+    // registers as spills and copies ~130 of them back per step (v_accvgpr_read, on the MFMAs' own issue port).
+    auto load_w = [&](const float* W, SaBf3 (&w)[NK][3], int pin) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const float* q = W + (long)(n * H + u0 + i) * H + kbeg + 32 * kk + 8 * g;
+                w[kk][n] = sa_split8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+                if (kk < pin) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+a"(w[kk][n].p[pl]));
+                }
+            }
+    };
+    SaBf3 wh[NK][3];
+    load_w(P.w_hh[l], wh, NK / 2);
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool timed = TIMED && P.timing != nullptr && tid == 0;
+    if (timed) { tprev = wall_clock64(); tacc[4] = clock64(); tacc[5] = tprev; }
+#define SA_TICK(k) if (TIMED && timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
+    __syncthreads();
+
+    sa_bf16x8 a[NK][3];  // the gathered k-slice of the own layer's h[t-1]: [k step][plane]
+    auto issue_gather = [&](sa_bf16x8 (&dst)[NK][3], __amdgpu_buffer_rsrc_t res, int tt, int aux) {
+        const int sbase = tt * s_hx + tile_off;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                dst[kk][pl] = __builtin_bit_cast(sa_bf16x8, aux == 16
+                    ? __builtin_amdgcn_raw_buffer_load_b128(res, gather_off, sbase + (pl * NKT + kk) * 1024, 16)
+                    : __builtin_amdgcn_raw_buffer_load_b128(res, gather_off, sbase + (pl * NKT + kk) * 1024, 16 | 2));
+    };
+    auto any_sentinel = [&](const sa_bf16x8 (&v)[NK][3]) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint4 q = __builtin_bit_cast(uint4, v[kk][pl]);
+                m = max(max(m, q.x), q.y);
+                m = max(max(m, q.z), q.w);
+            }
+        return m == kPlaneSentinel;
+    };
+    auto poll_until_fresh = [&](int tprev_idx, bool first_trip_issued) {  // flag-less hand-off inside the XCD
+        for (int spins = 0;; ++spins) {
+            if (!(first_trip_issued && spins == 0)) {
+                asm volatile("" ::: "memory");  // every trip re-issues its loads
+                issue_gather(a, hres, tprev_idx, 16);
+            }
+            if (__builtin_amdgcn_ballot_w64(any_sentinel(a)) == 0) break;
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+        }
+    };
+    // one product of a step: 6 piece products x 3 gates per 32-k step, smallest pieces first, gates interleaved (consecutive
+    // MFMAs never share an accumulator)
+    auto x6 = [&](const sa_bf16x8 (&v)[NK][3], const SaBf3 (&w)[NK][3], f32x4& d0, f32x4& d1, f32x4& d2, int lo, int hi) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+            if (kk >= lo && kk < hi)
+#pragma unroll
+                for (int o = 0; o < 6; ++o) {
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[kk][SA_X6_PA(o)], w[kk][0].p[SA_X6_PB(o)], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[kk][SA_X6_PA(o)], w[kk][1].p[SA_X6_PB(o)], d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[kk][SA_X6_PA(o)], w[kk][2].p[SA_X6_PB(o)], d2, 0, 0, 0);
+                }
+    };
+    auto publish = [&](char* base, int t, float v) {
+        const float vn = sa_quad_swap1(v);
+        unsigned p1, p2, p3;
+        sa_split2(odd ? vn : v, odd ? v : vn, p1, p2, p3);
+        char* q = base + (long)t * s_hx;
+        __hip_atomic_store(reinterpret_cast<unsigned*>(q + pub_a), odd ? p2 : p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(q + pub_b), p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // reduce over the four waves, gates, publish: everything after the step's MFMAs (see gru_fwd_fused_kernel for `report`)
+    auto finish = [&](int t, const f32x4 (&acc)[3], const f32x4& acc_hn, float e_ai_r, float e_ai_z, float e_ai_n,
+                      bool report) {
+        float4* rd = red + (t & 1) * 1024;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd[(wave * 4 + r) * 64 + lane] = make_float4(acc[0][r], acc[1][r], acc[2][r], acc_hn[r]);
+        __syncthreads();
+        if (exp_every == 1) {
+            if (report && tid == rep_tid) __hip_atomic_fetch_add(my_prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (report && tid == rep_tid && (t & (exp_every - 1)) == 0)
+                __hip_atomic_fetch_add(my_prog, (unsigned)exp_every, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float4 s0 = rd[(0 * 4 + wave) * 64 + lane], s1 = rd[(1 * 4 + wave) * 64 + lane];
+        const float4 s2 = rd[(2 * 4 + wave) * 64 + lane], s3 = rd[(3 * 4 + wave) * 64 + lane];
+        const float sr = ((s0.x + s1.x) + s2.x) + s3.x, sz = ((s0.y + s1.y) + s2.y) + s3.y;
+        const float sin_ = ((s0.z + s1.z) + s2.z) + s3.z, shn = ((s0.w + s1.w) + s2.w) + s3.w;
+        const float r = sa_fast_sigmoid(e_ai_r + sr + e_br);
+        const float z = sa_fast_sigmoid(e_ai_z + sz + e_bz);
+        const float q = shn + e_bn;
+        const float n = sa_fast_tanh(e_ai_n + sin_ + r * q);
+        const float h = live ? (1.0f - z) * n + z * hp : 0.f;  // rows beyond the batch publish zeros: a tile has no holes
+        publish(hx_own, t, h);
+        if (DROP) {  // what the layer above reads: published like h and AFTER it (the own layer's next step waits for h)
+            const float hd = h * sa_drop_factor(drop, drop_stream, (uint64_t)((long)t * hs_t + drop_idx0));
+            publish(hx_drop, t, has_drop ? hd : h);
+            p_hd[(long)t * s_hd] = hd;
+        }
+        p_h[(long)t * s_h] = h;
+        if (STASH) {  // streaming stores: the stash must not push anything out of the XCD's L2
+            float* st = p_st + (long)t * s_st;
+            __builtin_nontemporal_store(r, st);
+            __builtin_nontemporal_store(z, st + so);
+            __builtin_nontemporal_store(n, st + 2 * so);
+            __builtin_nontemporal_store(q, st + 3 * so);
+            __builtin_nontemporal_store(hp, st + 4 * so);
+        }
+        hp = h;
+    };
+
+    if (l == 0) {
+        // ---- layer 0: its input projection is one GEMM before the launch (ai0)
+        const float* p_ai = P.ai0 + (long)(live ? b : 0) * P.rb * 3 * H + u;
+        const long s_ai = (long)P.rt * 3 * H;
+        float nx_r, nx_z, nx_n;  // the values of the step about to be processed, requested a step ago
+        auto fetch_ai = [&](int tt) { const float* q = p_ai + (long)tt * s_ai; nx_r = q[0]; nx_z = q[H]; nx_n = q[2 * H]; };
+        fetch_ai(0);
+        if (T > 0) {  // t = 0 (peeled: no recurrent phase, nobody to wait for)
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+            finish(0, acc, acc_hn, e_r, e_z, e_n, false);
+            fetch_ai(T > 1 ? 1 : 0);
+            SA_TICK(3)
+        }
+        for (int t = 1; t < T; ++t) {
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+            SA_TICK(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pacing of the first polling trip (see gru_fwd_chunk_kernel)
+            poll_until_fresh(t - 1, false);
+            SA_TICK(1)
+            fetch_ai(t + 1 < T ? t + 1 : t);  // behind the poll (one in-order queue); the last step re-reads its own: unused
+            __builtin_amdgcn_sched_barrier(0);
+            x6(a, wh, acc[0], acc[1], acc_hn, 0, NK);
+            SA_TICK(2)
+            finish(t, acc, acc_hn, e_r, e_z, e_n, true);
+            SA_TICK(3)
+        }
+    } else {
+        // ---- layers >= 1: the input projection W_ih h_{l-1}[t] is formed in the kernel, on planes fetched a step ago
+        const float bi_r = P.b_ih[l][u], bi_z = P.b_ih[l][H + u], bi_n = P.b_ih[l][2 * H + u];
+        char* lower = (DROP && P.hxd[l - 1]) ? P.hxd[l - 1] : P.hx[l - 1];
+        __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc((void*)lower, 0, 0x7fffffff, 0x00020000);
+        const unsigned* lower_prog = P.prog + (l - 1) * P.nbt_all + role_y;
+        unsigned avail = 0;        // steps of the lower layer known to be published
+        unsigned cnt_pending = 0;  // the arrival counter as requested a step ago
+        SaBf3 wn[NK][3];           // W_ih fragments, resident like W_hh
+        load_w(P.w_ih[l], wn, NK);
+        sa_bf16x8 an[NK][3];       // the lower layer's planes of the step about to be processed
+        auto wait_lower = [&](int tt) {  // the lower layer has published step tt (every wave polls for itself)
+            if (avail >= (unsigned)(tt + 1)) return;
+            int spins = 0;
+            unsigned c;
+            while ((c = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)NTU * (unsigned)(tt + 1)) {
+                if (++spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+            }
+            avail = c / (unsigned)NTU;
+        };
+        if (T > 0) {
+            wait_lower(0);
+            issue_gather(an, lres, 0, 18);
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            x6(an, wn, acc[0], acc[1], acc[2], 0, NK);
+            SA_TICK(0)
+            const int t1 = T > 1 ? 1 : 0;
+            wait_lower(t1);
+            issue_gather(an, lres, t1, 18);
+            cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            SA_TICK(2)
+            finish(0, acc, acc_hn, bi_r, bi_z, bi_n, false);
+            SA_TICK(3)
+        }
+        for (int t = 1; t < T; ++t) {
+            f32x4 acc[3], acc_hn = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            x6(an, wn, acc[0], acc[1], acc[2], 0, kPollIt);
+            if (kPollIt < NK) {
+                __builtin_amdgcn_sched_barrier(0);
+                SA_TICK(0)
+                issue_gather(a, hres, t - 1, 16);
+                __builtin_amdgcn_sched_barrier(0);
+                SA_TICK(6)
+                x6(an, wn, acc[0], acc[1], acc[2], kPollIt, NK);
+                __builtin_amdgcn_sched_barrier(0);
+                SA_TICK(7)
+            } else {
+                SA_TICK(0)
+            }
+            // pacing as in layer 0: the first trip leaves once the previous step's own stores are acknowledged (with a narrow
+            // layer the input product alone is too short a delay: a trip issued right behind the stores comes back stale)
+            if (kPollIt >= NK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            poll_until_fresh(t - 1, kPollIt < NK);
+            SA_TICK(1)
+            {
+                asm volatile("" : "+v"(cnt_pending) :: "memory");  // consumed HERE, not where it was loaded
+                const unsigned got = cnt_pending / (unsigned)NTU;
+                if (got > avail) avail = got;
+                const int tn = t + 1 < T ? t + 1 : t;  // (the last step re-reads its own rows: unused)
+                wait_lower(tn);  // almost always satisfied by the value requested a step ago
+                issue_gather(an, lres, tn, 18);
+                cnt_pending = __hip_atomic_load(lower_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_sched_barrier(0);  // requested BEFORE the recurrent MFMAs (hipcc sinks them below otherwise)
+            }
+            x6(a, wh, acc[0], acc[1], acc_hn, 0, NK);
+            SA_TICK(2)
+            finish(t, acc, acc_hn, bi_r, bi_z, bi_n, true);
+            SA_TICK(3)
+        }
+    }
+    if (TIMED && timed) {
+        tacc[4] = clock64() - tacc[4]; tacc[5] = wall_clock64() - tacc[5];
+        unsigned long long* o = P.timing + 8 * ((l * P.nbt + role_y - P.bt0) * NTU + role_x);
+        for (int k = 0; k < 8; ++k) atomicAdd(&o[k], tacc[k]);
+    }
+#undef SA_TICK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
         unsigned done = T > 1 ? (unsigned)(T - 1) : 0u;
         if (exp_every > 1) done = T > 1 ? (unsigned)(((T - 1) / exp_every) * exp_every) : 0u;
         __hip_atomic_fetch_add(my_prog, (unsigned)T - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2224,6 +2580,36 @@ static FusedFwdFn fused_fwd_fn(int H, bool stash, bool drop, bool timed) {
     }
     return nullptr;
 }
+// gru_fwd_planes_kernel<IPG, POLL_AT, STASH, DROP, TIMED> (even IPG only; null: no such instance)
+template <int IPG, int POLL_AT>
+static FusedFwdFn planes_fwd_pick(bool stash, bool drop, bool timed) {
+    if (timed && !drop)
+        return stash ? gru_fwd_planes_kernel<IPG, POLL_AT, true, false, true> : gru_fwd_planes_kernel<IPG, POLL_AT, false, false, true>;
+    if (stash) return drop ? gru_fwd_planes_kernel<IPG, POLL_AT, true, true, false> : gru_fwd_planes_kernel<IPG, POLL_AT, true, false, false>;
+    return drop ? gru_fwd_planes_kernel<IPG, POLL_AT, false, true, false> : gru_fwd_planes_kernel<IPG, POLL_AT, false, false, false>;
+}
+static bool planes_fwd_shape(int H) { return H == 128 || H == 256 || H == 384 || H == 512; }
+static FusedFwdFn planes_fwd_fn(int H, bool stash, bool drop, bool timed) {
+    if (H == 512) {  // A/B (profiles/r06_forward_planes_experiments.txt): the first polling trip inside the input product
+        switch (sa_opt(SA_OPT_GRU_EXP) & 7) {
+            case 1: return planes_fwd_pick<8, 4>(stash, drop, timed);
+            case 2: return planes_fwd_pick<8, 6>(stash, drop, timed);
+        }
+    }
+    switch (H / 64) {
+        case 8: return planes_fwd_pick<8, 8>(stash, drop, timed);
+        case 6: return planes_fwd_pick<6, 8>(stash, drop, timed);
+        case 4: return planes_fwd_pick<4, 8>(stash, drop, timed);
+        case 2: return planes_fwd_pick<2, 8>(stash, drop, timed);
+    }
+    return nullptr;
+}
+// bytes of ONE layer's bf16-planes exchange buffer (gru_fwd_planes_kernel); 0: the shape does not run that kernel
+static size_t planes_fwd_bytes(int L, int D, int B, int T, int H) {
+    if (D != 1 || !planes_fwd_shape(H) || L > kMaxJobs) return 0;
+    const size_t n = (size_t)T * ((B + 15) / 16) * hx_step_bytes(H);
+    return n < 0x7fffffffull ? sa_align_up(n, 256) : 0;
+}
 typedef void (*FwdChunkFn)(PFwdJobs);
 // gru_fwd_chunk_kernel<IPG, STASH> for H = 64 IPG (the flag-less XCD-local persistent forward; null: no such instance)
 static FwdChunkFn fwd_chunk_fn(int H, bool stash) {
@@ -2290,7 +2676,9 @@ extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, i
     const int Imax = I0 > D * H ? I0 : D * H;
     const size_t pw = sa_align_up(sa_gemm_group_workspace_bytes(D, T * B, 3 * H, D == 1 ? I0 : Imax), 256);
     if (pw > gw) gw = pw;
-    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + kFwdDumpBytes + kSyncBytes;
+    // the planes of every layer's output and of the L - 1 dropped outputs (gru_fwd_planes_kernel)
+    const size_t hxw = (size_t)(2 * L - 1) * planes_fwd_bytes(L, D, B, T, H);
+    return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + hxw + kFwdDumpBytes + kSyncBytes;
 }
 
 namespace {
@@ -2330,7 +2718,10 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     chunk = clamp_chunk(chunk > 64 ? 64 : chunk, T);
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
-    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - kFwdDumpBytes - kSyncBytes;
+    const size_t hx_each = planes_fwd_bytes(L, D, B, T, H);
+    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - (size_t)(2 * L - 1) * hx_each -
+                             kFwdDumpBytes - kSyncBytes;
+    char* hx_base = (char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes - (size_t)(2 * L - 1) * hx_each;
     unsigned* sync = (unsigned*)((char*)workspace + workspace_bytes - kSyncBytes);
     const long DH = (long)D * H;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -2481,9 +2872,15 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     const bool flagless = xcd && flagless_mode();
     const size_t flds = xcd_lds((size_t)2 * 4 * 4 * 256 * sizeof(float));
     const bool fused_fwd = sa_opt(SA_OPT_GRU_FUSED) != 0 && flagless && flds <= 160 * 1024 && L * nbt <= kSyncErr;
+    // the bf16-planes form of the one-launch kernel (default where it exists): its exchange is the planes buffers, h_out
+    // needs no sentinel
+    const bool planes = fused_fwd && sa_opt(SA_OPT_GRU_FWD_PLANES) != 0 && hx_each > 0;
     FillBatch fills(stream, fused_fwd && fill_batch_enabled());
-    if (flagless)
+    if (planes) {
+        fills.add(hx_base, (size_t)(drop_on ? 2 * L - 1 : L) * hx_each / 4, kPlaneSentinel);  // (the buffers are contiguous)
+    } else if (flagless) {
         for (int l = 0; l < L; ++l) fills.add(h_out[l], (size_t)T * B * H, kSentinel);
+    }
     if (!fused_fwd) fills.flush();
     if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
     {   // the whole stack as ONE launch with in-kernel input projections (gru_fwd_fused_kernel); SA_GRU_FUSED=0: off
@@ -2492,7 +2889,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             fills.flush();
             if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
             const bool timing_on = sa_opt(SA_OPT_GRU_TIMING) != 0;
-            FusedFwdFn fused_fn = fused_fwd_fn(H, stash != nullptr, drop_on, timing_on);
+            FusedFwdFn fused_fn = planes ? planes_fwd_fn(H, stash != nullptr, drop_on, timing_on)
+                                         : fused_fwd_fn(H, stash != nullptr, drop_on, timing_on);
             if (!fused_fn) return CTC_STATUS_INVALID_VALUE;  // (xcd_shape_ok admits H = 128 .. 512 in steps of 64 only)
             if (hipFuncSetAttribute((const void*)fused_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)flds) != hipSuccess)
@@ -2506,7 +2904,11 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
             { const long r = sa_opt(SA_OPT_GRU_FWD_REPORT); Q.report_every = (r >= 1 && r <= 64 && (r & (r - 1)) == 0) ? (int)r : 4; }
             Q.drop = dc.drop; Q.drop_stream0 = dc.stream0;
-            for (int l = 0; l < kMaxJobs; ++l) Q.h_drop[l] = nullptr;
+            for (int l = 0; l < kMaxJobs; ++l) { Q.h_drop[l] = nullptr; Q.hx[l] = nullptr; Q.hxd[l] = nullptr; }
+            for (int l = 0; planes && l < L; ++l) {
+                Q.hx[l] = hx_base + (size_t)l * hx_each;
+                Q.hxd[l] = drop_on && l + 1 < L ? hx_base + (size_t)(L + l) * hx_each : nullptr;
+            }
             for (int l = 0; l < L; ++l) {
                 Q.w_ih[l] = w_ih[l]; Q.b_ih[l] = b_ih[l]; Q.w_hh[l] = w_hh[l]; Q.b_hh[l] = b_hh[l];
                 Q.h_out[l] = h_out[l]; Q.stash[l] = stash ? stash[l] : nullptr;
@@ -3279,7 +3681,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     // ONE launch for the whole backward recurrence of the stack (fused kernel only): every layer runs all T steps, a
     // lower layer picks each row of its d h_out up as the layer above stores it (sentinel pre-fill, see the kernel) --
     // T + a few steps per layer of lag instead of (T / chunk + L - 1) chunks, and no launch ramps in between.
-    const bool one_launch = fused && sa_opt(SA_OPT_GRU_BWD_ONE) != 0 && !sa_opt(SA_OPT_GRU_TIMING);
+    const bool one_launch = fused && sa_opt(SA_OPT_GRU_BWD_ONE) != 0;  // (r6: the phase clocks run in the one-launch kernel too)
     // ... and that launch writes the weight-gradient products' gate operand itself, packed (gru_bwd_fused_kernel<PACKG>)
     SharedPackLayout spl;
     const bool packg = one_launch && wg && (B % 16) == 0 && sa_opt(SA_OPT_GRU_PACK_IN_KERNEL) != 0 && packg_available(H, true) &&
@@ -3324,7 +3726,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
         if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
         PBwdJobs Q;
         Q.B = B; Q.H = H; Q.nbt_all = nbt; Q.ntile_u = ntile_u; Q.rb = 1; Q.rt = B; Q.flagless = 1;
-        Q.timing = nullptr; Q.drop = dc.drop;
+        Q.timing = sa_opt(SA_OPT_GRU_TIMING) ? (unsigned long long*)(sync + 512) : nullptr;  // 10 KB of the sync page
+        Q.drop = dc.drop;
         Q.pk_kb = packg ? (long)T * B / 16 : 0; Q.kpk_kb = 0;
         Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = xring; Q.reg = sync + kSyncReg; Q.w_rowmajor = rowmajor ? 1 : 0;
         if (packg) { issuer.gates_prepacked = true; issuer.gsum_parts = nbt; }
