@@ -197,6 +197,7 @@ struct PFwdJob {
     int t0, nsteps;      // first time index of this launch, number of steps
     int dt, t_first;     // +1 / -1 (reverse direction of a bidirectional layer); the sequence's very first time index
     unsigned base;       // arrivals per counter before this launch
+    char* hx;            // gru_fwd_chunk_planes_kernel: the job's bf16-planes exchange buffer (see gru_fwd_planes_kernel), or null
 };
 struct PFwdJobs {
     int n, B, H;
@@ -1324,6 +1325,163 @@ __global__ __launch_bounds__(256) void gru_fwd_planes_kernel(PFusedFwd P) {
         unsigned done = T > 1 ? (unsigned)(T - 1) : 0u;
         if (exp_every > 1) done = T > 1 ? (unsigned)(((T - 1) / exp_every) * exp_every) : 0u;
         __hip_atomic_fetch_add(my_prog, (unsigned)T - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
+}
+
+// --------------------------------------------------------------------- persistent forward chunk on bf16 planes (r6)
+// gru_fwd_chunk_kernel with the recurrent product on producer-written bf16 planes -- the two directions of a bidirectional
+// layer (every shipped config: 4 x biGRU-256), whose input projections stay GEMMs.  Same exchange layout, publish, gather,
+// reduce and gate arithmetic as gru_fwd_planes_kernel (see there); one planes buffer per direction, re-filled per layer.
+template <int IPG, bool STASH>
+__global__ __launch_bounds__(256) void gru_fwd_chunk_planes_kernel(PFwdJobs P) {
+    static_assert((IPG & 1) == 0, "a wave's K slice must be whole 32-k MFMA steps");
+    constexpr int H = 64 * IPG, NTU = H / 16, KS = 16 * IPG, NK = IPG / 2, NKT = H / 32;
+    constexpr int kStep = 3 * NKT * 1024;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE(P.prio);
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {  // more than 32 workgroups landed on this XCD
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / NTU, grp = s_role[0] * (32 / NTU) + sub;
+    if (sub >= 32 / NTU) return;
+    const int role_x = s_role[1] - sub * NTU, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
+    if (role_z >= P.n) return;
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+    const PFwdJob& J = P.j[role_z];
+    const int B = P.B;
+    const bool stamper = P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0;
+    if (stamper) P.stamp[0] = wall_clock64();
+    float4* red = reinterpret_cast<float4*>(psm);  // [2][source wave 4][register 4][lane 64] {r, z, n, -}
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const int row = 4 * g + wave;
+    const int b = b0 + row, u = u0 + i;
+    const bool live = b < B;
+    const float e_br = J.b_hh[u], e_bz = J.b_hh[H + u], e_bn = J.b_hh[2 * H + u];
+    const int kbeg = wave * KS;
+    int budget = P.spin_limit;
+    unsigned* errp = P.err;
+    const int t0 = J.t0, nsteps = J.nsteps, dt = J.dt, t_first = J.t_first;
+    const int s_hx = P.nbt_all * kStep;
+    __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)J.hx, 0, 0x7fffffff, 0x00020000);
+    const int gather_off = i * 64 + g * 16 + wave * NK * 1024;
+    const int tile_off = role_y * kStep;
+    const float* p_ai = J.ai + (long)(live ? b : 0) * P.rb * 3 * H + u;
+    const long s_ai = (long)P.rt * 3 * H;
+    float* dump = P.dump + blockIdx.x * 256 + tid;
+    float* p_h = live ? J.h_out + (long)b * J.hs_b + u : dump;
+    const long s_h = live ? J.hs_t : 0;
+    float* p_st = (STASH && live) ? J.stash + (long)b * P.rb * 5 * H + u : dump;
+    const long s_st = (STASH && live) ? (long)P.rt * 5 * H : 0;
+    const int so = (STASH && live) ? H : 0;
+    const bool odd = (i & 1) != 0;
+    const int pub_col = ((role_x & 1) * 16 + (i & ~1)) * 2 + row * 64 + (role_x >> 1) * 1024 + tile_off;
+    const int pub_a = pub_col + (odd ? NKT * 1024 : 0), pub_b = pub_col + 2 * NKT * 1024;
+    char* hx_own = J.hx;
+    float hp = 0.f;
+    if (live && t0 != t_first) hp = J.h_out[(long)b * J.hs_b + (long)(t0 - dt) * J.hs_t + u];
+    SaBf3 wh[NK][3];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const float* q = J.w_hh + (long)(n * H + u0 + i) * H + kbeg + 32 * kk + 8 * g;
+            wh[kk][n] = sa_split8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+        }
+    __syncthreads();
+
+    sa_bf16x8 a[NK][3];
+    auto poll_until_fresh = [&](int tprev) {
+        const int sbase = tprev * s_hx + tile_off;
+        for (int spins = 0;; ++spins) {
+            asm volatile("" ::: "memory");  // every trip re-issues its loads
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[kk][pl] = __builtin_bit_cast(sa_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hres, gather_off, sbase + (pl * NKT + kk) * 1024, 16));
+            unsigned m = 0u;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const uint4 q = __builtin_bit_cast(uint4, a[kk][pl]);
+                    m = max(max(m, q.x), q.y);
+                    m = max(max(m, q.z), q.w);
+                }
+            if (__builtin_amdgcn_ballot_w64(m == kPlaneSentinel) == 0) break;
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+        }
+    };
+    float nx_r, nx_z, nx_n;
+    auto fetch_ai = [&](int tt) { const float* q = p_ai + (long)tt * s_ai; nx_r = q[0]; nx_z = q[H]; nx_n = q[2 * H]; };
+    auto finish = [&](int s, int t, const f32x4 (&acc)[3], float e_r, float e_z, float e_n) {
+        float4* rd = red + (s & 1) * 1024;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd[(wave * 4 + r) * 64 + lane] = make_float4(acc[0][r], acc[1][r], acc[2][r], 0.f);
+        __syncthreads();
+        const float4 s0 = rd[(0 * 4 + wave) * 64 + lane], s1 = rd[(1 * 4 + wave) * 64 + lane];
+        const float4 s2 = rd[(2 * 4 + wave) * 64 + lane], s3 = rd[(3 * 4 + wave) * 64 + lane];
+        const float sr = ((s0.x + s1.x) + s2.x) + s3.x, sz = ((s0.y + s1.y) + s2.y) + s3.y, sn = ((s0.z + s1.z) + s2.z) + s3.z;
+        const float r = sa_fast_sigmoid(e_r + sr + e_br);
+        const float z = sa_fast_sigmoid(e_z + sz + e_bz);
+        const float q = sn + e_bn;
+        const float n = sa_fast_tanh(e_n + r * q);
+        const float h = live ? (1.0f - z) * n + z * hp : 0.f;  // rows beyond the batch publish zeros: a tile has no holes
+        {
+            const float vn = sa_quad_swap1(h);
+            unsigned p1, p2, p3;
+            sa_split2(odd ? vn : h, odd ? h : vn, p1, p2, p3);
+            char* qx = hx_own + (long)t * s_hx;
+            __hip_atomic_store(reinterpret_cast<unsigned*>(qx + pub_a), odd ? p2 : p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(qx + pub_b), p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        p_h[(long)t * s_h] = h;
+        if (STASH) {
+            float* st = p_st + (long)t * s_st;
+            st[0] = r; st[so] = z; st[2 * so] = n; st[3 * so] = q; st[4 * so] = hp;
+        }
+        hp = h;
+    };
+    fetch_ai(t0);
+    int s = 0;
+    if (t0 == t_first && nsteps > 0) {  // the sequence's first step (peeled: no recurrent term, nobody to wait for)
+        f32x4 acc[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+        fetch_ai(nsteps > 1 ? t0 + dt : t0);
+        finish(0, t0, acc, e_r, e_z, e_n);
+        s = 1;
+    }
+    for (; s < nsteps; ++s) {
+        const int t = t0 + s * dt;
+        f32x4 acc[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pacing of the first polling trip (see gru_fwd_chunk_kernel)
+        poll_until_fresh(t - dt);
+        fetch_ai(s + 1 < nsteps ? t + dt : t);  // behind the poll; the last step re-reads its own row: unused
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+            for (int o = 0; o < 6; ++o)
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][SA_X6_PA(o)], wh[kk][n].p[SA_X6_PB(o)], acc[n], 0, 0, 0);
+        finish(s, t, acc, e_r, e_z, e_n);
     }
     if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
@@ -2611,8 +2769,9 @@ static FusedFwdFn planes_fwd_fn(int H, bool stash, bool drop, bool timed) {
     return nullptr;
 }
 // bytes of ONE layer's bf16-planes exchange buffer (gru_fwd_planes_kernel); 0: the shape does not run that kernel
+static int planes_fwd_buffers(int L, int D) { return D == 1 ? 2 * L - 1 : 2; }  // bidirectional: one per direction, per layer in turn
 static size_t planes_fwd_bytes(int L, int D, int B, int T, int H) {
-    if (D != 1 || !planes_fwd_shape(H) || L > kMaxJobs) return 0;
+    if (!planes_fwd_shape(H) || L > kMaxJobs) return 0;
     const size_t n = (size_t)T * ((B + 15) / 16) * hx_step_bytes(H);
     return n < 0x7fffffffull ? sa_align_up(n, 256) : 0;
 }
@@ -2623,6 +2782,14 @@ static FwdChunkFn fwd_chunk_fn(int H, bool stash) {
 #define SA_FWD_CHUNK(I_) case I_: return stash ? gru_fwd_chunk_kernel<I_, true> : gru_fwd_chunk_kernel<I_, false>;
         SA_FWD_CHUNK(8) SA_FWD_CHUNK(7) SA_FWD_CHUNK(6) SA_FWD_CHUNK(5) SA_FWD_CHUNK(4) SA_FWD_CHUNK(3) SA_FWD_CHUNK(2)
 #undef SA_FWD_CHUNK
+    }
+    return nullptr;
+}
+static FwdChunkFn fwd_chunk_planes_fn(int H, bool stash) {
+    switch (H / 64) {
+#define SA_FWD_CHUNKP(I_) case I_: return stash ? gru_fwd_chunk_planes_kernel<I_, true> : gru_fwd_chunk_planes_kernel<I_, false>;
+        SA_FWD_CHUNKP(8) SA_FWD_CHUNKP(6) SA_FWD_CHUNKP(4) SA_FWD_CHUNKP(2)
+#undef SA_FWD_CHUNKP
     }
     return nullptr;
 }
@@ -2683,7 +2850,7 @@ extern "C" size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, i
     const size_t pw = sa_align_up(sa_gemm_group_workspace_bytes(D, T * B, 3 * H, D == 1 ? I0 : Imax), 256);
     if (pw > gw) gw = pw;
     // the planes of every layer's output and of the L - 1 dropped outputs (gru_fwd_planes_kernel)
-    const size_t hxw = (size_t)(2 * L - 1) * planes_fwd_bytes(L, D, B, T, H);
+    const size_t hxw = (size_t)planes_fwd_buffers(L, D) * planes_fwd_bytes(L, D, B, T, H);
     return (size_t)L * D * stack_ai_bytes(B, T, H) + gw + hxw + kFwdDumpBytes + kSyncBytes;
 }
 
@@ -2725,9 +2892,9 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     auto ai_of = [&](int l, int d) { return (float*)((char*)workspace + (size_t)(l * D + d) * stack_ai_bytes(B, T, H)); };
     char* gws = (char*)workspace + (size_t)L * D * stack_ai_bytes(B, T, H);
     const size_t hx_each = planes_fwd_bytes(L, D, B, T, H);
-    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - (size_t)(2 * L - 1) * hx_each -
+    const size_t gws_bytes = workspace_bytes - (size_t)L * D * stack_ai_bytes(B, T, H) - (size_t)planes_fwd_buffers(L, D) * hx_each -
                              kFwdDumpBytes - kSyncBytes;
-    char* hx_base = (char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes - (size_t)(2 * L - 1) * hx_each;
+    char* hx_base = (char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes - (size_t)planes_fwd_buffers(L, D) * hx_each;
     unsigned* sync = (unsigned*)((char*)workspace + workspace_bytes - kSyncBytes);
     const long DH = (long)D * H;
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
@@ -2747,7 +2914,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                    // the two directions of a layer share every launch
         const int bi_nbt = (B + 15) / 16, bi_tpp = tiles_per_pass(2, H);
         unsigned bi_launches = 0;
-        const size_t bi_lds = xcd_lds((size_t)2 * 4 * 3 * 256 * sizeof(float));  // WREG: the reduction scratch only
+        const size_t bi_lds = xcd_lds((size_t)2 * 4 * 4 * 256 * sizeof(float));  // the reduction scratch only (16-byte vectors in the planes kernel)
         const bool bi_xcd = n_aux <= 0 && xcd_shape_ok(2, B, H) && bi_lds <= 160 * 1024 && L * 2 * bi_nbt <= kSyncErr &&
                             (long)T * B * DH * 4 < 0x7fffffffL;
         if (bi_xcd) {
@@ -2816,7 +2983,13 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 Q.B = B; Q.H = H; Q.rb = 1; Q.rt = B; Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.timing = nullptr;
                 Q.xcd_mode = 1; Q.nbt_all = bi_nbt; Q.ntile_u = H / 16; Q.reg = sync + kSyncReg;
                 Q.flagless = flagless_mode() ? 1 : 0;
-                if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
+                // the bf16-planes form of the chunk kernel (default where it exists): the exchange is one planes buffer per
+                // direction, h_out needs no sentinel
+                const bool bi_planes = Q.flagless && hx_each > 0 && sa_opt(SA_OPT_GRU_FWD_PLANES) != 0;
+                if (bi_planes) {
+                    if (hipMemsetD32Async((hipDeviceptr_t)hx_base, (int)kPlaneSentinel, 2 * hx_each / 4, stream) != hipSuccess)
+                        return CTC_STATUS_MEMOPS_FAILED;
+                } else if (Q.flagless && !sentinel_fill(h_out[l], (size_t)T * B * DH, stream)) return CTC_STATUS_MEMOPS_FAILED;
                 Q.stamp = nullptr; Q.n = 2;
                 const int nlaunch = fside ? (T + S - 1) / S : 1;
                 for (int c = 0; c < nlaunch; ++c) {
@@ -2829,12 +3002,14 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                         J.counters = sync + (l * 2 + d) * bi_nbt;
                         J.hs_b = DH; J.hs_t = (long)B * DH; J.nsteps = n; J.base = (unsigned)(H / 16) * (unsigned)s0;
                         J.dt = d ? -1 : 1; J.t_first = d ? T - 1 : 0; J.t0 = d ? T - 1 - s0 : s0;
+                        J.hx = bi_planes ? hx_base + (size_t)d * hx_each : nullptr;
                     }
                     for (int bt0 = 0; bt0 < bi_nbt; bt0 += bi_tpp) {  // passes over the batch tiles
                         Q.bt0 = bt0; Q.nbt = min(bi_tpp, bi_nbt - bt0);
                         Q.reg_base = bi_launches++ * 32u;
                         Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
-                        FwdChunkFn cfn = Q.flagless ? fwd_chunk_fn(H, Q.j[0].stash != nullptr) : nullptr;  // (arrival counters: option gru.persist = 2)
+                        FwdChunkFn cfn = bi_planes ? fwd_chunk_planes_fn(H, Q.j[0].stash != nullptr)
+                                         : Q.flagless ? fwd_chunk_fn(H, Q.j[0].stash != nullptr) : nullptr;  // (arrival counters: option gru.persist = 2)
                         if (cfn) hipLaunchKernelGGL(cfn, dim3(256), dim3(256), bi_lds, stream, Q);
                         else hipLaunchKernelGGL(gru_fwd_persist_kernel<true>, dim3(256), dim3(256), bi_lds, stream, Q);
                     }
@@ -2985,7 +3160,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 J.ai = ai_of(l, 0); J.w_hh = w_hh[l]; J.b_hh = b_hh[l]; J.h_out = h_out[l];
                 J.stash = stash ? stash[l] : nullptr; J.counters = sync + l * nbt;
                 J.hs_b = H; J.hs_t = (long)B * H; J.t0 = c * chunk; J.nsteps = min(chunk, T - J.t0);
-                J.dt = 1; J.t_first = 0;
+                J.dt = 1; J.t_first = 0; J.hx = nullptr;
                 J.base = (unsigned)ntile_u * (unsigned)J.t0;
             }
             Q.n = n;

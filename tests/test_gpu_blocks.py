@@ -484,8 +484,8 @@ def test_xcd_local_persistent_kernels_bidirectional():
         res = []
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd_bi_%s.pt" % mode
-            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
-                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_TILED="0"), check=True, timeout=180)
+            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],  # (the planes kernel: budget test below)
+                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_TILED="0", SA_GRU_FWD_PLANES="0"), check=True, timeout=180)
             res.append(torch.load(out))
         for other in res[1:]:
             assert len(res[0]) == len(other) and all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
@@ -659,6 +659,57 @@ def test_planes_forward_error_budget(monkeypatch, L, B, T, I0, H, drop):
             assert float((got[2][l] - f32k[2][l]).abs().max()) <= 2e-6
             mask = torch.where(f32k[0][l] != 0, f32k[2][l] / f32k[0][l], torch.zeros_like(f32k[0][l])).double()
             inp = h64 * torch.round(mask * (1.0 - drop[0])) / (1.0 - drop[0])
+
+
+@pytest.mark.parametrize("L,B,T,I0,H", [(2, 8, 40, 24, 256), (2, 20, 31, 24, 512), (3, 48, 17, 16, 128), (1, 1, 5, 8, 256),
+                                        (2, 16, 23, 24, 384), (2, 32, 96, 64, 256)])
+def test_planes_bidirectional_forward_error_budget(monkeypatch, L, B, T, I0, H):
+    """The two directions of a bidirectional layer (every shipped config: 4 x biGRU-256) on gru_fwd_chunk_planes_kernel: the
+    same budget as test_planes_forward_error_budget against an fp64 restatement of the bidirectional stack (layer l + 1 reads
+    the concatenated directions, model.py:35-39), incl. the chunked projection overlap (T = 96) and a single row."""
+    from speech_amd import ops, _lib
+    torch.manual_seed(1)
+    k = 1.0 / H ** 0.5
+    mk = lambda *sh: torch.empty(*sh, device="cuda").uniform_(-k, k)
+    x = torch.randn(T, B, I0, device="cuda")
+    w_ih = [mk(3 * H, I0 if l == 0 else 2 * H) for l in range(L) for d in range(2)]
+    w_hh = [mk(3 * H, H) for l in range(L) for d in range(2)]
+    b_ih = [mk(3 * H) for l in range(L) for d in range(2)]
+    b_hh = [mk(3 * H) for l in range(L) for d in range(2)]
+    run = lambda: ops.gru_stack_fwd(x, w_ih, b_ih, w_hh, b_hh, L, 2, H, want_stash=True)
+    got = run()
+    monkeypatch.setenv("SA_GRU_FWD_PLANES", "0")
+    f32k = run()
+    monkeypatch.delenv("SA_GRU_FWD_PLANES")
+    torch.cuda.synchronize()
+    assert _lib.lib().sa_gru_persist_status() == 0
+    inp = x.double()
+    for l in range(L):
+        outs = []
+        for d in range(2):
+            kk = 2 * l + d
+            Wi, Wh, bi, bh = w_ih[kk].double(), w_hh[kk].double(), b_ih[kk].double(), b_hh[kk].double()
+            ai = inp @ Wi.t() + bi
+            h = torch.zeros(B, H, dtype=torch.float64, device="cuda")
+            hs, gates = [None] * T, [None] * T
+            for t in (range(T - 1, -1, -1) if d else range(T)):
+                ah = h @ Wh.t() + bh
+                r = torch.sigmoid(ai[t, :, :H] + ah[:, :H])
+                z = torch.sigmoid(ai[t, :, H:2 * H] + ah[:, H:2 * H])
+                n = torch.tanh(ai[t, :, 2 * H:] + r * ah[:, 2 * H:])
+                gates[t] = torch.cat([r, z, n, ah[:, 2 * H:], h], dim=1)
+                h = (1 - z) * n + z * h
+                hs[t] = h
+            outs.append(torch.stack(hs))
+            st64 = torch.stack(gates)
+            e_planes, e_f32 = float((got[1][kk].double() - st64).abs().max()), float((f32k[1][kk].double() - st64).abs().max())
+            assert e_planes <= max(4.0 * e_f32, 5e-7), (l, d, "stash", e_planes, e_f32)
+        h64 = torch.cat(outs, dim=2)
+        assert torch.isfinite(got[0][l]).all()
+        e_planes, e_f32 = float((got[0][l].double() - h64).abs().max()), float((f32k[0][l].double() - h64).abs().max())
+        assert e_planes <= max(4.0 * e_f32, 5e-7), (l, "h", e_planes, e_f32)
+        assert float((got[0][l] - f32k[0][l]).abs().max()) <= 1e-6
+        inp = h64
 
 
 def test_gemm_arithmetic_is_a_function_of_the_shape_not_of_the_workspace(monkeypatch):
