@@ -1006,8 +1006,15 @@ __host__ __device__ inline size_t hx_step_bytes(int H) { return (size_t)3 * (H /
 __device__ __forceinline__ float sa_fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-SA_LOG2E * x));
 }
+// tanh |x| = (1 - e) / (1 + e), e = exp(-2 |x|); below 0.25 the odd series through x^9 (next term 9e-9 of x) -- the quotient
+// form cancels there (the first version, 2 sigmoid(2 x) - 1, carried 1.2e-7 ABSOLUTE error at any x: fine for h, visible in
+// the smallest parameter gradients of the seq2seq config).  Relative error < 3e-7 everywhere.
 __device__ __forceinline__ float sa_fast_tanh(float x) {
-    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * SA_LOG2E * x)) - 1.0f;
+    const float ax = fabsf(x), x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(-2.0f * SA_LOG2E * ax);
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    return copysignf(ax < 0.25f ? small : big, x);
 }
 __device__ __forceinline__ float sa_quad_swap1(float v) {  // lane i <-> lane i ^ 1 (DPP quad_perm [1, 0, 3, 2])
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
@@ -1936,14 +1943,20 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
 #define SA_TICK(k) if (timed) { const unsigned long long now = wall_clock64(); tacc[k] += now - tprev; tprev = now; }
     f32x4v a[NITG];  // the gathered row block: rows = the batch tile, this wave's fragments of every exchanged gate
     const bool ring = packed >= 2;
-    auto gather = [&](int trow) {  // returns once no fragment holds the sentinel (or the call is lost)
+    auto gather_issue = [&](int trow) {
         const int abase = a0 + (ring ? (trow & (kXRing - 1)) : trow) * (int)(s_x * 4);
-        for (int spins = 0;; ++spins) {
-            asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
 #pragma unroll
-            for (int it = 0; it < NITG; ++it)
-                a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
+        for (int it = 0; it < NITG; ++it)
+            a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
+    };
+    // returns once no fragment holds the sentinel (or the call is lost); `issued`: the first trip is already in flight
+    auto gather = [&](int trow, bool issued = false) {
+        for (int spins = 0;; ++spins) {
+            if (!(issued && spins == 0)) {
+                asm volatile("" ::: "memory");  // every trip re-issues its loads (they are loop-invariant to the compiler)
+                gather_issue(trow);
+            }
             bool stale = false;
 #pragma unroll
             for (int it = 0; it < NITG; ++it) stale |= has_sentinel(a[it]);
