@@ -483,12 +483,29 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def planes_forward():
+    from speech_amd import _lib
+    try:
+        return _lib.get_option("gru.fwd_planes") != 0 and _lib.get_option("gru.fused") != 0
+    except Exception:
+        return False
+
+
 def roofline(prof, step_us, steps):
-    """Roofline of the dominant kernel: the GRU backward step kernel (largest share of the step in every rocprof
-    summary under profiles/).  Duration = mean launch-to-launch interval of the full-width step launches inside the
-    timed region, from device-side clock stamps (HIP events around single launches perturb the stream by several us);
-    work = the algorithmic bytes one launch moves (17*B*H*4 per layer-step x 4 layer-jobs)."""
+    """Roofline of the dominant kernel: the GRU backward recurrence (largest share of the step in every rocprof summary
+    under profiles/).  Duration = the kernel's own entry-to-exit device clock inside the timed region (HIP events around
+    single launches perturb the stream by several us); work = the algorithmic bytes one launch moves -- DESIGN.md 3.3's
+    count, 17 B H 4 bytes per backward layer-step and 10 B H 4 per forward one (SURVEY 8(d) prices the class of kernel in
+    bytes but gives no figure for the backward pass).  Because the recurrence kernels are not bandwidth-bound in any
+    useful sense, every entry also carries its matrix-pipe view: `mfma_frac` = the launch's algorithmic flops / its
+    duration / the peak of the arithmetic it actually runs (f32-input MFMA 157.3 TF for the backward kernel; 2500 / 6 =
+    416.7 fp32-equivalent TF for the forward kernel's split-bf16 products), and `pipe_busy` = SQ_VALU_MFMA_BUSY_CYCLES /
+    (4 x SQ_WAVE_CYCLES) from a separate rocprofv3 --pmc pass (profiles/pipe_busy.json, stamped like the traffic)."""
     out = {}
+    try:
+        busy = json.load(open(os.path.join(ROOT, "profiles", "pipe_busy.json")))
+    except Exception:
+        busy = {}
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot run inside this process):
     # profiles/hbm_traffic.json, each entry stamped with the hash of the kernel source it was measured on
     # (tools/pmc_traffic.py --stamp).  An entry whose stamp does not match the tree being benchmarked is STALE and is
@@ -507,6 +524,8 @@ def roofline(prof, step_us, steps):
             # separated by the chunk's GEMMs): duration = the kernel's own entry-to-exit clock
             # (more than 64 steps in one launch: the fused kernels that run the whole stack's recurrence in one launch)
             name, us = name.replace("_step_", "_fused_" if nsteps > 64 else "_persist_"), kern_us
+            if name == "gru_fwd_fused_kernel" and planes_forward():
+                name = "gru_fwd_planes_kernel"  # the default one-launch forward since round 6
         if us <= 0:
             continue
         nbytes = 4.0 * B * 512 * per_job * 4 * nsteps  # 4 layer-jobs x nsteps steps per launch, B x H fp32 each
@@ -514,12 +533,25 @@ def roofline(prof, step_us, steps):
         entry = traffic.get(name, {})
         stale = entry.get("source_sha") != sha_now
         tr = None if stale else entry.get("bytes_per_launch")
-        key = name.replace("_persist_", "_step_").replace("_fused_", "_step_")
+        key = name.replace("_persist_", "_step_").replace("_fused_", "_step_").replace("_planes_", "_step_")
+        # the matrix-pipe view: 2 B 3H H flops per product and layer-step; 4 recurrent + 3 second / input products per step
+        gflop = 2.0 * B * 1536 * 512 * 7 * nsteps / 1e9
+        fwd = "fwd" in name
+        mpeak = BF16_MFMA_PEAK_TFS / 6.0 if fwd else MFMA_F32_PEAK_TFS
+        pb = busy.get(name, {})
+        pb_ok = pb.get("source_sha") == sha_now
         out[key] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_stale": bool(stale and entry),
                     "avg_launch_us": us, "kernel_us": kern_us,
                     "kernel_us_note": "entry of the first block to exit of the LAST block (device clock, atomic max)",
-                    "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps}
+                    "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps,
+                    "gflop_per_launch": gflop, "mfma_tflops": gflop / us * 1e-3, "mfma_peak_tflops": mpeak,
+                    "mfma_frac": gflop / us * 1e-3 / mpeak,
+                    "mfma_note": ("both products of a step as six bf16 piece products per fp32 product (gru_fwd_planes_kernel): "
+                                  "peak = 2500 TF dense bf16 / 6" if fwd else
+                                  "exact fp32 products on v_mfma_f32_16x16x4_f32: peak = the f32-input MFMA rate"),
+                    "pipe_busy": pb.get("pipe_busy") if pb_ok else None,
+                    "pipe_busy_source": pb.get("source") if pb_ok else None}
     g = prof.get("gemm")
     gemm = None
     if g and g["ms"] > 0:
@@ -622,6 +654,19 @@ def main():
         "kernel_time_ms_per_step": {k: v["ms"] / r["prof_steps"] for k, v in sorted(r["prof"].items())},
     }
     out["roofline"], out["roofline_other"] = roofline(r["prof"], r["step_us"], r["prof_steps"])
+    # The step against the arithmetic it ACTUALLY uses: the backward recurrence on the f32-input MFMA
+    # (157.3 TF), the stack's GEMMs and the forward recurrence on split-bf16 products (2500 / 6 = 416.7 fp32-equivalent TF),
+    # everything else (convolutions, classifier, small products: 13.6 GFLOP) on the f32-input MFMA.
+    rec = 2.0 * B * 1536 * 512 * 7 * r["Tp"] / 1e9
+    gem = (r.get("stack_gemm") or {}).get("gflop_per_step") or 292.949
+    rest = 13.6
+    floor_ms = rec / MFMA_F32_PEAK_TFS + (gem + rec) / (BF16_MFMA_PEAK_TFS / 6.0) + rest / MFMA_F32_PEAK_TFS
+    out["step_floor_ms"] = floor_ms
+    out["step_floor_frac"] = floor_ms / ms
+    out["step_floor_note"] = ("matrix-pipe time of the step's %.1f GFLOP at the peak of the arithmetic each part runs: backward "
+                              "recurrence %.1f GFLOP at 157.3 TF, forward recurrence %.1f + stack GEMMs %.1f GFLOP at 416.7 "
+                              "fp32-equivalent TF (six bf16 piece products per fp32 product), the rest %.1f GFLOP at 157.3 TF; "
+                              "step_floor_frac = floor / ms_per_step" % (2 * rec + gem + rest, rec, rec, gem, rest))
     out["roofline_other"]["gemm_f32_small_calls"] = out["roofline_other"].pop("gemm_f32_kernel")  # fc / misc products
     out["roofline_other"]["gemm_f32_kernel"] = r.get("stack_gemm")
     if world == 1 and not args.no_cpu_baseline:

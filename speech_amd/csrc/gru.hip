@@ -3096,7 +3096,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
             Q.timing = timing_on && !drop_on ? (unsigned long long*)(sync + 256) : nullptr;
             if (Q.timing && hipMemsetAsync(sync + 256, 0, 256 * 8 * 8, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;  // (r4 kernel: 4 words per block)
             Q.dump = (float*)((char*)workspace + workspace_bytes - kSyncBytes - kFwdDumpBytes);
-            { const long r = sa_opt(SA_OPT_GRU_FWD_REPORT); Q.report_every = (r >= 1 && r <= 64 && (r & (r - 1)) == 0) ? (int)r : 4; }
+            { const long r = sa_opt(SA_OPT_GRU_FWD_REPORT); Q.report_every = (r >= 1 && r <= 64 && (r & (r - 1)) == 0) ? (int)r : 8; }
             Q.drop = dc.drop; Q.drop_stream0 = dc.stream0;
             for (int l = 0; l < kMaxJobs; ++l) { Q.h_drop[l] = nullptr; Q.hx[l] = nullptr; Q.hxd[l] = nullptr; }
             for (int l = 0; planes && l < L; ++l) {

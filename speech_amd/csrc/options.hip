@@ -39,7 +39,7 @@ Opt g_opts[SA_OPT_COUNT] = {
     {"gru.shared_pack", 1, 1, "backward: 0 = every weight-gradient product packs its own operands"},
     {"gru.pack_in_kernel", 1, 1, "backward: 0 = gate-gradient operands packed by a launch instead of by the recurrence kernel"},
     {"gru.bwd_one", 1, 1, "backward: 0 = the fused kernel chunk by chunk instead of one launch for the whole stack"},
-    {"gru.fwd_report", 4, 4, "forward: a layer reports its progress to the layer above every so many steps (1, 2, 4, 8 or 16)"},
+    {"gru.fwd_report", 8, 8, "forward: a layer reports its progress to the layer above every so many steps (1, 2, 4, 8 or 16)"},
     {"gru.fwd_planes", 1, 1, "forward: 0 = the one-launch kernel on f32-input MFMAs (bit-identical to the step kernels) instead of "
                              "the bf16-planes kernel (split-bf16 products, fp32-equivalent; H = 128, 256, 384, 512)"},
     {"gru.exp", 0, 0, "measurement tools only: selects a kernel variant under A/B test (0 = the shipped path; the variants of a round "

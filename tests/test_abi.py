@@ -143,7 +143,7 @@ def test_options_are_a_table_not_the_environment(monkeypatch):
     assert L.sa_option_name(-1) is None and L.sa_option_name(len(names)) is None
     L.sa_reset_options()
     defaults = {n: _lib.get_option(n) for n in names}
-    assert defaults["gru.fused"] == 1 and defaults["ctc.prob"] == -1 and defaults["gru.fwd_report"] == 4
+    assert defaults["gru.fused"] == 1 and defaults["ctc.prob"] == -1 and defaults["gru.fwd_report"] == 8
     assert _lib.set_option("gru.fused", 0) == 1 and _lib.get_option("gru.fused") == 0
     v = ctypes.c_long(0)
     assert L.sa_set_option(b"no.such_option", 1) == 2 and L.sa_get_option(b"no.such_option", ctypes.byref(v)) == 2
@@ -160,11 +160,11 @@ def test_options_are_a_table_not_the_environment(monkeypatch):
     assert _lib.get_option("gru.fused") == 0 and _lib.get_option("ctc.prob") == 2
     # a value set through set_option() survives somebody else's environment change (only the options whose
     # variable changed are touched) ...
-    _lib.set_option("gru.fwd_report", 8)
+    _lib.set_option("gru.fwd_report", 16)
     monkeypatch.delenv("SA_GRU_FUSED")
     _lib.lib()
-    assert _lib.get_option("gru.fused") == 1 and _lib.get_option("ctc.prob") == 2 and _lib.get_option("gru.fwd_report") == 8
-    _lib.set_option("gru.fwd_report", 4)
+    assert _lib.get_option("gru.fused") == 1 and _lib.get_option("ctc.prob") == 2 and _lib.get_option("gru.fwd_report") == 16
+    _lib.set_option("gru.fwd_report", 8)
     monkeypatch.delenv("SA_CTC_PROB")
     _lib.lib()
     assert {n: _lib.get_option(n) for n in names} == defaults
