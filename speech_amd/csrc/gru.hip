@@ -2221,6 +2221,22 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (c0 + k < C && r0 + tx < R) out[(long)(c0 + k) * R + r0 + tx] = tile[tx][k];
 }
 
+// up to 16 same-shape transposes in ONE launch (blockIdx.z selects the matrix): the bidirectional backward pass transposes
+// W_hh of every (layer, direction) -- eight 5 - 7 us launches per TIMIT step were 1 % of the step (r6)
+struct TransposeList { const float* in[16]; float* out[16]; };
+__global__ __launch_bounds__(256) void transpose_many_kernel(TransposeList l, int R, int C) {
+    __shared__ float tile[32][33];
+    const float* __restrict__ in = l.in[blockIdx.z];
+    float* __restrict__ out = l.out[blockIdx.z];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < C) tile[k][tx] = in[(long)(r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) out[(long)(c0 + k) * R + r0 + tx] = tile[tx][k];
+}
+
 // Column sums in two deterministic stages: grid (N/64, R) blocks each reduce a row range of 64 columns into
 // part[r][n]; the second kernel adds the R partials in order.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, long lda, int M, int N,
@@ -2399,11 +2415,19 @@ bool overlap_enabled() { return true; }
 // A whole-sequence product (input projection / input gradient: tall M, short K) with room for the packed split-bf16
 // copies of its operands, never split along K (these calls had no workspace before the packed path existed: the
 // summation order of the f32 kernel stays what the bit-identity tests of the recurrence kernels were written against).
+// A whole-layer product fills the chip by its output tiles alone at the BASELINE sizes (S-LIBRI: 125 x 12 tiles) and is
+// never split along K.  At the sizes the reference SHIPS (examples/*/ctc_config.json: batch 8 - 16, T' ~ 150: 9 x 4 tiles on
+// 256 CUs) it is a 36-block launch whose blocks walk the whole reduction alone -- 57 + 90 us for the two input-gradient
+// products of a TIMIT layer; there the library's split-K rule (deterministic fold) decides (r6).
+static int whole_no_split(int M, int N, int nprob) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * nprob;
+    return tiles >= 192 ? 1 : 0;
+}
 static ctcStatus_t gemm_whole(int trans_a, int trans_b, int M, int N, int K, const float* A, long lda, const float* B,
                               long ldb, float beta, float* C, long ldc, const float* bias, void* ws, size_t ws_bytes,
                               hipStream_t stream) {
     SaGemmOpts o;
-    o.no_split = 1; o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr;
+    o.no_split = whole_no_split(M, N, 1); o.colsum = nullptr; o.xcc_mask = 0; o.tile_counter = nullptr;
     return sa_gemm_f32_group_impl(1, trans_a, trans_b, M, N, K, 1.f, &A, lda, &B, ldb, beta, &C, ldc, &bias, nullptr, ws,
                                   ws_bytes, stream, &o);
 }
@@ -2965,7 +2989,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                     gA[d] = in + r0 * I; gB[d] = w_ih[l * 2 + d]; gC[d] = ai_of(l, d) + r0 * 3 * H; gbias[d] = b_ih[l * 2 + d];
                 }
                 SaGemmOpts o;
-                o.no_split = 1; o.colsum = nullptr; o.xcc_mask = mask;
+                o.no_split = mask ? 1 : whole_no_split(n * B, 3 * H, 2); o.colsum = nullptr; o.xcc_mask = mask;
                 o.tile_counter = mask ? sync + kSyncTiles + side_launch++ : nullptr;
                 o.err_word = g_health.dev;  // a filtered launch that did not cover its tiles stops the step's update
                 return sa_gemm_f32_group_impl(2, 0, 1, n * B, 3 * H, I, 1.f, gA, I, gB, I, 0.f, gC, 3 * H, gbias, nullptr,
@@ -3663,10 +3687,16 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     auto mid_of = [&](int l) { return (float*)(ws + (size_t)L * D * per_dir + (size_t)l * mid_bytes); };  // l < L-1
     const long DH = (long)D * H;
     auto transpose_whh = [&]() {   // W_hh^T per (layer, direction): what every kernel but the one-launch fused one reads
+        TransposeList tl;
+        int n = 0;
         for (int l = 0; l < L; ++l)
-            for (int d = 0; d < D; ++d)
-                hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, stream,
-                                   w_hh[l * D + d], wt_of(l, d), 3 * H, H);
+            for (int d = 0; d < D; ++d) {
+                tl.in[n] = w_hh[l * D + d]; tl.out[n] = wt_of(l, d);
+                if (++n == 16 || (l == L - 1 && d == D - 1)) {
+                    hipLaunchKernelGGL(transpose_many_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32, n), dim3(256), 0, stream, tl, 3 * H, H);
+                    n = 0;
+                }
+            }
     };
     dim3 grid((H + 15) / 16, (B + 15) / 16, 1);
     BwdJobs P;

@@ -484,8 +484,12 @@ def test_xcd_local_persistent_kernels_bidirectional():
         res = []
         for mode in ("0", "2", "3"):
             out = "/tmp/sa_xcd_bi_%s.pt" % mode
-            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],  # (the planes kernel: budget test below)
-                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_TILED="0", SA_GRU_FWD_PLANES="0"), check=True, timeout=180)
+            # (the planes kernel has its own budget test below; SA_GRU_FWD_CHUNKS=1: the layer's projection as ONE product in
+            # every mode -- since r6 a small product may be split along K by a rule of its own shape, so a projection cut into
+            # time chunks sums in another order than the whole one)
+            subprocess.run([sys.executable, "-c", code, out] + [str(v) for v in shape],
+                           env=dict(os.environ, SA_GRU_PERSIST=mode, SA_GRU_TILED="0", SA_GRU_FWD_PLANES="0", SA_GRU_FWD_CHUNKS="1"),
+                           check=True, timeout=180)
             res.append(torch.load(out))
         for other in res[1:]:
             assert len(res[0]) == len(other) and all(torch.equal(a, b) for a, b in zip(res[0], other)), shape
