@@ -3752,12 +3752,15 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 PBwdJobs Q;
                 Q.B = B; Q.H = H; Q.nbt_all = bi_nbt; Q.ntile_u = H / 16; Q.rb = 1; Q.rt = B;
                 Q.flagless = flagless_mode() ? 1 : 0;
-                if (Q.flagless)
+                if (Q.flagless) {  // both directions' exchange buffers in one launch
+                    FillBatch fb(stream, fill_batch_enabled());
                     for (int d = 0; d < 2; ++d)
-                        if (!sentinel_fill(bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : dah[l * 2 + d],
-                                           bi_tiled_fn ? (size_t)(xring_enabled() ? min(T, kXRing) : T) * bi_nbt * 16 * 3 * H
-                                                       : (size_t)T * B * 3 * H, stream))
-                            return CTC_STATUS_MEMOPS_FAILED;
+                        fb.add(bi_tiled_fn ? (float*)(ws + xch_off + (size_t)(l * 2 + d) * xch_each) : dah[l * 2 + d],
+                               bi_tiled_fn ? (size_t)(xring_enabled() ? min(T, kXRing) : T) * bi_nbt * 16 * 3 * H
+                                           : (size_t)T * B * 3 * H, kSentinel);
+                    fb.flush();
+                    if (!fb.ok) return CTC_STATUS_MEMOPS_FAILED;
+                }
                 Q.err = g_health.dev; Q.spin_limit = spin_limit(); Q.fault = fault_injection(); Q.prio = persist_prio(); Q.packed = (bi_tiled_fn && xring_enabled()) ? 2 : 1; Q.reg = sync + kSyncReg; Q.w_rowmajor = 0;
                 Q.stamp = nullptr; Q.n = 2; Q.timing = nullptr; Q.drop = sa_drop_make(0.f, 0ull);
                 Q.pk_kb = bi_packg ? (long)T * B / 16 : 0;

@@ -65,7 +65,7 @@ def m_step(name, F, V, cfg, B, T, L, iters):
     def step():
         model.zero_grad(set_to_none=True)
         loss = loss_fn(model.forward_impl(x), lab, None, None)
-        loss.backward()
+        ops.backward(loss)  # train.py:51 (loss.backward() without autograd's two scalar launches)
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         out["loss"] = loss
 
@@ -103,7 +103,7 @@ def m_transducer(iters, dropout=0.0):
     def step():
         model.zero_grad(set_to_none=True)
         loss = model.loss((inputs, labels))
-        loss.backward()
+        ops.backward(loss)  # train.py:51 (loss.backward() without autograd's two scalar launches)
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         out["loss"] = loss
 
@@ -138,7 +138,7 @@ def m_seq2seq(iters, dropout=0.0):
     def step():
         model.zero_grad(set_to_none=True)
         loss = model.loss((inputs, labels))
-        loss.backward()
+        ops.backward(loss)  # train.py:51 (loss.backward() without autograd's two scalar launches)
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0, norm_out=norm)
         out["loss"] = loss
 

@@ -54,7 +54,7 @@ for name in (args.case or ["slibri"]):
     def step():
         model.zero_grad(set_to_none=True)
         loss = loss_fn(model.forward_impl(x), lab, None, None)
-        loss.backward()
+        ops.backward(loss)  # train.py:51 (loss.backward() without autograd's two scalar launches)
         ops.clip_sgd_step(flat_p, flat_g, None, 1e-3, 0.0, 200.0)
         return loss
 
