@@ -2385,13 +2385,26 @@ static int current_device() {
 SideStream g_side_dev[kMaxDevices];
 #define g_side (g_side_dev[current_device()])
 
-// Holds the side stream back for ~`ticks` x 10 ns: enqueued in front of a batch of XCD-filtered GEMM launches so that the
-// persistent recurrence launch issued at the same moment on the caller's stream is DISPATCHED first -- its exit-at-once
+// Holds the side stream back until the persistent recurrence launch issued at the same moment on the caller's stream has
+// been DISPATCHED: enqueued in front of a batch of XCD-filtered GEMM launches.  The recurrence launch's exit-at-once
 // workgroups for the idle XCDs need a free slot there, and once GEMM blocks (hundreds of us each) fill those CUs the
 // in-order dispatcher keeps the whole recurrence launch waiting (measured: 0.5 ms per layer).
-__global__ void side_delay_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+// Rounds 2-5 guessed the moment with a 40 us spin on the wall clock (side_delay_kernel(4000)) -- an ordering by elapsed
+// ticks, fragile across clocks and boxes.  Every workgroup of a recurrence launch registers itself
+// in the sync page before anything else (reg[XCC id] += 1: how it learns its role), so "dispatched" is a fact that can be
+// read: the launch with index k is in once the eight counters sum to 256 (k + 1).  The wait is bounded (~0.3 ms: if the
+// recurrence launch never comes -- the persistent path switched off between the two enqueues -- the products just run).
+__global__ void side_wait_dispatched_kernel(const unsigned* __restrict__ reg, unsigned want_total) {
+    for (int polls = 0; polls < 256; ++polls) {
+        unsigned v[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v[x] = __hip_atomic_load(reg + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned sum = 0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) sum += v[x];
+        if (sum >= want_total) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 // uni = the layer wavefront of a unidirectional stack (all 8 XCDs busy: the GEMM blocks share CUs with recurrence
@@ -2403,7 +2416,7 @@ __global__ void side_delay_kernel(unsigned long long ticks) {
 // busy ones.  Three things had to hold before that paid (profiles/r02_bidirectional_overlap_trace.txt):
 //   * one tile per block, not a persistent tile loop: the dispatcher walks a grid in order, so long-lived GEMM blocks on
 //     the idle XCDs keep the NEXT recurrence launch from starting (its exit-at-once blocks for those XCDs find no room);
-//   * the recurrence launch must be dispatched BEFORE the GEMM blocks arrive (side_delay_kernel);
+//   * the recurrence launch must be dispatched BEFORE the GEMM blocks arrive (side_wait_dispatched_kernel);
 //   * the filtered GEMM must fit BESIDE a recurrence block (<= 232 registers: the one-stage kernel), or its own surplus
 //     blocks on the busy XCDs -- and the launch's completion -- wait for the recurrence to end.
 // With all three: bidirectional S-LIBRI 36.3 -> 30.9 ms per step (backward stack 22.2 -> 17.7 ms: the 2.9 ms of weight-
@@ -3000,7 +3013,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
                 st = project(0, stream, 0u);
                 if (st != CTC_STATUS_SUCCESS) return st;
                 if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;  // the layer's input is complete
-                hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);
+                hipLaunchKernelGGL(side_wait_dispatched_kernel, dim3(1), dim3(1), 0, g_side.s, (const unsigned*)(sync + kSyncReg),
+                                   256u * (bi_launches + 1u));  // the layer's first recurrence launch (enqueued below) is in
                 for (int c = 1; c < nck && c * S < T; ++c) {
                     st = project(c, g_side.s, bi_mask);
                     if (st != CTC_STATUS_SUCCESS) return st;
@@ -3820,7 +3834,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                     if (st != CTC_STATUS_SUCCESS) return st;
                     lo += n0; hi -= n0;
                     if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
-                    hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // the recurrence first
+                    hipLaunchKernelGGL(side_wait_dispatched_kernel, dim3(1), dim3(1), 0, g_side.s, (const unsigned*)(sync + kSyncReg),
+                                       256u * (bi_launches + 1u));  // the NEXT layer's recurrence launch is in
                     while (hi - lo >= 2) {
                         const int n = min(per_end, (hi - lo) / 2);
                         int e2[2] = {lo, hi - n};
@@ -3854,7 +3869,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 for (int d = 0; d < 2; ++d) wg_hi[l * 2 + d] = 0;
                 if (side && !dx_streamed) {
                     if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
-                    hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // ~40 us
+                    hipLaunchKernelGGL(side_wait_dispatched_kernel, dim3(1), dim3(1), 0, g_side.s, (const unsigned*)(sync + kSyncReg),
+                                       256u * (bi_launches + 1u));  // the NEXT layer's recurrence launch is in
                 } else if (!side && bi_side && !g_side.order(g_side.s, stream)) {  // the scratch operands are the side stream's
                     return CTC_STATUS_EXECUTION_FAILED;
                 }
@@ -3877,7 +3893,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                 for (int k = 0; k < L * 2; ++k) { spans[k][0] = spans[k][1] = 0; }
                 for (int d = 0; d < 2; ++d) { spans[l * 2 + d][1] = T; wg_hi[l * 2 + d] = 0; }
                 if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;
-                hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, g_side.s, 4000ull);  // ~40 us
+                hipLaunchKernelGGL(side_wait_dispatched_kernel, dim3(1), dim3(1), 0, g_side.s, (const unsigned*)(sync + kSyncReg),
+                                       256u * (bi_launches + 1u));  // the NEXT layer's recurrence launch is in
                 issuer.xcc_mask = bi_mask;
                 st = issuer.issue(spans, g_side.s, true);
                 issuer.xcc_mask = 0;
