@@ -545,8 +545,8 @@ def roofline(prof, step_us, steps):
                     "avg_launch_us": us, "kernel_us": kern_us,
                     "kernel_us_note": "entry of the first block to exit of the LAST block (device clock, atomic max)",
                     "samples": n, "bytes_per_launch": nbytes, "time_steps_per_launch": nsteps,
-                    "gflop_per_launch": gflop, "mfma_tflops": gflop / us * 1e-3, "mfma_peak_tflops": mpeak,
-                    "mfma_frac": gflop / us * 1e-3 / mpeak,
+                    "gflop_per_launch": gflop, "mfma_tflops": gflop / us * 1e3, "mfma_peak_tflops": mpeak,
+                    "mfma_frac": gflop / us * 1e3 / mpeak,
                     "mfma_note": ("both products of a step as six bf16 piece products per fp32 product (gru_fwd_planes_kernel): "
                                   "peak = 2500 TF dense bf16 / 6" if fwd else
                                   "exact fp32 products on v_mfma_f32_16x16x4_f32: peak = the f32-input MFMA rate"),

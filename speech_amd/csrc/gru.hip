@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fused_kernel(PFusedFwd P) {
 //     the planes and needs no sentinel fill.
 // NOT bit-identical to the step kernels any more (different products, different summation order, different transcendental
 // rounding): tests/test_gpu_blocks.py holds the stack against an fp64 restatement with an error budget instead, and every
-// oracle / golden comparison is unchanged.  Even IPG only (a wave's K slice is whole 32-k steps): H = 128, 256, 384, 512.
+// comparison against the CPU restatements and the golden fixtures is unchanged.  Even IPG only (a wave's K slice is whole 32-k steps): H = 128, 256, 384, 512.
 constexpr unsigned kPlaneSentinel = 0xffffffffu;
 __host__ __device__ inline size_t hx_step_bytes(int H) { return (size_t)3 * (H / 32) * 1024; }  // per (t, batch tile)
 

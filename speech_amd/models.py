@@ -113,7 +113,7 @@ class Model(nn.Module):
         if x.is_cuda or not self.is_cuda:
             return x
         if x.is_pinned():  # on the copy stream: it runs while the previous step's kernels still hold the compute stream
-            return _lib.h2d_async(x, list(self.parameters())[0].device, self._stage)
+            return _lib.h2d_async(x, self._first_param().device, self._stage)
         return x.cuda(non_blocking=True)
 
     def _collate_staged(self, *batch):
@@ -182,9 +182,23 @@ class Model(nn.Module):
             out = fn()
         return out
 
+    def _apply(self, fn, *args, **kwargs):  # .cuda() / .cpu() / .float(): drop the cached parameter references
+        self.__dict__.pop("_p0", None)
+        self.__dict__.pop("_enc_ps", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def _first_param(self):
+        """The model's first parameter, found once: module.parameters() walks every sub-module on each call, and the launch
+        path asked twice per batch (120 us of the 310 us a batch-1 CTC.infer spent on the host in front of its first kernel;
+        r6).  nn.Module.cuda() / .cpu() keep the Parameter OBJECTS and swap their data, so the reference stays valid."""
+        p = self.__dict__.get("_p0")
+        if p is None:
+            p = self.__dict__["_p0"] = next(self.parameters())
+        return p
+
     @property
     def is_cuda(self):
-        return list(self.parameters())[0].is_cuda
+        return self._first_param().is_cuda
 
     @property
     def encoder_dim(self):
@@ -192,6 +206,9 @@ class Model(nn.Module):
 
     # ---- HIP path --------------------------------------------------------------------------------------------------
     def _encoder_params(self):
+        ps = self.__dict__.get("_enc_ps")  # (the same Parameter objects for the life of the model: see _first_param)
+        if ps is not None:
+            return list(ps)
         ps = []
         for c in self.conv.children():
             if type(c) == nn.Conv2d:
@@ -200,6 +217,7 @@ class Model(nn.Module):
             for sfx in ([""] + (["_reverse"] if self.rnn.bidirectional else [])):
                 ps += [getattr(self.rnn, "%s_l%d%s" % (n, l, sfx))
                        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        self.__dict__["_enc_ps"] = tuple(ps)
         return ps
 
     def _run(self, x, head_w, head_b):

@@ -66,7 +66,7 @@ PY
       base=$(basename ${script%.py})
       ( cd /tmp && rm -rf /tmp/tr_${TAG}_$base && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_${TAG}_$base -o p -- python $ROOT/$script $rest > $ROOT/$O/${base}_trace.log 2>&1 )
       f=$(find /tmp/tr_${TAG}_$base -name "*kernel_trace.csv" | head -1)
-      python tools/trace_timeline.py $f clip_sgd_kernel ${TRACE_MIN_US:-25} > $O/${base}_timeline.txt 2>&1; head -150 $O/${base}_timeline.txt ;;
+      python tools/trace_timeline.py $f ${TRACE_MARKER:-clip_sgd_kernel} ${TRACE_MIN_US:-25} > $O/${base}_timeline.txt 2>&1; head -150 $O/${base}_timeline.txt ;;
     *) echo "unknown stage $name" ;;
   esac
 done
