@@ -1016,6 +1016,20 @@ __device__ __forceinline__ float sa_fast_tanh(float x) {
     const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
     return copysignf(ax < 0.25f ? small : big, x);
 }
+template <int N>
+__device__ __forceinline__ void sa_wait_vmcnt() {  // s_waitcnt vmcnt(N): all but the youngest N vector-memory operations done
+    static_assert(N >= 0 && N <= 9, "extend the table");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+}
 __device__ __forceinline__ float sa_quad_swap1(float v) {  // lane i <-> lane i ^ 1 (DPP quad_perm [1, 0, 3, 2])
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
 }
@@ -1026,6 +1040,8 @@ __global__ __launch_bounds__(256) void gru_fwd_planes_kernel(PFusedFwd P) {
     constexpr int H = 64 * IPG, NTU = H / 16, KS = 16 * IPG, NK = IPG / 2, NKT = H / 32;
     constexpr int kPollIt = POLL_AT >= 8 ? NK : (NK * POLL_AT) / 8;
     constexpr int kStep = 3 * NKT * 1024;  // bytes of the planes per (t, batch tile)
+    // vector-memory stores a step issues BEHIND its two publish stores (finish()): h_out, the stash, the dropped copy
+    constexpr int kAfterPublish = 1 + (STASH ? 5 : 0) + (DROP ? 3 : 0);
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
     SA_PERSIST_EXCLUSIVE(P.prio);
@@ -1230,7 +1246,10 @@ __global__ __launch_bounds__(256) void gru_fwd_planes_kernel(PFusedFwd P) {
             for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
             SA_TICK(0)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pacing of the first polling trip (see gru_fwd_chunk_kernel)
+            // pacing of the first polling trip (see gru_fwd_chunk_kernel): it leaves once this step's own PUBLISH stores are
+            // acknowledged -- not the stash / h_out stores behind them, whose acknowledgements come later and say nothing
+            // about the neighbours' rows (r6: 1.67 - 1.74 -> 1.64 ms per S-LIBRI stack forward)
+            sa_wait_vmcnt<kAfterPublish>();
             poll_until_fresh(t - 1, false);
             SA_TICK(1)
             fetch_ai(t + 1 < T ? t + 1 : t);  // behind the poll (one in-order queue); the last step re-reads its own: unused
@@ -1299,7 +1318,7 @@ __global__ __launch_bounds__(256) void gru_fwd_planes_kernel(PFusedFwd P) {
             // the input product -- the whole product then ran BEHIND the acknowledgements: 1.67 -> 1.90 ms per stack forward)
             if (kPollIt >= NK) {
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sa_wait_vmcnt<kAfterPublish>();
                 __builtin_amdgcn_sched_barrier(0);
             }
             poll_until_fresh(t - 1, kPollIt < NK);
@@ -1477,7 +1496,7 @@ __global__ __launch_bounds__(256) void gru_fwd_chunk_planes_kernel(PFwdJobs P) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float e_r = nx_r, e_z = nx_z, e_n = nx_n;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pacing of the first polling trip (see gru_fwd_chunk_kernel)
+        sa_wait_vmcnt<STASH ? 6 : 1>();  // pacing of the first polling trip: the step's own publish stores are acknowledged
         poll_until_fresh(t - dt);
         fetch_ai(s + 1 < nsteps ? t + dt : t);  // behind the poll; the last step re-reads its own row: unused
         __builtin_amdgcn_sched_barrier(0);
