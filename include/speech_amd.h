@@ -222,7 +222,17 @@ ctcStatus_t sa_gru_bwd(const float* dh_out, long hs_b, long hs_t, const float* h
  * layer by layer with both directions sharing each launch.  L <= 8.
  * aux_streams (n_aux >= 0 extra hipStream_t handles, may be NULL): a step launch is a latency chain that leaves the
  * chip idle, so the batch is cut into 1 + n_aux independent groups of rows whose step kernels run concurrently, one
- * group per stream; the groups rejoin `stream` (event wait) once per wavefront wave and at the end of the call. */
+ * group per stream; the groups rejoin `stream` (event wait) once per wavefront wave and at the end of the call.
+ * Arithmetic of the recurrence (fp32 storage and accumulation everywhere):
+ *   - on a 256-CU device, H in {128, 256, 384, 512} and (layers or directions) x ceil(B / 16) groups that fit its 8 XCDs: the
+ *     persistent kernels on producer-written bf16 planes (csrc/gru.hip, gru_fwd_planes_kernel / gru_fwd_chunk_planes_kernel):
+ *     h is split exactly into three bf16 pieces by the thread that computes it, W_hh / W_ih once per launch, and six of the nine
+ *     piece products run on the bf16 MFMA -- the split-bf16 arithmetic of the GEMMs above (dropped terms < 2^-26 of a product);
+ *     sigmoid / tanh on v_exp_f32 / v_rcp_f32 (relative error < 3e-7).  Against an fp64 evaluation its error is the error of the
+ *     exact-fp32 kernels (tests/test_gpu_blocks.py::test_planes_forward_error_budget); deterministic run to run;
+ *   - option "gru.fwd_planes" = 0, or any other shape: the f32-input MFMA kernels (exact fp32 products, expf / tanhf), whose
+ *     recurrence is bit-identical to one launch per time step.
+ * Which of the two a call runs is a function of its shape, the device and that option only. */
 size_t sa_gru_stack_fwd_workspace_bytes(int L, int D, int B, int T, int H, int I0);
 ctcStatus_t sa_gru_stack_fwd(const float* x, int I0, const float* const* w_ih, const float* const* b_ih,
                              const float* const* w_hh, const float* const* b_hh, float* const* h_out,
