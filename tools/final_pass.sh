@@ -15,6 +15,7 @@ python $R/tools/pmc_traffic.py /tmp/fp_fetch /tmp/fp_write gru_ > $O/hbm_traffic
 pass sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 pass mem "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR TA_BUSY_avr TCC_HIT_sum TCC_MISS_sum"
 python $R/tools/pmc_busy.py /tmp/fp_sq ${PROFILE_PREFIX:-r06}_pmc_gru_fused_kernels.txt > $O/pipe_busy.log 2>&1; cp $R/profiles/pipe_busy.json $O/pipe_busy.json
+python $R/tools/pmc_clock.py /tmp/fp_sq gemm_pk gru_ conv_ > $O/effective_clock.txt 2>&1
 { echo "pass sq"; python $R/tools/pmc_summary.py /tmp/fp_sq gru_; echo "pass mem"; python $R/tools/pmc_summary.py /tmp/fp_mem gru_; } > $O/pmc_gru_fused_kernels.txt 2>&1
 { echo "pass sq"; python $R/tools/pmc_summary.py /tmp/fp_sq gemm_pk; echo "pass mem"; python $R/tools/pmc_summary.py /tmp/fp_mem gemm_pk; } > $O/pmc_gemm_pk.txt 2>&1
 cd $R
