@@ -214,6 +214,12 @@ struct AbArgs {
     float gscale;         // every gradient element is multiplied by this (the caller's 1 / batch size)
     unsigned long long* dbg;  // debug (option ctc.dbg): wave 0 of block 0 stores {shader cycles, 100 MHz ticks} of its T loop
     unsigned long long* prof; // sa_ctc_profile_*: {earliest workgroup entry, latest workgroup exit} of this launch (100 MHz ticks) or null
+    // (r6) the batch reduction of the reduced form folded into the gated launch: the LAST workgroup of that launch to finish
+    // (a device-scope arrival counter, zeroed by the probability-domain launch in front of it and again by its last arrival)
+    // sums the costs in ctc_cost_sum_kernel's order and writes *loss_out = loss_scale * sum -- one launch fewer per loss
+    float* loss_out;          // or null
+    float loss_scale;
+    unsigned* done_ctr;       // one word of the workspace (behind the flags)
 };
 
 // One (direction, chunk) wave over all T steps.  DIR 0 = alpha (time forward), 1 = beta (time backward).
@@ -703,6 +709,24 @@ template <bool PROB>
 __device__ __forceinline__ void ctc_grad_row(const AbArgs& A, float* __restrict__ grads, long st, long sb, int b, int t,
                                              int lane, float* srt);
 
+// wave 0 of a workgroup of the GATED launch, on its way out (its utterance's cost is in memory): see AbArgs::loss_out
+__device__ __forceinline__ void ctc_fold_cost(const AbArgs& A, int lane) {
+    int last = 0;
+    if (lane == 0) {
+        __threadfence();  // this workgroup's cost (if it wrote one) before its arrival
+        last = atomicAdd(A.done_ctr, 1u) == gridDim.x - 1u;
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    __threadfence();
+    float v = 0.f;  // ctc_cost_sum_kernel's order: lane-strided partial sums, then the wave's DPP tree
+    for (int b = lane; b < (int)gridDim.x; b += 64) v += __hip_atomic_load(A.costs + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = sa_wave_sum_dpp(v);
+    if (lane == 0) {
+        *A.loss_out = v * A.loss_scale;
+        *A.done_ctr = 0u;
+    }
+}
+
 template <bool WITH_BETA, bool LDS_EM, bool PROB>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -725,7 +749,11 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
                     kU * A.K;  // [kU slack rows][T][K][kU slack rows] (LDS_EM only; see ctc_chain_p)
 
     const int b = blockIdx.x;
-    if (A.gate && A.flags[b] == 0) return;  // the log-domain pass behind a probability-domain one: flagged utterances only
+    if (A.gate && A.flags[b] == 0) {  // the log-domain pass behind a probability-domain one: flagged utterances only
+        if (A.loss_out && threadIdx.x < 64) ctc_fold_cost(A, threadIdx.x);
+        return;
+    }
+    if (PROB && A.done_ctr && b == 0 && threadIdx.x == 0) *A.done_ctr = 0u;  // (the gated launch behind this one counts arrivals)
     if (A.prof && threadIdx.x == 0) atomicMin(A.prof, (unsigned long long)wall_clock64());
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -871,6 +899,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(AbArgs A) {
         const int nw = blockDim.x >> 6;
         for (int t = wave; t < A.T_max; t += nw) ctc_grad_row<false>(A, A.grads, A.g_st, A.g_sb, b, t, lane, srt);
     }
+    if (!PROB && A.gate && A.loss_out && wave == 0) ctc_fold_cost(A, lane);  // (thread 0 wrote A.costs[b] above: same wave)
 }
 
 // ---------------------------------------------------------------------------------------------------------- K_C
@@ -1927,7 +1956,7 @@ static size_t ctc_ws_layout(int max_T, int max_L, int K, int B, size_t* off_ly2,
     *off_stash = o; o += sa_align_up((size_t)B * max_T * 6 * nch * 64 * sizeof(float), 256);
     *off_lp = o;    o += sa_align_up((size_t)B * sizeof(float) * 2, 256);
     *off_goffs = o; o += sa_align_up((size_t)B * 2 * nch * ctc_nbatch(max_T) * sizeof(float), 256);
-    *off_flags = o; o += sa_align_up((size_t)B * sizeof(int), 256);
+    *off_flags = o; o += sa_align_up((size_t)(B + 1) * sizeof(int), 256);  // + the gated launch's arrival counter
     *off_lsort = o; o += sa_align_up((size_t)B * (1 + nch * 64 + K) * sizeof(int), 256);
     return o;
 }
@@ -1978,7 +2007,7 @@ __global__ void ctc_cost_sum_kernel(const float* __restrict__ costs, int B, floa
 ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long stride_b, const int* d_flat_labels,
                           const int* d_label_lengths, const int* d_input_lengths, int alphabet_size, int minibatch,
                           int max_T, int max_L, int blank_label, float* d_costs, float grad_scale, void* workspace,
-                          size_t workspace_bytes, void* stream_);
+                          size_t workspace_bytes, void* stream_, float* d_loss = nullptr, bool* loss_done = nullptr);
 }  // namespace
 
 extern "C" ctcStatus_t sa_ctc_loss(const float* acts, float* grads, long stride_t, long stride_b,
@@ -1996,10 +2025,12 @@ extern "C" ctcStatus_t sa_ctc_loss_reduced(const float* acts, float* grads, long
                                            int max_L, int blank_label, float scale, float* d_costs, float* d_loss,
                                            void* workspace, size_t workspace_bytes, void* stream_) {
     if (!d_loss) return CTC_STATUS_INVALID_VALUE;
+    bool folded = false;  // the latency regime's gated launch sums the costs itself (AbArgs::loss_out)
     const ctcStatus_t s = ctc_loss_impl(acts, grads, stride_t, stride_b, d_flat_labels, d_label_lengths, d_input_lengths,
                                         alphabet_size, minibatch, max_T, max_L, blank_label, d_costs, scale, workspace,
-                                        workspace_bytes, stream_);
+                                        workspace_bytes, stream_, d_loss, &folded);
     if (s != CTC_STATUS_SUCCESS) return s;
+    if (folded) return CTC_STATUS_SUCCESS;
     hipLaunchKernelGGL(ctc_cost_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const float*)d_costs, minibatch,
                        scale, d_loss);
     SA_CHECK_LAUNCH();
@@ -2067,7 +2098,7 @@ namespace {
 ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long stride_b, const int* d_flat_labels,
                           const int* d_label_lengths, const int* d_input_lengths, int alphabet_size, int minibatch,
                           int max_T, int max_L, int blank_label, float* d_costs, float grad_scale, void* workspace,
-                          size_t workspace_bytes, void* stream_) {
+                          size_t workspace_bytes, void* stream_, float* d_loss, bool* loss_done) {
     SA_CLEAR_ERR();
     if (!acts || !d_flat_labels || !d_label_lengths || !d_input_lengths || !d_costs || !workspace)
         return CTC_STATUS_INVALID_VALUE;
@@ -2104,6 +2135,7 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
     A.grads = grads; A.g_st = stride_t; A.g_sb = stride_b; A.gscale = grad_scale;
     A.dbg = sa_opt(SA_OPT_CTC_DBG) ? (unsigned long long*)((char*)workspace + o_goffs) : nullptr;  // overwrites goffs[0..2]: debug only
     A.prof = nullptr;
+    A.loss_out = nullptr; A.loss_scale = grad_scale; A.done_ctr = (unsigned*)(ws + o_flags) + B;
 
     // K_A (log-softmax into the workspace); only != null: the utterances whose flag is set
     auto launch_ka = [&](const int* only) -> ctcStatus_t {
@@ -2247,6 +2279,7 @@ ctcStatus_t ctc_loss_impl(const float* acts, float* grads, long stride_t, long s
                 return CTC_STATUS_MEMOPS_FAILED;
             A.gate = 1;
             if (prob == 3) return CTC_STATUS_SUCCESS;  // debug: the probability-domain pass alone, flags left for inspection
+            if (d_loss && loss_done) { A.loss_out = d_loss; *loss_done = true; }  // the gated launch below folds the costs
         }
         s = launch_ab_any<false>(A, B, threads, ab_smem(false), grads != nullptr, ab_lds_em(false), stream);
         if (s != CTC_STATUS_SUCCESS) return s;
