@@ -1046,7 +1046,23 @@ int choose_splits(int M, int N, int K, int nprob = 1) {
 // 256 x 256 block tiles (half the LDS traffic per flop, one block per CU) when they fill the chip: no split-K and >= 85 %
 // of whole rounds of 256 CUs; else 128 x 128 tiles, two blocks per CU (measured, tools/gemm_bench.py: 4096^3 191 vs 182
 // TFLOP/s, d x of layer 0 132 vs 130; but the layer-0 projection 136 vs 156 and the weight gradients 89 vs 122).
-ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsigned* err_word = nullptr) {
+// A split-K factor that lets the 256 x 256 kernel (one block per CU, half the L2 -> LDS bytes per flop) take a product whose
+// OUTPUT is too small to fill the chip with 256-tiles -- the weight gradients: 6 x 2 x 7 = 84 tiles, 252 blocks at s = 3.
+// 0: none (the output is large, the tiles would be padded by more than 10 %, or a split would be shorter than 128 k-tiles).
+int big_tile_splits(int M, int N, int K, int nprob) {
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
+    const double waste = (double)((M + 255) / 256 * 256) * ((N + 255) / 256 * 256) / ((double)M * N);
+    if (waste > 1.10 || t256 >= 200) return 0;
+    const int ktiles = (K + PK_K - 1) / PK_K;
+    for (int s = 2; s <= 16; ++s) {
+        if (ktiles / s < 128) break;
+        const long blocks = t256 * s;
+        if ((double)blocks / (double)((blocks + 255) / 256 * 256) >= 0.90) return s;
+    }
+    return 0;
+}
+
+ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsigned* err_word = nullptr, bool force_big = false) {
     static bool pk_attr_dev[48] = {false};
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) devid = 0;
@@ -1070,7 +1086,7 @@ ctcStatus_t pk_launch(const GemmArgs& gp, int splits, hipStream_t stream, unsign
         return CTC_STATUS_SUCCESS;
     }
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * nprob;
-    const bool big_tile = splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85;
+    const bool big_tile = force_big || (splits == 1 && t256 >= 200 && (double)t256 / (double)((t256 + 255) / 256 * 256) >= 0.85);
     if (big_tile) {
         if (!pk_attr_dev[devid + 16]) {
             if (hipFuncSetAttribute((const void*)gemm_pk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1720,7 +1736,9 @@ ctcStatus_t sa_pk_rowsum_fold(int nprob, const float* cs_part, int nparts, int R
 }
 
 size_t sa_gemm_pk_group_workspace_bytes(int nprob, int M, int N, int K) {
-    const int s = choose_splits(M, N, K, nprob);
+    int s = choose_splits(M, N, K, nprob);
+    const int sb = big_tile_splits(M, N, K, nprob);  // the 256-tile kernel's own split factor (sa_gemm_pk_group)
+    if (sb > s) s = sb;
     return s > 1 ? (size_t)nprob * s * ((size_t)M * N + M) * sizeof(float) : 0;
 }
 
@@ -1748,6 +1766,13 @@ ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* 
         g.drop = *opts->drop; g.drop_stream = opts->drop_stream; g.drop_base = opts->drop_base;
         splits = 1;  // the mask goes on in the epilogue that writes the result
     }
+    bool force_big = false;
+    // (r6) grouped weight gradients 780 -> 726 us at S-LIBRI (224 -> 241 TF): 7 x 48 tiles x 3 splits of the 128-tile kernel, two
+    // blocks per CU, against 84 x 3 = 252 blocks of the 256-tile kernel, one per CU
+    if (!(opts && opts->drop && opts->drop->on()) && !(opts && opts->xcc_mask)) {
+        const int sb = big_tile_splits(M, N, K, nprob);
+        if (sb > 1 && workspace && workspace_bytes >= (size_t)nprob * sb * ((size_t)M * N + M) * sizeof(float)) { splits = sb; force_big = true; }
+    }
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)nprob * splits * ((size_t)M * N + M) * sizeof(float))) splits = 1;
     int kps = (K + splits - 1) / splits;
     kps = (kps + BK - 1) / BK * BK;
@@ -1761,7 +1786,7 @@ ctcStatus_t sa_gemm_pk_group(int nprob, int M, int N, int K, const char* const* 
     g.b_kb_stride = opts ? opts->b_kb_stride : 0;
     g.grid_x = (N + BN - 1) / BN; g.grid_y = (M + BM - 1) / BM; g.grid_z = nprob * splits;
     if (opts && opts->xcc_mask && opts->tile_counter) { g.xcc_mask = opts->xcc_mask; g.tile_counter = opts->tile_counter; }
-    const ctcStatus_t st = pk_launch(g, splits, stream, opts ? opts->err_word : nullptr);
+    const ctcStatus_t st = pk_launch(g, splits, stream, opts ? opts->err_word : nullptr, force_big && splits > 1);
     if (st != CTC_STATUS_SUCCESS) return st;
     SA_CHECK_LAUNCH();
     if (splits > 1) {
