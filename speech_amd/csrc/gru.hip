@@ -3102,9 +3102,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
         return CTC_STATUS_SUCCESS;
     }
 
-    // unidirectional: chunked layer wavefront.  Layer 0's input projection for all t up front.
-    st = gemm_whole(0, 1, T * B, 3 * H, I0, x, I0, w_ih[0], I0, 0.f, ai_of(0, 0), 3 * H, b_ih[0], gws, gws_bytes, stream);
-    if (st != CTC_STATUS_SUCCESS) return st;
+    // unidirectional: chunked layer wavefront.  Layer 0's input projection for all t up front (enqueued below, once the
+    // path is known: the planes pre-fill may go to the side stream in front of it).
     Chains ch(stream, aux_streams, n_aux, B);
     if (!ch.ok) return CTC_STATUS_EXECUTION_FAILED;
     P.tile_rows = ch.tile_rows;
@@ -3126,9 +3125,25 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     // the bf16-planes form of the one-launch kernel (default where it exists): its exchange is the planes buffers, h_out
     // needs no sentinel
     const bool planes = fused_fwd && sa_opt(SA_OPT_GRU_FWD_PLANES) != 0 && hx_each > 0;
+    // (r6) the planes pre-fill (196 MB of stores at S-LIBRI) goes to the library's side stream, BESIDE the operand packs and
+    // the layer-0 projection, instead of between the projection and the recurrence: the recurrence launch then starts on an
+    // L2 that is not full of dirty sentinel lines (its own time 1.53 -> 1.46 ms) at the price of slower packs beside the fill;
+    // net -0.03 ms per step in three one-box pairs (profiles/r06_forward_planes_experiments.txt; gru.exp bit 6 = in line: A/B)
+    const bool side_fill = planes && !(sa_opt(SA_OPT_GRU_EXP) & 64) && g_side.init();
+    if (side_fill) {
+        if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;  // (the previous call's kernels read these buffers)
+        FillBatch pf(g_side.s, true);
+        pf.add(hx_base, (size_t)(drop_on ? 2 * L - 1 : L) * hx_each / 4, kPlaneSentinel);
+        pf.flush();
+        if (!pf.ok) return CTC_STATUS_MEMOPS_FAILED;
+    }
+    st = gemm_whole(0, 1, T * B, 3 * H, I0, x, I0, w_ih[0], I0, 0.f, ai_of(0, 0), 3 * H, b_ih[0], gws, gws_bytes, stream);
+    if (st != CTC_STATUS_SUCCESS) return st;
+    if (side_fill && !g_side.order(g_side.s, stream)) return CTC_STATUS_EXECUTION_FAILED;
     FillBatch fills(stream, fused_fwd && fill_batch_enabled());
-    if (planes) {
+    if (planes && !side_fill) {
         fills.add(hx_base, (size_t)(drop_on ? 2 * L - 1 : L) * hx_each / 4, kPlaneSentinel);  // (the buffers are contiguous)
+    } else if (planes) {
     } else if (flagless) {
         for (int l = 0; l < L; ++l) fills.add(h_out[l], (size_t)T * B * H, kSentinel);
     }
