@@ -19,6 +19,7 @@
 //   forward : 3 gate tiles (r, z, n rows of W_hh) x K = H
 //   backward: 1 tile of dh_{t-1} = dah_t W_hh (rows of W_hh^T, transposed once per call) x K = 3H, then the gate
 //             gradients of step t-1 in the epilogue (they become the next launch's A operand).
+#include <type_traits>
 #include <stdlib.h>
 
 #include <mutex>
@@ -1866,7 +1867,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // consecutive k = the block's 16 units of one gate -- the A operand of the layer's input-gradient product
 // d in = sum over directions of dai W_ih, which runs between this layer's recurrence and the next one's.  Waves 0 .. 2 take
 // {dpr, dpz, dpn} out of the same LDS staging; no row-major copy of dai is left.
-template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false>
+template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false, int SPEC = 4>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
@@ -1877,6 +1878,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     // bidirectional step.
     constexpr bool RN = FUSE;
     constexpr int NG = 3, NITG = NG * IPG, XT = NG * (H / 16);
+    constexpr bool HAND = SPEC > 0 && FUSE && PACKG && !PACKK;  // the tail scheduled by hand (see there)
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
     SA_PERSIST_EXCLUSIVE(P.prio);
@@ -2091,19 +2093,66 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         const int t = t0 + s * dt;
         const bool have_next = t != t_first;
         if (have_next) {  // dh_t += dah_{t+1} W_hh   (K = 3H), A rows = batch, B rows = this block's 16 units
-            gather(t - dt);
-            SA_TICK(0)
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // even / odd fragments
+            if constexpr (SPEC > 0) {
+                // (r6) The product runs on the fragments AS THEY LAND, and the trip's loads are issued BETWEEN its MFMAs.  A wave
+                // issues in order, and handing a 1 KB load to the CU's one address path (64 B / clock, four waves contending)
+                // holds it for ~35 ns: 24 of them in a row were 0.8 us during which its matrix pipe stood still before the first
+                // fragment was even waited for (probe: issue .. first fragment consumed 1.1 - 1.3 us with an EMPTY queue in front).
+                // Now SPEC loads go out up front and one more behind the first MFMA of every fragment; the queue returns in
+                // order, so the wait in front of fragment `it` is vmcnt(SPEC - 1).  Whether the trip was complete is known at
+                // its end -- a stale one (polling trips per step 1.00 - 1.02) throws its sums away and goes again.  Scheduling
+                // barriers pin the order: left alone hipcc hoists every sentinel compare, and with them the wait for the LAST
+                // fragment, to the top.  2.66 -> 2.29 ms per S-LIBRI launch (profiles/r06_backward_experiments.txt).
+                const int tslot = ring ? ((t - dt) & (kXRing - 1)) : (t - dt);
+                const int abase = a0 + tslot * (int)(s_x * 4);
+                auto load1 = [&](int it) {
+                    a[it] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           dres, abase + 1024 * (it % IPG), (it / IPG) * 4 * IPG * 1024, 16));
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                f32x4 acc2, acc3;  // four chains, one per k of a fragment: neighbouring MFMAs never share a sum
+                for (int spins = 0;; ++spins) {
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                f32x4v f = a[it];
-                if (RN && it >= 2 * IPG) f = f * rn[RN ? it - 2 * IPG : 0];  // dqn = dpn * r
-                const float4 w = wr[it];
-                f32x4& d = (it & 1) ? acc1 : acc;  // two chains: the 40-cycle dependent latency is hidden
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w.x, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w.y, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w.z, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, w.w, d, 0, 0, 0);
+                    for (int it = 0; it < SPEC && it < NIT; ++it) load1(it);
+                    acc = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc; acc2 = acc; acc3 = acc;
+                    bool stale = false;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        f32x4v f = a[it];
+                        stale |= has_sentinel(f);
+                        if (RN && it >= 2 * IPG) f = f * rn[RN ? it - 2 * IPG : 0];  // dqn = dpn * r
+                        const float4 w = wr[it];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w.x, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (it + SPEC < NIT) load1(it + SPEC);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w.y, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w.z, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, w.w, acc3, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc = acc + acc2; acc1 = acc1 + acc3;
+                    if (timed) ++tacc[4];
+                    if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+                    if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+                }
+                SA_TICK(0)
+            } else {
+                gather(t - dt);
+                SA_TICK(0)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    f32x4v f = a[it];
+                    if (RN && it >= 2 * IPG) f = f * rn[RN ? it - 2 * IPG : 0];  // dqn = dpn * r
+                    const float4 w = wr[it];
+                    f32x4& d = (it & 1) ? acc1 : acc;  // two chains: the 40-cycle dependent latency is hidden
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w.x, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w.y, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w.z, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, w.w, d, 0, 0, 0);
+                }
             }
             float* rd = red + (s & 1) * 1024;
 #pragma unroll
@@ -2156,6 +2205,81 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
         // requested -- 21 vector-memory instructions per wave whose address processing (~0.8 us per step when issued
         // back to back, measured) is dealt out between the 96 MFMAs of the second product instead.  The product runs
         // unconditionally (bottom layer: zero weights; first step: no row -- the result goes to the dump slot).
+        if constexpr (HAND) {
+            // (r6) The tail by hand (FUSE, PACKG, not PACKK): the 3 IPG quads of second-product MFMAs with the step's 13 + IPG
+            // vector-memory instructions dealt out evenly behind them, one scheduling region each, the LOADS first -- d h_out
+            // of the layer above (another XCD wrote it through: the longest trip), the stash row, the r rows -- the stores
+            // behind them: the queue returns in order, so whatever is still on its way when the next gather goes out holds
+            // that gather's data back.  (hipcc's group barriers dealt out 8 of the 21 and issued the rest in a burst.)
+            float* ps = pks + (s & 1) * 1280 + uj * 20 + bi;
+            ps[0] = dpr; ps[320] = dpz; ps[640] = dpn; ps[960] = dqn;
+            gs0 += dpr; gs1 += dpz; gs2 += dpn; gs3 += dqn;
+            dh_run = dh;
+            z_next = z;
+            const int tn = s + 1 < nsteps ? t + dt : t;
+            f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+            auto quad = [&](int it) {
+                const float4 w = wx[FUSE ? it : 0];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, w.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, w.y, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, w.z, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, w.w, c3, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const float* st = p_st + (long)tn * s_st;
+            const float* rrow = p_rn + (long)(tn != t_first ? tn - dt : tn) * s_st;
+            constexpr int NRN = RN ? IPG : 0, NOPS = 13 + NRN;
+            // what the stores carry, formed in the region in front of the first of them
+            float fv = 0.f;
+            float* fdst = nullptr;
+            unsigned pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0, pc0 = 0, pc1 = 0;
+            char* pdst = nullptr;
+            long ppl = 0;
+            float* di = (live && bottom) ? p_di + (long)t * s_d : p_dump;  // the d x product of layer 0 reads dai row-major
+            const int g1 = (live && bottom) ? H : 0, g2 = (live && bottom) ? 2 * H : 0;
+            auto op = [&](int k) {  // k is a constant after unrolling
+                if (k == 0) dh = __hip_atomic_load(p_dh + (long)tn * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (k == 1) r = st[0];
+                else if (k == 2) z = st[H];
+                else if (k == 3) n = st[2 * H];
+                else if (k == 4) q = st[3 * H];
+                else if (k == 5) hp = st[4 * H];
+                else if (k < 6 + NRN) rn[RN ? k - 6 : 0] = *reinterpret_cast<const f32x4v*>(rrow + 16 * (k - 6));
+                else if (k == 6 + NRN) {  // the previous row's d h_out (flush2)
+                    const float* rd = red2 + ((s - 1) & 1) * 1024;
+                    fdst = pend_t >= 0 && live ? p_dx + (long)pend_t * s_dx : p_dump;
+                    fv = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
+                    if constexpr (DROP) fv *= sa_drop_factor(drop, dx_stream, (uint64_t)((long)(pend_t < 0 ? 0 : pend_t) * B * H + dx_idx0));
+                    __hip_atomic_store(fdst, fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (k == 7 + NRN) {  // the previous row's packed gate operand (pack_row)
+                    const float4 v = *reinterpret_cast<const float4*>(pk_src + ((s - 1) & 1) * 1280);
+                    sa_split2(v.x, v.y, pa0, pb0, pc0);
+                    sa_split2(v.z, v.w, pa1, pb1, pc1);
+                    const bool on = s > 0;
+                    pdst = on ? p_pk + (long)(t - dt) * s_pk : reinterpret_cast<char*>(J.dump + ((blockIdx.x * 256 + tid) & ~1));
+                    ppl = on ? 4096 : 0;
+                    *reinterpret_cast<uint2*>(pdst) = make_uint2(pa0, pa1);
+                } else if (k == 8 + NRN) *reinterpret_cast<uint2*>(pdst + ppl) = make_uint2(pb0, pb1);
+                else if (k == 9 + NRN) *reinterpret_cast<uint2*>(pdst + 2 * ppl) = make_uint2(pc0, pc1);
+                else if (k == 10 + NRN) di[0] = dpr;
+                else if (k == 11 + NRN) di[g1] = dpz;
+                else if (k == 12 + NRN) di[g2] = dpn;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                quad(it);
+#pragma unroll
+                for (int k = 0; k < NOPS; ++k)
+                    if (k * NIT / NOPS == it) op(k);  // op k behind quad floor(k NIT / NOPS): evenly, in order
+            }
+            float* rd2 = red2 + (s & 1) * 1024;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) rd2[wave * 256 + (g * 4 + rr) * 16 + i] = (c0[rr] + c1[rr]) + (c2[rr] + c3[rr]);
+            pend_t = fuse && have_next && s > 0 ? t - dt : -1;
+            SA_TICK(3)
+            continue;
+        }
         if constexpr (FUSE) flush2((s - 1) & 1, pend_t >= 0, pend_t);
         if constexpr (PACKG) {  // the packed operand the weight-gradient products read
             float* ps = pks + (s & 1) * 1280 + uj * 20 + bi;
@@ -2780,6 +2904,9 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg
         return nullptr;
     }
     if (packg && fuse) {
+        // (r6) every instance gathers pipelined (SPEC = 4 loads in flight; with PACKG the tail is scheduled by hand); gru.exp bit 4 =
+        // the round-5 form of the S-LIBRI instance: A/B
+        if (H == 512 && !drop && (sa_opt(SA_OPT_GRU_EXP) & 16)) return gru_bwd_fused_kernel<8, true, false, true, false, 0>;
         if (H == 512) return drop ? gru_bwd_fused_kernel<8, true, true, true> : gru_bwd_fused_kernel<8, true, false, true>;
         if (H == 256) return drop ? gru_bwd_fused_kernel<4, true, true, true> : gru_bwd_fused_kernel<4, true, false, true>;
         if (H == 128) return drop ? gru_bwd_fused_kernel<2, true, true, true> : gru_bwd_fused_kernel<2, true, false, true>;
@@ -3128,8 +3255,8 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
     // (r6) the planes pre-fill (196 MB of stores at S-LIBRI) goes to the library's side stream, BESIDE the operand packs and
     // the layer-0 projection, instead of between the projection and the recurrence: the recurrence launch then starts on an
     // L2 that is not full of dirty sentinel lines (its own time 1.53 -> 1.46 ms) at the price of slower packs beside the fill;
-    // net -0.03 ms per step in three one-box pairs (profiles/r06_forward_planes_experiments.txt; gru.exp bit 6 = in line: A/B)
-    const bool side_fill = planes && !(sa_opt(SA_OPT_GRU_EXP) & 64) && g_side.init();
+    // net -0.03 ms per step in three one-box pairs (profiles/r06_forward_planes_experiments.txt; gru.exp bit 10 = in line: A/B)
+    const bool side_fill = planes && !(sa_opt(SA_OPT_GRU_EXP) & 1024) && g_side.init();
     if (side_fill) {
         if (!g_side.order(stream, g_side.s)) return CTC_STATUS_EXECUTION_FAILED;  // (the previous call's kernels read these buffers)
         FillBatch pf(g_side.s, true);
@@ -3964,11 +4091,11 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     SharedPackLayout spl;
     const bool packg = one_launch && wg && (B % 16) == 0 && sa_opt(SA_OPT_GRU_PACK_IN_KERNEL) != 0 && packg_available(H, true) &&
                        issuer.shared_ok(spl);
+    const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed
     const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
     const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
-    const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed
     FillBatch fills(stream, one_launch && fill_batch_enabled());
     if (flagless)
         for (int l = 0; l < L; ++l)  // the exchanged values are their own flags (ring: kXRing time slots, re-armed in the kernel)
