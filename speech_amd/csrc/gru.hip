@@ -1867,7 +1867,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(PBwdJobs P) {
 // consecutive k = the block's 16 units of one gate -- the A operand of the layer's input-gradient product
 // d in = sum over directions of dai W_ih, which runs between this layer's recurrence and the next one's.  Waves 0 .. 2 take
 // {dpr, dpz, dpn} out of the same LDS staging; no row-major copy of dai is left.
-template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false, int SPEC = 4>
+template <int IPG, bool FUSE, bool DROP = false, bool PACKG = false, bool PACKK = false, int SPEC = 4, bool EARLY_ON = true>
 __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr int NIT = 3 * IPG, H = 64 * IPG, H3 = 3 * H;
     // Three gates are exchanged per step.  Without the second product they are {dpr, dpz, dqn}, what the recurrent product
@@ -1879,6 +1879,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     constexpr bool RN = FUSE;
     constexpr int NG = 3, NITG = NG * IPG, XT = NG * (H / 16);
     constexpr bool HAND = SPEC > 0 && FUSE && PACKG && !PACKK;  // the tail scheduled by hand (see there)
+    constexpr bool EARLY = HAND && EARLY_ON;
     extern __shared__ __attribute__((aligned(16))) float psm[];
     __shared__ int s_role[2];
     SA_PERSIST_EXCLUSIVE(P.prio);
@@ -2112,11 +2113,12 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 f32x4 acc2, acc3;  // four chains, one per k of a fragment: neighbouring MFMAs never share a sum
-                for (int spins = 0;; ++spins) {
-                    asm volatile("" ::: "memory");
+                auto trip = [&](auto PROLOGUE) -> bool {
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (decltype(PROLOGUE)::value) {
 #pragma unroll
-                    for (int it = 0; it < SPEC && it < NIT; ++it) load1(it);
+                        for (int it = 0; it < SPEC && it < NIT; ++it) load1(it);
+                    }
                     acc = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc; acc2 = acc; acc3 = acc;
                     bool stale = false;
 #pragma unroll
@@ -2134,6 +2136,16 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     acc = acc + acc2; acc1 = acc1 + acc3;
+                    return stale;
+                };
+                // EARLY (with the hand-scheduled tail): the first SPEC loads of this trip went out behind the LAST quads of the
+                // previous step's tail -- ~0.3 us before its end, ~1.9 us after the publish they look for (the hop is ~1.2) -- so
+                // the first fragments are there when the product starts; only a retry issues them here.
+                bool prologue = !(EARLY && s > 0);
+                for (int spins = 0;; ++spins) {
+                    asm volatile("" ::: "memory");
+                    const bool stale = prologue ? trip(std::true_type{}) : trip(std::false_type{});
+                    prologue = true;
                     if (timed) ++tacc[4];
                     if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
                     if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
@@ -2266,12 +2278,23 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                 else if (k == 12 + NRN) di[g2] = dpn;
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // EARLY: the next trip's first loads (time t: the row this step has just published), into fragments the product is done with
+            const int abase_next = a0 + (ring ? (t & (kXRing - 1)) : t) * (int)(s_x * 4);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 quad(it);
 #pragma unroll
                 for (int k = 0; k < NOPS; ++k)
                     if (k * NIT / NOPS == it) op(k);  // op k behind quad floor(k NIT / NOPS): evenly, in order
+                if constexpr (EARLY) {
+                    constexpr int NE = SPEC < NIT ? SPEC : NIT;
+                    if (it >= NIT - NE) {
+                        const int e = it - (NIT - NE);
+                        a[e] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              dres, abase_next + 1024 * (e % IPG), (e / IPG) * 4 * IPG * 1024, 16));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             float* rd2 = red2 + (s & 1) * 1024;
 #pragma unroll
@@ -2904,9 +2927,10 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg
         return nullptr;
     }
     if (packg && fuse) {
-        // (r6) every instance gathers pipelined (SPEC = 4 loads in flight; with PACKG the tail is scheduled by hand); gru.exp bit 4 =
-        // the round-5 form of the S-LIBRI instance: A/B
+        // (r6) every instance gathers pipelined (SPEC = 4 loads in flight; with PACKG the tail is scheduled by hand and carries the next
+        // trip's first loads); gru.exp bit 4 = the round-5 form of the S-LIBRI instance, bit 5 = without the early loads: A/B
         if (H == 512 && !drop && (sa_opt(SA_OPT_GRU_EXP) & 16)) return gru_bwd_fused_kernel<8, true, false, true, false, 0>;
+        if (H == 512 && !drop && (sa_opt(SA_OPT_GRU_EXP) & 32)) return gru_bwd_fused_kernel<8, true, false, true, false, 4, false>;
         if (H == 512) return drop ? gru_bwd_fused_kernel<8, true, true, true> : gru_bwd_fused_kernel<8, true, false, true>;
         if (H == 256) return drop ? gru_bwd_fused_kernel<4, true, true, true> : gru_bwd_fused_kernel<4, true, false, true>;
         if (H == 128) return drop ? gru_bwd_fused_kernel<2, true, true, true> : gru_bwd_fused_kernel<2, true, false, true>;
