@@ -229,9 +229,13 @@ struct PFwdJobs {
 
 constexpr unsigned kSentinel = 0x7fc0deadu;  // a quiet NaN no finite state or gradient can equal
 constexpr int kXRing = 4;  // time slots of the backward kernels' exchange ring (a power of two; see PBwdJobs::packed)
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+// (r6) the whole vector is cast, THEN its elements are compared: __builtin_bit_cast(unsigned, v.y) on an element of an
+// ext_vector_type compiled to a compare of element 0 (hipcc 7.2: all four terms read v.x, and a 16-byte load feeding only this
+// test was narrowed to a dword) -- rounds 1-5 tested the first dword of every 16 bytes only
 __device__ __forceinline__ bool has_sentinel(f32x4v v) {
-    return __builtin_bit_cast(unsigned, v.x) == kSentinel || __builtin_bit_cast(unsigned, v.y) == kSentinel ||
-           __builtin_bit_cast(unsigned, v.z) == kSentinel || __builtin_bit_cast(unsigned, v.w) == kSentinel;
+    const u32x4v q = __builtin_bit_cast(u32x4v, v);
+    return q.x == kSentinel || q.y == kSentinel || q.z == kSentinel || q.w == kSentinel;
 }
 
 // One XCD-local persistent workgroup per CU, by construction: the empty asm clobbers v255 and a7, which pins the
@@ -2120,11 +2124,18 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                         for (int it = 0; it < SPEC && it < NIT; ++it) load1(it);
                     }
                     acc = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc; acc2 = acc; acc3 = acc;
-                    bool stale = false;
+                    // every element XOR the sentinel, folded by unsigned minimum (4 v_xor + 2 v_min3 per fragment, in the shadow
+                    // of its MFMAs): zero at the end <=> the trip brought a sentinel.  Independent of the MFMAs' results: the
+                    // branch behind the last fragment does not wait for the matrix pipe to drain.
+                    unsigned fold = ~0u;
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         f32x4v f = a[it];
-                        stale |= has_sentinel(f);
+                        {
+                            const u32x4v q = __builtin_bit_cast(u32x4v, f) ^ kSentinel;
+                            fold = min(min(fold, q.x), q.y);
+                            fold = min(min(fold, q.z), q.w);
+                        }
                         if (RN && it >= 2 * IPG) f = f * rn[RN ? it - 2 * IPG : 0];  // dqn = dpn * r
                         const float4 w = wr[it];
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w.x, acc, 0, 0, 0);
@@ -2136,7 +2147,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     acc = acc + acc2; acc1 = acc1 + acc3;
-                    return stale;
+                    return fold == 0u;  // some element equals the sentinel
                 };
                 // EARLY (with the hand-scheduled tail): the first SPEC loads of this trip went out behind the LAST quads of the
                 // previous step's tail -- ~0.3 us before its end, ~1.9 us after the publish they look for (the hop is ~1.2) -- so

@@ -1,8 +1,10 @@
-# scratch: the command list of the current gpurun call (overwritten per call; see tools/README.md)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r6bs
-bash tools/ab_env.sh 3 SA_GRU_EXP=64 - 2>&1 | tee gpurun_out/r6bs/ab.txt
-export TRACE_MIN_US=0
-bash tools/gpu_run.sh r6bs "trace:tools/step_bench.py --no-prof" > /dev/null 2>&1
-sed -n 1,3p gpurun_out/r6bs/step_bench_timeline.txt; grep -n "gru_bwd\|pk_pack\|side_wait" gpurun_out/r6bs/step_bench_timeline.txt | cut -c1-140
-bash tools/gpu_run.sh r6bs "tests:baseline_configs or dropout or model or train_eval"
+mkdir -p gpurun_out/r6bx
+cp speech_amd/libspeech_amd.so tools/_ab_libs/new.so
+for r in 1 2 3; do for v in old new; do
+  cp tools/_ab_libs/$v.so speech_amd/libspeech_amd.so; touch speech_amd/libspeech_amd.so
+  echo "== $v"; bash tools/ab_env.sh 1 - 2>&1
+done; done | tee gpurun_out/r6bx/ab.txt
+cp tools/_ab_libs/new.so speech_amd/libspeech_amd.so; touch speech_amd/libspeech_amd.so
+python tools/gru_bwd_timing.py 2>&1 | grep "all blocks"
+bash tools/gpu_run.sh r6bx "tests:baseline_configs or fused or stack or dropout or health or fault"
