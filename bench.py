@@ -491,6 +491,16 @@ def planes_forward():
         return False
 
 
+def elements16_backward():
+    """The one-launch backward of the headline stack (H = 512, in-kernel packed gate operands) runs gru_bwd_fused16_kernel
+    unless option gru.exp bit 7 asks for the three-tile exchange."""
+    from speech_amd import _lib
+    try:
+        return (_lib.get_option("gru.exp") & 128) == 0 and _lib.get_option("gru.pack_in_kernel") != 0
+    except Exception:
+        return False
+
+
 def roofline(prof, step_us, steps):
     """Roofline of the dominant kernel: the GRU backward recurrence (largest share of the step in every rocprof summary
     under profiles/).  Duration = the kernel's own entry-to-exit device clock inside the timed region (HIP events around
@@ -526,6 +536,8 @@ def roofline(prof, step_us, steps):
             name, us = name.replace("_step_", "_fused_" if nsteps > 64 else "_persist_"), kern_us
             if name == "gru_fwd_fused_kernel" and planes_forward():
                 name = "gru_fwd_planes_kernel"  # the default one-launch forward since round 6
+            if name == "gru_bwd_fused_kernel" and elements16_backward():
+                name = "gru_bwd_fused16_kernel"  # the default one-launch backward at H = 512 since round 6 (16-byte elements)
         if us <= 0:
             continue
         nbytes = 4.0 * B * 512 * per_job * 4 * nsteps  # 4 layer-jobs x nsteps steps per launch, B x H fp32 each

@@ -2385,6 +2385,297 @@ __global__ __launch_bounds__(256) void gru_bwd_fused_kernel(PBwdJobs P) {
     if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
 }
 
+// ----------------------------------------------- (r6) the one-launch backward recurrence on 16-byte elements {dpr, dpz, dqn, dpn}
+// gru_bwd_fused_kernel<8, FUSE, DROP, PACKG> (H = 512) with another exchange layout.  That kernel publishes three 1 KB tiles per
+// step (three 4-byte stores per thread, three more to re-arm) and reads the r rows of the forward stash to form dqn = dpn r
+// (eight 16-byte loads per lane and step).  Here a thread publishes its element's FOUR gate gradients -- its own dqn among them --
+// with ONE 16-byte store, unit-major: element (unit k, batch row i) of a batch tile at ((k 16) + i) 16 bytes.  A wave's fragment is
+// then 1 KB contiguous again -- lane (i, g) holds the four gates of (row i, unit 4 f + g) -- and a 16x16x4 MFMA takes ONE gate of a
+// fragment: lane (i, g) supplies A[i][g] = that gate of unit 4 f + g, the weights' lane (n, g) holds W[gate][unit 4 f + g][n].
+// Per wave and step: 32 fragments (the same 128 KB per block as 24 + 8 r rows), 3 MFMAs per fragment and product, one publish and
+// one re-arm store instead of three each, no r rows, no multiply.  The pipelined trip, the hand-scheduled tail and the early loads
+// of the other kernel carry over (see there).  Sums over k in another order than that kernel's: H = 512 with PACKG only.
+template <bool DROP, int SPEC = 4>
+__global__ __launch_bounds__(256) void gru_bwd_fused16_kernel(PBwdJobs P) {
+    constexpr int H = 512, H3 = 3 * H, NF = H / 16;  // NF fragments of 4 units per wave (H / 4 units per wave)
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    __shared__ int s_role[2];
+    SA_PERSIST_EXCLUSIVE(P.prio);
+    if (threadIdx.x == 0) {
+        const int x = xcc_id();
+        s_role[0] = x;
+        s_role[1] = (int)(__hip_atomic_fetch_add(P.reg + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.reg_base);
+    }
+    __syncthreads();
+    if (s_role[1] < 0 || s_role[1] >= 32) {
+        if (threadIdx.x == 0) sa_raise(P.err, 2u);
+        return;
+    }
+    const int sub = s_role[1] / P.ntile_u, grp = s_role[0] * (32 / P.ntile_u) + sub;
+    if (sub >= 32 / P.ntile_u) return;
+    const int role_x = s_role[1] - sub * P.ntile_u, role_z = grp / P.nbt, role_y = grp - role_z * P.nbt + P.bt0;
+    if (role_z >= P.n) return;
+    if ((P.fault & 1) && role_x == 1 && role_y == 0 && role_z == 0) return;  // injected fault: a group one member short
+    const PBwdJob& J = P.j[role_z];
+    const int B = P.B;
+    if (P.stamp && threadIdx.x == 0 && role_x + role_y + role_z == 0) P.stamp[0] = wall_clock64();
+    float* red = psm;          // [2][4][256]: the four waves' partial sums of the recurrent product, per step parity
+    float* red2 = psm + 2048;  // [2][4][256]: the same for the input-gradient product
+    float* pks = psm + 4096;   // [2][4 gates][16 units][20]: a step's gate gradients, unit-major (16 used of 20)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int u0 = role_x * 16, b0 = role_y * 16;
+    const int bi = tid >> 4, uj = tid & 15;
+    const int b = b0 + bi, u = u0 + uj;
+    const bool live = b < B;
+    const bool fuse = J.dx_out != nullptr;
+    const bool bottom = !fuse;
+    int budget = P.spin_limit;
+    __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void*)J.xch, 0, 0x7fffffff, 0x00020000);
+    // Resident for the whole launch: W[gate][unit][u0 + i] of both matrices for the lane's unit of every fragment.
+    float wr[NF][3], wx[NF][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int k = wave * (H / 4) + 4 * f + g;  // the lane's unit of fragment f
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            if (P.w_rowmajor) {
+                wr[f][n] = J.w_hh_t[(long)(n * H + k) * H + u0 + i];
+                wx[f][n] = fuse ? J.w_ih_t[(long)(n * H + k) * H + u0 + i] : 0.f;
+            } else {
+                wr[f][n] = J.w_hh_t[(long)(u0 + i) * H3 + n * H + k];
+                wx[f][n] = fuse ? J.w_ih_t[(long)(u0 + i) * H3 + n * H + k] : 0.f;
+            }
+        }
+    }
+#define SA_KEEP(v) asm volatile("" : "+s"(v))
+    const int bl = live ? b : 0;
+    int t0 = J.t0, dt = J.dt, t_first = J.t_first, nsteps = J.nsteps;
+    long s_dh = J.ds_t, s_st = (long)P.rt * 5 * H, s_d = (long)P.rt * H3, s_dx = J.xs_t;
+    long s_x = (long)P.nbt_all * H * 64;  // floats of the exchange ring per time slot: nbt_all x H units x 16 rows x 4 gates
+    unsigned* errp = P.err;
+    SA_KEEP(t0); SA_KEEP(dt); SA_KEEP(t_first); SA_KEEP(nsteps);
+    SA_KEEP(s_dh); SA_KEEP(s_st); SA_KEEP(s_d); SA_KEEP(s_dx); SA_KEEP(s_x); SA_KEEP(errp);
+#undef SA_KEEP
+    const float* p_dh = J.dh_out + (long)bl * J.ds_b + u;
+    const float* p_st = J.stash + (long)bl * P.rb * 5 * H + u;
+    float* p_dump = J.dump + blockIdx.x * 256 + (tid & ~3);  // (16-byte dump slots: a quad of lanes shares one)
+    float* p_xs = J.xch + (((long)role_y * H + u) * 16 + bi) * 4;
+    float* p_di = J.dai + (long)bl * P.rb * H3 + u;
+    float* p_dx = fuse ? J.dx_out + (long)bl * J.xs_b + u : nullptr;
+    const int a0 = (int)(((((long)role_y * H + wave * (H / 4)) * 16) * 4 + lane * 4) * 4);  // bytes: the wave's first fragment, the lane's element
+    __syncthreads();
+
+    f32x4v a[NF];
+    auto slot_of = [&](int trow) { return trow & (kXRing - 1); };
+    auto load_frag = [&](int f, int abase) {
+        a[f] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(dres, abase, f * 1024, 16));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 ar, az, an;  // one chain per gate: neighbouring MFMAs never share a sum
+    auto trip = [&](int trow, auto PROLOGUE) -> bool {  // the recurrent product on the fragments as they land; true: stale
+        const int abase = a0 + slot_of(trow) * (int)(s_x * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(PROLOGUE)::value) {
+#pragma unroll
+            for (int f = 0; f < SPEC; ++f) load_frag(f, abase);
+        }
+        ar = f32x4{0.f, 0.f, 0.f, 0.f}; az = ar; an = ar;
+        unsigned fold = ~0u;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const f32x4v v = a[f];
+            {
+                const u32x4v q = __builtin_bit_cast(u32x4v, v) ^ kSentinel;
+                fold = min(min(fold, q.x), q.y);
+                fold = min(min(fold, q.z), q.w);
+            }
+            ar = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, wr[f][0], ar, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (f + SPEC < NF) load_frag(f + SPEC, abase);
+            az = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, wr[f][1], az, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, wr[f][2], an, 0, 0, 0);  // (.z = dqn, the producer's own)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return fold == 0u;
+    };
+    f32x4 cr, cz, cn;
+    auto triple = [&](int f) {  // the second product's share of fragment f (.w = dpn)
+        cr = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].x, wx[f][0], cr, 0, 0, 0);
+        cz = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].y, wx[f][1], cz, 0, 0, 0);
+        cn = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].w, wx[f][2], cn, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto second_done = [&](int par) {
+        float* rd2 = red2 + par * 1024;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) rd2[wave * 256 + (g * 4 + rr) * 16 + i] = (cr[rr] + cz[rr]) + cn[rr];
+    };
+    // the packed gate operand: wave w packs gate w; thread (unit pu, quarter pq) takes batch rows 4 pq .. 4 pq + 3 of the tile
+    const int pu = lane >> 2, pq = lane & 3;
+    const int prow = wave * H + u0 + pu, prl = prow & 127;
+    char* p_pk = J.gpk + ((size_t)(prow >> 7) * P.pk_kb + role_y) * 12288 + prl * 32 + ((((pq >> 1) ^ (prl >> 3)) & 1) << 4) + (pq & 1) * 8;
+    const long s_pk = (long)(B / 16) * 12288;
+    const float* pk_src = pks + wave * 320 + pu * 20 + 4 * pq;
+    char* pk_dump = reinterpret_cast<char*>(J.dump + ((blockIdx.x * 256 + tid) & ~1));
+    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gs3 = 0.f;
+    const SaDrop drop = P.drop;
+    const unsigned dx_stream = J.dx_drop_stream;
+    const long dx_idx0 = (long)bl * H + u;
+    auto flush_row = [&](int par, int trow) {  // add the four waves' parts of a row of d h_out[l-1], store it write-through
+        const float* rd = red2 + par * 1024;
+        float* dst = trow >= 0 && live ? p_dx + (long)trow * s_dx : J.dump + blockIdx.x * 256 + tid;
+        float v = ((rd[tid] + rd[256 + tid]) + rd[512 + tid]) + rd[768 + tid];
+        if constexpr (DROP) v *= sa_drop_factor(drop, dx_stream, (uint64_t)((long)(trow < 0 ? 0 : trow) * B * H + dx_idx0));
+        __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
+    float dh_run = 0.f, z_next = 0.f;
+    if (live && t0 != t_first) {
+        dh_run = J.dh_state[(long)b * H + u];
+        z_next = p_st[(long)(t0 - dt) * s_st + H];
+    }
+    {   // the first step's operands
+        dh = __hip_atomic_load(p_dh + (long)t0 * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* st = p_st + (long)t0 * s_st;
+        r = st[0]; z = st[H]; n = st[2 * H]; q = st[3 * H]; hp = st[4 * H];
+    }
+    int pend_t = -1;
+    for (int s = 0; s < nsteps; ++s) {
+        const int t = t0 + s * dt;
+        const bool have_next = t != t_first;
+        if (have_next) {  // dh_t += dah_{t+1} W_hh
+            bool prologue = !(s > 0);
+            for (int spins = 0;; ++spins) {
+                asm volatile("" ::: "memory");
+                const bool stale = prologue ? trip(t - dt, std::true_type{}) : trip(t - dt, std::false_type{});
+                prologue = true;
+                if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+                if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+            }
+            float* rd = red + (s & 1) * 1024;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) rd[wave * 256 + (g * 4 + rr) * 16 + i] = (ar[rr] + az[rr]) + an[rr];
+        }
+        __syncthreads();
+        for (int spins = 0; __builtin_amdgcn_ballot_w64(live && __builtin_bit_cast(unsigned, dh) == kSentinel) != 0; ++spins) {
+            if (__builtin_bit_cast(unsigned, dh) == kSentinel)
+                dh = __hip_atomic_load(p_dh + (long)t * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+        }
+        float dpr = 0.f, dpz = 0.f, dpn = 0.f, dqn = 0.f;
+        if (live) {
+            const float* rd = red + (s & 1) * 1024;
+            if (have_next) dh = gru_bwd_total_dh(dh, rd[tid], rd[256 + tid], rd[512 + tid], rd[768 + tid], dh_run, z_next);
+            gru_bwd_gates(dh, r, z, n, q, hp, dpr, dpz, dpn, dqn);
+        }
+        // the exchange: ONE 16-byte element (rows beyond the batch publish zeros -- an element has no holes a reader could wait on)
+        *reinterpret_cast<float4*>(p_xs + (long)slot_of(t) * s_x) = make_float4(dpr, dpz, dqn, dpn);
+        {   // re-arm the element two steps back (see gru_bwd_fused_kernel); the idle case hits the dump slot
+            const bool dead = have_next && (t - dt) != t_first;
+            float* rp = dead ? p_xs + (long)slot_of(t - 2 * dt) * s_x : p_dump;
+            const float sv = __builtin_bit_cast(float, kSentinel);
+            *reinterpret_cast<float4*>(rp) = make_float4(sv, sv, sv, sv);
+        }
+        // ---- the tail: the second product's 32 triples, the step's other 13 vector-memory instructions dealt out between them (the
+        // loads first), the next trip's first loads behind the last triples
+        {
+            float* ps = pks + (s & 1) * 1280 + uj * 20 + bi;
+            ps[0] = dpr; ps[320] = dpz; ps[640] = dpn; ps[960] = dqn;
+        }
+        gs0 += dpr; gs1 += dpz; gs2 += dpn; gs3 += dqn;
+        dh_run = dh;
+        z_next = z;
+        const int tn = s + 1 < nsteps ? t + dt : t;
+        cr = f32x4{0.f, 0.f, 0.f, 0.f}; cz = cr; cn = cr;
+        const float* st = p_st + (long)tn * s_st;
+        float* di = (live && bottom) ? p_di + (long)t * s_d : J.dump + blockIdx.x * 256 + tid;  // the d x product of layer 0 reads dai row-major
+        const int g1 = (live && bottom) ? H : 0, g2 = (live && bottom) ? 2 * H : 0;
+        const int abase_next = a0 + slot_of(t) * (int)(s_x * 4);
+        unsigned pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0, pc0 = 0, pc1 = 0;
+        char* pdst = pk_dump;
+        long ppl = 0;
+        constexpr int NOPS = 13;
+        auto op = [&](int k) {  // k is a constant after unrolling
+            if (k == 0) dh = __hip_atomic_load(p_dh + (long)tn * s_dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (k == 1) r = st[0];
+            else if (k == 2) z = st[H];
+            else if (k == 3) n = st[2 * H];
+            else if (k == 4) q = st[3 * H];
+            else if (k == 5) hp = st[4 * H];
+            else if (k == 6) flush_row((s - 1) & 1, pend_t);
+            else if (k == 7) {  // the previous row's packed gate operand
+                const float4 v = *reinterpret_cast<const float4*>(pk_src + ((s - 1) & 1) * 1280);
+                sa_split2(v.x, v.y, pa0, pb0, pc0);
+                sa_split2(v.z, v.w, pa1, pb1, pc1);
+                const bool on = s > 0;
+                pdst = on ? p_pk + (long)(t - dt) * s_pk : pk_dump;
+                ppl = on ? 4096 : 0;
+                *reinterpret_cast<uint2*>(pdst) = make_uint2(pa0, pa1);
+            } else if (k == 8) *reinterpret_cast<uint2*>(pdst + ppl) = make_uint2(pb0, pb1);
+            else if (k == 9) *reinterpret_cast<uint2*>(pdst + 2 * ppl) = make_uint2(pc0, pc1);
+            else if (k == 10) di[0] = dpr;
+            else if (k == 11) di[g1] = dpz;
+            else if (k == 12) di[g2] = dpn;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            triple(f);
+#pragma unroll
+            for (int k = 0; k < NOPS; ++k)
+                if (k * NF / NOPS == f) op(k);
+            if (f >= NF - SPEC) load_frag(f - (NF - SPEC), abase_next);
+        }
+        second_done(s & 1);
+        pend_t = fuse && have_next && s > 0 ? t - dt : -1;
+    }
+    const int tl = t0 + (nsteps - 1) * dt;
+    if (fuse) {  // the chunk's last row, published by the step that just ended
+        for (int spins = 0;; ++spins) {
+            asm volatile("" ::: "memory");
+            const bool stale = trip(tl, std::true_type{});
+            if (__builtin_amdgcn_ballot_w64(stale) == 0) break;
+            if (spins > budget) { if (lane == 0) sa_raise(errp, 1u); budget = 0; break; }
+        }
+        cr = f32x4{0.f, 0.f, 0.f, 0.f}; cz = cr; cn = cr;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) triple(f);
+        second_done(nsteps & 1);
+        __syncthreads();
+        flush_row((nsteps - 1) & 1, pend_t);
+        flush_row(nsteps & 1, tl);
+    } else {
+        __syncthreads();
+    }
+    if (nsteps > 0) {  // the last step's staged gates (a barrier has passed on either branch above)
+        const float4 v = *reinterpret_cast<const float4*>(pk_src + ((nsteps - 1) & 1) * 1280);
+        unsigned pa0, pa1, pb0, pb1, pc0, pc1;
+        sa_split2(v.x, v.y, pa0, pb0, pc0);
+        sa_split2(v.z, v.w, pa1, pb1, pc1);
+        char* pdst = p_pk + (long)tl * s_pk;
+        *reinterpret_cast<uint2*>(pdst) = make_uint2(pa0, pa1);
+        *reinterpret_cast<uint2*>(pdst + 4096) = make_uint2(pb0, pb1);
+        *reinterpret_cast<uint2*>(pdst + 8192) = make_uint2(pc0, pc1);
+    }
+    __syncthreads();
+    {   // bias gradients: this batch tile's row sums, unit-major in LDS, 16 rows folded by the first 64 threads
+        float* ps = pks + uj * 20 + bi;
+        ps[0] = gs0; ps[320] = gs1; ps[640] = gs2; ps[960] = gs3;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float* qq = pks + (tid >> 4) * 320 + (tid & 15) * 20;
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tsum += qq[k];
+        J.gsum[(long)role_y * 4 * H + (tid >> 4) * H + u0 + (tid & 15)] = tsum;
+    }
+    if (live) J.dh_state[(long)b * H + u] = dh_run;
+    if (P.stamp && threadIdx.x == 0) atomicMax(P.stamp + 1, (unsigned long long)wall_clock64());  // the LAST block out
+}
+
 // ------------------------------------------------------------------------------------------------------- small helpers
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
                                                         int C) {
@@ -2930,7 +3221,7 @@ static bool xring_enabled() { return true; }  // (the backward exchange as T pre
 static bool tiled_enabled() {  // SA_GRU_TILED=0: the round-1 recurrence kernels (row-major exchange; bit-identical to the step kernels)
     return sa_opt(SA_OPT_GRU_TILED) != 0;
 }
-static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false) {
+static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg = false, bool allow16 = false) {
     if (!tiled_enabled()) return nullptr;
     if (packg && !fuse) {  // bidirectional layers: gate operands and the input-gradient operand
         if (H == 512) return gru_bwd_fused_kernel<8, false, false, true, true>;
@@ -2940,6 +3231,8 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg
     if (packg && fuse) {
         // (r6) every instance gathers pipelined (SPEC = 4 loads in flight; with PACKG the tail is scheduled by hand and carries the next
         // trip's first loads); gru.exp bit 4 = the round-5 form of the S-LIBRI instance, bit 5 = without the early loads: A/B
+        // (r6) H = 512: the exchange on 16-byte elements {dpr, dpz, dqn, dpn} (gru_bwd_fused16_kernel); gru.exp bit 7 = three tiles: A/B
+        if (H == 512 && allow16 && !(sa_opt(SA_OPT_GRU_EXP) & 128)) return drop ? gru_bwd_fused16_kernel<true> : gru_bwd_fused16_kernel<false>;
         if (H == 512 && !drop && (sa_opt(SA_OPT_GRU_EXP) & 16)) return gru_bwd_fused_kernel<8, true, false, true, false, 0>;
         if (H == 512 && !drop && (sa_opt(SA_OPT_GRU_EXP) & 32)) return gru_bwd_fused_kernel<8, true, false, true, false, 4, false>;
         if (H == 512) return drop ? gru_bwd_fused_kernel<8, true, true, true> : gru_bwd_fused_kernel<8, true, false, true>;
@@ -2952,6 +3245,8 @@ static BwdPersistFn bwd_fused_fn(int H, bool fuse, bool drop = false, bool packg
 #undef SA_BWD_FUSED
     return nullptr;
 }
+// gru_bwd_fused16_kernel exchanges FOUR values per element: its ring holds 4 H floats per batch row and slot
+static bool bwd_fused_is16(BwdPersistFn fn) { return fn == gru_bwd_fused16_kernel<true> || fn == gru_bwd_fused16_kernel<false>; }
 // the backward kernel has a form that packs the weight gradients' operands itself (PACKG / PACKK) for these widths
 static bool packg_available(int H, bool fuse) { return H == 512 || H == 256 || (fuse && H == 128); }
 typedef void (*FusedFwdFn)(PFusedFwd);
@@ -4127,7 +4422,8 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     const bool packg = one_launch && wg && (B % 16) == 0 && sa_opt(SA_OPT_GRU_PACK_IN_KERNEL) != 0 && packg_available(H, true) &&
                        issuer.shared_ok(spl);
     const int xring = tiled && xring_enabled() ? 2 : 1;  // PBwdJobs::packed
-    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg) : nullptr;
+    const BwdPersistFn tiled_fn = tiled ? bwd_fused_fn(H, fused, fused && drop_on, packg, xring == 2 && T >= 8) : nullptr;
+    const int xgates = tiled_fn != nullptr && bwd_fused_is16(tiled_fn) ? 4 : 3;  // values per element in the exchange ring
     const size_t flds = xcd_lds((size_t)(4 * 4 * 256 + (packg ? 2 * 4 * 16 * 20 : 0)) * sizeof(float));
     auto wih_t_of = [&](int l) { return (float*)(ws + wih_t_off + (size_t)(l - 1) * wih_t_each); };  // l >= 1
     auto xch_of = [&](int l) { return (float*)(ws + xch_off + (size_t)l * xch_each); };
@@ -4135,7 +4431,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
     if (flagless)
         for (int l = 0; l < L; ++l)  // the exchanged values are their own flags (ring: kXRing time slots, re-armed in the kernel)
             fills.add(tiled ? xch_of(l) : dah[l],
-                      tiled ? (size_t)(xring == 2 ? min(T, kXRing) : T) * nbt * 16 * 3 * H : (size_t)T * B * 3 * H, kSentinel);
+                      tiled ? (size_t)(xring == 2 ? min(T, kXRing) : T) * nbt * 16 * xgates * H : (size_t)T * B * 3 * H, kSentinel);
     if (!one_launch) fills.flush();
     if (!fills.ok) return CTC_STATUS_MEMOPS_FAILED;
     // the one-launch kernel reads its weight fragments from the matrices as stored (PBwdJobs::w_rowmajor): 2 L - 1 transpose
