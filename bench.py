@@ -545,7 +545,7 @@ def roofline(prof, step_us, steps):
         entry = traffic.get(name, {})
         stale = entry.get("source_sha") != sha_now
         tr = None if stale else entry.get("bytes_per_launch")
-        key = name.replace("_persist_", "_step_").replace("_fused_", "_step_").replace("_planes_", "_step_")
+        key = name.replace("_persist_", "_step_").replace("_fused16_", "_step_").replace("_fused_", "_step_").replace("_planes_", "_step_")
         # the matrix-pipe view: 2 B 3H H flops per product and layer-step; 4 recurrent + 3 second / input products per step
         gflop = 2.0 * B * 1536 * 512 * 7 * nsteps / 1e9
         fwd = "fwd" in name

@@ -1,2 +1,3 @@
+# scratch: the command list of the current gpurun call (overwritten per call; see tools/README.md)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-bash tools/gpu_run.sh r6cg tests
+bash tools/gpu_run.sh r6final4 "tests:health or dist or bench" "bench:--steps 20 --warmup 5" smoke
