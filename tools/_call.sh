@@ -1,3 +1,4 @@
-# scratch: the command list of the current gpurun call (overwritten per call; see tools/README.md)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-bash tools/gpu_run.sh r6final4 "tests:health or dist or bench" "bench:--steps 20 --warmup 5" smoke
+mkdir -p gpurun_out/r6ch
+timeout 900 bash tools/ab_env.sh 3 - SA_GRU_EXP=1 2>&1 | tee gpurun_out/r6ch/ab.txt
+SA_GRU_EXP=1 timeout 600 bash tools/gpu_run.sh r6ch "tests:planes or baseline_configs"
