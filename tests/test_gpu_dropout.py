@@ -155,6 +155,41 @@ def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatc
             assert torch.equal(grads["kernel"][k], grads["shared"][k]), k
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_backward_on_16_byte_elements_gives_the_three_tile_gradients(monkeypatch, p_drop):
+    # gru_bwd_fused16_kernel (H = 512 with the in-kernel packed gate operand: a thread publishes {dpr, dpz, dqn, dpn} with one
+    # 16-byte store, no r rows are read, an MFMA takes one gate of a fragment) against gru_bwd_fused_kernel<8, FUSE, DROP, PACKG>
+    # (option gru.exp bit 7: three 1 KB tiles per step, dqn = dpn r formed by the consumer): the same products summed over k in
+    # another order -- every parameter gradient to fp32 summation-order noise, with and without inter-layer dropout.  T' = 58
+    # steps: the ring (4 slots) wraps many times; B = 32: two batch tiles.
+    from speech_amd.models import CTC
+    cfg = {"dropout": p_drop, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 512, "layers": 3, "bidirectional": False}}}
+    monkeypatch.setenv("SA_GEMM_EXACT", "0")  # (every product packed, whatever its size: the path the in-kernel operand belongs to)
+    rng = np.random.RandomState(11)
+    B = 32
+    x = rng.randn(B, 120, 40).astype(np.float32)
+    labels = tuple(rng.randint(0, 20, 6) for _ in range(B))
+    batch = (tuple(x[b] for b in range(B)), labels)
+    grads = {}
+    for mode, exp in (("elements16", "0"), ("tiles3", "128")):
+        monkeypatch.setenv("SA_GRU_EXP", exp)
+        torch.manual_seed(3)
+        model = CTC(40, 20, cfg).cuda()
+        model.set_train()
+        model._plan.fixed_seed = 99
+        loss = model.loss(batch)
+        loss.backward()
+        assert torch.isfinite(loss)
+        grads[mode] = {k: q.grad.clone() for k, q in model.named_parameters()}
+    for k, want in grads["tiles3"].items():
+        got = grads["elements16"][k]
+        assert torch.isfinite(got).all(), k
+        rel = float((got - want).norm() / want.norm().clamp_min(1e-20))
+        assert rel <= 2e-6, (k, rel)
+    # (two different kernels did run: the same sums in another order do not agree bit for bit over 3.9 M weight gradients)
+    assert any(not torch.equal(grads["elements16"][k], grads["tiles3"][k]) for k in grads["tiles3"])
+
+
 @pytest.mark.parametrize("H,B", [(384, 32), (320, 20)])
 def test_widths_between_the_kernel_templates(H, B):
     # the XCD-local kernels take every multiple of 64 from 128 to 512 (H / 16 unit tiles per sync group; the CUs of an XCD
