@@ -155,18 +155,17 @@ def test_shared_packed_operands_give_the_per_product_weight_gradients(monkeypatc
             assert torch.equal(grads["kernel"][k], grads["shared"][k]), k
 
 
-@pytest.mark.parametrize("p_drop", [0.0, 0.3])
-def test_backward_on_16_byte_elements_gives_the_three_tile_gradients(monkeypatch, p_drop):
+@pytest.mark.parametrize("p_drop,B", [(0.0, 32), (0.3, 32), (0.0, 48)])
+def test_backward_on_16_byte_elements_gives_the_three_tile_gradients(monkeypatch, p_drop, B):
     # gru_bwd_fused16_kernel (H = 512 with the in-kernel packed gate operand: a thread publishes {dpr, dpz, dqn, dpn} with one
     # 16-byte store, no r rows are read, an MFMA takes one gate of a fragment) against gru_bwd_fused_kernel<8, FUSE, DROP, PACKG>
     # (option gru.exp bit 7: three 1 KB tiles per step, dqn = dpn r formed by the consumer): the same products summed over k in
     # another order -- every parameter gradient to fp32 summation-order noise, with and without inter-layer dropout.  T' = 58
-    # steps: the ring (4 slots) wraps many times; B = 32: two batch tiles.
+    # steps: the ring (4 slots) wraps many times; B = 32: two batch tiles; B = 48: three, in two passes of the launch.
     from speech_amd.models import CTC
     cfg = {"dropout": p_drop, "encoder": {"conv": [[32, 5, 32, 2]], "rnn": {"dim": 512, "layers": 3, "bidirectional": False}}}
     monkeypatch.setenv("SA_GEMM_EXACT", "0")  # (every product packed, whatever its size: the path the in-kernel operand belongs to)
     rng = np.random.RandomState(11)
-    B = 32
     x = rng.randn(B, 120, 40).astype(np.float32)
     labels = tuple(rng.randint(0, 20, 6) for _ in range(B))
     batch = (tuple(x[b] for b in range(B)), labels)
