@@ -456,7 +456,32 @@ __global__ __launch_bounds__(256) void pk_pack_kcontig_kernel(PackArgs a) {
     char* __restrict__ dst = a.dst + blockIdx.z * a.dst_stride + (size_t)blockIdx.y * a.kb_stride * PK_TILE;
     const int tid = threadIdx.x, k4 = tid & 3;
     const int kb_end = min(a.KB, ((int)blockIdx.x + 1) * a.kt);
-    for (int kb = blockIdx.x * a.kt; kb < kb_end; ++kb) {
+    // (r6) Whole k-tiles of a full-width interior block: FOUR k-tiles' loads (eight 16-byte loads per thread) in flight before the first
+    // split -- one k-tile at a time was a chain of kt L2 / HBM round trips per block (x of the S-LIBRI step: 52 us for 127 MB).
+    int kb = blockIdx.x * a.kt;
+    if (a.vec && blockIdx.y * BM + BM <= a.R) {
+        for (; kb + 4 <= kb_end && (kb + 4) * PK_K <= a.K; kb += 4) {
+            float4 v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    v[u][i] = *reinterpret_cast<const float4*>(src + (long)(blockIdx.y * BM + (tid >> 2) + 64 * i) * a.ld + (kb + u) * PK_K + 4 * k4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    split2(v[u][i].x, v[u][i].y, a1, a2, a3);
+                    split2(v[u][i].z, v[u][i].w, b1, b2, b3);
+                    char* d = dst + (size_t)(kb + u) * PK_TILE + pk_off(0, (tid >> 2) + 64 * i, k4 >> 1) + 8 * (k4 & 1);
+                    *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(d + PK_PLANE) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2*>(d + 2 * PK_PLANE) = make_uint2(a3, b3);
+                }
+        }
+    }
+    for (; kb < kb_end; ++kb) {
         char* tile = dst + (size_t)kb * PK_TILE;
         const int k = kb * PK_K + 4 * k4;
 #pragma unroll
