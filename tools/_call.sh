@@ -1,7 +1,4 @@
-# scratch: the command list of the current gpurun call (overwritten per call; see tools/README.md)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-bash tools/gpu_run.sh r6final6 "bench:--steps 20 --warmup 5" "prof:--steps 20 --warmup 5 --no-cpu-baseline --headline-only"
-export TRACE_MIN_US=0
-bash tools/gpu_run.sh r6final6 "trace:tools/step_bench.py --no-prof" > /dev/null 2>&1
-mv gpurun_out/r6final6/step_bench_timeline.txt gpurun_out/r6final6/train_step_timeline.txt
-head -2 gpurun_out/r6final6/train_step_timeline.txt
+mkdir -p gpurun_out/r6cw
+SA_GRU_EXP=1 timeout 600 bash tools/gpu_run.sh r6cw "tests:planes"
+timeout 900 bash tools/ab_env.sh 4 - SA_GRU_EXP=1 2>&1 | tee gpurun_out/r6cw/ab.txt
