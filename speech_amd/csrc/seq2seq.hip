@@ -10,6 +10,8 @@
 
 namespace {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // stash (B, 4H): r | z | n | gh_n (the hidden-side pre-activation of the candidate gate, needed by the backward)
@@ -102,18 +104,19 @@ __device__ __forceinline__ void att_stage(const AttArgs& A, int b, int t0, float
         const int t = t0 + i - pad;
         axp[i] = (A.ax_prev && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
     }
-    // eight loads in flight per thread: one load -> LDS store per trip is a serial chain of L2 round trips
-    // (H * KS / 256 = 15 of them at the shipped shapes, and it was most of the score / backward kernels' time)
+    // sixteen loads in flight per thread: one load -> LDS store per trip is a serial chain of round trips (H * KS / 256 =
+    // 15 of them at the shipped shapes, and it was most of the score / backward kernels' time; eight in flight (r4) still
+    // made it two, on an L2 that every launch finds cold)
     const int n = A.H * A.KS, stride = blockDim.x;
-    for (int base = 0; base < n; base += stride * 8) {
-        float r[8];
+    for (int base = 0; base < n; base += stride * 16) {
+        float r[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int i = base + j * stride + (int)threadIdx.x;
             r[j] = i < n ? A.conv_w[i] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int i = base + j * stride + (int)threadIdx.x;
             if (i < n) cw[i] = r[j];
         }
@@ -302,6 +305,13 @@ struct AttBwd {
     float* gb_dgi = nullptr;            // (B, 3H)
     float* gb_dgh = nullptr;            // (B, 3H)
     float* gb_dh_prev = nullptr;        // (B, H): read (dh_c, the gradient arriving from the next token's GRU) then written
+    // (r6) attention_bwd_main2_kernel: stages 1 - 3 in ONE launch.  The softmax backward needs s = sum_t ax[t] d ax[t] over the
+    // whole utterance, and d ax[t] = d_sx . eh[t] + d_ax_next[t], so s = d_sx . (sum_t ax[t] eh[t]) + sum_t ax[t] d_ax_next[t]
+    // = d_sx . sx + ...: the forward's context vector (sx = oin - ox, both stashed) replaces the pass over the utterance that
+    // made stage 1 a launch of its own; a block forms d ax for its own 16 steps from the eh rows it loads anyway.
+    const float* oin = nullptr;         // (B, H) ox + sx of this token (the fc's input)
+    int sb_chunks = 0;                  // != 0: dpax holds (B, nchunk) per-chunk sums of d score (main2), folded into g_nn_b
+                                        // by attention_bwd_fold_kernel's last block row
 };
 
 // ---- backward, stage 1: d ax[t] = (from the next token) + d_sx . eh[t].  grid (ceil(T / 16), B), a wave per time step
@@ -447,6 +457,154 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
     }
 }
 
+// ---- backward, stages 1 - 3 in one launch (H <= 256, H % 4 == 0: a thread per hidden unit).  grid (nchunk, B), 256 threads.
+// Every load of the block is issued up front (the chunk's eh / d_eh rows, the utterance's alignment rows, the staging of the
+// taps); ONE barrier later every thread holds s and the chunk's 16 d score values (17 wave sums by DPP, combined across the
+// four waves from LDS in a fixed order); phase 1 is attention_bwd_main_kernel's; phase 2 (q[t][k] = sum_h d_pre[t,h]
+// cw[h,k], a (16 x H)(H x 16) product that was a 256-iteration LDS loop per (step, tap)) runs on v_mfma_f32_16x16x4_f32, the
+// hidden units dealt to the four waves four at a time, the four partial tiles added in wave order.
+// dynamic LDS: axp[kAttTB + KS - 1] | cw[H * KS] | red[4][17] axs[16] daxn[16] (100) | dp_tile[kAttTB][H + 1] | qp[4][256]
+constexpr int kRed2 = 100;
+__global__ __launch_bounds__(256) void attention_bwd_main2_kernel(AttArgs A, AttBwd G) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* axp = reinterpret_cast<float*>(smem_raw);
+    float* cw = axp + kAttTB + A.KS - 1;
+    float* red = cw + A.H * A.KS;
+    float* axs = red + 68;
+    float* daxn = axs + kAttTB;
+    float* dp_tile = red + kRed2;
+    float* qp = dp_tile + kAttTB * (A.H + 1);
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * kAttTB;
+    const int nt = min(kAttTB, A.T - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool active = tid < A.H;
+    const int h = active ? tid : 0;
+    const float* ehb = A.eh + (long)b * A.T * A.H;
+    float* dehb = G.d_eh + (long)b * A.T * A.H;
+    const float* axb = G.ax + (long)b * A.T;
+    const float* dnb = G.d_ax_next ? G.d_ax_next + (long)b * A.T : nullptr;
+    const long bh = (long)b * A.H + h;
+    // ---- every global load of the block, before anything waits
+    float ev[kAttTB], dv[kAttTB];
+#pragma unroll
+    for (int tl = 0; tl < kAttTB; ++tl) {
+        const long o = (long)(t0 + (tl < nt ? tl : 0)) * A.H + h;
+        ev[tl] = ehb[o];
+        dv[tl] = dehb[o];
+    }
+    const float oxh = A.ox[bh];
+    const float dsxh = active ? G.d_sx[bh] + (G.d_sx2 ? G.d_sx2[bh] : 0.f) : 0.f;
+    const float sxh = G.oin[bh] - oxh;
+    const float w = A.nn_w[h];
+    const float cb = A.ax_prev ? A.conv_b[h] : 0.f;
+    // the unit's own taps straight from the matrix (one batch with everything above: staging all H * KS taps through LDS
+    // first was two more dependent round trips, and a kernel starts on a cold L2); LDS gets them for phase 2's B operand
+    float cwr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cwr[k] = (A.ax_prev && k < A.KS) ? A.conv_w[h * A.KS + k] : 0.f;
+    float axw = 0.f;   // the alignment window of the location term: ax_prev[t0 - pad + tid], zero beyond the ends
+    if (tid < kAttTB + A.KS - 1) {
+        const int t = t0 + tid - (A.KS - 1) / 2;
+        axw = (A.ax_prev && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
+    }
+    float sp = dsxh * sxh;
+    if (dnb)
+        for (int t = tid; t < A.T; t += 256) sp += axb[t] * dnb[t];
+    if (tid < kAttTB) {
+        const bool ok = tid < nt;
+        axs[tid] = ok ? axb[t0 + tid] : 0.f;
+        daxn[tid] = (ok && dnb) ? dnb[t0 + tid] : 0.f;
+    }
+    if (tid < kAttTB + A.KS - 1) axp[tid] = axw;
+    if (active && A.ax_prev) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < A.KS) cw[h * A.KS + k] = cwr[k];
+    }
+    // ---- 17 sums over the block: s and d_sx . eh[t] of the chunk's steps
+    {
+        const float v = sa_wave_sum_dpp(sp);
+        if (lane == 0) red[wave * 17 + 16] = v;
+    }
+#pragma unroll
+    for (int tl = 0; tl < kAttTB; ++tl) {
+        const float v = sa_wave_sum_dpp(dsxh * ev[tl]);
+        if (lane == 0) red[wave * 17 + tl] = v;
+    }
+    __syncthreads();
+    const float ssum = (red[16] + red[17 + 16]) + (red[34 + 16] + red[51 + 16]);
+    float dpr[kAttTB], axsr[kAttTB];
+    float sb = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < kAttTB; ++tl) {
+        const float dax = ((red[tl] + red[17 + tl]) + (red[34 + tl] + red[51 + tl])) + daxn[tl];
+        axsr[tl] = axs[tl];
+        dpr[tl] = axsr[tl] * (dax - ssum) * A.scale;   // 0 beyond the utterance's end (axs = 0)
+        sb += dpr[tl];
+    }
+    if (tid == 0) G.dpax[(long)b * G.nchunk + chunk] = sb;   // the score bias' gradient, per chunk (folded by stage 4)
+    const int W = 2 + A.KS;
+    if (active) {
+        float a_ox = 0.f, a_nw = 0.f;
+        float a_cw[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a_cw[k] = 0.f;
+        float axr[kAttTB + 15];
+#pragma unroll
+        for (int i = 0; i < kAttTB + 15; ++i) axr[i] = i < kAttTB + A.KS - 1 ? axp[i] : 0.f;
+#pragma unroll
+        for (int tl = 0; tl < kAttTB; ++tl) {
+            if (tl < nt) {
+                float pre = ev[tl] + oxh;
+                if (A.ax_prev) {
+                    float c = cb;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) c += cwr[k] * axr[tl + k];   // taps beyond KS are zeros: no guard
+                    pre += c;
+                }
+                const float dp = pre > 0.f ? dpr[tl] * w : 0.f;
+                a_ox += dp;
+                a_nw += dpr[tl] * fmaxf(pre, 0.f);
+                if (A.ax_prev) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a_cw[k] += dp * axr[tl + k];
+                }
+                dehb[(long)(t0 + tl) * A.H + h] = dv[tl] + (axsr[tl] * dsxh + dp);
+                dp_tile[tl * (A.H + 1) + h] = dp;
+            }
+        }
+        float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + h) * W;
+        p[0] = a_ox;
+        p[1] = a_nw;
+        for (int k = 0; k < A.KS; ++k) p[2 + k] = a_cw[k];
+    }
+    if (!A.ax_prev) return;
+    __syncthreads();
+    {   // A[m = step][k = unit] from dp_tile, B[k = unit][n = tap] from cw (column 15 and the rows beyond nt are never stored)
+        const int m = lane & 15, kq = lane >> 4;
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int nk = A.H >> 2;
+        int ks = wave;
+        for (; ks + 4 < nk; ks += 8) {
+            const int h0 = ks * 4 + kq, h1 = h0 + 16;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dp_tile[m * (A.H + 1) + h0], cw[h0 * A.KS + m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dp_tile[m * (A.H + 1) + h1], cw[h1 * A.KS + m], acc1, 0, 0, 0);
+        }
+        if (ks < nk) {
+            const int h0 = ks * 4 + kq;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dp_tile[m * (A.H + 1) + h0], cw[h0 * A.KS + m], acc0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qp[wave * 256 + (4 * kq + r) * 16 + m] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    {
+        const int tl = tid >> 4, k = tid & 15;
+        const float v = (qp[tid] + qp[256 + tid]) + (qp[512 + tid] + qp[768 + tid]);
+        if (tl < nt && k < A.KS) G.q[((long)b * A.T + t0 + tl) * A.KS + k] = v;
+    }
+}
+
 // ---- backward, stage 4: fold the chunks.  grid (2 + KS + 1, B), 256 threads: block (j, b) folds quantity j of the
 // per-chunk partials for every hidden unit (j = 0: d_pre sums -> d_ox and conv bias, 1: nn weight, 2 + k: conv tap k);
 // the last block row gathers d ax_prev from q.  (One block per utterance doing all 17 quantities serially was 25 us of
@@ -459,22 +617,37 @@ __global__ __launch_bounds__(256) void attention_bwd_fold_kernel(AttArgs A, AttB
         for (int h = threadIdx.x; h < A.H; h += 256) {
             const float* p = G.part + ((long)b * G.nchunk * A.H + h) * W + j;
             const long cs = (long)A.H * W;
-            float acc = 0.f;
-            int c = 0;
-            for (; c + 4 <= G.nchunk; c += 4) {
-                const float v0 = p[c * cs], v1 = p[(c + 1) * cs], v2 = p[(c + 2) * cs], v3 = p[(c + 3) * cs];
-                acc += v0; acc += v1; acc += v2; acc += v3;
-            }
-            for (; c < G.nchunk; ++c) acc += p[c * cs];
+            // what the sum is added to / continued with is fetched with the partials: one round trip, not two or three
+            const long i = (long)b * A.H + h;
+            float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, dha = 0.f, dhc = 0.f, hp = 0.f, old = 0.f;
             if (j == 0) {
-                G.d_ox[(long)b * A.H + h] = acc;
-                if (A.ax_prev) G.g_conv_b[(long)b * A.H + h] += acc;
-                if (G.gb_dgi) {   // grucell_gates_bwd_kernel for (b, h): dh = dOIN + d_ox + (from the next token's GRU)
-                    const long i = (long)b * A.H + h;
+                if (A.ax_prev) old = G.g_conv_b[i];
+                if (G.gb_dgi) {
                     const float* sg = G.gb_stash + (long)b * 4 * A.H;
-                    const float r = sg[h], z = sg[A.H + h], n = sg[2 * A.H + h], ghn = sg[3 * A.H + h];
-                    const float g = G.gb_dh_a[i] + acc + G.gb_dh_prev[i];
-                    const float hp = G.gb_h_prev ? G.gb_h_prev[i] : 0.f;
+                    r = sg[h]; z = sg[A.H + h]; n = sg[2 * A.H + h]; ghn = sg[3 * A.H + h];
+                    dha = G.gb_dh_a[i]; dhc = G.gb_dh_prev[i];
+                    hp = G.gb_h_prev ? G.gb_h_prev[i] : 0.f;
+                }
+            } else if (j == 1) {
+                old = G.g_nn_w[i];
+            } else {
+                old = G.g_conv_w[i * A.KS + j - 2];
+            }
+            // sixteen chunks' partials in flight (four (r4) made a T' = 197 utterance's 13 chunks four dependent trips)
+            float acc = 0.f;
+            for (int c0 = 0; c0 < G.nchunk; c0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = c0 + u < G.nchunk ? p[(c0 + u) * cs] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (c0 + u < G.nchunk) acc += v[u];
+            }
+            if (j == 0) {
+                G.d_ox[i] = acc;
+                if (A.ax_prev) G.g_conv_b[i] = old + acc;
+                if (G.gb_dgi) {   // grucell_gates_bwd_kernel for (b, h): dh = dOIN + d_ox + (from the next token's GRU)
+                    const float g = dha + acc + dhc;
                     const float dn = g * (1.0f - z) * (1.0f - n * n);
                     const float dz = g * (hp - n) * z * (1.0f - z);
                     const float dr = dn * ghn * r * (1.0f - r);
@@ -485,12 +658,18 @@ __global__ __launch_bounds__(256) void attention_bwd_fold_kernel(AttArgs A, AttB
                     G.gb_dh_prev[i] = g * z;
                 }
             } else if (j == 1) {
-                G.g_nn_w[(long)b * A.H + h] += acc;
+                G.g_nn_w[i] = old + acc;
             } else {
-                G.g_conv_w[((long)b * A.H + h) * A.KS + j - 2] += acc;
+                G.g_conv_w[i * A.KS + j - 2] = old + acc;
             }
         }
         return;
+    }
+    if (G.sb_chunks && threadIdx.x < 64) {   // main2's per-chunk sums of d score (a lane per chunk: one round trip)
+        float acc = 0.f;
+        for (int c = threadIdx.x; c < G.nchunk; c += 64) acc += G.dpax[(long)b * G.nchunk + c];
+        acc = sa_wave_sum_dpp(acc);
+        if (threadIdx.x == 0) G.g_nn_b[b] += acc;
     }
     if (!A.ax_prev) return;
     const int pad = (A.KS - 1) / 2;
@@ -672,7 +851,6 @@ extern "C" ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows,
 
 namespace {
 
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // C[m, n] = sum_k A[m, k] B[n, k] (+ bias[n]) (+ C[m, n])  for few rows m: a workgroup owns a 16 x 16 output tile,
 // its four waves split K (v_mfma_f32_16x16x4_f32, 16-byte k-contiguous operand loads on both sides, LDS reduce).
@@ -1006,6 +1184,9 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * (H + 1)) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
     const bool fuse_b = true;
+    const size_t smem2 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + kRed2 + (size_t)kAttTB * (H + 1) + 4 * 256) * sizeof(float);
+    const bool one_launch = H <= 256 && sa_opt(SA_OPT_S2S_BWD_ONE) != 0 &&
+                            att_smem((const void*)attention_bwd_main2_kernel, smem2);
     for (int t = U1 - 1; t >= 0; --t) {
         const bool has_next = t + 1 < U1;
         const float* hx = HX + (long)t * B * H;
@@ -1026,9 +1207,15 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
             G.gb_h_prev = t > 0 ? HX + (long)(t - 1) * B * H : nullptr;
             G.gb_dgi = dgi; G.gb_dgh = dgh; G.gb_dh_prev = d_hprev;
         }
-        hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
-        if (!fuse_b) hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
-        hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
+        if (one_launch) {   // (r6) stages 1 - 3 in one launch: three launches per token
+            G.oin = OIN + (long)t * B * H;
+            G.sb_chunks = 1;
+            hipLaunchKernelGGL(attention_bwd_main2_kernel, dim3(nchunk, B), dim3(256), smem2, stream, A, G);
+        } else {
+            hipLaunchKernelGGL(attention_bwd_dax_kernel, dim3(nchunk, B), dim3(256), 0, stream, A, G);
+            if (!fuse_b) hipLaunchKernelGGL(attention_bwd_softmax_kernel, dim3(B), dim3(256), 0, stream, A, G);
+            hipLaunchKernelGGL(attention_bwd_main_kernel, dim3(nchunk, B), dim3(256), smem, stream, A, G);
+        }
         hipLaunchKernelGGL(attention_bwd_fold_kernel, dim3(2 + KS + 1, B), dim3(256), 0, stream, A, G);
         if (!fuse_b)
             hipLaunchKernelGGL(grucell_gates_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream,

@@ -262,3 +262,36 @@ def test_greedy_infer_in_the_library_equals_the_step_by_step_loop():
             enc = m.encode(x.cuda())
             _, want = m.infer_decode(enc, y[:, 0:1].cuda(), 7, max_len)
         assert np.array_equal(np.array(got), want.cpu().numpy()), (seed, got, want)
+
+
+def test_one_launch_attention_backward_equals_the_two_launch_stages():
+    """(r6) attention_bwd_main2_kernel (d ax, the softmax and the score network of a token in ONE launch: s = d_sx . sx + sum_t
+    ax d_ax_next instead of a pass over the utterance, the tap product on f32 MFMAs) against the round-4 stages it replaces
+    (option s2s.bwd_one = 0): every gradient of the decoder call within 2e-5 of the tensor's max magnitude, at a tiny shape
+    (H = 16: one MFMA per wave, a last chunk of 11 steps) and at the shipped WSJ shape (H = 256, T' = 197: a last chunk of 5)."""
+    from speech_amd import _lib
+    from speech_amd.models import Seq2Seq
+    for (dim, F, T, B, U, conv) in ((16, 20, 90, 3, 7, [[4, 5, 9, 2]]), (256, 40, 400, 4, 12, [[8, 5, 8, 2]])):
+        cfg = {"dropout": 0.0, "encoder": {"conv": conv, "rnn": {"dim": dim, "bidirectional": True, "layers": 1}},
+               "decoder": {"embedding_dim": dim, "layers": 1, "log_t": True}}
+        torch.manual_seed(11)
+        m = Seq2Seq(F, 12, cfg).cuda()
+        m.set_train()
+        rng = np.random.RandomState(3)
+        inputs = tuple(rng.randn(T, F).astype(np.float32) for _ in range(B))
+        labels = tuple([11] + list(rng.randint(0, 10, U - 2)) + [10] for _ in range(B))
+        got = {}
+        try:
+            for one in (1, 0):
+                _lib.set_option("s2s.bwd_one", one)
+                m.zero_grad(set_to_none=True)
+                m.loss((inputs, labels)).backward()
+                got[one] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+        finally:
+            _lib.set_option("s2s.bwd_one", 1)
+        for n in got[1]:
+            a, w = got[1][n], got[0][n]
+            assert np.isfinite(a).all(), n
+            # the score bias' gradient is analytically zero (the softmax is shift invariant): both paths deliver rounding noise
+            tol = 1e-6 if n.endswith("attend.nn.1.fc.bias") else 2e-5 * max(np.abs(w).max(), 1e-3)
+            assert np.abs(a - w).max() <= tol, (dim, n, np.abs(a - w).max(), np.abs(w).max())

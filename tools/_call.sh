@@ -1,4 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r6cy
-SA_GRU_EXP=256 timeout 900 bash tools/gpu_run.sh r6cy "tests:baseline_configs or shared_packed or model"
-timeout 1200 bash tools/ab_env.sh 5 - SA_GRU_EXP=256 2>&1 | tee gpurun_out/r6cy/ab.txt
+mkdir -p gpurun_out/r6s3
+timeout 900 bash tools/gpu_run.sh r6s3 "tests:seq2seq or s2s or Seq2Seq or config_4 or options"
+timeout 300 python tools/s2s_train_profile.py 20 > gpurun_out/r6s3/plain.log 2>&1; tail -1 gpurun_out/r6s3/plain.log
+timeout 600 bash tools/gpu_run.sh r6s3 "profpy:tools/s2s_train_profile.py 10" | head -16 | cut -c1-150
