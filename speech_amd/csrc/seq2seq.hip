@@ -457,18 +457,26 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
     }
 }
 
-// ---- backward, stages 1 - 3 in one launch (H <= 256, H % 4 == 0: a thread per hidden unit).  grid (nchunk, B), 256 threads.
-// Every load of the block is issued up front (the chunk's eh / d_eh rows, the utterance's alignment rows, the staging of the
-// taps); ONE barrier later every thread holds s and the chunk's 16 d score values (17 wave sums by DPP, combined across the
-// four waves from LDS in a fixed order); phase 1 is attention_bwd_main_kernel's; phase 2 (q[t][k] = sum_h d_pre[t,h]
-// cw[h,k], a (16 x H)(H x 16) product that was a 256-iteration LDS loop per (step, tap)) runs on v_mfma_f32_16x16x4_f32, the
-// hidden units dealt to the four waves four at a time, the four partial tiles added in wave order.
-// dynamic LDS: axp[kAttTB + KS - 1] | cw[H * KS] | red[4][17] axs[16] daxn[16] (100) | dp_tile[kAttTB][H + 1] | qp[4][256]
+// ---- backward, stages 1 - 3 in one launch (H <= 256, H % 4 == 0).  grid (nchunk, B), 256 threads.
+// One wave per SIMD runs this kernel's instruction stream alone, so the stream's LENGTH is the kernel's time: a thread per
+// hidden unit walking its 16 steps (the round-4 layout) was ~2900 instructions, 480 of them the two 16 x 15 tap sums.  Here
+// a wave owns up to four tiles of 16 hidden units in the MFMA accumulator layout -- lane (kq = lane / 16, m = lane % 16)
+// holds steps 4 kq .. 4 kq + 3 of unit 16 tile + m -- and the tap sums are f32 MFMAs (v_mfma_f32_16x16x4_f32, exact fp32 FMA
+// chains in k order):
+//   location term  c[t][h] = conv_b[h] + sum_k ax_prev[t + k - pad] cw[h][k]   A = the alignment window (Toeplitz), B = cw^T
+//   tap gradients  a_cw[h][k] = sum_t d_pre[t][h] ax_prev[t + k - pad]         A = d_pre as it sits in the accumulator
+//                  (column 15 of B is ones: the same product delivers a_ox[h] = sum_t d_pre[t][h])
+//   a_nw[h] = sum_t d score[t] relu(pre[t][h])                                 A = the products, B = ones
+//   q[t][k] = sum_h d_pre[t][h] cw[h][k]   (phase 2, out of an LDS tile of d_pre; was a 256-iteration LDS loop per (t, k))
+// Every global load of the block is issued up front; ONE barrier later every lane holds s and its four d score values (the
+// 16 sums d_sx . eh[t] by DPP row sums, combined across the waves from LDS in wave order).
+// dynamic LDS: axp[32] | cw[H * KS] | red[4][17] axs[16] daxn[16] (100) | dp_tile[kAttTB][H + 1] | qp[4][256]
 constexpr int kRed2 = 100;
+constexpr int kAxp2 = 32;
 __global__ __launch_bounds__(256) void attention_bwd_main2_kernel(AttArgs A, AttBwd G) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* axp = reinterpret_cast<float*>(smem_raw);
-    float* cw = axp + kAttTB + A.KS - 1;
+    float* cw = axp + kAxp2;
     float* red = cw + A.H * A.KS;
     float* axs = red + 68;
     float* daxn = axs + kAttTB;
@@ -477,37 +485,45 @@ __global__ __launch_bounds__(256) void attention_bwd_main2_kernel(AttArgs A, Att
     const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * kAttTB;
     const int nt = min(kAttTB, A.T - t0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool active = tid < A.H;
-    const int h = active ? tid : 0;
+    const int m = lane & 15, kq = lane >> 4;
+    const int ntile = (A.H + 15) >> 4;
     const float* ehb = A.eh + (long)b * A.T * A.H;
     float* dehb = G.d_eh + (long)b * A.T * A.H;
     const float* axb = G.ax + (long)b * A.T;
     const float* dnb = G.d_ax_next ? G.d_ax_next + (long)b * A.T : nullptr;
-    const long bh = (long)b * A.H + h;
+    const bool loc = A.ax_prev != nullptr;
     // ---- every global load of the block, before anything waits
-    float ev[kAttTB], dv[kAttTB];
+    float ev[4][4], dv[4][4], cwB[4][4], oxh[4], dsxh[4], wv[4], cbv[4];
+    float sp = 0.f;
 #pragma unroll
-    for (int tl = 0; tl < kAttTB; ++tl) {
-        const long o = (long)(t0 + (tl < nt ? tl : 0)) * A.H + h;
-        ev[tl] = ehb[o];
-        dv[tl] = dehb[o];
+    for (int jj = 0; jj < 4; ++jj) {
+        const int h = (wave + 4 * jj) * 16 + m;
+        const bool hv = h < A.H;   // false for the whole wave beyond the last tile, for some lanes inside a ragged last tile
+        const int hc = hv ? h : 0;
+        const long bh = (long)b * A.H + hc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tl = 4 * kq + r;
+            const long o = (long)(t0 + (tl < nt ? tl : 0)) * A.H + hc;
+            ev[jj][r] = ehb[o];
+            dv[jj][r] = dehb[o];
+        }
+        oxh[jj] = A.ox[bh];
+        dsxh[jj] = hv ? G.d_sx[bh] + (G.d_sx2 ? G.d_sx2[bh] : 0.f) : 0.f;
+        wv[jj] = hv ? A.nn_w[hc] : 0.f;
+        cbv[jj] = loc ? A.conv_b[hc] : 0.f;
+        if (kq == 0) sp += dsxh[jj] * (G.oin[bh] - oxh[jj]);   // a unit sits in four lanes (one per step group): counted once
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = 4 * s4 + kq;
+            cwB[jj][s4] = (loc && hv && k < A.KS) ? A.conv_w[hc * A.KS + k] : 0.f;
+        }
     }
-    const float oxh = A.ox[bh];
-    const float dsxh = active ? G.d_sx[bh] + (G.d_sx2 ? G.d_sx2[bh] : 0.f) : 0.f;
-    const float sxh = G.oin[bh] - oxh;
-    const float w = A.nn_w[h];
-    const float cb = A.ax_prev ? A.conv_b[h] : 0.f;
-    // the unit's own taps straight from the matrix (one batch with everything above: staging all H * KS taps through LDS
-    // first was two more dependent round trips, and a kernel starts on a cold L2); LDS gets them for phase 2's B operand
-    float cwr[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) cwr[k] = (A.ax_prev && k < A.KS) ? A.conv_w[h * A.KS + k] : 0.f;
     float axw = 0.f;   // the alignment window of the location term: ax_prev[t0 - pad + tid], zero beyond the ends
-    if (tid < kAttTB + A.KS - 1) {
+    if (tid < kAxp2) {
         const int t = t0 + tid - (A.KS - 1) / 2;
-        axw = (A.ax_prev && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
+        axw = (loc && tid < kAttTB + A.KS - 1 && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
     }
-    float sp = dsxh * sxh;
     if (dnb)
         for (int t = tid; t < A.T; t += 256) sp += axb[t] * dnb[t];
     if (tid < kAttTB) {
@@ -515,73 +531,97 @@ __global__ __launch_bounds__(256) void attention_bwd_main2_kernel(AttArgs A, Att
         axs[tid] = ok ? axb[t0 + tid] : 0.f;
         daxn[tid] = (ok && dnb) ? dnb[t0 + tid] : 0.f;
     }
-    if (tid < kAttTB + A.KS - 1) axp[tid] = axw;
-    if (active && A.ax_prev) {
+    if (tid < kAxp2) axp[tid] = axw;
+    if (loc) {   // the taps into LDS for phase 2's B operand (every element of cw is held by exactly one lane)
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k < A.KS) cw[h * A.KS + k] = cwr[k];
+        for (int jj = 0; jj < 4; ++jj) {
+            const int h = (wave + 4 * jj) * 16 + m;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 4 * s4 + kq;
+                if (h < A.H && k < A.KS) cw[h * A.KS + k] = cwB[jj][s4];
+            }
+        }
     }
-    // ---- 17 sums over the block: s and d_sx . eh[t] of the chunk's steps
+    // ---- the block's 17 sums: s, and d_sx . eh[t] for the chunk's steps (a lane: its four steps over its four units, then the
+    // row of 16 lanes by DPP, then the four waves through LDS)
     {
         const float v = sa_wave_sum_dpp(sp);
         if (lane == 0) red[wave * 17 + 16] = v;
     }
 #pragma unroll
-    for (int tl = 0; tl < kAttTB; ++tl) {
-        const float v = sa_wave_sum_dpp(dsxh * ev[tl]);
-        if (lane == 0) red[wave * 17 + tl] = v;
+    for (int r = 0; r < 4; ++r) {
+        float v = (dsxh[0] * ev[0][r] + dsxh[1] * ev[1][r]) + (dsxh[2] * ev[2][r] + dsxh[3] * ev[3][r]);
+        v += SA_DPP_F(0.f, v, 0x111, 0xf);
+        v += SA_DPP_F(0.f, v, 0x112, 0xf);
+        v += SA_DPP_F(0.f, v, 0x114, 0xf);
+        v += SA_DPP_F(0.f, v, 0x118, 0xf);
+        if (m == 15) red[wave * 17 + 4 * kq + r] = v;
     }
     __syncthreads();
     const float ssum = (red[16] + red[17 + 16]) + (red[34 + 16] + red[51 + 16]);
-    float dpr[kAttTB], axsr[kAttTB];
-    float sb = 0.f;
+    float dpr[4], axsr[4];
 #pragma unroll
-    for (int tl = 0; tl < kAttTB; ++tl) {
+    for (int r = 0; r < 4; ++r) {
+        const int tl = 4 * kq + r;
         const float dax = ((red[tl] + red[17 + tl]) + (red[34 + tl] + red[51 + tl])) + daxn[tl];
-        axsr[tl] = axs[tl];
-        dpr[tl] = axsr[tl] * (dax - ssum) * A.scale;   // 0 beyond the utterance's end (axs = 0)
-        sb += dpr[tl];
+        axsr[r] = axs[tl];
+        dpr[r] = axsr[r] * (dax - ssum) * A.scale;   // 0 beyond the utterance's end (axs = 0)
     }
-    if (tid == 0) G.dpax[(long)b * G.nchunk + chunk] = sb;   // the score bias' gradient, per chunk (folded by stage 4)
+    {   // the score bias' gradient, per chunk (folded by stage 4)
+        const int tl = lane & 15;
+        const float dax = ((red[tl] + red[17 + tl]) + (red[34 + tl] + red[51 + tl])) + daxn[tl];
+        const float v = sa_wave_sum_dpp(lane < 16 ? axs[tl] * (dax - ssum) * A.scale : 0.f);
+        if (tid == 0) G.dpax[(long)b * G.nchunk + chunk] = v;
+    }
+    float aA[4], bX[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        aA[s4] = axp[m + 4 * s4 + kq];                         // A[step m][tap 4 s4 + kq] of the location term
+        bX[s4] = m < 15 ? axp[4 * kq + s4 + m] : 1.0f;         // B[step 4 kq + s4][tap m]; column 15: ones
+    }
     const int W = 2 + A.KS;
-    if (active) {
-        float a_ox = 0.f, a_nw = 0.f;
-        float a_cw[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a_cw[k] = 0.f;
-        float axr[kAttTB + 15];
+    for (int jj = 0; jj < 4; ++jj) {
+        const int tile = wave + 4 * jj;
+        if (tile < ntile) {
+            const int h = tile * 16 + m;
+            const bool hv = h < A.H;
+            f32x4_t c1 = {cbv[jj], cbv[jj], cbv[jj], cbv[jj]};
 #pragma unroll
-        for (int i = 0; i < kAttTB + 15; ++i) axr[i] = i < kAttTB + A.KS - 1 ? axp[i] : 0.f;
+            for (int s4 = 0; s4 < 4; ++s4) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[s4], cwB[jj][s4], c1, 0, 0, 0);
+            float dp[4], nw[4];
 #pragma unroll
-        for (int tl = 0; tl < kAttTB; ++tl) {
-            if (tl < nt) {
-                float pre = ev[tl] + oxh;
-                if (A.ax_prev) {
-                    float c = cb;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) c += cwr[k] * axr[tl + k];   // taps beyond KS are zeros: no guard
-                    pre += c;
+            for (int r = 0; r < 4; ++r) {
+                const int tl = 4 * kq + r;
+                const float pre = (ev[jj][r] + oxh[jj]) + c1[r];
+                dp[r] = pre > 0.f ? dpr[r] * wv[jj] : 0.f;                  // wv = 0 beyond H, dpr = 0 beyond nt
+                nw[r] = hv ? dpr[r] * fmaxf(pre, 0.f) : 0.f;
+                if (hv && tl < nt) {
+                    dehb[(long)(t0 + tl) * A.H + h] = dv[jj][r] + (axsr[r] * dsxh[jj] + dp[r]);
+                    dp_tile[tl * (A.H + 1) + h] = dp[r];
                 }
-                const float dp = pre > 0.f ? dpr[tl] * w : 0.f;
-                a_ox += dp;
-                a_nw += dpr[tl] * fmaxf(pre, 0.f);
-                if (A.ax_prev) {
+            }
+            f32x4_t c2 = {0.f, 0.f, 0.f, 0.f}, c3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) a_cw[k] += dp * axr[tl + k];
+            for (int r = 0; r < 4; ++r) {
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[r], bX[r], c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(nw[r], 1.0f, c3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // accumulator row 4 kq + r = unit, column m = tap (15: a_ox)
+                const int hh = tile * 16 + 4 * kq + r;
+                if (hh < A.H) {
+                    float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + hh) * W;
+                    if (loc && m < A.KS) p[2 + m] = c2[r];
+                    if (m == 15) { p[0] = c2[r]; p[1] = c3[r]; }
                 }
-                dehb[(long)(t0 + tl) * A.H + h] = dv[tl] + (axsr[tl] * dsxh + dp);
-                dp_tile[tl * (A.H + 1) + h] = dp;
             }
         }
-        float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + h) * W;
-        p[0] = a_ox;
-        p[1] = a_nw;
-        for (int k = 0; k < A.KS; ++k) p[2 + k] = a_cw[k];
     }
-    if (!A.ax_prev) return;
+    if (!loc) return;
     __syncthreads();
     {   // A[m = step][k = unit] from dp_tile, B[k = unit][n = tap] from cw (column 15 and the rows beyond nt are never stored)
-        const int m = lane & 15, kq = lane >> 4;
         f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const int nk = A.H >> 2;
         int ks = wave;
@@ -1184,7 +1224,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     const size_t smem = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + 2 * kAttTB + (size_t)kAttTB * (H + 1)) * sizeof(float);
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
     const bool fuse_b = true;
-    const size_t smem2 = ((size_t)(kAttTB + KS - 1) + (size_t)H * KS + kRed2 + (size_t)kAttTB * (H + 1) + 4 * 256) * sizeof(float);
+    const size_t smem2 = ((size_t)kAxp2 + (size_t)H * KS + kRed2 + (size_t)kAttTB * (H + 1) + 4 * 256) * sizeof(float);
     const bool one_launch = H <= 256 && sa_opt(SA_OPT_S2S_BWD_ONE) != 0 &&
                             att_smem((const void*)attention_bwd_main2_kernel, smem2);
     for (int t = U1 - 1; t >= 0; --t) {

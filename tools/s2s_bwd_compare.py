@@ -1,0 +1,32 @@
+"""Every gradient of a Seq2Seq loss with the one-launch attention backward (s2s.bwd_one = 1) against the two-launch stages (0):
+    python tools/s2s_bwd_compare.py    -> per tensor: max |diff|, max |want|"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_amd import _lib  # noqa: E402
+from speech_amd.models import Seq2Seq  # noqa: E402
+
+for (dim, F, T, B, U, conv) in ((16, 20, 90, 3, 7, [[4, 5, 9, 2]]), (256, 40, 400, 4, 12, [[8, 5, 8, 2]])):
+    cfg = {"dropout": 0.0, "encoder": {"conv": conv, "rnn": {"dim": dim, "bidirectional": True, "layers": 1}},
+           "decoder": {"embedding_dim": dim, "layers": 1, "log_t": True}}
+    torch.manual_seed(11)
+    m = Seq2Seq(F, 12, cfg).cuda()
+    m.set_train()
+    rng = np.random.RandomState(3)
+    inputs = tuple(rng.randn(T, F).astype(np.float32) for _ in range(B))
+    labels = tuple([11] + list(rng.randint(0, 10, U - 2)) + [10] for _ in range(B))
+    got = {}
+    for one in (1, 0):
+        _lib.set_option("s2s.bwd_one", one)
+        m.zero_grad(set_to_none=True)
+        m.loss((inputs, labels)).backward()
+        got[one] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+    _lib.set_option("s2s.bwd_one", 1)
+    print("dim", dim)
+    for n in got[1]:
+        a, w = got[1][n], got[0][n]
+        print("  %-28s diff %.3e  max %.3e  finite %s" % (n, np.abs(a - w).max(), np.abs(w).max(), np.isfinite(a).all()))
