@@ -291,7 +291,7 @@ struct AttBwd {
     float* g_nn_w;           // (B, H)     +=
     float* g_nn_b;           // (B)        +=
     float* dpax;             // workspace (B, T): d ax, then d score
-    float* part;             // workspace (B, nchunk, H, 2 + KS): per-chunk sums of d_pre, d_pre-weighted terms
+    float* part;             // workspace (B, nchunk, 2 + KS, H): per-chunk sums of d_pre, d_pre-weighted terms
     float* q;                // workspace (B, T, KS): sum_h d_pre[t,h] conv_w[h,k]
     int nchunk;
     // (r4) fusions of the training loop (zero / null outside sa_s2s_decoder_bwd):
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(256) void attention_bwd_main_kernel(AttArgs A, AttB
                 dp_tile[tl * (A.H + 1) + h] = dp;
             }
         }
-        float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + h) * W;
+        float* p = G.part + ((long)b * G.nchunk + chunk) * W * A.H + h;   // (B, nchunk, 2 + KS, H): quantity-major
         p[0] = a_ox;
-        p[1] = a_nw;
-        for (int k = 0; k < A.KS; ++k) p[2 + k] = a_cw[k];
+        p[A.H] = a_nw;
+        for (int k = 0; k < A.KS; ++k) p[(long)(2 + k) * A.H] = a_cw[k];
     }
     if (!A.ax_prev) return;
     __syncthreads();
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void attention_bwd_main2_kernel(AttArgs A, Att
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         aA[s4] = axp[m + 4 * s4 + kq];                         // A[step m][tap 4 s4 + kq] of the location term
-        bX[s4] = m < 15 ? axp[4 * kq + s4 + m] : 1.0f;         // B[step 4 kq + s4][tap m]; column 15: ones
+        bX[s4] = m < 15 ? axp[4 * kq + s4 + m] : 1.0f;         // [tap m][step 4 kq + s4] of the window; tap 15: ones
     }
     const int W = 2 + A.KS;
 #pragma unroll
@@ -602,20 +602,23 @@ __global__ __launch_bounds__(256) void attention_bwd_main2_kernel(AttArgs A, Att
                     dp_tile[tl * (A.H + 1) + h] = dp[r];
                 }
             }
+            // the products transposed (the window as A, d_pre as B): accumulator row 4 kq + r = tap (15: a_ox), column m = unit,
+            // so a quantity's 16 units of the tile are one 64-byte run of the quantity-major partials (B, nchunk, 2 + KS, H)
             f32x4_t c2 = {0.f, 0.f, 0.f, 0.f}, c3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[r], bX[r], c2, 0, 0, 0);
-                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(nw[r], 1.0f, c3, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bX[r], dp[r], c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, nw[r], c3, 0, 0, 0);
             }
+            if (hv) {
+                float* p = G.part + ((long)b * G.nchunk + chunk) * W * A.H + h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {   // accumulator row 4 kq + r = unit, column m = tap (15: a_ox)
-                const int hh = tile * 16 + 4 * kq + r;
-                if (hh < A.H) {
-                    float* p = G.part + (((long)b * G.nchunk + chunk) * A.H + hh) * W;
-                    if (loc && m < A.KS) p[2 + m] = c2[r];
-                    if (m == 15) { p[0] = c2[r]; p[1] = c3[r]; }
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 4 * kq + r;
+                    if (n == 15) p[0] = c2[r];
+                    else if (loc && n < A.KS) p[(long)(2 + n) * A.H] = c2[r];
                 }
+                if (kq == 0) p[A.H] = c3[0];
             }
         }
     }
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256) void attention_bwd_fold_kernel(AttArgs A, AttB
     if (j < W) {
         if (j >= 2 && !A.ax_prev) return;
         for (int h = threadIdx.x; h < A.H; h += 256) {
-            const float* p = G.part + ((long)b * G.nchunk * A.H + h) * W + j;
+            const float* p = G.part + ((long)b * G.nchunk * W + j) * A.H + h;
             const long cs = (long)A.H * W;
             // what the sum is added to / continued with is fetched with the partials: one round trip, not two or three
             const long i = (long)b * A.H + h;
