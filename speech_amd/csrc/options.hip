@@ -44,8 +44,9 @@ Opt g_opts[SA_OPT_COUNT] = {
                              "the bf16-planes kernel (split-bf16 products, fp32-equivalent; H = 128, 256, 384, 512)"},
     {"gru.exp", 0, 0, "measurement tools only: selects a kernel variant under A/B test (0 = the shipped path; the variants of a round "
                       "are listed in that round's profiles/*experiment*.txt)"},
-    {"s2s.bwd_one", 1, 1, "Seq2Seq decoder backward: 0 = the attention's d ax / score-network stages as two launches per token "
-                          "(a pass over the utterance for the softmax) instead of one (H <= 256)"},
+    {"s2s.bwd_one", 1, 1, "Seq2Seq attention (H <= 256): 0 = the round-4 kernels (score network on the VALU in both directions, "
+                          "the backward's d ax / score-network stages as two launches per token) instead of the MFMA-layout "
+                          "kernels (attention_score2_kernel, attention_bwd_main2_kernel: one launch per token)"},
 };
 }  // namespace
 

@@ -7,6 +7,7 @@
 //   (scheduled sampling :93 and greedy decode :157).
 // All tensors fp32, contiguous, DEVICE.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -202,6 +203,107 @@ __global__ __launch_bounds__(256) void attention_score_kernel(AttArgs A, float* 
         const float v = sa_wave_sum_dpp(vs[q]);
         if (lane == 0 && t0 + tl < A.T) score[(long)b * A.T + t0 + tl] = (v + nb) * A.scale;
     }
+}
+
+// ---- forward, stage 1 in the MFMA accumulator layout (r6; H <= 256).  Same grid.  The round-4 kernel above gives a wave four
+// steps and walks the units in the lanes: 4 x 15 tap FMAs per unit and step on the VALU, the eh loads inside the unit loop
+// (four dependent trips).  Here, as in attention_bwd_main2_kernel, a wave owns up to four tiles of 16 units, lane (kq, m) holds
+// steps 4 kq .. 4 kq + 3 of unit 16 tile + m, the location term is four v_mfma_f32_16x16x4_f32 per tile (the same FMA chain in
+// k order: the pre-activation's bits, hence the ReLU mask, are the backward kernels'), every load goes out before the gates,
+// and the sum over the units is a DPP row sum + the four waves through LDS.
+// dynamic LDS: axp[32] | oxs[H] | red[4][16]
+__global__ __launch_bounds__(256) void attention_score2_kernel(AttArgs A, float* __restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* axp = reinterpret_cast<float*>(smem_raw);
+    float* oxs = axp + 32;
+    float* red = oxs + A.H;
+    const int b = blockIdx.y, t0 = blockIdx.x * kAttTB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int ntile = (A.H + 15) >> 4;
+    const float* ehb = A.eh + (A.eh_shared ? 0l : (long)b * A.T * A.H);
+    const bool loc = A.ax_prev != nullptr;
+    float ev[4][4], cwB[4][4], wv[4], cbv[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int h = (wave + 4 * jj) * 16 + m;
+        const bool hv = h < A.H;
+        const int hc = hv ? h : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[jj][r] = ehb[(long)min(t0 + 4 * kq + r, A.T - 1) * A.H + hc];
+        wv[jj] = hv ? A.nn_w[hc] : 0.f;
+        cbv[jj] = loc ? A.conv_b[hc] : 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = 4 * s4 + kq;
+            cwB[jj][s4] = (loc && hv && k < A.KS) ? A.conv_w[hc * A.KS + k] : 0.f;
+        }
+    }
+    if (tid < 32) {
+        const int t = t0 + tid - (A.KS - 1) / 2;
+        axp[tid] = (loc && tid < kAttTB + A.KS - 1 && t >= 0 && t < A.T) ? A.ax_prev[(long)b * A.T + t] : 0.f;
+    }
+    if (A.gi) {  // fused GRUCell gates (grucell_gates_fwd_kernel's arithmetic): h of this utterance into LDS
+        for (int j = tid; j < A.H; j += 256) {
+            const float* a = A.gi + (long)b * 3 * A.H;
+            const float* c = A.gh + (long)b * 3 * A.H;
+            const float r = sigmoidf_(a[j] + c[j]);
+            const float z = sigmoidf_(a[A.H + j] + c[A.H + j]);
+            const float ghn = c[2 * A.H + j];
+            const float n = tanhf(a[2 * A.H + j] + r * ghn);
+            const float h = (1.0f - z) * n + z * A.h_prev[(long)b * A.H + j];
+            oxs[j] = h;
+            if (blockIdx.x == 0) {
+                A.ox_out[(long)b * A.H + j] = h;
+                if (A.gate_stash) {
+                    float* st = A.gate_stash + (long)b * 4 * A.H;
+                    st[j] = r; st[A.H + j] = z; st[2 * A.H + j] = n; st[3 * A.H + j] = ghn;
+                }
+            }
+        }
+    } else {
+        for (int j = tid; j < A.H; j += 256) oxs[j] = A.ox[(long)b * A.H + j];
+    }
+    __syncthreads();
+    float aA[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) aA[s4] = axp[m + 4 * s4 + kq];
+    float vs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int tile = wave + 4 * jj;
+        if (tile < ntile) {
+            const int h = tile * 16 + m;
+            const float oxh = oxs[h < A.H ? h : 0];
+            f32x4_t c1 = {cbv[jj], cbv[jj], cbv[jj], cbv[jj]};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[s4], cwB[jj][s4], c1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vs[r] += fmaxf((ev[jj][r] + oxh) + c1[r], 0.f) * wv[jj];   // wv = 0 beyond H
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = vs[r];
+        v += SA_DPP_F(0.f, v, 0x111, 0xf);
+        v += SA_DPP_F(0.f, v, 0x112, 0xf);
+        v += SA_DPP_F(0.f, v, 0x114, 0xf);
+        v += SA_DPP_F(0.f, v, 0x118, 0xf);
+        if (m == 15) red[wave * 16 + 4 * kq + r] = v;
+    }
+    __syncthreads();
+    if (tid < kAttTB && t0 + tid < A.T) {
+        const float v = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+        score[(long)b * A.T + t0 + tid] = (v + A.nn_b[0]) * A.scale;
+    }
+}
+
+// the score launch: the MFMA-layout kernel for H <= 256 (option s2s.bwd_one != 0: forward and backward switch together)
+static void score_launch(const AttArgs& A, float* score, int grid_y, size_t smem_round4, hipStream_t stream) {
+    const dim3 grid((A.T + kAttTB - 1) / kAttTB, grid_y);
+    if (A.H <= 256 && sa_opt(SA_OPT_S2S_BWD_ONE) != 0)
+        hipLaunchKernelGGL(attention_score2_kernel, grid, dim3(256), (size_t)(32 + A.H + 64) * sizeof(float), stream, A, score);
+    else
+        hipLaunchKernelGGL(attention_score_kernel, grid, dim3(256), smem_round4, stream, A, score);
 }
 
 // ---- forward, stage 2: softmax over time and the context.  grid B, 256 threads.  dynamic LDS: a[T] | red[4] | pad | part[4][H]
@@ -830,7 +932,7 @@ extern "C" ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const 
     const size_t smem2 = ((size_t)T + 8 + 4 * (size_t)H) * sizeof(float);
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
-    hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+    score_launch(A, score, B, smem1, stream);
     hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, (float*)nullptr);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
@@ -890,8 +992,6 @@ extern "C" ctcStatus_t sa_argmax_rows(const float* x, long long* out, long rows,
 // -- the same move as sa_gru_stack_* for the encoder.  Tokens are strictly sequential (token t's input contains token
 // t-1's context), batch rows are few (B = 16 in the shipped config), so the projections are "skinny" products.
 // =====================================================================================================================
-#include "internal.h"
-
 namespace {
 
 
@@ -1114,8 +1214,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
             }
         }
         float* score = (float*)(ws + L.att);
-        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), fuse ? smem1f : smem1, stream,
-                           A, score);
+        score_launch(A, score, B, fuse ? smem1f : smem1, stream);
         hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, AX + (long)t * B * T,
                            sx, OIN + (long)t * B * H);
     }
@@ -1165,7 +1264,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_step(const float* eh, const long long* idx
     hipLaunchKernelGGL(grucell_gates_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, gi, gh, hprev, hx,
                        (float*)nullptr, B, H);
     AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
-    hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+    score_launch(A, score, B, smem1, stream);
     hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
     SkinnyProb q{oin, P[P_FCW], P[P_FCB], out, K, H, 0, H, H, K};
     skinny_launch(&q, 1, B, stream);
@@ -1581,7 +1680,7 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
         AttArgs A{eh, hx, t > 0 ? (const float*)axprev : (const float*)nullptr, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale,
                   W, T, H, KS, 1};
         A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx;   // the GRUCell gates inside the score kernel
-        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, W), dim3(256), smem1, stream, A, score);
+        score_launch(A, score, W, smem1, stream);
         hipLaunchKernelGGL(attention_context_kernel, dim3(W), dim3(256), smem2, stream, A, score, ax, sx, oin);
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
         skinny_launch(&q, 1, W, stream);
@@ -1729,7 +1828,7 @@ extern "C" ctcStatus_t sa_s2s_greedy_decode(const float* eh, const float* const*
         skinny_launch(pr, 2, B, stream);
         AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
         A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx;   // the GRUCell gates inside the score kernel
-        hipLaunchKernelGGL(attention_score_kernel, dim3((T + kAttTB - 1) / kAttTB, B), dim3(256), smem1, stream, A, score);
+        score_launch(A, score, B, smem1, stream);
         hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
         skinny_launch(&q, 1, B, stream);

@@ -1,4 +1,5 @@
-"""Every gradient of a Seq2Seq loss with the one-launch attention backward (s2s.bwd_one = 1) against the two-launch stages (0):
+"""The loss and every gradient of a Seq2Seq batch with the MFMA-layout attention kernels (s2s.bwd_one = 1: score network forward,
+one-launch backward) against the round-4 kernels (0):
     python tools/s2s_bwd_compare.py    -> per tensor: max |diff|, max |want|"""
 import os
 import sys
@@ -23,8 +24,10 @@ for (dim, F, T, B, U, conv) in ((16, 20, 90, 3, 7, [[4, 5, 9, 2]]), (256, 40, 40
     for one in (1, 0):
         _lib.set_option("s2s.bwd_one", one)
         m.zero_grad(set_to_none=True)
-        m.loss((inputs, labels)).backward()
+        loss = m.loss((inputs, labels))
+        loss.backward()
         got[one] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
+        got[one]["(loss)"] = np.float64(loss.item())
     _lib.set_option("s2s.bwd_one", 1)
     print("dim", dim)
     for n in got[1]:
