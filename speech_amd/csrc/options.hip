@@ -44,9 +44,10 @@ Opt g_opts[SA_OPT_COUNT] = {
                              "the bf16-planes kernel (split-bf16 products, fp32-equivalent; H = 128, 256, 384, 512)"},
     {"gru.exp", 0, 0, "measurement tools only: selects a kernel variant under A/B test (0 = the shipped path; the variants of a round "
                       "are listed in that round's profiles/*experiment*.txt)"},
-    {"s2s.bwd_one", 1, 1, "Seq2Seq attention (H <= 256): 0 = the round-4 kernels (score network on the VALU in both directions, "
-                          "the backward's d ax / score-network stages as two launches per token) instead of the MFMA-layout "
-                          "kernels (attention_score2_kernel, attention_bwd_main2_kernel: one launch per token)"},
+    {"s2s.kernels", 3, 3, "Seq2Seq attention, H <= 256 (bits): 1 = the backward's d ax / softmax / score-network stages as ONE launch "
+                          "per token in the MFMA accumulator layout (attention_bwd_main2_kernel; 0: the round-4 stages, two "
+                          "launches); 2 = the forward's score network in that layout and the context on four workgroups per "
+                          "utterance (attention_score2_kernel, attention_context2_kernel; 0: the round-4 kernels)"},
 };
 }  // namespace
 

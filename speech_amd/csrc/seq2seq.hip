@@ -297,10 +297,10 @@ __global__ __launch_bounds__(256) void attention_score2_kernel(AttArgs A, float*
     }
 }
 
-// the score launch: the MFMA-layout kernel for H <= 256 (option s2s.bwd_one != 0: forward and backward switch together)
+// the score launch: the MFMA-layout kernel for H <= 256 (option s2s.kernels bit 1)
 static void score_launch(const AttArgs& A, float* score, int grid_y, size_t smem_round4, hipStream_t stream) {
     const dim3 grid((A.T + kAttTB - 1) / kAttTB, grid_y);
-    if (A.H <= 256 && sa_opt(SA_OPT_S2S_BWD_ONE) != 0)
+    if (A.H <= 256 && (sa_opt(SA_OPT_S2S_KERNELS) & 2) != 0)
         hipLaunchKernelGGL(attention_score2_kernel, grid, dim3(256), (size_t)(32 + A.H + 64) * sizeof(float), stream, A, score);
     else
         hipLaunchKernelGGL(attention_score_kernel, grid, dim3(256), smem_round4, stream, A, score);
@@ -378,6 +378,100 @@ __global__ __launch_bounds__(256) void attention_context_kernel(AttArgs A, const
         if (A.ix_next) A.ix_next[(long)b * A.H + h] = A.emb[yn * A.H + h] + v;   // s2s_embed_add_kernel's sum
     }
     if (A.ix_next && threadIdx.x == 0) A.idx_next[b] = yn;
+}
+
+// ---- forward, stage 2 on four workgroups per utterance (r6; H = 16, 32, 64, 128 or 256).  One workgroup walking its
+// utterance's T x H encoder states alone (above) is as slow as one CU's address path: 200 KB in 6 us at the shipped shapes.
+// Here workgroup (b, q) redoes the softmax (T values) and forms the context of a QUARTER of the hidden units: its 256 threads
+// are H / 16 lanes of four units x 4096 / H time groups, a thread adds rows g, g + G, ... (eight 16-byte loads in flight),
+// the groups are added in group order through LDS.  Quarter 0 writes the alignment.
+// dynamic LDS: a[T] | red[4] | pad | part[G][H / 4]
+__global__ __launch_bounds__(256) void attention_context2_kernel(AttArgs A, const float* __restrict__ score,
+                                                                 float* __restrict__ ax, float* __restrict__ sx,
+                                                                 float* __restrict__ oin /* ox + sx, or NULL */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* a = reinterpret_cast<float*>(smem_raw);
+    float* red = a + A.T;
+    float* part = a + ((A.T + 4 + 3) & ~3);
+    const int b = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const float* ehb = A.eh + (A.eh_shared ? 0l : (long)b * A.T * A.H);
+    const int HB = A.H >> 2, L4 = HB >> 2, G = 256 / L4;   // units per workgroup, 16-byte lanes per row, time groups
+    const int g = tid / L4, c = tid - g * L4;
+    const float4* e4 = reinterpret_cast<const float4*>(ehb + q * HB) + c;   // row t: e4[t * (H / 4)]
+    const int H4 = A.H >> 2;
+    // the first eight rows of the thread go out before the softmax (they do not depend on it)
+    float4 v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v0[u] = e4[(long)min(g + u * G, A.T - 1) * H4];
+    float mx = -3.0e38f;
+    for (int t = tid; t < A.T; t += 256) {
+        a[t] = score[(long)b * A.T + t];
+        mx = fmaxf(mx, a[t]);
+    }
+    mx = block_reduce(mx, red, true);
+    float s = 0.f;
+    for (int t = tid; t < A.T; t += 256) {
+        const float e = __expf(a[t] - mx);
+        a[t] = e;
+        s += e;
+    }
+    s = block_reduce(s, red, false);
+    const float inv = 1.0f / s;
+    for (int t = tid; t < A.T; t += 256) {
+        const float v = a[t] * inv;
+        a[t] = v;
+        if (q == 0) ax[(long)b * A.T + t] = v;
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int t = g + u * G;
+        if (t < A.T) {
+            const float at = a[t];
+            acc.x += at * v0[u].x; acc.y += at * v0[u].y; acc.z += at * v0[u].z; acc.w += at * v0[u].w;
+        }
+    }
+    for (int t0 = g + 8 * G; t0 < A.T; t0 += 8 * G) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = e4[(long)min(t0 + u * G, A.T - 1) * H4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * G;
+            if (t < A.T) {
+                const float at = a[t];
+                acc.x += at * v[u].x; acc.y += at * v[u].y; acc.z += at * v[u].z; acc.w += at * v[u].w;
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(part + g * HB + 4 * c) = acc;
+    __syncthreads();
+    if (tid < HB) {
+        float v = 0.f;
+        for (int gg = 0; gg < G; ++gg) v += part[gg * HB + tid];
+        const int h = q * HB + tid;
+        sx[(long)b * A.H + h] = v;
+        if (oin) oin[(long)b * A.H + h] = A.ox[(long)b * A.H + h] + v;
+        if (A.ix_next) {
+            const long long yn = A.y_next[(long)b * A.y_stride];
+            A.ix_next[(long)b * A.H + h] = A.emb[yn * A.H + h] + v;   // s2s_embed_add_kernel's sum
+            if (q == 0 && tid == 0) A.idx_next[b] = yn;
+        }
+    }
+}
+
+static bool context2_ok(int H) { return H == 16 || H == 32 || H == 64 || H == 128 || H == 256; }
+static size_t context2_smem(int T, int H) { return ((size_t)((T + 4 + 3) & ~3) + (size_t)(4096 / H) * (H / 4)) * sizeof(float); }
+
+// the context launch: four workgroups per utterance where the width allows (option s2s.kernels bit 1)
+static void context_launch(const AttArgs& A, const float* score, float* ax, float* sx, float* oin, int rows,
+                           size_t smem_round4, hipStream_t stream) {
+    if (context2_ok(A.H) && (sa_opt(SA_OPT_S2S_KERNELS) & 2) != 0 && context2_smem(A.T, A.H) <= 48 * 1024)
+        hipLaunchKernelGGL(attention_context2_kernel, dim3(rows, 4), dim3(256), context2_smem(A.T, A.H), stream, A, score, ax, sx,
+                           oin);
+    else
+        hipLaunchKernelGGL(attention_context_kernel, dim3(rows), dim3(256), smem_round4, stream, A, score, ax, sx, oin);
 }
 
 struct AttBwd {
@@ -933,7 +1027,7 @@ extern "C" ctcStatus_t sa_attention_fwd(const float* eh, const float* ox, const 
     if (!att_smem((const void*)attention_score_kernel, smem1) || !att_smem((const void*)attention_context_kernel, smem2))
         return CTC_STATUS_INVALID_VALUE;
     score_launch(A, score, B, smem1, stream);
-    hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, (float*)nullptr);
+    context_launch(A, score, ax, sx, (float*)nullptr, B, smem2, stream);
     SA_CHECK_LAUNCH();
     return CTC_STATUS_SUCCESS;
 }
@@ -1215,8 +1309,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, c
         }
         float* score = (float*)(ws + L.att);
         score_launch(A, score, B, fuse ? smem1f : smem1, stream);
-        hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, AX + (long)t * B * T,
-                           sx, OIN + (long)t * B * H);
+        context_launch(A, score, AX + (long)t * B * T, sx, OIN + (long)t * B * H, B, smem2, stream);
     }
     SA_CHECK_LAUNCH();
     return sa_gemm_f32_impl(0, 1, U1 * B, K, H, 1.0f, OIN, H, P[P_FCW], H, 0.0f, out, K, P[P_FCB], nullptr,
@@ -1265,7 +1358,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_step(const float* eh, const long long* idx
                        (float*)nullptr, B, H);
     AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
     score_launch(A, score, B, smem1, stream);
-    hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
+    context_launch(A, score, ax, sx, oin, B, smem2, stream);
     SkinnyProb q{oin, P[P_FCW], P[P_FCB], out, K, H, 0, H, H, K};
     skinny_launch(&q, 1, B, stream);
     SA_CHECK_LAUNCH();
@@ -1327,7 +1420,7 @@ extern "C" ctcStatus_t sa_s2s_decoder_bwd(const float* eh, const float* const* p
     if (!att_smem((const void*)attention_bwd_main_kernel, smem)) return CTC_STATUS_INVALID_VALUE;
     const bool fuse_b = true;
     const size_t smem2 = ((size_t)kAxp2 + (size_t)H * KS + kRed2 + (size_t)kAttTB * (H + 1) + 4 * 256) * sizeof(float);
-    const bool one_launch = H <= 256 && sa_opt(SA_OPT_S2S_BWD_ONE) != 0 &&
+    const bool one_launch = H <= 256 && (sa_opt(SA_OPT_S2S_KERNELS) & 1) != 0 &&
                             att_smem((const void*)attention_bwd_main2_kernel, smem2);
     for (int t = U1 - 1; t >= 0; --t) {
         const bool has_next = t + 1 < U1;
@@ -1681,7 +1774,7 @@ extern "C" ctcStatus_t sa_s2s_beam_search(const float* eh, const float* const* p
                   W, T, H, KS, 1};
         A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx;   // the GRUCell gates inside the score kernel
         score_launch(A, score, W, smem1, stream);
-        hipLaunchKernelGGL(attention_context_kernel, dim3(W), dim3(256), smem2, stream, A, score, ax, sx, oin);
+        context_launch(A, score, ax, sx, oin, W, smem2, stream);
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
         skinny_launch(&q, 1, W, stream);
         BeamBufs Q{st, (int*)(ws + L.tok), (int*)(ws + L.par), logits, hx, ax, sx, hprev, axprev, ix, P[P_EMB],
@@ -1829,7 +1922,7 @@ extern "C" ctcStatus_t sa_s2s_greedy_decode(const float* eh, const float* const*
         AttArgs A{eh, hx, ax_prev, P[P_CW], P[P_CB], P[P_NW], P[P_NB], scale, B, T, H, KS};
         A.gi = gi; A.gh = gh; A.h_prev = hprev; A.ox_out = hx;   // the GRUCell gates inside the score kernel
         score_launch(A, score, B, smem1, stream);
-        hipLaunchKernelGGL(attention_context_kernel, dim3(B), dim3(256), smem2, stream, A, score, ax, sx, oin);
+        context_launch(A, score, ax, sx, oin, B, smem2, stream);
         SkinnyProb q{oin, P[P_FCW], P[P_FCB], logits, K, H, 0, H, H, K};
         skinny_launch(&q, 1, B, stream);
         hipLaunchKernelGGL(s2s_greedy_pick_kernel, dim3(B), dim3(64), 0, stream, st, (const float*)logits, d_tokens, idx, count, B,

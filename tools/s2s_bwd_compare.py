@@ -1,5 +1,5 @@
-"""The loss and every gradient of a Seq2Seq batch with the MFMA-layout attention kernels (s2s.bwd_one = 1: score network forward,
-one-launch backward) against the round-4 kernels (0):
+"""The loss and every gradient of a Seq2Seq batch with the MFMA-layout attention kernels (s2s.kernels = 3: score network and context forward,
+one-launch backward) against the round-4 backward on the same forward (2) and the round-4 kernels throughout (0):
     python tools/s2s_bwd_compare.py    -> per tensor: max |diff|, max |want|"""
 import os
 import sys
@@ -21,15 +21,16 @@ for (dim, F, T, B, U, conv) in ((16, 20, 90, 3, 7, [[4, 5, 9, 2]]), (256, 40, 40
     inputs = tuple(rng.randn(T, F).astype(np.float32) for _ in range(B))
     labels = tuple([11] + list(rng.randint(0, 10, U - 2)) + [10] for _ in range(B))
     got = {}
-    for one in (1, 0):
-        _lib.set_option("s2s.bwd_one", one)
+    for one in (3, 2, 0):
+        _lib.set_option("s2s.kernels", one)
         m.zero_grad(set_to_none=True)
         loss = m.loss((inputs, labels))
         loss.backward()
         got[one] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}
         got[one]["(loss)"] = np.float64(loss.item())
-    _lib.set_option("s2s.bwd_one", 1)
+    _lib.set_option("s2s.kernels", 3)
     print("dim", dim)
-    for n in got[1]:
-        a, w = got[1][n], got[0][n]
-        print("  %-28s diff %.3e  max %.3e  finite %s" % (n, np.abs(a - w).max(), np.abs(w).max(), np.isfinite(a).all()))
+    for n in got[3]:
+        a, w, w0 = got[3][n], got[2][n], got[0][n]
+        print("  %-28s diff %.3e  (vs round-4 forward too: %.3e)  max %.3e  finite %s" %
+              (n, np.abs(a - w).max(), np.abs(a - w0).max(), np.abs(w).max(), np.isfinite(a).all()))
