@@ -255,6 +255,7 @@ class Model(nn.Module):
             flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = flat_p[off:off + k].view(p.shape)
             p._grad_slot = flat_g[off:off + k].view(p.shape)  # EncoderFunction.backward writes gradients here
+            p._grad_by_ref = bool(by_reference)               # ... and every other node that owns parameters (ops.slot_hand_over)
             p.grad = None
             off += k
         self._flat = (flat_p, flat_g)
@@ -286,12 +287,14 @@ class _LinearFunction(torch.autograd.Function):
         # parameters re-homed by Model.flatten_parameters_() carry a slot of the flat gradient buffer (one use of the
         # layer per step: the slot is written, not accumulated)
         ctx.slots = (getattr(w, "_grad_slot", None), getattr(b, "_grad_slot", None))
+        ctx.param_refs = (w, b)
         return ops.gemm(x, w, trans_b=True, bias=b)
 
     @staticmethod
     def backward(ctx, dy):
         from . import ops
         x, w = ctx.saved_tensors
+        carry = ops.slot_carry(ctx.param_refs, ctx.slots)
         dy = dy.contiguous()
         n_out = dy.shape[1]
         if n_out % 4 and dy.shape[0] >= 4096:
@@ -311,10 +314,10 @@ class _LinearFunction(torch.autograd.Function):
             dy_t[:, :rows].copy_(dy.t())
             x_p = x if rows_p == rows else torch.nn.functional.pad(x, (0, 0, 0, rows_p - rows))
             dw = ops.gemm(dy_t, x_p, out=ctx.slots[0])
-            return dx, dw, ops.colsum(dy, out=ctx.slots[1])
+            return (dx,) + tuple(ops.slot_hand_over(ctx.param_refs, ctx.slots, (dw, ops.colsum(dy, out=ctx.slots[1])), carry))
         dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
         dw, db = ops.gemm_tn_colsum(dy, x, out=ctx.slots[0], colsum_out=ctx.slots[1])
-        return dx, dw, db
+        return (dx,) + tuple(ops.slot_hand_over(ctx.param_refs, ctx.slots, (dw, db), carry))
 
 
 def zero_pad_concat(inputs, min_t=0, stage=None):

@@ -367,6 +367,36 @@ def add_rows(a, b, out=None):
     return out
 
 
+# ---- gradients handed over by reference (Model.flatten_parameters_(by_reference=True)) --------------------------------------
+# A backward node that wrote a parameter's gradient into its slot of the flat buffer and RETURNS that view makes autograd's
+# accumulator clone it into a fresh p.grad: one device copy per parameter and step (and a second copy of the gradients in
+# memory) that nothing reads -- the optimiser works on the flat buffer.  The encoder's node (speech_amd/encoder.py) has
+# handed its slots over by reference since round 3; these three helpers do the same for every other node that owns
+# parameters (the Seq2Seq decoder's 11, the Transducer's prediction network / embedding / joint, LinearND).
+def slot_carry(params, slots):
+    """A parameter whose .grad already IS its slot (a second backward without zero_grad, or a parameter two nodes use) expects
+    '+=', but the kernels OVERWRITE the slot: keep what is there, to be added back by slot_hand_over()."""
+    return [(slot, slot.clone()) for p, slot in zip(params, slots)
+            if slot is not None and getattr(p, "_grad_by_ref", False) and p.grad is not None and
+            p.grad.data_ptr() == slot.data_ptr()]
+
+
+def slot_hand_over(params, slots, grads, carry=()):
+    """grads with None where the gradient sits in the parameter's slot and p.grad is (made) that slot."""
+    for slot, old in carry:
+        add_rows(slot.view(1, -1), old.view(1, -1), out=slot.view(1, -1))
+    out = list(grads)
+    for i, (p, slot) in enumerate(zip(params, slots)):
+        if slot is None or out[i] is not slot or not getattr(p, "_grad_by_ref", False) or not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = slot
+            out[i] = None
+        elif p.grad.data_ptr() == slot.data_ptr():
+            out[i] = None
+    return out
+
+
 def clip_sgd_step(params, grads, momentum_buf, lr, momentum, max_norm, grad_scale=1.0, norm_out=None):
     """Fused train.py:32,35 on flat buffers.  Returns the device scalar holding the pre-clip gradient norm.
     `grads` may carry ONE extra trailing element (Model.flatten_parameters_ allocates it): the health flag written by

@@ -203,6 +203,7 @@ class DecoderFunction(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.saved = (eh, plist, IDX, IX, ST, HX, AX, OIN, scale, (B, T, U, H, E, KS, K, V))
             ctx.slots = [getattr(p, "_grad_slot", None) for p in params]
+            ctx.param_refs = params
             ctx.shapes = [tuple(p.shape) for p in params]
         aligns = AX.transpose(0, 1)
         ctx.mark_non_differentiable(aligns)
@@ -214,7 +215,9 @@ class DecoderFunction(torch.autograd.Function):
         dev = eh.device
         dO = d_out.transpose(0, 1).contiguous()
         d_eh = torch.empty(B, T, H, dtype=torch.float32, device=dev)
-        # every gradient goes straight into its slot of the flat buffer when the parameter has one
+        # every gradient goes straight into its slot of the flat buffer when the parameter has one (and is handed over by
+        # reference: ops.slot_hand_over -- autograd cloned all 11 into fresh .grad tensors every step before)
+        carry = ops.slot_carry(ctx.param_refs, ctx.slots)
         grads = [s if s is not None else torch.empty(shape, dtype=torch.float32, device=dev)
                  for s, shape in zip(ctx.slots, ctx.shapes)]
         L = _L()
@@ -223,7 +226,7 @@ class DecoderFunction(torch.autograd.Function):
                                         _lib.ptr(ST), _lib.ptr(HX), _lib.ptr(AX), _lib.ptr(OIN), B, T, U, H, E, KS, K, V,
                                         scale, _lib.ptr(d_eh), _ptr_array(grads), _lib.ptr(ws), ws.numel(),
                                         _lib.cur_stream()), "sa_s2s_decoder_bwd")
-        return (d_eh, None, None, None) + tuple(grads)
+        return (d_eh, None, None, None) + tuple(ops.slot_hand_over(ctx.param_refs, ctx.slots, grads, carry))
 
 
 class XentFunction(torch.autograd.Function):

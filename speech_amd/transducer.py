@@ -111,16 +111,18 @@ class EmbeddingFunction(torch.autograd.Function):
                                                n, E, _lib.cur_stream()), "sa_embedding_fwd")
         ctx.flat, ctx.shape_t = flat, (V, E)
         ctx.slot = getattr(table, "_grad_slot", None)
+        ctx.table_ref = table
         return out.view(tuple(idx.shape) + (E,))
 
     @staticmethod
     def backward(ctx, dout):
         V, E = ctx.shape_t
         d = dout.contiguous().view(-1, E)
+        carry = ops.slot_carry((ctx.table_ref,), (ctx.slot,))
         dt = ctx.slot if ctx.slot is not None else torch.empty(V, E, dtype=torch.float32, device=d.device)
         _lib.check(_lib.lib().sa_embedding_bwd(_lib.ptr(d), _lib.ptr(ctx.flat), _lib.ptr(dt), d.shape[0], E, V,
                                                _lib.cur_stream()), "sa_embedding_bwd")
-        return None, dt
+        return None, ops.slot_hand_over((ctx.table_ref,), (ctx.slot,), (dt,), carry)[0]
 
 
 class DropoutFunction(torch.autograd.Function):
@@ -154,6 +156,7 @@ class GRUStackFunction(torch.autograd.Function):
         if need:
             ctx.saved = (xt, h_out, stash, w_ih, w_hh, L, H)
             ctx.slots = [getattr(p, "_grad_slot", None) for p in params]
+            ctx.param_refs = params
         return h_out[-1].transpose(0, 1)
 
     @staticmethod
@@ -161,6 +164,7 @@ class GRUStackFunction(torch.autograd.Function):
         xt, h_out, stash, w_ih, w_hh, L, H = ctx.saved
         U, B, E = xt.shape
         dtop = dy.transpose(0, 1).contiguous()
+        carry = ops.slot_carry(ctx.param_refs, ctx.slots)
         dai, dah, dx = ops.gru_stack_bwd(dtop, stash, w_ih, w_hh, L, 1, H, E, want_dx=True)
         grads = []
         for l in range(L):
@@ -170,7 +174,7 @@ class GRUStackFunction(torch.autograd.Function):
             grads += [ops.gemm(dai2, lay_in, trans_a=True, out=s[0]),
                       ops.gemm(dah2, stash[l].view(U * B, 5 * H)[:, 4 * H:], trans_a=True, out=s[1]),
                       ops.colsum(dai2, out=s[2]), ops.colsum(dah2, out=s[3])]
-        return (dx.transpose(0, 1), None) + tuple(grads)
+        return (dx.transpose(0, 1), None) + tuple(ops.slot_hand_over(ctx.param_refs, ctx.slots, grads, carry))
 
 
 class JointFunction(torch.autograd.Function):
@@ -222,6 +226,7 @@ class FusedJointFunction(torch.autograd.Function):
                                                  B, T, U1, H, K, _lib.cur_stream()), "sa_joint_fused_fwd")
         ctx.save_for_backward(xa, ya, w, logp)
         ctx.slots = (getattr(w2, "_grad_slot", None), getattr(b2, "_grad_slot", None))
+        ctx.param_refs = (w2, b2)
         return logp
 
     @staticmethod
@@ -233,12 +238,13 @@ class FusedJointFunction(torch.autograd.Function):
         L = _lib.lib()
         ws = _lib.WORKSPACE.get(L.sa_joint_fused_workspace_bytes(B, T, U1, H, K), xa.device, "joint_fused")
         dxa, dya = torch.empty_like(xa), torch.empty_like(ya)
+        carry = ops.slot_carry(ctx.param_refs, ctx.slots)
         dw = ctx.slots[0] if ctx.slots[0] is not None else torch.empty_like(w)
         db = ctx.slots[1] if ctx.slots[1] is not None else torch.empty(K, dtype=torch.float32, device=xa.device)
         _lib.check(L.sa_joint_fused_bwd(_lib.ptr(glp), _lib.ptr(logp), _lib.ptr(xa), _lib.ptr(ya), _lib.ptr(w),
                                         _lib.ptr(dxa), _lib.ptr(dya), _lib.ptr(dw), _lib.ptr(db), B, T, U1, H, K,
                                         _lib.ptr(ws), ws.numel(), _lib.cur_stream()), "sa_joint_fused_bwd")
-        return dxa, dya, dw, db
+        return (dxa, dya) + tuple(ops.slot_hand_over(ctx.param_refs, ctx.slots, (dw, db), carry))
 
 
 class LogSoftmaxFunction(torch.autograd.Function):

@@ -305,3 +305,22 @@ def test_mfma_layout_attention_kernels_against_the_round4_kernels():
             # (the location conv's gradients all but cancel, tests/test_gpu_baseline_configs.py: 3e-3 / 3e-2 of their max)
             loose = 1e-6 if zero else (3e-2 if "attend.conv" in n else 1e-3) * max(np.abs(w0).max(), 1e-3)
             assert np.abs(a - w0).max() <= loose, (dim, n, np.abs(a - w0).max(), np.abs(w0).max())
+
+
+def test_flat_buffer_gradients_are_handed_over_by_reference_by_every_node():
+    """After flatten_parameters_() every parameter's .grad IS its slot of the flat buffer after a backward pass -- the decoder's 11
+    as well as the encoder's (autograd cloned the decoder's into fresh tensors every step before r6) -- and a second backward
+    without zero_grad accumulates (2 x the gradient), as autograd's own accumulation would."""
+    g = fixture()
+    m = build(g, flatten=True)
+    m.set_train()
+    m.zero_grad(set_to_none=True)
+    m.loss(batch_of(g)).backward()
+    once = {}
+    for name, p in m.named_parameters():
+        assert p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr(), name
+        once[name] = p.grad.detach().cpu().numpy().copy()
+    m.loss(batch_of(g)).backward()
+    for name, p in m.named_parameters():
+        got = p.grad.detach().cpu().numpy()
+        assert np.abs(got - 2 * once[name]).max() <= 1e-5 * max(np.abs(once[name]).max(), 1e-3), name
