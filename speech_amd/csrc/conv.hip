@@ -277,6 +277,10 @@ __host__ __device__ inline bool conv_direct_ok(int C, int O, int kh, int kw, int
 struct DirGeom {
     int B, C, T, F, O, kh, kw, s, To, Fo, K, TT;   // K = kh * kw: the taps of ONE input channel
     long ys_b, ys_c, ys_t;
+    // where conv_dirc_kernel<GRAD = true> stores position (t, f): dx[b][ch][dts t + dt0][dfs f + df0] of a (dT, dF) image.
+    // The whole-image form has (T, F, 1, 0, 1, 0); a PHASE of a strided conv's input gradient (below) owns the rows and
+    // columns of one parity.
+    int dT, dF, dts, dt0, dfs, df0;
     // nn.Dropout behind the ReLU (model.py:25-27).  Forward: the epilogue multiplies element (b, c, t', f') by the factor
     // of mask index ((b O + c) T' + t') F' + f' (dropout.h).  Backward: y is the DROPPED output, so [y > 0] is already
     // "ReLU passed AND kept" and the gradient only needs the 1 / (1 - p) of the kept elements: dscale.
@@ -470,10 +474,11 @@ __device__ __forceinline__ void dirc_group(const DircArgs& a, DircCursor& cu, fl
 // order -- every wave NQ full tiles, whatever the row width -- and stages the slab rows those positions touch.
 // GRAD = false: forward; true: input gradient.  kw is even and GS divides kw / 2.
 template <bool GRAD, int NQ, int GS>
-__global__ __launch_bounds__(256) void conv_dirc_kernel(DircArgs a) {
+__device__ __forceinline__ void dirc_body(const DircArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const DirGeom& g = a.g;
     const int b = blockIdx.y, p_first = blockIdx.x * (128 * NQ);
+    if (p_first >= (GRAD ? g.T * g.F : g.To * g.Fo)) return;   // (a phase launch's grid is the largest phase's)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, r = lane & 31;
     const int n_outer = GRAD ? g.O : g.C;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_dirc_kernel(DircArgs a) {
             const int ch = (e & 3) + 8 * (e >> 2) + 4 * h;
             if (ch >= n_inner) continue;
             if (GRAD) {
-                a.dst[(((long)b * g.C + ch) * g.T + t) * g.F + fo] = acc[q][e];
+                a.dst[(((long)b * g.C + ch) * g.dT + g.dts * t + g.dt0) * g.dF + g.dfs * fo + g.df0] = acc[q][e];
             } else {
                 float v = fmaxf(acc[q][e] + a.bias[ch], 0.f);
                 // wave-uniform branch (a kernel argument); the mask index is the element's NCHW position, whatever
@@ -537,6 +542,39 @@ __global__ __launch_bounds__(256) void conv_dirc_kernel(DircArgs a) {
             }
         }
     }
+}
+
+template <bool GRAD, int NQ, int GS>
+__global__ __launch_bounds__(256) void conv_dirc_kernel(DircArgs a) { dirc_body<GRAD, NQ, GS>(a); }
+
+// ---- the input gradient of a STRIDE-2 conv by phases (r6).  The zero-stuffed form above multiplies three stuffed zeros for
+// every gradient value (the shipped configs stack two stride-2 convs: the second one's input gradient was 411 us of a 4.1 ms
+// TIMIT step, twice its forward pass).  Position (t, f) only ever meets taps (i, j) with i = t, j = f (mod 2), so the rows
+// and columns of one parity (pt, pf) are a STRIDE-1 transposed conv of the compact masked dy with the taps of that parity,
+//     dx[2 t' + pt][2 f' + pf] = sum_{i', j'} m[t' - i'][f' - j'] w[pt + 2 i'][pf + 2 j'],
+// which is this same kernel on a smaller geometry (T' = ceil((T - pt) / 2) rows, kh' = ceil((kh - pt) / 2) tap rows, kw / 2
+// tap columns, s = 1) storing through the (dts, dt0, dfs, df0) map: four phases in ONE launch (blockIdx.z), a quarter of the
+// products.  The non-zero products of a position are the zero-stuffed form's, in the same order (channel, tap row, tap
+// column ascending; a tap pair of the MFMA is two taps of one parity instead of a tap and a stuffed zero): bit-identical.
+struct DircPhases { DircArgs p[4]; };
+template <int NQ, int GS>
+__global__ __launch_bounds__(256) void conv_dirc_phase_kernel(DircPhases A) { dirc_body<true, NQ, GS>(A.p[blockIdx.z]); }
+
+// the four phases' transposed weights, one after the other (each padded like conv_wt_kernel's): phase ph = 2 pt + pf at
+// float offset sum_{q < ph} (O khq kwq 32 + pad);  wt_ph[(o K' + i' kw' + j') 32 + c] = w[o][c][pt + 2 i'][pf + 2 j']
+__global__ __launch_bounds__(256) void conv_wt_phase_kernel(const float* __restrict__ w, float* __restrict__ wt, int O, int C,
+                                                           int kh, int kw) {
+    const int ph = blockIdx.y, pt = ph >> 1, pf = ph & 1;
+    const int kwp = kw >> 1, khp = (kh - pt + 1) >> 1, Kp = khp * kwp;
+    long base = 0;
+    for (int q = 0; q < ph; ++q) base += (long)O * (((kh - (q >> 1) + 1) >> 1) * kwp) * 32 + kDircWtPad;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)O * Kp * 32 + kDircWtPad) return;
+    if (i >= (long)O * Kp * 32) { wt[base + i] = 0.f; return; }
+    const int c = (int)(i & 31);
+    const int k = (int)((i >> 5) % Kp), o = (int)((i >> 5) / Kp);
+    const int ip = k / kwp, jp = k - ip * kwp;
+    wt[base + i] = c < C ? w[((long)o * C + c) * (kh * kw) + (pt + 2 * ip) * kw + pf + 2 * jp] : 0.f;
 }
 
 // Weight / bias gradient, any number of input channels <= 32.  512 threads: the 8 waves are CW channel slots x PW = 8 / CW
@@ -783,6 +821,7 @@ static DirGeom dir_geom(const ConvGeom& g, long ys_b, long ys_c, long ys_t, int 
     d.K = g.kh * g.kw;
     d.ys_b = ys_b; d.ys_c = ys_c; d.ys_t = ys_t;
     d.TT = TT;
+    d.dT = g.T; d.dF = g.F; d.dts = 1; d.dt0 = 0; d.dfs = 1; d.df0 = 0;
     d.drop = sa_drop_make(0.f, 0ull); d.drop_stream = 0u; d.dscale = 1.f;
     return d;
 }
@@ -882,6 +921,59 @@ static ctcStatus_t dirc_launch(const DircArgs& a, const ConvGeom& g, bool grad, 
     return CTC_STATUS_SUCCESS;
 }
 
+// ---- phases of a stride-2 input gradient: geometry, eligibility, launch
+static ConvGeom dirc_phase_geom(const ConvGeom& g, int ph) {
+    const int pt = ph >> 1, pf = ph & 1;
+    ConvGeom q = g;
+    q.T = (g.T - pt + 1) / 2; q.F = (g.F - pf + 1) / 2;
+    q.kh = (g.kh - pt + 1) / 2; q.kw = g.kw / 2; q.s = 1;
+    return q;
+}
+static bool dirc_phases_ok(const ConvGeom& g) {   // every phase has rows, columns and taps, and an even tap-row width
+    return g.s == 2 && g.kh >= 2 && (g.kw & 3) == 0 && g.T >= 2 && g.F >= 2 && sa_opt(SA_OPT_CONV_DX_PHASES) != 0 &&
+           dirc_nq(dirc_phase_geom(g, 0), true) > 0;
+}
+static size_t dir_wt_phase_bytes(const ConvGeom& g) {
+    return sa_align_up(((size_t)g.O * g.kh * g.kw * 32 + 4 * kDircWtPad) * sizeof(float), 256);
+}
+template <int GS>
+static void (*dirc_phase_fn(int nq))(DircPhases) {
+    return nq == 1 ? conv_dirc_phase_kernel<1, GS> : nq == 2 ? conv_dirc_phase_kernel<2, GS>
+           : nq == 3 ? conv_dirc_phase_kernel<3, GS> : conv_dirc_phase_kernel<4, GS>;
+}
+static ctcStatus_t dirc_phase_launch(const DircArgs& whole, const ConvGeom& g, const float* w, float* wt, hipStream_t stream) {
+    hipLaunchKernelGGL(conv_wt_phase_kernel, dim3((unsigned)(((long)g.O * ((g.kh + 1) / 2) * (g.kw / 2) * 32 + kDircWtPad + 255) / 256), 4),
+                       dim3(256), 0, stream, w, wt, g.O, g.C, g.kh, g.kw);
+    const ConvGeom g0 = dirc_phase_geom(g, 0);   // the largest phase decides the tiles per wave
+    const int nq = dirc_nq(g0, true);
+    const int kwh = g0.kw / 2;
+    const int gs = kwh % 8 == 0 ? 8 : kwh % 4 == 0 ? 4 : kwh % 2 == 0 ? 2 : 1;
+    DircPhases A;
+    size_t lds = 0;
+    long off = 0, npos_max = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+        const ConvGeom q = dirc_phase_geom(g, ph);
+        DircArgs& a = A.p[ph];
+        a = whole;
+        a.wt = wt + off;
+        off += (long)g.O * q.kh * q.kw * 32 + kDircWtPad;
+        a.g.T = q.T; a.g.F = q.F; a.g.kh = q.kh; a.g.kw = q.kw; a.g.s = 1; a.g.K = q.kh * q.kw;
+        a.g.dT = g.T; a.g.dF = g.F; a.g.dts = 2; a.g.dt0 = ph >> 1; a.g.dfs = 2; a.g.df0 = ph & 1;
+        const size_t l = dirc_lds(q, true, nq);
+        lds = l > lds ? l : lds;
+        const long npos = (long)q.T * q.F;
+        npos_max = npos > npos_max ? npos : npos_max;
+    }
+    if (lds > 64 * 1024) return CTC_STATUS_INVALID_VALUE;
+    void (*fn)(DircPhases) = gs == 8 ? dirc_phase_fn<8>(nq) : gs == 4 ? dirc_phase_fn<4>(nq) : gs == 2 ? dirc_phase_fn<2>(nq)
+                                                                                                  : dirc_phase_fn<1>(nq);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return CTC_STATUS_EXECUTION_FAILED;
+    hipLaunchKernelGGL(fn, dim3((unsigned)((npos_max + 128 * nq - 1) / (128 * nq)), g.B, 4), dim3(256), lds, stream, A);
+    return CTC_STATUS_SUCCESS;
+}
+
 static bool dir_fwd_ok(const ConvGeom& g) {
     return conv_direct_ok(g.C, g.O, g.kh, g.kw, g.s, g.F, g.Fo) && dirc_nq(g, false) > 0;
 }
@@ -970,7 +1062,7 @@ extern "C" size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, i
         const size_t gw5 = (size_t)dir_dw_blocks(g) * g.C * 32 * 32 * dir_nt(g.kh * g.kw) * sizeof(float);
         if (gw5 > gw) gw = gw5;
         if (dir_dx_ok(g))  // no column matrices at all: partials | transposed weights | packed masked gradient
-            return sa_align_up(gw, 256) + dir_wt_bytes(g, true) + sa_align_up((size_t)npos * g.O * sizeof(float), 256) + 512;
+            return sa_align_up(gw, 256) + dir_wt_phase_bytes(g) + sa_align_up((size_t)npos * g.O * sizeof(float), 256) + 512;
     }
     return sa_align_up((size_t)npos * g.K * sizeof(float), 256) +   // cols, reused for dcols
            sa_align_up((size_t)npos * g.O * sizeof(float), 256) +   // dyp
@@ -1006,13 +1098,13 @@ static ctcStatus_t conv2d_relu_bwd_impl(const float* x, const float* w, const fl
         const int nslab_t = (g.To + TT - 1) / TT;
         const int nb = dir_dw_blocks(g);
         const size_t part_bytes = sa_align_up((size_t)nb * g.C * 32 * 32 * NT * sizeof(float), 256);
-        if (gws_bytes < part_bytes + (dx ? dir_wt_bytes(g, true) : 0)) return CTC_STATUS_INVALID_VALUE;
+        if (gws_bytes < part_bytes + (dx ? dir_wt_phase_bytes(g) : 0)) return CTC_STATUS_INVALID_VALUE;
         const float* dpk = nullptr;
         if (dir_dw_packed(g)) {  // the masked gradient packed position-major ([position][O])
             float* pk = dyp;
             if (dir_dx_ok(g)) {
-                pk = (float*)(gws + part_bytes + dir_wt_bytes(g, true));
-                if (gws_bytes < part_bytes + dir_wt_bytes(g, true) + (size_t)npos * g.O * sizeof(float))
+                pk = (float*)(gws + part_bytes + dir_wt_phase_bytes(g));
+                if (gws_bytes < part_bytes + dir_wt_phase_bytes(g) + (size_t)npos * g.O * sizeof(float))
                     return CTC_STATUS_INVALID_VALUE;
             }
             hipLaunchKernelGGL(relu_mask_pack_kernel, dim3(grid_for(npos * g.O)), dim3(256), 0, stream, dy, y, pk, g, ys_b,
@@ -1031,12 +1123,17 @@ static ctcStatus_t conv2d_relu_bwd_impl(const float* x, const float* w, const fl
         SA_CHECK_LAUNCH();
         if (dx) {
             float* wt = (float*)(gws + part_bytes);
-            hipLaunchKernelGGL(conv_wt_kernel, dim3((unsigned)(((long)g.O * Kc * 32 + kDircWtPad + 255) / 256)), dim3(256), 0,
-                               stream, w, wt, g.O, g.C, Kc, 1);
             DircArgs a;
             a.src = dy; a.y = y; a.wt = wt; a.bias = nullptr; a.dst = dx;
             a.g = dg;
-            const ctcStatus_t st = dirc_launch(a, g, true, stream);
+            ctcStatus_t st;
+            if (dirc_phases_ok(g)) {   // (r6) stride 2: four stride-1 phases in one launch, no stuffed zeros
+                st = dirc_phase_launch(a, g, w, wt, stream);
+            } else {
+                hipLaunchKernelGGL(conv_wt_kernel, dim3((unsigned)(((long)g.O * Kc * 32 + kDircWtPad + 255) / 256)), dim3(256),
+                                   0, stream, w, wt, g.O, g.C, Kc, 1);
+                st = dirc_launch(a, g, true, stream);
+            }
             if (st != CTC_STATUS_SUCCESS) return st;
             SA_CHECK_LAUNCH();
         }

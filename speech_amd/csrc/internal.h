@@ -8,7 +8,7 @@ enum SaOpt {
     SA_OPT_CTC_PROB, SA_OPT_CTC_WIDE, SA_OPT_CTC_DIRECT, SA_OPT_CTC_DBG, SA_OPT_GEMM_EXACT, SA_OPT_GEMM_THIN,
     SA_OPT_GRU_PERSIST, SA_OPT_GRU_SPIN_LIMIT, SA_OPT_GRU_FAULT, SA_OPT_GRU_FWD_CHUNKS, SA_OPT_GRU_FUSE_DX, SA_OPT_GRU_TILED,
     SA_OPT_GRU_FUSED, SA_OPT_GRU_TIMING, SA_OPT_GRU_SHARED_PACK, SA_OPT_GRU_PACK_IN_KERNEL, SA_OPT_GRU_BWD_ONE,
-    SA_OPT_GRU_FWD_REPORT, SA_OPT_GRU_FWD_PLANES, SA_OPT_GRU_EXP, SA_OPT_S2S_KERNELS, SA_OPT_COUNT
+    SA_OPT_GRU_FWD_REPORT, SA_OPT_GRU_FWD_PLANES, SA_OPT_GRU_EXP, SA_OPT_S2S_KERNELS, SA_OPT_CONV_DX_PHASES, SA_OPT_COUNT
 };
 long sa_opt(SaOpt id);
 

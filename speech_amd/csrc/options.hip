@@ -48,6 +48,8 @@ Opt g_opts[SA_OPT_COUNT] = {
                           "per token in the MFMA accumulator layout (attention_bwd_main2_kernel; 0: the round-4 stages, two "
                           "launches); 2 = the forward's score network in that layout and the context on four workgroups per "
                           "utterance (attention_score2_kernel, attention_context2_kernel; 0: the round-4 kernels)"},
+    {"conv.dx_phases", 1, 1, "direct conv, input gradient at stride 2: 0 = the zero-stuffed transposed conv (three products in four "
+                             "on stuffed zeros) instead of four stride-1 phases in one launch (bit-identical results)"},
 };
 }  // namespace
 

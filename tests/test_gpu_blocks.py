@@ -814,3 +814,36 @@ def test_thin_products_of_the_classifier(monkeypatch, M, N, K):
     monkeypatch.delenv("SA_GEMM_THIN", raising=False)
     assert np.array_equal(np.isnan(thin), np.isnan(tiled)) and np.array_equal(np.isposinf(thin), np.isposinf(tiled))
     assert np.isposinf(thin[:N - 1, 3]).all() and np.isfinite(thin[:N - 1, :3]).all()
+
+
+@pytest.mark.parametrize("B,C,T,F,O,kh,kw,s", [(2, 8, 24, 40, 32, 5, 32, 2), (1, 32, 51, 33, 32, 5, 8, 2),
+                                               (2, 32, 37, 41, 32, 4, 12, 2), (8, 32, 150, 65, 32, 5, 32, 2),
+                                               (2, 16, 9, 10, 8, 2, 4, 2)])
+@pytest.mark.parametrize("layout", ["nchw", "tbf"])
+def test_stride2_input_gradient_by_phases_is_the_zero_stuffed_form_bit_for_bit(B, C, T, F, O, kh, kw, s, layout):
+    """(r6) conv_dirc_phase_kernel: the input gradient of a stride-2 direct conv as four stride-1 phases in one launch (rows /
+    columns of one parity meet the taps of that parity) against the zero-stuffed transposed conv it replaces (option
+    conv.dx_phases = 0): the same non-zero products in the same order, so dx is BIT-identical (dw / db do not change path);
+    odd and even extents, an even tap-row count, the TIMIT stacked conv's shape; and the oracle on top."""
+    from speech_amd import ops, _lib
+    rng = np.random.RandomState(T + F + kw)
+    x = rng.randn(B, C, T, F)
+    w = rng.randn(O, C, kh, kw) / np.sqrt(C * kh * kw)
+    b = rng.randn(O) * 0.1
+    y_ref, cols = E.conv_relu_fwd(x, w, b, s)
+    _, _, To, Fo = y_ref.shape
+    y, ys = ops.conv2d_relu_fwd(dev(x), dev(w), dev(b), s, layout)
+    dy = rng.randn(*y_ref.shape)
+    dy_l = dy if layout == "nchw" else dy.transpose(2, 0, 1, 3).reshape(To, B, O * Fo)
+    got = {}
+    try:
+        for phases in (1, 0):
+            _lib.set_option("conv.dx_phases", phases)
+            dx, dw, db = ops.conv2d_relu_bwd(dev(x), dev(w), y, dev(dy_l), ys, s, need_dx=True)
+            got[phases] = [t.cpu().numpy().copy() for t in (dx, dw, db)]
+    finally:
+        _lib.set_option("conv.dx_phases", 1)
+    for a, o in zip(got[1], got[0]):
+        assert np.array_equal(a, o)
+    dx_ref, _, _ = E.conv_relu_bwd(dy, y_ref, cols, x.shape, w, s, need_dx=True)
+    close(torch.from_numpy(got[1][0]), dx_ref, rtol=2e-5, atol_scale=1e-5)
