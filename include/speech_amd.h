@@ -164,7 +164,10 @@ ctcStatus_t sa_conv2d_relu_fwd(const float* x, const float* w, const float* bias
                                float* keep_cols /* or NULL */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above: dy (same strides as y), y (to mask the ReLU) -> dw (+=0: overwritten), dbias, and dx
- * (NCHW, overwritten) unless dx == NULL.  workspace >= sa_conv2d_bwd_workspace_bytes(). */
+ * (NCHW, overwritten) unless dx == NULL.  workspace >= sa_conv2d_bwd_workspace_bytes().
+ * The input gradient of a direct conv at stride 2 (kw a multiple of 4) runs as four stride-1 phases in one launch -- the
+ * rows / columns of one parity against the taps of that parity -- instead of a transposed conv over a zero-stuffed dy;
+ * the results are bit-identical (option "conv.dx_phases" = 0 selects the zero-stuffed form). */
 size_t sa_conv2d_bwd_workspace_bytes(int B, int in_c, int T, int F, int out_c, int kh, int kw, int s);
 ctcStatus_t sa_conv2d_relu_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                                float* dbias, int B, int in_c, int T, int F, int out_c, int kh, int kw, int s,
@@ -493,7 +496,12 @@ ctcStatus_t sa_attention_bwd(const float* eh, const float* ox, const float* ax_p
  *   (t >= 1; NULL = teacher forcing), the argmax of token t-1's logits (scheduled sampling, :91-96).
  *   Time-major outputs / stashes for the backward: out (U-1,B,K) logits, IDX (U-1,B) int64 inputs actually used,
  *   IX (U-1,B,E), ST (U-1,B,4H), HX (U-1,B,H), AX (U-1,B,T) alignments, OIN (U-1,B,H) = state + context.
- *   bwd: d_out (U-1,B,K) -> d_eh (B,T,H) and every parameter gradient (grads[i] written, not accumulated). */
+ *   bwd: d_out (U-1,B,K) -> d_eh (B,T,H) and every parameter gradient (grads[i] written, not accumulated).
+ *   Kernel forms (option "s2s.kernels", bits; default 3; H <= 256): bit 0 -- the attention backward of a token as ONE launch in
+ *   the MFMA accumulator layout (the softmax's sum over the utterance from the stashed context: OIN - HX) instead of the
+ *   round-4 stages (two launches); bit 1 -- the forward's score network in that layout and the context on four workgroups per
+ *   utterance (also in sa_attention_fwd, sa_s2s_decoder_step, sa_s2s_beam_search, sa_s2s_greedy_decode).  fp32 throughout:
+ *   the location term is an exact fp32 FMA chain in tap order on v_mfma_f32_16x16x4_f32 in every form. */
 size_t sa_s2s_decoder_workspace_bytes(int B, int T, int U1, int H, int E, int KS, int K);
 ctcStatus_t sa_s2s_decoder_fwd(const float* eh, const long long* y, const unsigned char* sample,
                                const float* const* params, int B, int T, int U, int H, int E, int KS, int K, float scale,

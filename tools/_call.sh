@@ -1,4 +1,3 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r6s15
-timeout 600 bash tools/gpu_run.sh r6s15 "profpy:tools/timit_profile.py" > gpurun_out/r6s15/stage.log 2>&1
-grep -E "conv_|Name" gpurun_out/r6s15/timit_profile_kernel_stats.csv | cut -c1-200
+mkdir -p gpurun_out/r6final7
+timeout 2400 bash tools/gpu_run.sh r6final7 tests smoke "bench:--steps 20 --warmup 5" "prof:--steps 20 --warmup 5 --no-cpu-baseline --headline-only" configs
