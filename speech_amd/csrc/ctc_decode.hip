@@ -122,24 +122,38 @@ __global__ __launch_bounds__(64) void ctc_beam1_kernel(BeamArgs A) {
     float pb = 0.0f, pnb = NEG_INF_F;
     int last = -1, len = 0;
     const bool live = lane < S;
-    float p_next = (live && T > 0) ? lp[lane] : NEG_INF_F;
-    for (int t = 0; t < T; ++t) {
-        const float p = p_next;
-        if (t + 1 < T) p_next = live ? lp[(long)(t + 1) * A.st + lane] : NEG_INF_F;  // the next row, a step ahead
+    // (r6) the rows EIGHT steps ahead, in a register ring: one step ahead (rounds 3 - 5) made a step as long as a load's
+    // round trip -- 1.46 us where its arithmetic is ~0.3 (CTC.infer at B = 1 spent a tenth of the call here)
+    constexpr int kAhead = 8;
+    float ring[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) ring[u] = T > 0 ? lp[(long)min(u, T - 1) * A.st + (live ? lane : 0)] : 0.f;
+    for (int t0 = 0; t0 < T; t0 += kAhead) {
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int t = t0 + u;
+        if (t >= T) break;   // wave-uniform
+        const float p = live ? ring[u] : NEG_INF_F;
+        // unconditional load at a clamped address, the RAW value into the ring (a load under a branch, or a select on its
+        // result, makes every step wait for the load it has just issued); rows beyond T - 1 are never consumed
+        ring[u] = lp[(long)min(t + kAhead, T - 1) * A.st + (live ? lane : 0)];
         float npb = NEG_INF_F, npnb = NEG_INF_F, score = NEG_INF_F, ord = 3.0e38f;
         // log-probability of the prefix's last symbol (`last` is wave-uniform: v_readlane, outside divergent flow)
         const float q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), last >= 0 ? last : 0));
+        // lse(pb + p, pnb + p) is the blank lane's new p_b AND every other lane's extension: once, outside the divergent flow
+        // (the two branches each carried their own double-precision exp + log: three in series per step, now two)
+        const float both = ref_lse2(pb + p, pnb + p);
         if (live) {
             ord = (float)(2 * lane);
             if (lane == A.blank) {
-                npb = ref_lse2(pb + p, pnb + p);
+                npb = both;
                 if (last >= 0) {
                     npnb = pnb + q;                       // ref_lse3(-inf, merge, ., 2) = merge exactly
                     ord = fminf(ord, (float)(2 * last + 1));
                 }
                 score = ref_lse2(npb, npnb);
             } else {
-                npnb = (lane != last) ? ref_lse2(pb + p, pnb + p) : pb + p;   // ctc_decoder.py:88-96
+                npnb = (lane != last) ? both : pb + p;   // ctc_decoder.py:88-96
                 score = npnb;                             // ref_lse3(-inf, npnb, ., 2) = npnb exactly
             }
         }
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(64) void ctc_beam1_kernel(BeamArgs A) {
             if (lane == 0 && len < A.T_max) out[len] = w;
             ++len;
         }
+      }
     }
     if (lane == 0) {
         A.out_lens[b] = len < A.T_max ? len : A.T_max;
