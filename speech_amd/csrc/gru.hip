@@ -3201,7 +3201,15 @@ static bool xcd_shape_ok(int jobs, int B, int H) {
     return jobs <= 8 * (32 / ntile_u);  // at least one batch tile per pass (see tiles_per_pass)
 }
 // batch tiles one persistent launch can host next to `jobs` concurrent jobs: 8 XCDs x (32 / ntile_u) groups
-static int tiles_per_pass(int jobs, int H) { return (8 * (32 / (H / 16))) / jobs; }
+// (r6) groups of 16 units an XCD's 32 CUs host.  Only meaningful for a shape xcd_shape_ok() takes, but the bidirectional
+// passes evaluate it BEFORE they know that: H < 16 (H / 16 = 0) and H > 512 (32 / 33 = 0 as a divisor further down) were an
+// integer division by zero on the host -- a bidirectional stack of width 4, 8 or 528+ killed the process with SIGFPE instead
+// of taking the step kernels (found by tools/s2s_shape_sweep.py).
+static int groups_per_xcd(int H) {
+    const int nt = H / 16;
+    return nt >= 1 && nt <= 32 ? 32 / nt : 1;
+}
+static int tiles_per_pass(int jobs, int H) { return (8 * groups_per_xcd(H)) / (jobs > 0 ? jobs : 1); }
 // XCD-local kernels are one-per-CU through their register reservation (SA_PERSIST_EXCLUSIVE), so they ask for the LDS
 // they use and nothing more (an XCD-filtered side-stream GEMM block fits beside them)
 static size_t xcd_lds(size_t need) { return need; }
@@ -3455,7 +3463,7 @@ ctcStatus_t stack_fwd_impl(const float* x, int I0, const float* const* w_ih, con
         // others on the side stream, XCD-filtered to the idle XCDs, BESIDE the recurrence launches of the earlier chunks
         // (the same mechanism as the backward pass's weight gradients: one tile per block, the <= 170-register kernel, a
         // delay kernel so that the recurrence launch is dispatched first).
-        const int per_xcd = 32 / (H / 16);
+        const int per_xcd = groups_per_xcd(H);
         const int bi_used = (2 * min(bi_tpp, bi_nbt) + per_xcd - 1) / per_xcd;
         const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
         const int nck = fwd_chunks(T);
@@ -4227,7 +4235,7 @@ ctcStatus_t stack_bwd_impl(const float* dh_top, const float* const* stash, const
                             (long)T * B * 3 * H * 4 < 0x7fffffffL;
         // a layer's groups (2 directions x the batch tiles of a pass) sit on XCDs 0 .. used-1: the weight gradients of
         // the layer above run on the OTHER XCDs meanwhile (XCD-filtered persistent-tile GEMM launches on the side stream)
-        const int bi_used = (2 * min(bi_tpp, bi_nbt) + (32 / (H / 16)) - 1) / (32 / (H / 16));
+        const int bi_used = (2 * min(bi_tpp, bi_nbt) + groups_per_xcd(H) - 1) / groups_per_xcd(H);
         const unsigned bi_mask = bi_used >= 8 ? 0u : (0xffu & ~((1u << bi_used) - 1u));
         const bool bi_side = wg && bi_xcd && bi_mask && overlap_enabled() && g_side.init();
         issuer.counters = sync + kSyncTiles; issuer.max_counters = kSyncTileWords; issuer.err_word = g_health.dev;

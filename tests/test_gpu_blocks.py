@@ -280,7 +280,10 @@ def test_clip_sgd_step(momentum, gscale):
 
 # ------------------------------------------------------------------------------------------- the GRU stack (wavefront)
 @pytest.mark.parametrize("L,D,B,T,I0,H,chunk", [(4, 1, 5, 23, 12, 16, 5), (3, 1, 32, 9, 40, 64, 4), (2, 2, 3, 11, 10, 24, 0),
-                                              (1, 1, 2, 7, 6, 8, 32), (4, 1, 2, 40, 8, 16, 0)])
+                                              (1, 1, 2, 7, 6, 8, 32), (4, 1, 2, 40, 8, 16, 0),
+                                              # bidirectional stacks narrower than one 16-unit group / wider than an XCD's
+                                              # 32 groups: the host's XCD arithmetic divided by zero (SIGFPE) before r6
+                                              (2, 2, 2, 5, 6, 8, 0), (1, 2, 1, 3, 4, 4, 0), (1, 2, 2, 4, 8, 528, 0)])
 def test_gru_stack_matches_oracle(L, D, B, T, I0, H, chunk):
     """sa_gru_stack_fwd/bwd (chunked layer wavefront for D=1, paired directions for D=2) vs the per-layer oracle."""
     from speech_amd import ops

@@ -324,3 +324,16 @@ def test_flat_buffer_gradients_are_handed_over_by_reference_by_every_node():
     for name, p in m.named_parameters():
         got = p.grad.detach().cpu().numpy()
         assert np.abs(got - 2 * once[name]).max() <= 1e-5 * max(np.abs(once[name]).max(), 1e-3), name
+
+
+def test_edge_shapes_of_the_attention_kernels():
+    """tools/s2s_shape_sweep.py: widths that are not a multiple of 16 (4, 8, 20, 36, 200), one-chunk utterances, one utterance, one
+    token, tap counts 1 .. 15 -- the MFMA-layout kernels against the round-4 backward on the same forward (2e-5 of max) and against
+    the round-4 kernels throughout; the narrow bidirectional encoders of the first two cases killed the process with SIGFPE
+    before round 6 (an integer division by zero in the host's XCD arithmetic of sa_gru_stack_fwd)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "s2s_shape_sweep.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "all shapes agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,3 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r6s22
-for sh in 0 1 2 3; do echo "threshold 8 GF >> $sh"; SA_GRU_EXP=$((sh * 1048576)) timeout 600 python tools/bench_configs.py --only M-TIMIT,M-S2S 2>/dev/null | grep -E "workload|train_step_ms" | paste - - | cut -c1-130; done | tee gpurun_out/r6s22/pk_threshold.txt
+mkdir -p gpurun_out/r6s24
+for i in 0 1 2 3 4 5 6 7 8; do timeout 300 python tools/s2s_shape_sweep.py $i 2>&1 | grep -v "amdgpu\|^  \.\." ; done | tee gpurun_out/r6s24/sweep.txt
+timeout 900 bash tools/gpu_run.sh r6s24 "tests:gru_stack_matches_oracle"
