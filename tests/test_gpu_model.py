@@ -219,3 +219,17 @@ def test_padding_a_batch_ahead_changes_nothing_but_where_it_runs():
     (2.0 * model.loss(batches[0])).backward()     # a non-unit seed still scales the saved gradient
     for a, p in zip(want, model.parameters()):
         torch.testing.assert_close(p.grad, 2.0 * a, rtol=1e-6, atol=1e-7)
+
+
+def test_edge_shapes_of_the_ctc_train_step():
+    """tools/ctc_shape_sweep.py: twelve CTC models the persistent recurrences do not take or barely take -- widths 4 .. 1024 incl.
+    12, 100, 520, 640; one utterance and ragged batches of 17 / 33; uni- and bidirectional; dropout -- loss (1e-5) and every
+    gradient (1e-3 of max) of the default kernel selection against the one-launch-per-time-step kernels, then CTC.infer.  (A
+    bidirectional stack narrower than 16 units or wider than 512 killed the process with SIGFPE before round 6.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ctc_shape_sweep.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "all shapes agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
