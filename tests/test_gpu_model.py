@@ -233,3 +233,16 @@ def test_edge_shapes_of_the_ctc_train_step():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ctc_shape_sweep.py")], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "all shapes agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_edge_shapes_of_the_transducer_train_step():
+    """tools/rnnt_shape_sweep.py: eight RNN-Transducer models outside the fused joint's / persistent recurrences' shapes (encoder
+    widths 4 .. 640, embeddings 4 .. 300, one utterance, ragged label lengths down to one label, two prediction layers, dropout):
+    loss and gradients of the default kernel selection against the step kernels, then the greedy decode."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rnnt_shape_sweep.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "all shapes agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
