@@ -93,6 +93,24 @@ def test_matches_oracle(B, T, K, Lmin, Lmax):
     compare(*make(B * 1000 + T, B, T, K, Lmin, Lmax))
 
 
+def test_forty_random_small_and_odd_shapes():
+    """A fuzz over the corners the fixed cases do not enumerate: 1 .. 40 utterances, 1 .. 80 frames, alphabets of 2 .. 90, label
+    lengths from empty to LONGER than the frames (infeasible -> +inf cost, zero gradient as the oracle's), ragged input lengths,
+    blank first or last, both layouts."""
+    rng = np.random.RandomState(20260930)
+    for i in range(40):
+        B, T, K = int(rng.randint(1, 41)), int(rng.randint(1, 81)), int(rng.randint(2, 91))
+        Lmax = int(rng.randint(0, T + 4))
+        acts, labs, al, ll = make(1000 + i, B, T, K, 0, Lmax, ragged_T=bool(rng.randint(2)), scale=float(rng.choice([0.5, 1.0, 4.0])))
+        blank = None if rng.randint(2) else 0
+        if blank == 0:
+            labs = (labs + 1).astype(np.int32) if K > 1 else labs   # labels 1 .. K - 1 around a blank of 0
+        if rng.randint(2):
+            compare(acts, labs, al, ll, blank=blank)
+        else:
+            compare(np.ascontiguousarray(acts.transpose(1, 0, 2)), labs, al, ll, blank=blank, batch_first=False)
+
+
 def test_ragged_input_lengths_and_time_major():
     acts, labs, al, ll = make(7, 6, 120, 29, 5, 40, ragged_T=True)
     compare(acts, labs, al, ll)

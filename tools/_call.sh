@@ -1,3 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r6s28
-timeout 600 python -X faulthandler tools/s2s_shape_sweep.py 2>&1 | grep -v "amdgpu\|Extension modules" | tee gpurun_out/r6s28/sweep.txt
+mkdir -p gpurun_out/r6s29
+timeout 900 bash tools/gpu_run.sh r6s29 "tests:forty_random"
+grep -n "^E  \|Error" gpurun_out/r6s29/pytest_forty_random.log | head -10
