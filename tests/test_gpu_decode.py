@@ -86,3 +86,24 @@ def test_greedy_kats_and_random():
     got = decoder.greedy_decode(torch.from_numpy(x).cuda(), blank=28, lengths=lens)
     for b, n in enumerate(lens):
         assert list(got[b]) == decoder_ref.greedy(x[b, :n], 28)
+
+
+def test_thirty_random_small_shapes_match_the_restatement():
+    """A fuzz over what the fixed cases do not enumerate: 1 .. 9 utterances of 1 .. 60 frames (ragged), alphabets of 2 .. 40, beams
+    1 .. 16 (beam 1 = the one-wave kernel with its row ring and shared log-sum-exp, r6), blank first or last, peaked and flat
+    rows: labels identical to oracle/decoder_ref.py, scores to 1e-5."""
+    from speech_amd import decoder
+    rng = np.random.RandomState(930)
+    for i in range(30):
+        B, T, S = int(rng.randint(1, 10)), int(rng.randint(1, 61)), int(rng.randint(2, 41))
+        beam = int(rng.choice([1, 1, 2, 3, 5, 8, 16]))
+        blank = 0 if rng.randint(2) else S - 1
+        probs = softmax32(float(rng.choice([0.5, 2.0, 6.0])) * rng.randn(B, T, S))
+        lens = [int(rng.randint(1, T + 1)) for _ in range(B)]
+        got, nll = decoder.beam_decode(torch.from_numpy(probs).cuda(), beam_size=beam, blank=blank, lengths=lens)
+        nll = nll.cpu().numpy()
+        for b in range(B):
+            want, want_nll = decoder_ref.decode(probs[b, :lens[b]], beam, blank)
+            assert got[b] == tuple(want), (i, b, B, T, S, beam, blank)
+            if np.isfinite(want_nll):
+                assert abs(nll[b] - float(want_nll)) <= 1e-5 * max(1.0, abs(float(want_nll))), (i, b)
