@@ -222,7 +222,7 @@ def test_padding_a_batch_ahead_changes_nothing_but_where_it_runs():
 
 
 def test_edge_shapes_of_the_ctc_train_step():
-    """tools/ctc_shape_sweep.py: fifteen CTC models the persistent recurrences do not take or barely take -- widths 4 .. 1024 incl.
+    """tools/ctc_shape_sweep.py: eighteen CTC models the persistent recurrences do not take or barely take -- widths 4 .. 1024 incl.
     12, 100, 520, 640; one utterance and ragged batches of 17 / 33; uni- and bidirectional; dropout -- loss (1e-5) and every
     gradient (1e-3 of max) of the default kernel selection against the one-launch-per-time-step kernels, then CTC.infer.  (A
     bidirectional stack narrower than 16 units or wider than 512 killed the process with SIGFPE before round 6.)"""

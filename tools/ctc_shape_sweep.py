@@ -21,7 +21,10 @@ cases = [(4, 1, True, 2, 60, 20, [[4, 5, 8, 2]], 0.0), (8, 2, False, 1, 40, 20, 
          (64, 1, False, 2, 200, 40, [[32, 5, 32, 2]], 0.0), (384, 2, True, 9, 50, 24, [[8, 5, 8, 2]], 0.0),
          # one and two output frames (T' = 1, 2): a recurrence of a single step, labels of at most one symbol
          (256, 2, False, 3, 5, 24, [[8, 5, 8, 2]], 0.0), (128, 1, True, 2, 7, 24, [[8, 5, 8, 2]], 0.0),
-         (512, 4, False, 32, 9, 24, [[8, 5, 8, 2]], 0.0)]
+         (512, 4, False, 32, 9, 24, [[8, 5, 8, 2]], 0.0),
+         # more batch tiles than one pass of the persistent kernels hosts (B = 64, 100, 130)
+         (512, 2, False, 64, 44, 24, [[8, 5, 8, 2]], 0.2), (256, 2, True, 100, 40, 24, [[8, 5, 8, 2]], 0.0),
+         (128, 1, False, 130, 36, 24, [[8, 5, 8, 2]], 0.0)]
 if len(sys.argv) > 1:
     cases = [cases[int(sys.argv[1])]]
 bad = 0
