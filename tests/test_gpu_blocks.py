@@ -278,6 +278,25 @@ def test_clip_sgd_step(momentum, gscale):
         assert total > 200.0  # the clip branch was exercised
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 1023, 1025, 65537, (1 << 21) + 7])
+def test_clip_sgd_step_at_sizes_around_the_vector_and_block_boundaries(n):
+    """The fused norm / clip / update on flat buffers whose length is not a multiple of 4 (16-byte loads), of a block, of the
+    grid's stride -- and on an unaligned VIEW of a larger buffer (a parameter subset): against the numpy restatement."""
+    from speech_amd import ops
+    rng = np.random.RandomState(n % 1000)
+    p0, g0 = rng.randn(n), 400.0 * rng.randn(n) / np.sqrt(n)
+    for off in (0, 1):
+        big_p, big_g = torch.zeros(n + 3, device="cuda"), torch.zeros(n + 3, device="cuda")
+        p, g = big_p[off:off + n], big_g[off:off + n]
+        p.copy_(dev(p0)); g.copy_(dev(g0))
+        mom = torch.zeros(n + 3, device="cuda")[off:off + n]
+        P, total = E.clip_and_sgd({"p": p0}, {"p": g0}, 1e-2, 200.0, 0.9, {})
+        norm = ops.clip_sgd_step(p, g, mom, 1e-2, 0.9, 200.0)
+        assert abs(float(norm) - total) < 1e-5 * total
+        close(p, P["p"], rtol=1e-5, atol_scale=1e-6)
+        assert float(big_p[off + n:].abs().max()) == 0.0 and (off == 0 or float(big_p[0]) == 0.0)   # nothing outside the view
+
+
 # ------------------------------------------------------------------------------------------- the GRU stack (wavefront)
 @pytest.mark.parametrize("L,D,B,T,I0,H,chunk", [(4, 1, 5, 23, 12, 16, 5), (3, 1, 32, 9, 40, 64, 4), (2, 2, 3, 11, 10, 24, 0),
                                               (1, 1, 2, 7, 6, 8, 32), (4, 1, 2, 40, 8, 16, 0),

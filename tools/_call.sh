@@ -1,3 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r6s32
-for i in 15 16 17; do timeout 300 python -X faulthandler tools/ctc_shape_sweep.py $i 2>&1 | grep -v "amdgpu\|Extension modules" | head -14; done | tee gpurun_out/r6s32/sweep.txt
+mkdir -p gpurun_out/r6s33
+timeout 900 bash tools/gpu_run.sh r6s33 "tests:vector_and_block_boundaries"
+grep -n "^E  \|Error" gpurun_out/r6s33/pytest_vector_and_block_boundaries.log | head -10
